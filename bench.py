@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- CTI fused-forward samples/sec (BASELINE.json metric) on N MI355X GPUs of one node.
+
+One "step" = one TCNet.forward (reference src/tc.py:41-52) over one batch of synthetic tensors of BASELINE.json
+configs[1]: B=256 per GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, h_mm=512, glimpse=2, fp32 in / fp32 out,
+inputs resident in HBM before the timed region.  The batch axis shards across GPUs with no data-path collective
+(forward-only replicas, weak scaling: 256 rows per GPU); the only collectives are the timing barrier and the
+max-over-ranks of the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|bf16x3] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1]
+C2 = dict(B=256, V=36, Q=14, A=3129, v_dim=2048, q_dim=1024, a_dim=300, h_mm=512, rank=32, glimpse=2)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: f32 MFMA / dense bf16 MFMA
+SEED = 1204                                                         # the reference's default seed (src/FFOE/main.py:53)
+
+
+def flops_per_sample(c):
+    """tucker = 2h(V*vd + Q*qd + A*ad), rank = 2h^2(V+Q+A), core = mode-1/2 + 2*V*Q*A*G*h."""
+    h, hr, R, G = c["h_mm"], c["h_mm"] // c["rank"], c["rank"], c["glimpse"]
+    tucker = 2 * h * (c["V"] * c["v_dim"] + c["Q"] * c["q_dim"] + c["A"] * c["a_dim"])
+    rank = 2 * h * h * (c["V"] + c["Q"] + c["A"])
+    core_final = 2 * c["V"] * c["Q"] * c["A"] * G * h
+    core_12 = 2 * c["V"] * R * hr * hr * G * hr + 2 * c["V"] * c["Q"] * R * hr * G * hr
+    return dict(tucker=tucker, rank=rank, core_final=core_final, core_12=core_12, total=tucker + rank + core_final + core_12)
+
+
+def synth_inputs(c, B, seed, device):
+    """v ~ |N(0,1)| with a random number of trailing all-zero rows per sample (bottom-up features are post-ReLU and
+    zero-padded by trim_collate, reference src/utils.py:127-136); q, a ~ N(0,1) at the raw widths configs[1] names."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    v = torch.randn(B, c["V"], c["v_dim"], generator=g).abs_()
+    nv = torch.randint(10, c["V"] + 1, (B,), generator=g)
+    for b in range(B):
+        v[b, int(nv[b]):] = 0
+    q = torch.randn(B, c["Q"], c["q_dim"], generator=g)
+    a = torch.randn(B, c["A"], c["a_dim"], generator=g)
+    return v.to(device), q.to(device), a.to(device)
+
+
+def cpu_baseline(c, state, seed, budget_s=20.0):
+    """The oracle (numpy restatement of the reference's CPU path, oracle/cti_oracle.py) timed on this host's cores on a
+    bounded sample of the same workload: B_cpu samples of the C2 shapes, repeated until ~budget_s of CPU work."""
+    from oracle import cti_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    Bc = 4
+    v, q, a = synth_inputs(c, Bc, seed + 17, "cpu")
+    v, q, a = v.numpy(), q.numpy(), a.numpy()
+    O.tcnet_forward(v[:1], q[:1], a[:1], state)                  # warm-up (BLAS threads, page faults)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.tcnet_forward(v, q, a, state)
+        n += Bc
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 1024:
+            break
+    return {"value": n / el, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle.tcnet_forward (numpy fp32), %d samples of the C2 shapes in batches of %d, %.1f s" % (n, Bc, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
+    ap.add_argument("--precision", default=os.environ.get("CTI_PRECISION", "fp32"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import cti_amd
+    cti_amd.set_precision(args.precision)
+    c = dict(C2, B=args.batch)
+    torch.manual_seed(SEED)                                      # identical parameters on every rank
+    net = cti_amd.TCNet(c["v_dim"], c["q_dim"], c["a_dim"], c["h_mm"], 1, c["rank"], c["glimpse"]).to(dev).eval()
+    v, q, a = synth_inputs(c, c["B"], SEED + 1 + rank, dev)      # a different shard of the global batch per rank
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(v, q, a)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        cti_amd.ops.profile_start()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(v, q, a)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kt = cti_amd.ops.profile_stop()
+    assert out.shape == (c["B"], c["V"], c["Q"], c["A"], c["glimpse"]) and bool(torch.isfinite(out[0, 0, 0, 0]).all())
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        fl = flops_per_sample(c)
+        core_ms = float(np.mean(kt["paralind_core"]))
+        core_flops = fl["core_final"] * c["B"]                   # algorithmic flops of ONE launch of the dominant kernel
+        achieved = core_flops / (core_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        kern = {k: round(float(np.mean(ms)), 3) for k, ms in sorted(kt.items())}
+        res = {
+            "metric": "CTI fused-forward samples/sec at B=256 (V=36x2048)",
+            "value": world * c["B"] * args.steps / el, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (bf16x3 split products, f32 accumulate)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: TCNet.forward fp32, B=%d/GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, "
+                                   "h_mm=512, glimpse=2" % c["B"], "global_batch": world * c["B"], "precision": args.precision,
+                       "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
+                       "gflop_per_sample": round(fl["total"] / 1e9, 4)},
+            "roofline": {"bound": "mfma", "kernel": "paralind_core (mode-3 product + rank sum, batched NT GEMM 504x3129x512 x%d)" % (c["B"] * c["glimpse"]),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "launch_ms": core_ms, "flops_per_launch": core_flops},
+            "whole_step_tflops": fl["total"] * c["B"] * args.steps / el / 1e12,
+            "kernel_ms": kern,
+        }
+        if not args.no_cpu_baseline:
+            state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
+            res["cpu_baseline"] = cpu_baseline(c, state, SEED, args.cpu_budget)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

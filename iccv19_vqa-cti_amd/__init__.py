@@ -1,0 +1,16 @@
+"""iccv19_vqa-cti_amd -- MI355X-native Compact Trilinear Interaction hot path.
+
+Drop-in `nn.Module`s for the reference's TCNet / BCNet / BiAttention / TriAttention / FCNet / ModeProduct whose
+forward runs in hand-written gfx950 HIP kernels (csrc/) reached through the C ABI of include/cti_hip.h.
+The directory name carries a hyphen, so import it through the repo-root `cti_amd` module (or `dropin/src/*`)."""
+from . import _lib, ops                                        # noqa: F401
+from .fc import FCNet, WNLinear                                # noqa: F401
+from .tc import TCNet                                          # noqa: F401
+from .bc import BCNet                                          # noqa: F401
+from .attention import BiAttention, TriAttention, StackedAttention   # noqa: F401
+from .Tensor import ModeProduct                                # noqa: F401
+from .ops import set_precision, get_precision                  # noqa: F401
+from ._lib import CtiError                                     # noqa: F401
+
+__all__ = ["FCNet", "WNLinear", "TCNet", "BCNet", "BiAttention", "TriAttention", "StackedAttention", "ModeProduct",
+           "ops", "set_precision", "get_precision", "CtiError"]

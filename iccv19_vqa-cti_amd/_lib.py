@@ -1,0 +1,72 @@
+"""ctypes binding of libcti_hip.so (the C ABI declared in include/cti_hip.h).  No torch types cross this boundary:
+pointers are `tensor.data_ptr()` integers, the stream is `torch.cuda.current_stream().cuda_stream`."""
+import ctypes as C
+import os
+
+from . import _build
+
+_i64, _int, _vp, _sz = C.c_int64, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); must list every function include/cti_hip.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "cti_abi_version": (_int, []),
+    "cti_last_error_string": (C.c_char_p, []),
+    "cti_wn_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp]),
+    "cti_wn_linear_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_wn_linear_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
+    "cti_zero_row_mask": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),
+    "cti_teff_scramble": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_paralind_mbuild_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_paralind_core_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_paralind_core_workspace_bytes": (_sz, [_int, _int, _int, _int, _int, _int]),
+    "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
+    "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),
+    "cti_masked_softmax_bi_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "cti_tri_pool_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_pool_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_logits_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+}
+
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+ACT_NONE, ACT_RELU = 0, 1
+
+_lib = None
+
+
+class CtiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (building first if the in-tree .so is missing or stale and hipcc is present).  There is NO fallback:
+    without the library every op of this package raises."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this machine: use the prebuilt copy if there is one
+            if not os.path.isfile(path):
+                raise CtiError("libcti_hip.so is missing and could not be built: %s" % e)
+    try:
+        l = C.CDLL(path)
+    except OSError as e:
+        raise CtiError("cannot load %s: %s (the CTI modules have no non-HIP path)" % (path, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            f = getattr(l, name)
+        except AttributeError:
+            raise CtiError("%s does not export %s -- rebuild it (python -c 'import __graft_entry__ as g; g.build()')" % (path, name))
+        f.restype, f.argtypes = res, args
+    if l.cti_abi_version() != 1:
+        raise CtiError("libcti_hip.so ABI version %d, expected 1" % l.cti_abi_version())
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cti_last_error_string().decode("utf-8", "replace")
+        raise CtiError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,57 @@
+"""BiAttention / TriAttention -- drop-ins for the reference's src/attention.py:14-59.
+
+Both return `(p, logits)` with `logits` already -inf-filled on the all-zero rows of `v` (the reference fills them
+in place, attention.py:37,56).  The zero-row mask is an exact bit test (every element +-0), the softmax is one
+masked kernel (Bi: a wave per contiguous row; Tri: G interleaved softmaxes over the strided (v,q,a) axis)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .bc import BCNet
+from .tc import TCNet
+
+
+class BiAttention(nn.Module):
+    def __init__(self, x_dim, y_dim, z_dim, glimpse, dropout=[.2, .5]):
+        super(BiAttention, self).__init__()
+        self.glimpse = glimpse
+        self.logits = BCNet(x_dim, y_dim, z_dim, glimpse, dropout=dropout, k=3)._weight_norm_h_mat()
+
+    def forward(self, v, q, v_mask=True):
+        """
+        v: [batch, k, vdim]
+        q: [batch, qdim]
+        """
+        p, logits = self.forward_all(v, q, v_mask)
+        return p, logits
+
+    def forward_all(self, v, q, v_mask=True):
+        logits = self.logits(v, q)                                  # b x g x v x q
+        mask = ops.zero_row_mask(v) if v_mask else None
+        p = ops.masked_softmax_bi_(logits, mask)
+        return p, logits
+
+
+class TriAttention(nn.Module):
+    def __init__(self, v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, k, dropout=[.2, .5]):
+        super(TriAttention, self).__init__()
+        self.glimpse = glimpse
+        self.TriAtt = TCNet(v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, dropout=dropout, k=k)
+
+    def forward(self, v, q, a):
+        logits = self.TriAtt(v, q, a)
+        if logits.dim() != 5:
+            # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises
+            raise RuntimeError("TriAttention needs glimpse >= 2 (the reference fails the same way: a 5-D mask is "
+                               "expanded to the 4-D logits at src/attention.py:55)")
+        mask = ops.zero_row_mask(v)
+        p = ops.masked_softmax_tri_(logits, mask)
+        return p, logits
+
+
+class StackedAttention(nn.Module):
+    """SAN baseline (src/attention.py:62-152) is a different model (`--model san`), outside the CTI hot path."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("StackedAttention is outside the CTI hot path; use the reference's class")

@@ -1,0 +1,77 @@
+"""BCNet -- drop-in for the reference's src/bc.py (bilinear connect network, Kim et al. BAN).
+
+forward: the three h_out branches of src/bc.py:41-68; the `h_out <= 32` branch never materialises the
+(B,G,V,D) broadcast product of bc.py:55 (0.9 GB at B=256, G=8): the bilinear logits kernel folds h into the v row
+on the fly.  forward_with_weights (bc.py:70-78): two projections + one fused bilinear sum-pool (with the k-group
+sum-pooling of bc.py:75-77 inside)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fc import FCNet, WNLinear, _grad_guard
+
+
+class BCNet(nn.Module):
+    """Simple class for non-linear bilinear connect network"""
+
+    def __init__(self, v_dim, q_dim, h_dim, h_out, act='ReLU', dropout=[.2, .5], k=1):
+        super(BCNet, self).__init__()
+        self.c = 32
+        self.k = k
+        self.v_dim = v_dim; self.q_dim = q_dim
+        self.h_dim = h_dim; self.h_out = h_out
+
+        self.v_net = FCNet([v_dim, h_dim * self.k], act=act, dropout=dropout[0])
+        self.q_net = FCNet([q_dim, h_dim * self.k], act=act, dropout=dropout[0])
+        self.dropout = nn.Dropout(dropout[1])  # attention
+        if 1 < k:
+            self.p_net = nn.AvgPool1d(self.k, stride=self.k)
+
+        if None == h_out:
+            pass
+        elif h_out <= self.c:
+            self.h_mat = nn.Parameter(torch.Tensor(1, h_out, 1, h_dim * self.k).normal_())
+            self.h_bias = nn.Parameter(torch.Tensor(1, h_out, 1, 1).normal_())
+        else:
+            self.h_net = WNLinear(h_dim * self.k, h_out)
+
+    def _weight_norm_h_mat(self):
+        """What `weight_norm(BCNet, name='h_mat', dim=None)` (src/attention.py:19-20) does to the parameters:
+        h_mat -> h_mat_g () = ||h_mat||_F and h_mat_v = h_mat, registered after h_bias."""
+        h = self.h_mat.data
+        del self._parameters['h_mat']
+        self.h_mat_g = nn.Parameter(torch.norm(h).clone())
+        self.h_mat_v = nn.Parameter(h.clone())
+        return self
+
+    def _h(self):
+        if 'h_mat' in self._parameters:
+            return self.h_mat[0, :, 0, :], None
+        return self.h_mat_v[0, :, 0, :], ops.wn_scale(self.h_mat_v, self.h_mat_g)
+
+    def _attn_dropout(self, x):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("train-mode dropout of the CTI path is not built yet (eval mode only)")
+        return x
+
+    def forward(self, v, q):
+        _grad_guard(v, q, *self.parameters())
+        if None == self.h_out:
+            v_ = self.v_net(v)
+            q_ = self.q_net(q)
+            return ops.bi_pool(v_, q_, None, 1).unsqueeze(1)              # b x 1 x h_dim
+        elif self.h_out <= self.c:
+            v_ = self._attn_dropout(self.v_net(v))
+            q_ = self.q_net(q)
+            h, hs = self._h()
+            return ops.bi_logits(v_, q_, h, hs, self.h_bias)              # b x h_out x v x q
+        else:
+            v_ = self._attn_dropout(self.v_net(v))
+            q_ = self.q_net(q)
+            return ops.bi_logits(v_, q_, self.h_net.weight_v, self.h_net.scale(), self.h_net.bias)
+
+    def forward_with_weights(self, v, q, w):
+        _grad_guard(v, q, w, *self.parameters())
+        v_ = self.v_net(v)
+        q_ = self.q_net(q)
+        return ops.bi_pool(v_, q_, w.float(), self.k)

@@ -1,0 +1,171 @@
+// cti_paralind.hip -- weight-norm scale, zero-row mask, T_eff scramble and the mode-1/mode-2 stage ("M build")
+// of the PARALIND core.  All HBM/L2-bound helpers: coalesced loads along the innermost axis, wave-shuffle
+// reductions (64-wide), no GEMM reshaping.
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+// ---- scale[i] = g[i] / ||V_i||_F ------------------------------------------------------------------------------
+// One 1024-thread workgroup per matrix; float4 loads when the slice is 16-B aligned; the block sum is a fixed
+// tree (wave shuffles, then 16 partials through LDS) so the result is run-to-run deterministic.
+__global__ __launch_bounds__(1024) void wn_scale_kernel(const float* __restrict__ wv, const float* __restrict__ g,
+                                                        float* __restrict__ scale, int64_t elems) {
+    __shared__ float part[16];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const float* v = wv + (int64_t)i * elems;
+    float s = 0.f;
+    if (((reinterpret_cast<uintptr_t>(v) & 15) == 0) && ((elems & 3) == 0)) {
+        const float4* v4 = reinterpret_cast<const float4*>(v);
+        const int64_t n4 = elems >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int64_t j = t; j < n4; j += 1024) {
+            const float4 x = v4[j];
+            s0 = fmaf(x.x, x.x, s0); s1 = fmaf(x.y, x.y, s1); s2 = fmaf(x.z, x.z, s2); s3 = fmaf(x.w, x.w, s3);
+        }
+        s = (s0 + s1) + (s2 + s3);
+    } else {
+        for (int64_t j = t; j < elems; j += 1024) s = fmaf(v[j], v[j], s);
+    }
+    s = wave_sum(s);
+    if ((t & 63) == 0) part[t >> 6] = s;
+    __syncthreads();
+    if (t < 64) {
+        float x = t < 16 ? part[t] : 0.f;
+        x = wave_sum(x);
+        if (t == 0) scale[i] = g[i] / sqrtf(x);
+    }
+}
+
+// ---- mask[r] = every element of row r is +-0 ---------------------------------------------------------------------
+// One wave per row; OR of the magnitude bits, so -0.0 counts as zero and NaN / inf / subnormals do not.
+__global__ __launch_bounds__(256) void zero_row_mask_kernel(const float* __restrict__ v, int64_t ldv,
+                                                            uint8_t* __restrict__ mask, int64_t rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = v + row * ldv;
+    unsigned bits = 0u;
+    if (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((dim & 3) == 0)) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(p);
+        for (int j = lane; j < (dim >> 2); j += 64) {
+            const uint4 x = p4[j];
+            bits |= (x.x | x.y | x.z | x.w);
+        }
+    } else {
+        const unsigned* pu = reinterpret_cast<const unsigned*>(p);
+        for (int j = lane; j < dim; j += 64) bits |= pu[j];
+    }
+    const bool nz = (bits & 0x7fffffffu) != 0u;
+    const bool any_nz = __any(nz);
+    if (lane == 0) mask[row] = any_nz ? 0 : 1;
+}
+
+// ---- T_eff scramble -------------------------------------------------------------------------------------------
+// For fixed (r, i) the reference's mode-1 step (src/Tensor.py:6-8) transposes the (j,k) axes of T[i] = (J,K,G),
+// flattens in (k,j,g) order and re-reads the flat axis as (G,K,J), exposed as (j,k,g) by .transpose(4,2):
+//   T_eff[r,i,j,k,g] = flat[(g*K + k)*J + j],  flat[(k'*J + j')*G + g'] = T[r,i,j',k',g'].
+__device__ __forceinline__ int teff_src_index(int j, int k, int g, int J, int K, int G) {
+    const int f = (g * K + k) * J + j;
+    const int gs = f % G, js = (f / G) % J, ks = f / (G * J);
+    return (js * K + ks) * G + gs;
+}
+__global__ __launch_bounds__(256) void teff_kernel(const float* __restrict__ src, float* __restrict__ dst, int J, int K, int G,
+                                                   int64_t total, int inverse) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int inner = J * K * G;
+    const int64_t ri = idx / inner;
+    const int e = (int)(idx - ri * inner);
+    const int g = e % G, k = (e / G) % K, j = e / (G * K);
+    const int s = teff_src_index(j, k, g, J, K, G);
+    if (!inverse) dst[idx] = src[ri * inner + s];
+    else          dst[ri * inner + s] = src[idx];
+}
+
+// ---- M build: modes 1 and 2 of the core ------------------------------------------------------------------------
+// One workgroup per (b, v).  Per rank r: X[j,k,g] = sum_i T_eff[r,i,j,k,g] * Vr[b,v,r,i] (T_eff read coalesced along
+// its contiguous (j,k,g) axis, L2-resident: R*hr^3*G floats = 1 MiB at the default sizes), kept in LDS; then
+// M[b,v,q,g,r*K+k] = sum_j X[j,k,g] * Qr[b,q,r,j].  35 MFLOP per sample at C2: three orders of magnitude below
+// the mode-3 GEMM that consumes M, so this stage is written for simplicity, not for the MFMA.
+__global__ __launch_bounds__(256) void mbuild_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
+                                                     const float* __restrict__ Teff, float* __restrict__ M,
+                                                     int V, int Q, int R, int I, int J, int K, int G) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int inner = J * K * G;             // (j,k,g)
+    float* X = sm;                           // [inner]
+    float* vs = sm + inner;                  // [I]   Vr slice
+    float* qs = vs + I;                      // [Q*J] Qr slice
+    const int bv = blockIdx.x;               // b*V + v
+    const int b = bv / V;
+    const int t = threadIdx.x;
+    const int KK = R * K;
+    const float* vrow = Vr + (int64_t)bv * R * I;
+    const float* qbase = Qr + (int64_t)b * Q * R * J;
+    float* mbase = M + (int64_t)bv * Q * G * KK;
+    for (int r = 0; r < R; ++r) {
+        for (int e = t; e < I; e += 256) vs[e] = vrow[r * I + e];
+        for (int e = t; e < Q * J; e += 256) qs[e] = qbase[(int64_t)(e / J) * R * J + r * J + (e % J)];
+        __syncthreads();
+        const float* Tr = Teff + (int64_t)r * I * inner;
+        for (int e = t; e < inner; e += 256) {
+            float s = 0.f;
+            for (int i = 0; i < I; ++i) s = fmaf(Tr[(int64_t)i * inner + e], vs[i], s);
+            X[e] = s;
+        }
+        __syncthreads();
+        // outputs (q, g, k): k fastest so that the K floats of one (q,g) row segment are written together
+        for (int o = t; o < Q * G * K; o += 256) {
+            const int k = o % K, g = (o / K) % G, q = o / (K * G);
+            float s = 0.f;
+            for (int j = 0; j < J; ++j) s = fmaf(X[(j * K + k) * G + g], qs[q * J + j], s);
+            mbase[((int64_t)q * G + g) * KK + r * K + k] = s;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems,
+                            void* stream) {
+    CTI_REQUIRE_PTR(weight_v); CTI_REQUIRE_PTR(weight_g); CTI_REQUIRE_PTR(scale);
+    CTI_REQUIRE(n_mats > 0 && elems > 0, CTI_E_SHAPE, "cti_wn_scale: n_mats=%d elems=%lld", n_mats, (long long)elems);
+    hipLaunchKernelGGL(wn_scale_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), weight_v, weight_g, scale, elems);
+    return launch_status("cti_wn_scale");
+}
+
+extern "C" int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream) {
+    CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(mask);
+    CTI_REQUIRE(rows > 0 && dim > 0 && ldv >= dim, CTI_E_SHAPE, "cti_zero_row_mask: rows=%lld dim=%d ldv=%lld",
+                (long long)rows, dim, (long long)ldv);
+    hipLaunchKernelGGL(zero_row_mask_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), v, ldv,
+                       mask, rows, dim);
+    return launch_status("cti_zero_row_mask");
+}
+
+extern "C" int cti_teff_scramble(const float* src, float* dst, int R, int I, int J, int K, int G, int inverse, void* stream) {
+    CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst);
+    CTI_REQUIRE(R > 0 && I > 0 && J > 0 && K > 0 && G > 0, CTI_E_SHAPE, "cti_teff_scramble: R=%d I=%d J=%d K=%d G=%d", R, I, J, K, G);
+    CTI_REQUIRE(src != dst, CTI_E_SHAPE, "cti_teff_scramble: in-place scramble is not supported");
+    const int64_t total = (int64_t)R * I * J * K * G;
+    hipLaunchKernelGGL(teff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, J, K, G,
+                       total, inverse);
+    return launch_status("cti_teff_scramble");
+}
+
+extern "C" int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const float* Teff, float* M, int B, int V,
+                                       int Q, int R, int I, int J, int K, int G, void* stream) {
+    CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(M);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && I > 0 && J > 0 && K > 0 && G > 0, CTI_E_SHAPE,
+                "cti_paralind_mbuild_fwd: B=%d V=%d Q=%d R=%d I=%d J=%d K=%d G=%d", B, V, Q, R, I, J, K, G);
+    const size_t lds = sizeof(float) * ((size_t)J * K * G + I + (size_t)Q * J);
+    CTI_REQUIRE(lds <= 64 * 1024, CTI_E_SHAPE, "cti_paralind_mbuild_fwd: J*K*G + I + Q*J = %zu floats exceed 64 KiB of LDS",
+                lds / 4);
+    hipLaunchKernelGGL(mbuild_kernel, dim3((unsigned)(B * V)), dim3(256), lds, as_stream(stream), Vr, Qr, Teff, M, V, Q, R,
+                       I, J, K, G);
+    return launch_status("cti_paralind_mbuild_fwd");
+}

@@ -1,0 +1,251 @@
+"""Tensor-level wrappers over the C ABI: argument checking, output allocation (torch = device memory + stream
+plumbing only) and the launch.  Every function requires CUDA(ROCm) tensors and raises otherwise -- there is no
+CPU or eager-PyTorch path in this package."""
+import torch
+
+from . import _lib as L
+
+_PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
+_default_prec = "fp32"
+
+
+def set_precision(name):
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade) or 'bf16'."""
+    global _default_prec
+    if name not in _PREC:
+        raise ValueError("precision must be one of %s" % sorted(_PREC))
+    _default_prec = name
+
+
+def get_precision():
+    return _default_prec
+
+
+def _prec(p):
+    return _PREC[p or _default_prec]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
+_prof = None
+
+
+def profile_start():
+    """Start recording a (start, end) event pair around every launch family, on the stream it is launched on."""
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """Stop recording; returns {name: [ms, ...]} (synchronises)."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (rec or {}).items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record(torch.cuda.current_stream())
+            _prof.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise L.CtiError("%s is on %s: the CTI modules run on an MI355X through libcti_hip.so only (no CPU path)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _rows2d(x):
+    """(…, d) -> contiguous-row 2-D view (rows, d) with a row stride; copies only when the layout demands it."""
+    d = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= d:
+        return x, x.stride(0)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.view(-1, d), d
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def wn_scale(weight_v, weight_g):
+    """scale[i] = g[i] / ||V_i||_F.  weight_v: (n_mats, ...) contiguous or a single matrix with scalar g."""
+    _req(weight_v, "weight_v"); _req(weight_g, "weight_g")
+    n = weight_g.numel()
+    wv = weight_v.contiguous()
+    g = weight_g.contiguous().view(-1)
+    out = torch.empty(n, device=wv.device, dtype=torch.float32)
+    L.check(L.lib().cti_wn_scale(wv.data_ptr(), g.data_ptr(), out.data_ptr(), n, wv.numel() // n, _stream()), "cti_wn_scale")
+    return out
+
+
+def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None):
+    """act(scale[n // scale_div] * x @ weight_v.T + bias) through the MFMA GEMM."""
+    _req(x, "x"); _req(weight_v, "weight_v")
+    out_dim, in_dim = weight_v.shape
+    if x.shape[-1] != in_dim:
+        raise ValueError("x has %d features, the layer expects %d" % (x.shape[-1], in_dim))
+    x2, ldx = _rows2d(x)
+    w = weight_v if (weight_v.stride(1) == 1) else weight_v.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty(x.shape[:-1] + (out_dim,), device=x.device, dtype=torch.float32)
+    if rows == 0:
+        return y
+    pr = _prec(prec)
+    lib = L.lib()
+    wsb = lib.cti_wn_linear_workspace_bytes(rows, in_dim, out_dim, pr)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
+    with _timed("wn_linear_%dx%dx%d" % (rows, in_dim, out_dim)):
+      L.check(lib.cti_wn_linear_fwd(x2.data_ptr(), ldx, w.data_ptr(), w.stride(0), _ptr(scale), int(scale_div), _ptr(bias),
+                                  y.data_ptr(), out_dim, rows, in_dim, out_dim, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                  _ptr(ws), wsb, _stream()), "cti_wn_linear_fwd")
+    return y
+
+
+def zero_row_mask(v):
+    """(B, V, d) -> uint8 (B, V): 1 where the row is all zeros (reference `0 == v.abs().sum(2)`)."""
+    _req(v, "v")
+    x2, ld = _rows2d(v)
+    mask = torch.empty(v.shape[:-1], device=v.device, dtype=torch.uint8)
+    L.check(L.lib().cti_zero_row_mask(x2.data_ptr(), ld, mask.data_ptr(), x2.shape[0], v.shape[-1], _stream()), "cti_zero_row_mask")
+    return mask
+
+
+def teff_scramble(T, inverse=False):
+    """T: (R, I, J, K, G) contiguous -> T_eff (same shape); inverse=True maps a T_eff-shaped tensor back."""
+    _req(T, "T")
+    T = T.contiguous()
+    R, I, J, K, G = T.shape
+    out = torch.empty_like(T)
+    L.check(L.lib().cti_teff_scramble(T.data_ptr(), out.data_ptr(), R, I, J, K, G, 1 if inverse else 0, _stream()), "cti_teff_scramble")
+    return out
+
+
+def paralind_mbuild(Vr, Qr, Teff):
+    """Vr (B,V,R*I), Qr (B,Q,R*J), Teff (R,I,J,K,G) -> M (B,V,Q,G,R*K)."""
+    _req(Vr, "Vr"); _req(Qr, "Qr"); _req(Teff, "Teff")
+    R, I, J, K, G = Teff.shape
+    B, V, _ = Vr.shape
+    Q = Qr.shape[1]
+    assert Vr.shape[2] == R * I and Qr.shape[2] == R * J and Qr.shape[0] == B
+    Vr, Qr, Teff = Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
+    M = torch.empty((B, V, Q, G, R * K), device=Vr.device, dtype=torch.float32)
+    with _timed("paralind_mbuild"):
+      L.check(L.lib().cti_paralind_mbuild_fwd(Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), M.data_ptr(), B, V, Q, R, I, J, K, G,
+                                            _stream()), "cti_paralind_mbuild_fwd")
+    return M
+
+
+def paralind_core(M, Ar, prec=None):
+    """M (B,V,Q,G,K), Ar (B,A,K) -> out (B,V,Q,A,G) contiguous."""
+    _req(M, "M"); _req(Ar, "Ar")
+    B, V, Q, G, K = M.shape
+    A = Ar.shape[1]
+    assert Ar.shape[0] == B and Ar.shape[2] == K
+    M, Ar = M.contiguous(), Ar.contiguous()
+    out = torch.empty((B, V, Q, A, G), device=M.device, dtype=torch.float32)
+    pr = _prec(prec)
+    lib = L.lib()
+    wsb = lib.cti_paralind_core_workspace_bytes(B, V * Q, A, G, K, pr)
+    ws = torch.empty(wsb, device=M.device, dtype=torch.uint8) if wsb else None
+    with _timed("paralind_core"):
+      L.check(lib.cti_paralind_core_fwd(M.data_ptr(), Ar.data_ptr(), out.data_ptr(), B, V * Q, A, G, K, pr, _ptr(ws), wsb, _stream()),
+            "cti_paralind_core_fwd")
+    return out
+
+
+def masked_softmax_tri_(logits, mask):
+    """In place -inf fill of `logits` (B,V,Q,A,G contiguous) on masked rows; returns p (same shape)."""
+    _req(logits, "logits"); _req(mask, "mask", torch.uint8)
+    assert logits.is_contiguous() and mask.is_contiguous()
+    B, V, Q, A, G = logits.shape
+    p = torch.empty_like(logits)
+    lib = L.lib()
+    wsb = lib.cti_softmax_tri_workspace_bytes(B, V, Q * A, G)
+    ws = torch.empty(wsb, device=logits.device, dtype=torch.uint8)
+    with _timed("masked_softmax_tri"):
+      L.check(lib.cti_masked_softmax_tri_fwd(logits.data_ptr(), mask.data_ptr(), p.data_ptr(), B, V, Q * A, G, ws.data_ptr(), wsb,
+                                           _stream()), "cti_masked_softmax_tri_fwd")
+    return p
+
+
+def masked_softmax_bi_(logits, mask):
+    """logits (B,G,V,Q) contiguous, mask (B,V) uint8 or None; in place -inf fill; returns p."""
+    _req(logits, "logits")
+    assert logits.is_contiguous()
+    if mask is not None:
+        _req(mask, "mask", torch.uint8)
+    B, G, V, Q = logits.shape
+    p = torch.empty_like(logits)
+    L.check(L.lib().cti_masked_softmax_bi_fwd(logits.data_ptr(), _ptr(mask), p.data_ptr(), B, G, V, Q, _stream()),
+            "cti_masked_softmax_bi_fwd")
+    return p
+
+
+def tri_pool(vt, qt, at, w):
+    """out[b,d] = sum_vqa vt[b,v,d] w[b,v,q,a] qt[b,q,d] at[b,a,d]; w may be any strided (B,V,Q,A) view."""
+    for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
+        _req(t, n)
+    B, V, D = vt.shape
+    Q, A = qt.shape[1], at.shape[1]
+    if tuple(w.shape) != (B, V, Q, A):
+        raise ValueError("w must be (B,V,Q,A) = %s, got %s" % ((B, V, Q, A), tuple(w.shape)))
+    vt, qt, at = vt.contiguous(), qt.contiguous(), at.contiguous()
+    out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
+    sb, sv, sq, sa = w.stride()
+    L.check(L.lib().cti_tri_pool_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
+                                     B, V, Q, A, D, _stream()), "cti_tri_pool_fwd")
+    return out
+
+
+def bi_pool(vt, qt, w, k=1):
+    """out[b,n] = sum_{t<k} sum_vq vt[b,v,nk+t] w[b,v,q] qt[b,q,nk+t]; w=None means all ones."""
+    _req(vt, "vt"); _req(qt, "qt")
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    vt, qt = vt.contiguous(), qt.contiguous()
+    if w is not None:
+        _req(w, "w")
+        if tuple(w.shape) != (B, V, Q):
+            raise ValueError("w must be (B,V,Q) = %s, got %s" % ((B, V, Q), tuple(w.shape)))
+        sb, sv, sq = w.stride()
+    else:
+        sb = sv = sq = 0
+    out = torch.empty((B, D // k), device=vt.device, dtype=torch.float32)
+    L.check(L.lib().cti_bi_pool_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, out.data_ptr(), B, V, Q, D, k, _stream()),
+            "cti_bi_pool_fwd")
+    return out
+
+
+def bi_logits(vt, qt, h, h_scale, h_bias):
+    """logits[b,g,v,q] = h_scale * sum_d vt[b,v,d] h[g,d] qt[b,q,d] + h_bias[g]."""
+    _req(vt, "vt"); _req(qt, "qt"); _req(h, "h")
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    G = h.shape[0]
+    vt, qt, h = vt.contiguous(), qt.contiguous(), h.contiguous()
+    hb = h_bias.contiguous().view(-1) if h_bias is not None else None
+    out = torch.empty((B, G, V, Q), device=vt.device, dtype=torch.float32)
+    L.check(L.lib().cti_bi_logits_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V,
+                                      Q, D, _stream()), "cti_bi_logits_fwd")
+    return out

@@ -1,0 +1,84 @@
+"""TCNet -- drop-in for the reference's src/tc.py (Compact Trilinear Interaction, PARALIND decomposition).
+
+Same constructor / forward / forward_with_weights signatures, attributes and state_dict layout
+(`T_g (1,R,hr,hr,hr,G,h_out)`, `{v,q,a}_tucker.main.1.*`, `{v,q,a}_net.<r>.main.1.*`).
+
+forward (src/tc.py:41-52): 3 Tucker projections (one MFMA GEMM each), the 3 x R rank nets as 3 packed h -> R*hr
+GEMMs with per-rank weight-norm scales in the epilogue, then T_eff scramble -> modes 1+2 (M build) -> mode 3 + rank
+sum as one batched MFMA GEMM.  ~700 torch launches of the reference become 12.
+forward_with_weights (src/tc.py:54-61): 3 projections + one fused trilinear sum-pool kernel."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .fc import FCNet, _grad_guard
+
+
+class TCNet(nn.Module):
+    def __init__(self, v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, act='ReLU', dropout=[.2, .5], k=1):
+        super(TCNet, self).__init__()
+        self.v_dim = v_dim
+        self.q_dim = q_dim
+        self.a_dim = a_dim
+        self.h_out = h_out
+        self.rank = rank
+        self.h_dim = h_dim * k
+        self.hv_dim = int(h_dim / rank)
+        self.hq_dim = int(h_dim / rank)
+        self.ha_dim = int(h_dim / rank)
+        self._act = act
+
+        self.v_tucker = FCNet([v_dim, self.h_dim], act=act, dropout=dropout[1])
+        self.q_tucker = FCNet([q_dim, self.h_dim], act=act, dropout=dropout[0])
+        self.a_tucker = FCNet([a_dim, self.h_dim], act=act, dropout=dropout[0])
+        if self.h_dim < 1024:
+            self.a_tucker = FCNet([a_dim, self.h_dim], act=act, dropout=dropout[0])      # built twice, like tc.py:26,28
+            self.v_net = nn.ModuleList([FCNet([self.h_dim, self.hv_dim], act=act, dropout=dropout[1]) for _ in range(rank)])
+            self.q_net = nn.ModuleList([FCNet([self.h_dim, self.hq_dim], act=act, dropout=dropout[0]) for _ in range(rank)])
+            self.a_net = nn.ModuleList([FCNet([self.h_dim, self.ha_dim], act=act, dropout=dropout[0]) for _ in range(rank)])
+            if h_out > 1:
+                self.ho_dim = int(h_out / rank)
+                h_out = self.ho_dim
+            self.T_g = nn.Parameter(torch.Tensor(1, rank, self.hv_dim, self.hq_dim, self.ha_dim, glimpse, h_out).normal_())
+        self.dropout = nn.Dropout(dropout[1])                 # constructed and unused, like tc.py:38
+
+    # ---- packed rank nets: R x FCNet([h, hr]) == one (R*hr, h) GEMM with per-rank scale ---------------------------
+    def _rank_pack(self, nets):
+        lins = [n.main[-2] if isinstance(n.main[-1], nn.ReLU) else n.main[-1] for n in nets]
+        wv = torch.cat([l.weight_v for l in lins], 0)                      # (R*hr, h)
+        g = torch.stack([l.weight_g for l in lins])                        # (R,)
+        b = torch.cat([l.bias for l in lins], 0)                           # (R*hr,)
+        return wv, g, b
+
+    def _rank_proj(self, x, nets):
+        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in nets[0].main):
+            raise NotImplementedError("train-mode dropout of the CTI path is not built yet (eval mode only)")
+        if self._act not in ('ReLU', ''):
+            raise NotImplementedError("packed rank nets support act in {'ReLU', ''}")
+        wv, g, b = self._rank_pack(nets)
+        hr = wv.shape[0] // len(nets)
+        scale = ops.wn_scale(wv.view(len(nets), -1), g)
+        return ops.wn_linear(x, wv, scale, hr, b, relu=(self._act == 'ReLU'))
+
+    def forward(self, v, q, a):
+        _grad_guard(v, q, a, self.T_g)
+        v_tucker = self.v_tucker(v)
+        q_tucker = self.q_tucker(q)
+        a_tucker = self.a_tucker(a)
+        Vr = self._rank_proj(v_tucker, self.v_net)            # (B,V,R*hr)
+        Qr = self._rank_proj(q_tucker, self.q_net)
+        Ar = self._rank_proj(a_tucker, self.a_net)
+        T = self.T_g
+        if T.size(6) != 1:
+            raise RuntimeError("TCNet.forward: h_out must be 1 (src/Tensor.py:6 cannot view the core otherwise)")
+        Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
+        M = ops.paralind_mbuild(Vr, Qr, Teff)
+        f_emb = ops.paralind_core(M, Ar)                       # (B,V,Q,A,G)
+        return f_emb.squeeze(4)
+
+    def forward_with_weights(self, v, q, a, w):
+        _grad_guard(v, q, a, w)
+        v_ = self.v_tucker(v)                                  # b x v x d
+        q_ = self.q_tucker(q)
+        a_ = self.a_tucker(a)
+        return ops.tri_pool(v_, q_, a_, w.float())

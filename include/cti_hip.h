@@ -1,0 +1,126 @@
+/* cti_hip.h -- C ABI of libcti_hip.so: the MI355X (gfx950) kernels of the Compact Trilinear Interaction hot path.
+ *
+ * The reference (aioz-ai/ICCV19_VQA-CTI) is pure Python/PyTorch and has no FFI of its own; each entry point
+ * below replaces one torch op sequence of the reference's hot path (file:line given per function) and is what a
+ * ctypes binding in the reference's src/{fc,tc,bc,attention,Tensor}.py would call (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller (PyTorch's caching
+ *    allocator in the shipped host code), including workspaces; the library allocates nothing and keeps no
+ *    mutable global state apart from a thread-local last-error string;
+ *  - all tensors are fp32, row-major, innermost dimension contiguous unless a stride argument says otherwise;
+ *  - every launch goes to the hipStream_t passed as the last argument (`void*`, 0 = the null stream); no host
+ *    synchronisation, no hipMalloc/hipFree inside (safe under hipGraph capture);
+ *  - return value: 0 = success; negative = CTI_E_* argument error (nothing was launched); positive = hipError_t
+ *    from the launch.  cti_last_error_string() describes the last failure on the calling thread;
+ *  - the device is whatever is current on the calling thread (hipSetDevice by the caller).
+ */
+#ifndef CTI_HIP_H
+#define CTI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTI_ABI_VERSION 1
+
+enum {
+    CTI_OK = 0,
+    CTI_E_NULL = -1,      /* a required pointer is NULL            */
+    CTI_E_SHAPE = -2,     /* a size is <= 0 or inconsistent        */
+    CTI_E_ALIGN = -3,     /* a pointer / leading dimension is not aligned as the precision mode requires */
+    CTI_E_UNSUPPORTED = -4, /* flag / mode not built                */
+    CTI_E_WORKSPACE = -5  /* workspace too small                   */
+};
+
+/* arithmetic mode of the MFMA contractions */
+enum {
+    CTI_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate                      */
+    CTI_PREC_BF16X3 = 1,  /* fp32 operands split into bf16 hi+lo planes, 3 bf16 MFMAs per product, fp32 acc.   */
+    CTI_PREC_BF16 = 2     /* operands rounded to bf16 once, 1 MFMA per product, fp32 accumulate                 */
+};
+
+enum { CTI_ACT_NONE = 0, CTI_ACT_RELU = 1 };
+
+int cti_abi_version(void);
+const char* cti_last_error_string(void);
+
+/* ---- FCNet: weight_norm(Linear, dim=None) [+ReLU]  (reference src/fc.py:20-29,33-34) ------------------------- */
+
+/* scale[i] = g[i] / ||V_i||_F for n_mats matrices stored back to back, `elems` floats each.
+ * Replaces the weight_norm pre-forward hook (torch `_weight_norm`: norm, div, mul over the whole weight) that
+ * src/fc.py:22,27 installs; the scaled weight itself is never materialised (the scale is a GEMM-epilogue factor). */
+int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems, void* stream);
+
+/* y[r, n] = act( scale[n / scale_div] * sum_k x[r, k] * w[n, k] + bias[n] )          (src/fc.py:33-34, nn.Linear)
+ * x: rows x in_dim, row stride ldx;  w: out_dim x in_dim (weight_v), row stride ldw;  y: rows x out_dim, row stride ldy.
+ * scale: device array of ceil(out_dim / scale_div) floats (scale_div = out_dim for one FCNet layer; = h/rank for the
+ * rank nets of src/tc.py:29-31 packed as one out_dim = h matrix); NULL = 1.  bias: NULL = 0.
+ * prec: CTI_PREC_*.  For CTI_PREC_BF16X3 / CTI_PREC_BF16 `workspace` must hold cti_wn_linear_workspace_bytes(). */
+int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* scale, int scale_div,
+                      const float* bias, float* y, int64_t ldy, int64_t rows, int in_dim, int out_dim, int act,
+                      int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_wn_linear_workspace_bytes(int64_t rows, int in_dim, int out_dim, int prec);
+
+/* ---- zero-row mask  (src/attention.py:36,55: `0 == v.abs().sum(2)`) ------------------------------------------- */
+/* mask[r] = 1 iff every element of row r is +-0 (bit-exact statement of the reference's test for finite input). */
+int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream);
+
+/* ---- PARALIND core  (src/tc.py:46-52 -> src/Tensor.py:3-20) ---------------------------------------------------- */
+
+/* T_eff[r,i,j,k,g] = T[r,i,<scrambled (j,k,g)>]: the fixed index scramble src/Tensor.py:6-8 applies for G > 1
+ * (SURVEY.md 3.4).  src: (R,I,J,K,G) contiguous (= T_g (1,R,hr,hr,hr,G,1) with I=J=K=hr); dst: same shape.
+ * inverse != 0 scatters instead of gathers (maps a T_eff-shaped gradient back to T_g's layout). */
+int cti_teff_scramble(const float* src, float* dst, int R, int I, int J, int K, int G, int inverse, void* stream);
+
+/* M[b,v,q,g,r*K+k] = sum_ij T_eff[r,i,j,k,g] * Vr[b,v,r*I+i] * Qr[b,q,r*J+j]
+ * (mode-1 and mode-2 products of src/Tensor.py:6-13; r stays in the contraction index of the mode-3 GEMM).
+ * Vr: (B,V,R*I), Qr: (B,Q,R*J) contiguous (outputs of the packed rank nets); M: (B,V,Q,G,R*K) contiguous. */
+int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const float* Teff, float* M, int B, int V, int Q,
+                            int R, int I, int J, int K, int G, void* stream);
+
+/* out[b,vq,a,g] = sum_K M[b,vq,g,K] * Ar[b,a,K]   (mode-3 product + the sum over ranks, src/Tensor.py:16-20 and the
+ * running `+ f_emb` of src/tc.py:50).  M: (B,VQ,G,K); Ar: (B,A,K); out: (B,VQ,A,G) contiguous = the logical
+ * (B,V,Q,A,G) tensor TCNet.forward returns.  prec / workspace as for cti_wn_linear_fwd. */
+int cti_paralind_core_fwd(const float* M, const float* Ar, float* out, int B, int VQ, int A, int G, int K,
+                          int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int prec);
+
+/* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
+
+/* Tri: logits (B, V, QA, G) contiguous, G innermost.  In place: rows v with mask[b,v] != 0 are filled with -inf
+ * (the reference's `logits.data.masked_fill_`), then p[b,:,g] = softmax over the flattened (v,qa) axis per (b,g).
+ * An all-masked sample yields NaN like the reference.  workspace: cti_softmax_tri_workspace_bytes(). */
+int cti_masked_softmax_tri_fwd(float* logits, const uint8_t* mask, float* p, int B, int V, int64_t QA, int G,
+                               void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_softmax_tri_workspace_bytes(int B, int V, int64_t QA, int G);
+
+/* Bi: logits (B, G, V, Q) contiguous; mask (B,V) or NULL (v_mask=False); p[b,g,:] = softmax over (v,q). */
+int cti_masked_softmax_bi_fwd(float* logits, const uint8_t* mask, float* p, int B, int G, int V, int Q, void* stream);
+
+/* ---- attention-weighted sum-pools  (src/tc.py:59 einsum, src/bc.py:73 + :75-77) -------------------------------- */
+
+/* out[b,d] = sum_{v,q,a} vt[b,v,d] * w[b,v,q,a] * qt[b,q,d] * at[b,a,d].  vt/qt/at contiguous (B,*,D);
+ * w is addressed with element strides (w_sb, w_sv, w_sq, w_sa) so that the caller can pass `att[..., g]`. */
+int cti_tri_pool_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream);
+
+/* out[b,n] = sum_{t<k} sum_{v,q} vt[b,v,n*k+t] * w[b,v,q] * qt[b,q,n*k+t],  n < D/k.  w == NULL means w = 1
+ * (that is BCNet.forward with h_out=None, src/bc.py:42-47: out is then (B,1,D) with k = 1). */
+int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                    float* out, int B, int V, int Q, int D, int k, void* stream);
+
+/* ---- bilinear attention logits  (src/bc.py:52-58; also :63-68 with h = weight-normalised h_net) ---------------- */
+/* logits[b,g,v,q] = h_scale[0] * sum_d vt[b,v,d] * h[g,d] * qt[b,q,d] + h_bias[g].
+ * h: (G,D) (= h_mat_v or h_net.weight_v); h_scale: device scalar (g/||h||_F from cti_wn_scale) or NULL = 1;
+ * h_bias: (G) or NULL.  The (B,G,V,D) intermediate of src/bc.py:55 is never materialised. */
+int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                      float* logits, int B, int G, int V, int Q, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTI_HIP_H */

@@ -43,7 +43,8 @@ def save(name, cfg, params=None, inputs=None, outputs=None, grads=None):
         for k, v in (dd or {}).items():
             if isinstance(v, torch.Tensor):
                 v = v.detach().cpu().contiguous().numpy()
-            d[pre + k] = np.ascontiguousarray(v)
+            v = np.asarray(v)
+            d[pre + k] = v if v.ndim == 0 else np.ascontiguousarray(v)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print("%-34s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))

@@ -1,0 +1,121 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/cti_hip.h
+declares (no compute without a GPU), argument errors come back as negative codes with a message, and the module
+mirrors keep the reference's constructor signatures and state_dict layout."""
+import inspect
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = cti_amd.pkg._lib
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "cti_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cti_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    names = _declared()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(L.SIGNATURES) == names           # the ctypes table and the header list the same functions
+    assert lib.cti_abi_version() == 1
+
+
+def test_argument_errors_do_not_launch():
+    lib = L.lib()
+    assert lib.cti_wn_scale(None, None, None, 1, 4, None) == -1          # CTI_E_NULL
+    assert b"NULL" in lib.cti_last_error_string()
+    assert lib.cti_zero_row_mask(1, 4, 1, 0, 4, None) == -2              # CTI_E_SHAPE (rows = 0) -- pointers not touched
+    assert lib.cti_wn_linear_fwd(1, 4, 1, 4, None, 1, None, 1, 4, 2, 4, 4, 7, 0, None, 0, None) == -4   # bad act
+    assert lib.cti_softmax_tri_workspace_bytes(4, 36, 14 * 4, 2) > 0
+    assert lib.cti_softmax_tri_workspace_bytes(0, 36, 56, 2) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(cti_amd.CtiError):
+        cti_amd.ops.zero_row_mask(torch.zeros(2, 3, 4))
+    m = cti_amd.FCNet([4, 3]).eval()
+    with torch.no_grad(), pytest.raises(cti_amd.CtiError):
+        m(torch.zeros(2, 4))
+
+
+def test_state_dict_layout_matches_reference_at_real_dims():
+    ref = json.load(open(os.path.join(gu.GOLDEN, "g11_state_keys.json")))
+    built = {
+        "TriAttention(2048,1024,1024,512,1,32,2,1)": cti_amd.TriAttention(2048, 1024, 1024, 512, 1, 32, 2, 1),
+        "TCNet(2048,1024,1024,512,1,32,1,k=2)": cti_amd.TCNet(2048, 1024, 1024, 512, 1, 32, 1, dropout=[.2, .5], k=2),
+        "BiAttention(2048,1024,1024,8)": cti_amd.BiAttention(2048, 1024, 1024, 8),
+        "BCNet(2048,1024,1024,None,k=1)": cti_amd.BCNet(2048, 1024, 1024, None, k=1),
+    }
+    for name, m in built.items():
+        mine = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        assert mine == ref[name], name            # same names, shapes AND order (named_parameters order = flat-grad order)
+
+
+@pytest.mark.parametrize("fixture,build", [
+    ("g3_tcnet_small", lambda c: cti_amd.TriAttention(c["v_dim"], c["q_dim"], c["a_dim"], c["h_dim"], 1, c["rank"], c["glimpse"], c["k"])),
+    ("g7_biattention_g8", lambda c: cti_amd.BiAttention(c["x_dim"], c["y_dim"], c["z_dim"], c["glimpse"])),
+    ("g6_bcnet_h40_k1", lambda c: cti_amd.BCNet(c["v_dim"], c["q_dim"], c["h_dim"], c["h_out"], k=c["k"])),
+    ("g6_bcnet_h2_k3", lambda c: cti_amd.BCNet(c["v_dim"], c["q_dim"], c["h_dim"], c["h_out"], k=c["k"])),
+    ("g0_fcnet_2layer", lambda c: cti_amd.FCNet(c["dims"], act=c["act"], dropout=c["dropout"])),
+    ("g0_fcnet_noact", lambda c: cti_amd.FCNet(c["dims"], act=c["act"], dropout=c["dropout"])),
+])
+def test_reference_checkpoints_load_strictly(fixture, build):
+    fx = gu.load(fixture)
+    m = build(fx.cfg)
+    sd = {k: torch.from_numpy(v) for k, v in fx.p.items()}
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), fx.p[k])
+
+
+def test_constructor_signatures_match_reference():
+    def names(f):
+        return list(inspect.signature(f).parameters)
+    assert names(cti_amd.TCNet.__init__) == ["self", "v_dim", "q_dim", "a_dim", "h_dim", "h_out", "rank", "glimpse", "act", "dropout", "k"]
+    assert names(cti_amd.BCNet.__init__) == ["self", "v_dim", "q_dim", "h_dim", "h_out", "act", "dropout", "k"]
+    assert names(cti_amd.BiAttention.__init__) == ["self", "x_dim", "y_dim", "z_dim", "glimpse", "dropout"]
+    assert names(cti_amd.TriAttention.__init__) == ["self", "v_dim", "q_dim", "a_dim", "h_dim", "h_out", "rank", "glimpse", "k", "dropout"]
+    assert names(cti_amd.FCNet.__init__) == ["self", "dims", "act", "dropout"]
+    assert names(cti_amd.ModeProduct) == ["tensor", "matrix_1", "matrix_2", "matrix_3", "matrix_4", "n_way"]
+    assert names(cti_amd.TCNet.forward_with_weights) == ["self", "v", "q", "a", "w"]
+    assert names(cti_amd.BCNet.forward_with_weights) == ["self", "v", "q", "w"]
+    assert names(cti_amd.BiAttention.forward_all) == ["self", "v", "q", "v_mask"]
+
+
+def test_same_seed_same_parameters_as_reference_fixture():
+    """The mirrors consume the RNG exactly like the reference constructors: make_golden.py built g7_biattention_g2
+    after torch.manual_seed(51)."""
+    fx = gu.load("g7_biattention_g2")
+    c = fx.cfg
+    torch.manual_seed(51)
+    m = cti_amd.BiAttention(c["x_dim"], c["y_dim"], c["z_dim"], c["glimpse"])
+    for k, v in m.state_dict().items():
+        assert np.allclose(v.numpy(), fx.p[k], rtol=0, atol=1e-6), k
+
+
+def test_teff_index_arithmetic_host_mirror():
+    """The device scramble (csrc/cti_paralind.hip:teff_src_index) restated in Python against the G2 fixture."""
+    fx = gu.load("g2_teff_index_maps")
+    for key, ref in fx.o.items():
+        hr, G = (int(t[2:] if t.startswith("hr") else t[1:]) for t in key.split("_"))
+        J = K = hr
+        for i in range(hr):
+            for j in range(J):
+                for k in range(K):
+                    for g in range(G):
+                        f = (g * K + k) * J + j
+                        gs, js, ks = f % G, (f // G) % J, f // (G * J)
+                        assert ref[i, j, k, g] == i * J * K * G + (js * K + ks) * G + gs
