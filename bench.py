@@ -141,7 +141,7 @@ def main():
 
     if rank == 0:
         fl = flops_per_sample(c)
-        core_ms = float(np.mean(kt["paralind_core"]))
+        core_ms = float(np.mean(kt.get("paralind_core", kt.get("tcnet_forward"))))
         core_flops = fl["core_final"] * c["B"]                   # algorithmic flops of ONE launch of the dominant kernel
         achieved = core_flops / (core_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]

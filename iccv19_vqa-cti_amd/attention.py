@@ -39,12 +39,11 @@ class TriAttention(nn.Module):
         self.TriAtt = TCNet(v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, dropout=dropout, k=k)
 
     def forward(self, v, q, a):
-        logits = self.TriAtt(v, q, a)
+        logits, mask = self.TriAtt(v, q, a, _want_mask=True)
         if logits.dim() != 5:
             # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises
             raise RuntimeError("TriAttention needs glimpse >= 2 (the reference fails the same way: a 5-D mask is "
                                "expanded to the 4-D logits at src/attention.py:55)")
-        mask = ops.zero_row_mask(v)
         p = ops.masked_softmax_tri_(logits, mask)
         return p, logits
 

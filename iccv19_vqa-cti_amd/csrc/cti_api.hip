@@ -24,10 +24,11 @@ using namespace cti;
 extern "C" int cti_abi_version(void) { return CTI_ABI_VERSION; }
 extern "C" const char* cti_last_error_string(void) { return err_buf(); }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 extern "C" size_t cti_wn_linear_workspace_bytes(int64_t rows, int in_dim, int out_dim, int prec) {
-    (void)rows; (void)in_dim; (void)out_dim;
-    if (prec == CTI_PREC_F32) return 0;
-    return 0;
+    if (prec == CTI_PREC_F32 || rows <= 0 || in_dim <= 0 || out_dim <= 0) return 0;
+    return align256(planes_bytes(rows + PLANE_SLACK_ROWS, in_dim)) + align256(planes_bytes(out_dim + PLANE_SLACK_ROWS, in_dim));
 }
 
 extern "C" int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* scale, int scale_div,
@@ -47,16 +48,31 @@ extern "C" int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, in
     p.nb1 = 1; p.nb2 = 1;
     p.M = (int)rows; p.N = out_dim; p.K = in_dim;
     p.scale = scale; p.scale_div = scale ? scale_div : 1; p.bias = bias; p.relu = (act == CTI_ACT_RELU);
-    switch (prec) {
-        case CTI_PREC_F32: return gemm_nt_f32(p, as_stream(stream));
-        default: return fail(CTI_E_UNSUPPORTED, "cti_wn_linear_fwd: precision mode %d is not built", prec);
+    if (prec == CTI_PREC_F32) return gemm_nt_f32(p, as_stream(stream));
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_wn_linear_fwd: precision mode %d", prec);
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(workspace_bytes >= cti_wn_linear_workspace_bytes(rows, in_dim, out_dim, prec), CTI_E_WORKSPACE,
+                "cti_wn_linear_fwd: workspace %zu < %zu", workspace_bytes, cti_wn_linear_workspace_bytes(rows, in_dim, out_dim, prec));
+    {
+        const int Kp = planes_kp(in_dim);
+        unsigned short* xh = static_cast<unsigned short*>(workspace);
+        unsigned short* xl = xh + (size_t)(rows + PLANE_SLACK_ROWS) * Kp;
+        unsigned short* wh = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(rows + PLANE_SLACK_ROWS, in_dim)));
+        unsigned short* wl = wh + (size_t)(out_dim + PLANE_SLACK_ROWS) * Kp;
+        int rc = split_planes(x, ldx, rows, in_dim, xh, xl, as_stream(stream)); if (rc) return rc;
+        rc = split_planes(w, ldw, out_dim, in_dim, wh, wl, as_stream(stream)); if (rc) return rc;
+        PlaneGemmArgs g{};
+        g.Ah = xh; g.Al = xl; g.Bh = wh; g.Bl = wl; g.lda = Kp; g.ldb = Kp; g.nb1 = 1; g.nb2 = 1;
+        g.M = (int)rows; g.N = out_dim; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0;
+        g.C = y; g.ldc_m = ldy; g.ldc_n = 1;
+        g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = (act == CTI_ACT_RELU);
+        return gemm_nt_planes(g, as_stream(stream));
     }
 }
 
 extern "C" size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int prec) {
-    (void)B; (void)VQ; (void)A; (void)G; (void)K;
-    if (prec == CTI_PREC_F32) return 0;
-    return 0;
+    if (prec == CTI_PREC_F32 || B <= 0 || VQ <= 0 || A <= 0 || G <= 0 || K <= 0) return 0;
+    return align256(planes_bytes((int64_t)B * VQ * G + PLANE_SLACK_ROWS, K)) + align256(planes_bytes((int64_t)B * A + PLANE_SLACK_ROWS, K));
 }
 
 extern "C" int cti_paralind_core_fwd(const float* M, const float* Ar, float* out, int B, int VQ, int A, int G, int K, int prec,
@@ -73,8 +89,25 @@ extern "C" int cti_paralind_core_fwd(const float* M, const float* Ar, float* out
     p.nb1 = B; p.nb2 = G;
     p.M = VQ; p.N = A; p.K = K;
     p.scale = nullptr; p.scale_div = 1; p.bias = nullptr; p.relu = 0;
-    switch (prec) {
-        case CTI_PREC_F32: return gemm_nt_f32(p, as_stream(stream));
-        default: return fail(CTI_E_UNSUPPORTED, "cti_paralind_core_fwd: precision mode %d is not built", prec);
+    if (prec == CTI_PREC_F32) return gemm_nt_f32(p, as_stream(stream));
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_paralind_core_fwd: precision mode %d", prec);
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(workspace_bytes >= cti_paralind_core_workspace_bytes(B, VQ, A, G, K, prec), CTI_E_WORKSPACE,
+                "cti_paralind_core_fwd: workspace %zu < %zu", workspace_bytes, cti_paralind_core_workspace_bytes(B, VQ, A, G, K, prec));
+    {
+        const int Kp = planes_kp(K);
+        const int64_t mrows = (int64_t)B * VQ * G, arows = (int64_t)B * A;
+        unsigned short* mh = static_cast<unsigned short*>(workspace);
+        unsigned short* ml = mh + (size_t)(mrows + PLANE_SLACK_ROWS) * Kp;
+        unsigned short* ah = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(mrows + PLANE_SLACK_ROWS, K)));
+        unsigned short* al = ah + (size_t)(arows + PLANE_SLACK_ROWS) * Kp;
+        int rc = split_planes(M, K, mrows, K, mh, ml, as_stream(stream)); if (rc) return rc;
+        rc = split_planes(Ar, K, arows, K, ah, al, as_stream(stream)); if (rc) return rc;
+        PlaneGemmArgs c{};
+        c.Ah = mh; c.Al = ml; c.Bh = ah; c.Bl = al; c.lda = Kp; c.ldb = Kp;
+        c.sA1 = (int64_t)VQ * G * Kp; c.sB1 = (int64_t)A * Kp; c.nb1 = B; c.nb2 = 1;
+        c.M = VQ * G; c.N = A; c.Kp = Kp; c.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; c.epi = 3; c.gdiv = G;
+        c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)VQ * A * G;
+        return gemm_nt_planes(c, as_stream(stream));
     }
 }

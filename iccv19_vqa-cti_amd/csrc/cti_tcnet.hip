@@ -1,0 +1,181 @@
+// cti_tcnet.hip -- TCNet.forward (reference src/tc.py:41-52) as ONE C-ABI call: the whole launch sequence with the
+// intermediates chained in the layout the next kernel consumes (bf16 hi/lo planes between MFMA GEMMs, fp32 where a
+// VALU kernel reads them), so that no intermediate makes an extra fp32 round trip through HBM.
+//
+//   scales (weight-norm) -> [split inputs + weights] -> 3 Tucker GEMMs -> 3 packed rank GEMMs -> T_eff scramble
+//   -> M build (modes 1+2) -> mode-3 GEMM + rank sum, written as out[b,v,q,a,g]
+#include "cti_common.h"
+
+namespace cti {
+int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
+                int V, int Q, int R, int hr, int G, int ldm, hipStream_t st);
+}
+using namespace cti;
+
+namespace {
+
+struct Bump {
+    char* base; size_t off, cap;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct Planes { unsigned short* hi; unsigned short* lo; int Kp; };
+Planes take_planes(Bump& w, int64_t rows, int K) {
+    const int Kp = planes_kp(K);
+    const size_t n = (size_t)(rows + PLANE_SLACK_ROWS) * Kp;
+    Planes p;
+    p.hi = static_cast<unsigned short*>(w.take(2 * sizeof(unsigned short) * n));
+    p.lo = p.hi ? p.hi + n : nullptr;
+    p.Kp = Kp;
+    return p;
+}
+
+struct Dims { int B, V, Q, A, vd, qd, ad, h, R, G; };
+
+// One pass over the carve plan: with base == nullptr it only measures.
+struct Plan {
+    float* scale_t[3]; float* scale_r[3]; float* Teff;
+    // fp32 mode
+    float* t32[3]; float* r32[3]; float* M32;
+    // planes mode
+    Planes xin[3], wt[3], wr[3], tp[3], Arp, Mp;
+    float* Vr; float* Qr;
+    size_t bytes;
+};
+
+Plan carve(const Dims& d, int prec, void* ws) {
+    Plan p{};
+    Bump w{static_cast<char*>(ws), 0, 0};
+    const int hr = d.h / d.R;
+    const int64_t rows[3] = {(int64_t)d.B * d.V, (int64_t)d.B * d.Q, (int64_t)d.B * d.A};
+    const int in[3] = {d.vd, d.qd, d.ad};
+    for (int s = 0; s < 3; ++s) { p.scale_t[s] = static_cast<float*>(w.take(sizeof(float))); p.scale_r[s] = static_cast<float*>(w.take(sizeof(float) * d.R)); }
+    p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
+    const int64_t mrows = (int64_t)d.B * d.V * d.Q * d.G;
+    if (prec == CTI_PREC_F32) {
+        for (int s = 0; s < 3; ++s) {
+            p.t32[s] = static_cast<float*>(w.take(sizeof(float) * rows[s] * d.h));
+            p.r32[s] = static_cast<float*>(w.take(sizeof(float) * rows[s] * d.h));
+        }
+        p.M32 = static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
+    } else {
+        for (int s = 0; s < 3; ++s) {
+            p.xin[s] = take_planes(w, rows[s], in[s]);
+            p.wt[s] = take_planes(w, d.h, in[s]);
+            p.wr[s] = take_planes(w, d.h, d.h);
+            p.tp[s] = take_planes(w, rows[s], d.h);
+        }
+        p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
+        p.Qr = static_cast<float*>(w.take(sizeof(float) * rows[1] * d.h));
+        p.Arp = take_planes(w, rows[2], d.h);
+        p.Mp = take_planes(w, mrows, d.h);
+    }
+    p.bytes = (w.off + 255) & ~(size_t)255;
+    return p;
+}
+
+int check_dims(const Dims& d) {
+    CTI_REQUIRE(d.B > 0 && d.V > 0 && d.Q > 0 && d.A > 0 && d.vd > 0 && d.qd > 0 && d.ad > 0 && d.h > 0 && d.R > 0 && d.G > 0, CTI_E_SHAPE,
+                "cti_tcnet_forward: B=%d V=%d Q=%d A=%d v_dim=%d q_dim=%d a_dim=%d h=%d R=%d G=%d", d.B, d.V, d.Q, d.A, d.vd, d.qd, d.ad, d.h, d.R, d.G);
+    CTI_REQUIRE(d.h % d.R == 0, CTI_E_SHAPE, "cti_tcnet_forward: h=%d is not a multiple of rank=%d", d.h, d.R);
+    return CTI_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                                    int G, int prec) {
+    Dims d{B, V, Q, A, v_dim, q_dim, a_dim, h, R, G};
+    if (B <= 0 || V <= 0 || Q <= 0 || A <= 0 || v_dim <= 0 || q_dim <= 0 || a_dim <= 0 || h <= 0 || R <= 0 || G <= 0 || h % R) return 0;
+    return carve(d, prec, nullptr).bytes;
+}
+
+extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                                 const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                                 const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                                 uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                 int G, int act, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
+    CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
+    CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
+    Dims d{B, V, Q, A, v_dim, q_dim, a_dim, h, R, G};
+    int rc = check_dims(d); if (rc) return rc;
+    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_tcnet_forward: act=%d", act);
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_tcnet_forward: prec=%d", prec);
+    for (int s = 0; s < 3; ++s)
+        CTI_REQUIRE(tucker_wv[s] && tucker_g[s] && tucker_b[s] && rank_wv[s] && rank_g[s] && rank_b[s], CTI_E_NULL, "cti_tcnet_forward: weight pointer %d is NULL", s);
+    const Plan p = carve(d, prec, workspace);
+    CTI_REQUIRE(workspace_bytes >= p.bytes, CTI_E_WORKSPACE, "cti_tcnet_forward: workspace %zu < %zu", workspace_bytes, p.bytes);
+    hipStream_t st = as_stream(stream);
+    const int hr = h / R;
+    const float* x[3] = {v, q, a};
+    const int in[3] = {v_dim, q_dim, a_dim};
+    const int64_t rows[3] = {(int64_t)B * V, (int64_t)B * Q, (int64_t)B * A};
+    const int relu = act == CTI_ACT_RELU;
+
+    if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
+    for (int s = 0; s < 3; ++s) {
+        rc = cti_wn_scale(tucker_wv[s], tucker_g[s], p.scale_t[s], 1, (int64_t)h * in[s], stream); if (rc) return rc;
+        rc = cti_wn_scale(rank_wv[s], rank_g[s], p.scale_r[s], R, (int64_t)hr * h, stream); if (rc) return rc;
+    }
+    rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, stream); if (rc) return rc;
+    const int64_t mrows_per_b = (int64_t)V * Q * G;
+
+    if (prec == CTI_PREC_F32) {
+        for (int s = 0; s < 3; ++s) {
+            rc = cti_wn_linear_fwd(x[s], in[s], tucker_wv[s], in[s], p.scale_t[s], h, tucker_b[s], p.t32[s], h, rows[s], in[s], h, act,
+                                   CTI_PREC_F32, nullptr, 0, stream); if (rc) return rc;
+            rc = cti_wn_linear_fwd(p.t32[s], h, rank_wv[s], h, p.scale_r[s], hr, rank_b[s], p.r32[s], h, rows[s], h, h, act,
+                                   CTI_PREC_F32, nullptr, 0, stream); if (rc) return rc;
+        }
+        rc = mbuild_fast(p.r32[0], p.r32[1], p.Teff, p.M32, nullptr, nullptr, B, V, Q, R, hr, G, h, st);
+        if (rc == CTI_E_UNSUPPORTED) rc = cti_paralind_mbuild_fwd(p.r32[0], p.r32[1], p.Teff, p.M32, B, V, Q, R, hr, hr, hr, G, stream);
+        if (rc) return rc;
+        return cti_paralind_core_fwd(p.M32, p.r32[2], out, B, V * Q, A, G, h, CTI_PREC_F32, nullptr, 0, stream);
+    }
+
+    const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    for (int s = 0; s < 3; ++s) {
+        rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, st); if (rc) return rc;
+        rc = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, st); if (rc) return rc;
+        rc = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, st); if (rc) return rc;
+    }
+    const int Kh = planes_kp(h);
+    for (int s = 0; s < 3; ++s) {
+        PlaneGemmArgs g{};                                   // Tucker: planes -> planes
+        g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
+        g.lda = p.xin[s].Kp; g.ldb = p.wt[s].Kp; g.nb1 = 1; g.nb2 = 1;
+        g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
+        g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.ldp = Kh; g.Np = Kh;
+        g.scale = p.scale_t[s]; g.scale_div = h; g.bias = tucker_b[s]; g.relu = relu;
+        rc = gemm_nt_planes(g, st); if (rc) return rc;
+        PlaneGemmArgs r{};                                   // packed rank nets: planes -> fp32 (v, q) or planes (a)
+        r.Ah = p.tp[s].hi; r.Al = p.tp[s].lo; r.Bh = p.wr[s].hi; r.Bl = p.wr[s].lo;
+        r.lda = Kh; r.ldb = Kh; r.nb1 = 1; r.nb2 = 1;
+        r.M = (int)rows[s]; r.N = h; r.Kp = Kh; r.terms = terms;
+        r.scale = p.scale_r[s]; r.scale_div = hr; r.bias = rank_b[s]; r.relu = relu;
+        if (s < 2) { r.epi = 0; r.C = s == 0 ? p.Vr : p.Qr; r.ldc_m = h; r.ldc_n = 1; }
+        else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.ldp = Kh; r.Np = Kh; }
+        rc = gemm_nt_planes(r, st); if (rc) return rc;
+    }
+    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, Kh, st);
+    if (rc == CTI_E_UNSUPPORTED) {
+        // generic M build writes fp32 (B,V,Q,G,h) into the (larger) plane buffer's tail is not possible: use out as scratch
+        // only when it is big enough, else report.  out holds B*V*Q*A*G floats; M needs B*V*Q*G*h.
+        CTI_REQUIRE(A >= h, CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr);
+        rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, stream); if (rc) return rc;
+        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, st);
+    }
+    if (rc) return rc;
+    PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
+    c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;
+    c.lda = Kh; c.ldb = Kh; c.sA1 = mrows_per_b * Kh; c.sB1 = (int64_t)A * Kh; c.nb1 = B; c.nb2 = 1;
+    c.M = (int)mrows_per_b; c.N = A; c.Kp = Kh; c.terms = terms; c.epi = 3; c.gdiv = G;
+    c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)V * Q * A * G;
+    return gemm_nt_planes(c, st);
+}

@@ -174,6 +174,49 @@ def paralind_core(M, Ar, prec=None):
     return out
 
 
+def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None):
+    """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
+    the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  Returns out (B,V,Q,A,G) [, mask (B,V)]."""
+    import ctypes as C
+    for t, n in ((v, "v"), (q, "q"), (a, "a"), (T_g, "T_g")):
+        _req(t, n)
+    v, q, a = v.contiguous(), q.contiguous(), a.contiguous()
+    B, V, vd = v.shape
+    Q, qd = q.shape[1], q.shape[2]
+    A, ad = a.shape[1], a.shape[2]
+    if q.shape[0] != B or a.shape[0] != B:
+        raise ValueError("v, q, a must share the batch dimension")
+    h = tucker[0][0].shape[0]
+    R = rank[0][1].numel()
+    G = T_g.shape[5]
+    if T_g.shape[6] != 1:
+        raise RuntimeError("TCNet.forward: h_out must be 1 (src/Tensor.py:6 cannot view the core otherwise)")
+    keep = []
+
+    def arr(ts):
+        ts = [_req(t, "weight").contiguous() for t in ts]
+        keep.extend(ts)
+        return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+    for s, dim in enumerate((vd, qd, ad)):
+        if tuple(tucker[s][0].shape) != (h, dim) or tuple(rank[s][0].shape) != (h, h):
+            raise ValueError("weight shapes do not match the inputs")
+    twv, tg, tb = arr([t[0] for t in tucker]), arr([t[1] for t in tucker]), arr([t[2] for t in tucker])
+    rwv, rg, rb = arr([t[0] for t in rank]), arr([t[1] for t in rank]), arr([t[2] for t in rank])
+    Tg = T_g.contiguous()
+    out = torch.empty((B, V, Q, A, G), device=v.device, dtype=torch.float32)
+    mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
+    pr = _prec(prec)
+    lib = L.lib()
+    wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
+    ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
+    with _timed("tcnet_forward"):
+        L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+                                      _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                      ws.data_ptr(), wsb, _stream()), "cti_tcnet_forward")
+    return (out, mask) if want_mask else out
+
+
 def masked_softmax_tri_(logits, mask):
     """In place -inf fill of `logits` (B,V,Q,A,G contiguous) on masked rows; returns p (same shape)."""
     _req(logits, "logits"); _req(mask, "mask", torch.uint8)

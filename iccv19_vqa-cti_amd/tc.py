@@ -60,8 +60,36 @@ class TCNet(nn.Module):
         scale = ops.wn_scale(wv.view(len(nets), -1), g)
         return ops.wn_linear(x, wv, scale, hr, b, relu=(self._act == 'ReLU'))
 
-    def forward(self, v, q, a):
+    def _last_linear(self, net):
+        return net.main[-2] if isinstance(net.main[-1], nn.ReLU) else net.main[-1]
+
+    def _fused_args(self):
+        """(tucker, rank) argument lists of ops.tcnet_forward; the packed rank weights are cached until a parameter
+        changes (optimizer steps bump `_version`, load_state_dict / .to() change `data_ptr`)."""
+        nets = (self.v_net, self.q_net, self.a_net)
+        key = tuple((p.data_ptr(), p._version) for ns in nets for n in ns for p in n.parameters())
+        if getattr(self, "_pack_key", None) != key:
+            self._pack = [tuple(t.detach() for t in self._rank_pack(ns)) for ns in nets]
+            self._pack_key = key
+        tucker = []
+        for net in (self.v_tucker, self.q_tucker, self.a_tucker):
+            l = self._last_linear(net)
+            tucker.append((l.weight_v.detach(), l.weight_g.detach(), l.bias.detach()))
+        return tucker, self._pack
+
+    def _fusable(self):
+        return (self._act in ('ReLU', '') and not self.training and all(len([m for m in n.main if hasattr(m, "weight_v")]) == 1
+                for n in (self.v_tucker, self.q_tucker, self.a_tucker)))
+
+    def forward(self, v, q, a, _want_mask=False):
         _grad_guard(v, q, a, self.T_g)
+        if self._fusable():
+            tucker, rank = self._fused_args()
+            res = ops.tcnet_forward(v.float(), q.float(), a.float(), tucker, rank, self.T_g.detach(), relu=(self._act == 'ReLU'),
+                                    want_mask=_want_mask)
+            if _want_mask:
+                return res[0].squeeze(4), res[1]
+            return res.squeeze(4)
         v_tucker = self.v_tucker(v)
         q_tucker = self.q_tucker(q)
         a_tucker = self.a_tucker(a)
@@ -74,6 +102,8 @@ class TCNet(nn.Module):
         Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
         M = ops.paralind_mbuild(Vr, Qr, Teff)
         f_emb = ops.paralind_core(M, Ar)                       # (B,V,Q,A,G)
+        if _want_mask:
+            return f_emb.squeeze(4), ops.zero_row_mask(v)
         return f_emb.squeeze(4)
 
     def forward_with_weights(self, v, q, a, w):

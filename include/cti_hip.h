@@ -89,6 +89,22 @@ int cti_paralind_core_fwd(const float* M, const float* Ar, float* out, int B, in
                           int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int prec);
 
+/* ---- TCNet.forward as one call  (src/tc.py:41-52) --------------------------------------------------------------- */
+/* out[b,v,q,a,g] = TCNet.forward(v, q, a) in eval mode (dropout = identity): 3 Tucker projections, the 3 x R rank nets
+ * (passed PACKED: rank_wv[s] is (h, h) = the R weight_v matrices (h/R, h) stacked, rank_g[s] (R), rank_b[s] (h)),
+ * T_eff scramble, modes 1+2, mode 3 + rank sum.  Arrays of 3 are in (v, q, a) order and live on the HOST; the pointers
+ * in them are device pointers.  tucker_wv[s]: (h, in_s) contiguous, tucker_g[s]: scalar, tucker_b[s]: (h).
+ * v (B,V,v_dim), q (B,Q,q_dim), a (B,A,a_dim), out (B,V,Q,A,G) contiguous.  zero_mask: NULL or (B,V) bytes, filled as
+ * cti_zero_row_mask(v) (what TriAttention needs next).  All intermediates live in `workspace`
+ * (cti_tcnet_forward_workspace_bytes); between MFMA GEMMs they stay bf16 hi/lo planes (no fp32 round trip). */
+int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                      const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                      const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                      uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                      int G, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                         int G, int prec);
+
 /* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
 
 /* Tri: logits (B, V, QA, G) contiguous, G innermost.  In place: rows v with mask[b,v] != 0 are filled with -inf
