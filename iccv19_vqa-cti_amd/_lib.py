@@ -19,7 +19,11 @@ SIGNATURES = {
     "cti_paralind_mbuild_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_core_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_paralind_core_workspace_bytes": (_sz, [_int, _int, _int, _int, _int, _int]),
-    "cti_tcnet_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _sz, _vp]),
+    "cti_event_create": (_vp, []),
+    "cti_event_destroy": (_int, [_vp]),
+    "cti_event_record": (_int, [_vp, _vp]),
+    "cti_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "cti_tcnet_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _sz, _vp, _vp, _vp]),
     "cti_tcnet_forward_workspace_bytes": (_sz, [_int] * 11),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),

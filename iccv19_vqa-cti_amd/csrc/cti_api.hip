@@ -24,6 +24,24 @@ using namespace cti;
 extern "C" int cti_abi_version(void) { return CTI_ABI_VERSION; }
 extern "C" const char* cti_last_error_string(void) { return err_buf(); }
 
+extern "C" void* cti_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { fail(CTI_E_UNSUPPORTED, "cti_event_create: hipEventCreate failed"); return nullptr; }
+    return e;
+}
+extern "C" int cti_event_destroy(void* ev) { return ev ? (int)hipEventDestroy(static_cast<hipEvent_t>(ev)) : CTI_OK; }
+extern "C" int cti_event_record(void* ev, void* stream) {
+    CTI_REQUIRE_PTR(ev);
+    hipError_t e = hipEventRecord(static_cast<hipEvent_t>(ev), as_stream(stream));
+    return e == hipSuccess ? CTI_OK : fail((int)e, "cti_event_record: %s", hipGetErrorString(e));
+}
+extern "C" int cti_event_elapsed_ms(void* begin, void* end, float* ms) {
+    CTI_REQUIRE_PTR(begin); CTI_REQUIRE_PTR(end); CTI_REQUIRE_PTR(ms);
+    hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(end));
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, static_cast<hipEvent_t>(begin), static_cast<hipEvent_t>(end));
+    return e == hipSuccess ? CTI_OK : fail((int)e, "cti_event_elapsed_ms: %s", hipGetErrorString(e));
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t cti_wn_linear_workspace_bytes(int64_t rows, int in_dim, int out_dim, int prec) {

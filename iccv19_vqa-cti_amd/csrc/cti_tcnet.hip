@@ -99,7 +99,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                                  const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                                  uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
-                                 int G, int act, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                 void* ev_core_end, void* stream) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -136,7 +137,10 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         rc = mbuild_fast(p.r32[0], p.r32[1], p.Teff, p.M32, nullptr, nullptr, B, V, Q, R, hr, G, h, st);
         if (rc == CTI_E_UNSUPPORTED) rc = cti_paralind_mbuild_fwd(p.r32[0], p.r32[1], p.Teff, p.M32, B, V, Q, R, hr, hr, hr, G, stream);
         if (rc) return rc;
-        return cti_paralind_core_fwd(p.M32, p.r32[2], out, B, V * Q, A, G, h, CTI_PREC_F32, nullptr, 0, stream);
+        if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
+        rc = cti_paralind_core_fwd(p.M32, p.r32[2], out, B, V * Q, A, G, h, CTI_PREC_F32, nullptr, 0, stream);
+        if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
+        return rc;
     }
 
     const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
@@ -177,5 +181,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     c.lda = Kh; c.ldb = Kh; c.sA1 = mrows_per_b * Kh; c.sB1 = (int64_t)A * Kh; c.nb1 = B; c.nb2 = 1;
     c.M = (int)mrows_per_b; c.N = A; c.Kp = Kh; c.terms = terms; c.epi = 3; c.gdiv = G;
     c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)V * Q * A * G;
-    return gemm_nt_planes(c, st);
+    if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
+    rc = gemm_nt_planes(c, st);
+    if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
+    return rc;
 }

@@ -44,7 +44,22 @@ def profile_stop():
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
-    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (rec or {}).items()}
+    return {k: [pr.ms() if isinstance(pr, _LibEventPair) else pr[0].elapsed_time(pr[1]) for pr in v] for k, v in (rec or {}).items()}
+
+
+class _LibEventPair:
+    """Two hipEvent_t handles owned through the C ABI (cti_event_*)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def ms(self):
+        import ctypes as C
+        out = C.c_float(0)
+        lib = L.lib()
+        L.check(lib.cti_event_elapsed_ms(self.a, self.b, C.byref(out)), "cti_event_elapsed_ms")
+        lib.cti_event_destroy(self.a); lib.cti_event_destroy(self.b)
+        return float(out.value)
 
 
 class _timed:
@@ -210,10 +225,14 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     lib = L.lib()
     wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
+    ev0 = ev1 = None
+    if _prof is not None:                       # hipEvents around the mode-3 GEMM, recorded by the library on the launch stream
+        ev0, ev1 = lib.cti_event_create(), lib.cti_event_create()
+        _prof.setdefault("paralind_core", []).append(_LibEventPair(ev0, ev1))
     with _timed("tcnet_forward"):
         L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                       _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
-                                      ws.data_ptr(), wsb, _stream()), "cti_tcnet_forward")
+                                      ws.data_ptr(), wsb, ev0, ev1, _stream()), "cti_tcnet_forward")
     return (out, mask) if want_mask else out
 
 

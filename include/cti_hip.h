@@ -48,6 +48,12 @@ enum { CTI_ACT_NONE = 0, CTI_ACT_RELU = 1 };
 int cti_abi_version(void);
 const char* cti_last_error_string(void);
 
+/* hipEvent_t helpers for hosts without HIP bindings (timing on the launch stream). elapsed_ms synchronises on `end`. */
+void* cti_event_create(void);
+int cti_event_destroy(void* ev);
+int cti_event_record(void* ev, void* stream);
+int cti_event_elapsed_ms(void* begin, void* end, float* ms);
+
 /* ---- FCNet: weight_norm(Linear, dim=None) [+ReLU]  (reference src/fc.py:20-29,33-34) ------------------------- */
 
 /* scale[i] = g[i] / ||V_i||_F for n_mats matrices stored back to back, `elems` floats each.
@@ -96,12 +102,15 @@ size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int
  * in them are device pointers.  tucker_wv[s]: (h, in_s) contiguous, tucker_g[s]: scalar, tucker_b[s]: (h).
  * v (B,V,v_dim), q (B,Q,q_dim), a (B,A,a_dim), out (B,V,Q,A,G) contiguous.  zero_mask: NULL or (B,V) bytes, filled as
  * cti_zero_row_mask(v) (what TriAttention needs next).  All intermediates live in `workspace`
- * (cti_tcnet_forward_workspace_bytes); between MFMA GEMMs they stay bf16 hi/lo planes (no fp32 round trip). */
+ * (cti_tcnet_forward_workspace_bytes); between MFMA GEMMs they stay bf16 hi/lo planes (no fp32 round trip).
+ * ev_core_begin / ev_core_end: NULL, or hipEvent_t handles (cti_event_create) recorded on `stream` immediately before and
+ * after the mode-3 GEMM launch -- how bench.py measures the dominant kernel inside the timed region. */
 int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                       const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                       const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                       uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
-                      int G, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
+                      int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                      void* ev_core_end, void* stream);
 size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                          int G, int prec);
 
