@@ -38,6 +38,35 @@ __device__ __forceinline__ float wave_max(float x) {
     return x;
 }
 
+// ---- weight-norm scales of several layers in two launches (cti_paralind.hip) --------------------------------------
+constexpr int WN_MAX = 8;
+constexpr int64_t WN_CHUNK = 16384;
+struct WnBatch {
+    int n;
+    const float* wv[WN_MAX]; const float* g[WN_MAX]; float* scale[WN_MAX];
+    int n_mats[WN_MAX]; int64_t elems[WN_MAX];
+    int chunks_per_mat[WN_MAX]; int chunk_begin[WN_MAX + 1]; int mat_begin[WN_MAX + 1];   // filled by wn_batch_finish
+};
+void wn_batch_finish(WnBatch& d);
+size_t wn_batch_partials(const WnBatch& d);
+int wn_scale_batch(const WnBatch& d, float* partial, hipStream_t st);
+
+// XCD-aware tile order (gfx950: 8 XCDs, private 4 MiB L2 each; workgroups are dealt round-robin, so ids congruent mod 8
+// share an L2).  Each XCD walks a CONTIGUOUS chunk of the virtual tile sequence (bijective for any grid size), and inside
+// one GEMM the axis with fewer tiles runs fastest, so the operand that is re-read most stays L2-resident:
+// mode-3 GEMM: the 8 row tiles of M[b] (2 MiB) stay in L2 while the 25 column tiles of A^[b] stream through once;
+// projection GEMMs: the 4 column tiles of the weights (L2-resident anyway) run back to back on one activation tile.
+// Placement is a speed matter only: any mapping computes the same tiles.
+__device__ __forceinline__ void tile_coords(int id, int total, int tiles_m, int tiles_n, int& z, int& tm, int& tn) {
+    const int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
+    const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int tiles = tiles_m * tiles_n;
+    z = vid / tiles;
+    const int t = vid - z * tiles;
+    if (tiles_m <= tiles_n) { tm = t % tiles_m; tn = t / tiles_m; }
+    else                    { tn = t % tiles_n; tm = t / tiles_n; }
+}
+
 // ---- strided, batched NT GEMM (both operands K-contiguous) used by the projection layers and the PARALIND core
 struct GemmP {
     const float* A; const float* B; float* C;

@@ -99,8 +99,11 @@ __global__ __launch_bounds__(NT) void gemm_planes_kernel(PlaneGemmP p) {
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_n = ((EPI == EPI_PLANES ? p.Np : p.N) + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const int z = blockIdx.y, b1 = z / p.nb2, b2 = z % p.nb2;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    int z, tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, z, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int b1 = z / p.nb2, b2 = z % p.nb2;
     const int64_t offA = b1 * p.sA1 + b2 * p.sA2 + (int64_t)m0 * p.lda;
     const int64_t offB = b1 * p.sB1 + b2 * p.sB2 + (int64_t)n0 * p.ldb;
     const unsigned short* Ah = p.Ah + offA; const unsigned short* Al = p.Al + offA;
@@ -301,8 +304,9 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (ncols + BN - 1) / BN;
     const long long nb = (long long)a.nb1 * a.nb2;
-    if (nb > 65535) return fail(CTI_E_SHAPE, "gemm_nt_planes: batch count %lld exceeds grid.y", nb);
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nb, 1);
+    const long long total = nb * tiles_m * tiles_n;
+    if (total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm_nt_planes: %lld tiles exceed the grid", total);
+    dim3 grid((unsigned)total, 1, 1);
     const size_t lds = 2 * STAGE_BYTES;
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
     const int key = (a.terms == 3 ? 4 : 0) + epi;

@@ -68,10 +68,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_f32_kernel(GemmP p) {
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int z = blockIdx.y;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    int z, tm, tn;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, z, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
     const int b1 = z / p.nb2, b2 = z % p.nb2;
 
     const float* A = p.A + b1 * p.sA1 + b2 * p.sA2 + (int64_t)m0 * p.lda;
@@ -152,8 +152,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_f32_kernel(GemmP p) {
 int gemm_nt_f32(const GemmP& p, hipStream_t st) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const long long nb = (long long)p.nb1 * p.nb2;
-    if (nb > 65535) return fail(CTI_E_SHAPE, "gemm_nt_f32: batch count %lld exceeds grid.y", nb);
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nb, 1);
+    const long long total = nb * tiles_m * tiles_n;
+    if (total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm_nt_f32: %lld tiles exceed the grid", total);
+    dim3 grid((unsigned)total, 1, 1);
     const size_t lds = sizeof(float) * 4 * BK * LDT;          // 66,048 B: above the 64 KiB default, so opt in once
     static thread_local int attr_dev = -1;
     int dev = 0;

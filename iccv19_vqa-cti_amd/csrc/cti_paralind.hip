@@ -37,6 +37,38 @@ __global__ __launch_bounds__(1024) void wn_scale_kernel(const float* __restrict_
     }
 }
 
+// ---- the same for several layers in two launches (used by cti_tcnet_forward) -------------------------------------
+// Launch 1: one 256-thread workgroup per 16,384-element chunk of any matrix -> partial sum of squares (fixed tree).
+// Launch 2: one wave per matrix adds its chunk partials in index order -> scale.  Deterministic, and a 1M-element
+// Tucker weight is read by 64 CUs instead of one.
+__global__ __launch_bounds__(256) void wn_partial_kernel(WnBatch d, float* __restrict__ partial) {
+    __shared__ float part[4];
+    int c = blockIdx.x, e = 0;
+    while (e + 1 < d.n && c >= d.chunk_begin[e + 1]) ++e;                 // which layer this chunk belongs to
+    c -= d.chunk_begin[e];
+    const int cpm = d.chunks_per_mat[e];
+    const int mat = c / cpm, ch = c % cpm;
+    const float* v = d.wv[e] + (int64_t)mat * d.elems[e];
+    const int64_t lo = (int64_t)ch * WN_CHUNK, hi = min(d.elems[e], lo + WN_CHUNK);
+    float s = 0.f;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) s = fmaf(v[j], v[j], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(64) void wn_final_kernel(WnBatch d, const float* __restrict__ partial) {
+    int m = blockIdx.x, e = 0;
+    while (e + 1 < d.n && m >= d.mat_begin[e + 1]) ++e;
+    m -= d.mat_begin[e];
+    const int cpm = d.chunks_per_mat[e];
+    const float* p = partial + d.chunk_begin[e] + m * cpm;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cpm; c += 64) s += p[c];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) d.scale[e][m] = d.g[e][m] / sqrtf(s);
+}
+
 // ---- mask[r] = every element of row r is +-0 ---------------------------------------------------------------------
 // One wave per row; OR of the magnitude bits, so -0.0 counts as zero and NaN / inf / subnormals do not.
 __global__ __launch_bounds__(256) void zero_row_mask_kernel(const float* __restrict__ v, int64_t ldv,
@@ -129,6 +161,25 @@ __global__ __launch_bounds__(256) void mbuild_kernel(const float* __restrict__ V
 }  // namespace cti
 
 using namespace cti;
+
+namespace cti {
+size_t wn_batch_partials(const WnBatch& d) { return (size_t)d.chunk_begin[d.n]; }
+void wn_batch_finish(WnBatch& d) {
+    int cb = 0, mb = 0;
+    for (int e = 0; e < d.n; ++e) {
+        d.chunks_per_mat[e] = (int)((d.elems[e] + WN_CHUNK - 1) / WN_CHUNK);
+        d.chunk_begin[e] = cb; d.mat_begin[e] = mb;
+        cb += d.chunks_per_mat[e] * d.n_mats[e]; mb += d.n_mats[e];
+    }
+    d.chunk_begin[d.n] = cb; d.mat_begin[d.n] = mb;
+}
+int wn_scale_batch(const WnBatch& d, float* partial, hipStream_t st) {
+    hipLaunchKernelGGL(wn_partial_kernel, dim3((unsigned)d.chunk_begin[d.n]), dim3(256), 0, st, d, partial);
+    int rc = launch_status("wn_scale_batch/partial"); if (rc) return rc;
+    hipLaunchKernelGGL(wn_final_kernel, dim3((unsigned)d.mat_begin[d.n]), dim3(64), 0, st, d, partial);
+    return launch_status("wn_scale_batch/final");
+}
+}  // namespace cti
 
 extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems,
                             void* stream) {

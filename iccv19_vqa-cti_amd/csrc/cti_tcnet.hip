@@ -39,7 +39,7 @@ struct Dims { int B, V, Q, A, vd, qd, ad, h, R, G; };
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
-    float* scale_t[3]; float* scale_r[3]; float* Teff;
+    float* scale_t[3]; float* scale_r[3]; float* Teff; float* wn_partial;
     // fp32 mode
     float* t32[3]; float* r32[3]; float* M32;
     // planes mode
@@ -56,6 +56,11 @@ Plan carve(const Dims& d, int prec, void* ws) {
     const int in[3] = {d.vd, d.qd, d.ad};
     for (int s = 0; s < 3; ++s) { p.scale_t[s] = static_cast<float*>(w.take(sizeof(float))); p.scale_r[s] = static_cast<float*>(w.take(sizeof(float) * d.R)); }
     p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
+    {
+        size_t chunks = 0;
+        for (int s = 0; s < 3; ++s) chunks += (size_t)(((int64_t)d.h * in[s] + WN_CHUNK - 1) / WN_CHUNK) + (size_t)d.R * (((int64_t)hr * d.h + WN_CHUNK - 1) / WN_CHUNK);
+        p.wn_partial = static_cast<float*>(w.take(sizeof(float) * chunks));
+    }
     const int64_t mrows = (int64_t)d.B * d.V * d.Q * d.G;
     if (prec == CTI_PREC_F32) {
         for (int s = 0; s < 3; ++s) {
@@ -120,9 +125,15 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     const int relu = act == CTI_ACT_RELU;
 
     if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
-    for (int s = 0; s < 3; ++s) {
-        rc = cti_wn_scale(tucker_wv[s], tucker_g[s], p.scale_t[s], 1, (int64_t)h * in[s], stream); if (rc) return rc;
-        rc = cti_wn_scale(rank_wv[s], rank_g[s], p.scale_r[s], R, (int64_t)hr * h, stream); if (rc) return rc;
+    {
+        WnBatch wb{};
+        wb.n = 6;
+        for (int s = 0; s < 3; ++s) {
+            wb.wv[s] = tucker_wv[s]; wb.g[s] = tucker_g[s]; wb.scale[s] = p.scale_t[s]; wb.n_mats[s] = 1; wb.elems[s] = (int64_t)h * in[s];
+            wb.wv[3 + s] = rank_wv[s]; wb.g[3 + s] = rank_g[s]; wb.scale[3 + s] = p.scale_r[s]; wb.n_mats[3 + s] = R; wb.elems[3 + s] = (int64_t)hr * h;
+        }
+        wn_batch_finish(wb);
+        rc = wn_scale_batch(wb, p.wn_partial, st); if (rc) return rc;
     }
     rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, stream); if (rc) return rc;
     const int64_t mrows_per_b = (int64_t)V * Q * G;
