@@ -98,6 +98,6 @@ int planes_kp(int K);
 size_t planes_bytes(int64_t rows_alloc, int K);
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
-constexpr int PLANE_SLACK_ROWS = 128;          // rows a GEMM tile may read past the last valid row
+constexpr int PLANE_SLACK_ROWS = 256;          // rows a GEMM tile may read past the last valid row
 
 }  // namespace cti

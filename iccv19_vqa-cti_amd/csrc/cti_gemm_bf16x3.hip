@@ -19,9 +19,9 @@ namespace cti {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int PLANE_BYTES = BM * BK * 2;                  // one bf16 plane tile: 8 KiB
-constexpr int STAGE_BYTES = 4 * PLANE_BYTES;              // A_hi, A_lo, B_hi, B_lo: 32 KiB
+constexpr int BN = 128, BK = 32, NSTAGE = 3;
+constexpr int ROW_BYTES = BK * 2;                         // one tile row of one plane: 64 B = 4 chunks of 16 B
+constexpr int B_PLANE = BN * ROW_BYTES;                   // 8 KiB
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -74,16 +74,16 @@ struct PlaneGemmP {
 };
 enum { EPI_F32 = 0, EPI_PLANES = 1, EPI_INTERLEAVE2 = 2, EPI_INTERLEAVE = 3 };
 
-// LDS-DMA of one 128 x 32 bf16 plane tile (8 KiB = 512 chunks of 16 B; 2 per thread).  LDS position p (chunk index)
-// = (row = p >> 2, c' = p & 3) receives source chunk c = c' ^ ((row >> 2) & 3) of that row.
+// LDS-DMA of one ROWS x 32 bf16 plane tile (ROWS*4 chunks of 16 B, ROWS*4/NTHR per thread).  LDS position p (chunk
+// index) = (row = p >> 2, c' = p & 3) receives source chunk c = c' ^ ((row >> 2) & 3) of that row.
+template <int ROWS, int NTHR>
 __device__ __forceinline__ void dma_plane(const unsigned short* __restrict__ g, int64_t ld, int k0, char* lds_plane, int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = t + 256 * i;
+    for (int i = 0; i < ROWS * 4 / NTHR; ++i) {
+        const int p = t + NTHR * i;
         const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
         const unsigned short* src = g + (int64_t)row * ld + k0 + c * 8;
-        // wave-uniform LDS base of this wave-instruction: chunk index of lane 0 = (t & ~63) + 256 * i
-        char* dst = lds_plane + ((t & ~63) + 256 * i) * 16;
+        char* dst = lds_plane + ((t & ~63) + NTHR * i) * 16;          // wave-uniform base; the hardware adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -93,9 +93,16 @@ __device__ __forceinline__ bf16x8 frag(const char* lds_plane, int row, int chunk
     return *reinterpret_cast<const bf16x8*>(lds_plane + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
 
-template <int TERMS, int EPI>
-__global__ __launch_bounds__(NT) void gemm_planes_kernel(PlaneGemmP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][A_hi | A_lo | B_hi | B_lo]
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// WM = waves along M (2 or 4); the workgroup is WM x 2 waves, each owning a 64 x 64 sub-tile: tile (WM*64) x 128 x 32.
+template <int TERMS, int EPI, int WM>
+__global__ __launch_bounds__(WM * 128) void gemm_planes_kernel(PlaneGemmP p) {
+    constexpr int BM = WM * 64, NTHR = WM * 128;
+    constexpr int A_PLANE = BM * ROW_BYTES;
+    constexpr int STAGE = 2 * (A_PLANE + B_PLANE);                       // [A_hi | A_lo | B_hi | B_lo]
+    constexpr int NDMA = (TERMS == 3 ? 2 : 1) * (BM * 4 / NTHR + BN * 4 / NTHR);   // DMA instructions per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NSTAGE stages; reused by the staged epilogue
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_n = ((EPI == EPI_PLANES ? p.Np : p.N) + BN - 1) / BN;
@@ -117,28 +124,33 @@ __global__ __launch_bounds__(NT) void gemm_planes_kernel(PlaneGemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto stage = [&](int buf, int k0) {
-        char* s = smem + buf * STAGE_BYTES;
-        dma_plane(Ah, p.lda, k0, s, t);
-        dma_plane(Bh, p.ldb, k0, s + 2 * PLANE_BYTES, t);
+    auto stage = [&](int slot, int k0) {
+        char* s = smem + slot * STAGE;
+        dma_plane<BM, NTHR>(Ah, p.lda, k0, s, t);
+        dma_plane<BN, NTHR>(Bh, p.ldb, k0, s + 2 * A_PLANE, t);
         if (TERMS == 3) {
-            dma_plane(Al, p.lda, k0, s + PLANE_BYTES, t);
-            dma_plane(Bl, p.ldb, k0, s + 3 * PLANE_BYTES, t);
+            dma_plane<BM, NTHR>(Al, p.lda, k0, s + A_PLANE, t);
+            dma_plane<BN, NTHR>(Bl, p.ldb, k0, s + 2 * A_PLANE + B_PLANE, t);
         }
     };
 
+    // 3-slot LDS ring, two K-steps of LDS-DMA in flight behind the MFMAs.  Per step: a COUNTED vmcnt retires exactly the
+    // oldest tile (this wave's share), the raw barrier makes every wave's share visible and proves that the slot about to
+    // be refilled (read one step ago) is idle, then the refill is issued and the MFMAs run.  No vmcnt(0) in the loop.
     const int nk = p.Kp / BK;
     stage(0, 0);
-    __syncthreads();                              // emits s_waitcnt vmcnt(0): the DMA has landed for every wave
+    if (nk > 1) stage(1, BK);
     const int r = lane & 31, h = lane >> 5;
-    int cur = 0;
+    int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-        const char* s = smem + cur * STAGE_BYTES;
-        const char* sAh = s + (wm * 64) * 64;
-        const char* sAl = s + PLANE_BYTES + (wm * 64) * 64;
-        const char* sBh = s + 2 * PLANE_BYTES + (wn * 64) * 64;
-        const char* sBl = s + 3 * PLANE_BYTES + (wn * 64) * 64;
+        if (kt + 1 < nk) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, (kt + 2) * BK);          // slot of step kt+2 == slot of step kt-1
+        const char* s = smem + slot * STAGE;
+        const char* sAh = s + (wm * 64) * ROW_BYTES;
+        const char* sAl = s + A_PLANE + (wm * 64) * ROW_BYTES;
+        const char* sBh = s + 2 * A_PLANE + (wn * 64) * ROW_BYTES;
+        const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * 64) * ROW_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int c = 2 * ks + h;
@@ -160,9 +172,9 @@ __global__ __launch_bounds__(NT) void gemm_planes_kernel(PlaneGemmP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();                          // vmcnt(0) + barrier: next buffer landed, this one free to refill
-        cur ^= 1;
+        slot = slot == 2 ? 0 : slot + 1;
     }
+    __syncthreads();                              // every wave is done reading the ring before the epilogue reuses it
 
     if (EPI == EPI_PLANES || EPI == EPI_F32) {
         // Staged epilogue.  Each wave parks its 64 x 64 fp32 sub-tile in its own 16 KiB of the (now idle) LDS
@@ -302,18 +314,35 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.Ph = a.Ph; p.Pl = a.Pl; p.ldp = a.ldp; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     if (a.Kp % BK != 0 || (a.lda & 7) || (a.ldb & 7)) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d lda=%lld ldb=%lld", a.Kp, (long long)a.lda, (long long)a.ldb);
     const int ncols = a.epi == 1 ? a.Np : a.N;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (ncols + BN - 1) / BN;
     const long long nb = (long long)a.nb1 * a.nb2;
-    const long long total = nb * tiles_m * tiles_n;
+    const int tiles_n = (ncols + BN - 1) / BN;
+    // 256-row tiles (8 waves, 144 KiB ring) once they still give every CU work; else 128-row tiles (4 waves, 96 KiB)
+    const long long t256 = nb * ((a.M + 255) / 256) * tiles_n;
+    const int wm = (a.M > 128 && t256 >= 256) ? 4 : 2;
+    const int BMt = wm * 64;
+    const long long total = nb * ((a.M + BMt - 1) / BMt) * tiles_n;
     if (total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm_nt_planes: %lld tiles exceed the grid", total);
     dim3 grid((unsigned)total, 1, 1);
-    const size_t lds = 2 * STAGE_BYTES;
+    const size_t lds = (size_t)NSTAGE * 2 * (BMt * ROW_BYTES + B_PLANE);
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
-    const int key = (a.terms == 3 ? 4 : 0) + epi;
+    const int key = (wm == 4 ? 8 : 0) + (a.terms == 3 ? 4 : 0) + epi;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define CTI_ATTR(T, E, W) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<T, E, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                            if (e_ != hipSuccess) return fail((int)e_, "gemm_nt_planes: hipFuncSetAttribute: %s", hipGetErrorString(e_)); }
+    if (attr_dev != dev) {
+        CTI_ATTR(1, 0, 2) CTI_ATTR(1, 1, 2) CTI_ATTR(1, 2, 2) CTI_ATTR(1, 3, 2) CTI_ATTR(3, 0, 2) CTI_ATTR(3, 1, 2) CTI_ATTR(3, 2, 2) CTI_ATTR(3, 3, 2)
+        CTI_ATTR(1, 0, 4) CTI_ATTR(1, 1, 4) CTI_ATTR(1, 2, 4) CTI_ATTR(1, 3, 4) CTI_ATTR(3, 0, 4) CTI_ATTR(3, 1, 4) CTI_ATTR(3, 2, 4) CTI_ATTR(3, 3, 4)
+        attr_dev = dev;
+    }
+#undef CTI_ATTR
     switch (key) {
-#define CTI_L(T, E) hipLaunchKernelGGL((gemm_planes_kernel<T, E>), grid, dim3(NT), lds, st, p); break;
-        case 0: CTI_L(1, 0) case 1: CTI_L(1, 1) case 2: CTI_L(1, 2) case 3: CTI_L(1, 3)
-        case 4: CTI_L(3, 0) case 5: CTI_L(3, 1) case 6: CTI_L(3, 2) case 7: CTI_L(3, 3)
+#define CTI_L(T, E, W) hipLaunchKernelGGL((gemm_planes_kernel<T, E, W>), grid, dim3(W * 128), lds, st, p); break;
+        case 0: CTI_L(1, 0, 2) case 1: CTI_L(1, 1, 2) case 2: CTI_L(1, 2, 2) case 3: CTI_L(1, 3, 2)
+        case 4: CTI_L(3, 0, 2) case 5: CTI_L(3, 1, 2) case 6: CTI_L(3, 2, 2) case 7: CTI_L(3, 3, 2)
+        case 8: CTI_L(1, 0, 4) case 9: CTI_L(1, 1, 4) case 10: CTI_L(1, 2, 4) case 11: CTI_L(1, 3, 4)
+        case 12: CTI_L(3, 0, 4) case 13: CTI_L(3, 1, 4) case 14: CTI_L(3, 2, 4) case 15: CTI_L(3, 3, 4)
 #undef CTI_L
         default: return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: epi=%d terms=%d", a.epi, a.terms);
     }
