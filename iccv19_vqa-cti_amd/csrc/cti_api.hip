@@ -73,14 +73,15 @@ extern "C" int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, in
                 "cti_wn_linear_fwd: workspace %zu < %zu", workspace_bytes, cti_wn_linear_workspace_bytes(rows, in_dim, out_dim, prec));
     {
         const int Kp = planes_kp(in_dim);
+        const int64_t ra = rows + PLANE_SLACK_ROWS, rb = out_dim + PLANE_SLACK_ROWS;
         unsigned short* xh = static_cast<unsigned short*>(workspace);
-        unsigned short* xl = xh + (size_t)(rows + PLANE_SLACK_ROWS) * Kp;
-        unsigned short* wh = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(rows + PLANE_SLACK_ROWS, in_dim)));
-        unsigned short* wl = wh + (size_t)(out_dim + PLANE_SLACK_ROWS) * Kp;
-        int rc = split_planes(x, ldx, rows, in_dim, xh, xl, as_stream(stream)); if (rc) return rc;
-        rc = split_planes(w, ldw, out_dim, in_dim, wh, wl, as_stream(stream)); if (rc) return rc;
+        unsigned short* xl = xh + (size_t)ra * Kp;
+        unsigned short* wh = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(ra, in_dim)));
+        unsigned short* wl = wh + (size_t)rb * Kp;
+        int rc = split_planes(x, ldx, rows, in_dim, xh, xl, ra, as_stream(stream)); if (rc) return rc;
+        rc = split_planes(w, ldw, out_dim, in_dim, wh, wl, rb, as_stream(stream)); if (rc) return rc;
         PlaneGemmArgs g{};
-        g.Ah = xh; g.Al = xl; g.Bh = wh; g.Bl = wl; g.lda = Kp; g.ldb = Kp; g.nb1 = 1; g.nb2 = 1;
+        g.Ah = xh; g.Al = xl; g.Bh = wh; g.Bl = wl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows; g.N = out_dim; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0;
         g.C = y; g.ldc_m = ldy; g.ldc_n = 1;
         g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = (act == CTI_ACT_RELU);
@@ -115,15 +116,16 @@ extern "C" int cti_paralind_core_fwd(const float* M, const float* Ar, float* out
     {
         const int Kp = planes_kp(K);
         const int64_t mrows = (int64_t)B * VQ * G, arows = (int64_t)B * A;
+        const int64_t ra = mrows + PLANE_SLACK_ROWS, rb = arows + PLANE_SLACK_ROWS;
         unsigned short* mh = static_cast<unsigned short*>(workspace);
-        unsigned short* ml = mh + (size_t)(mrows + PLANE_SLACK_ROWS) * Kp;
-        unsigned short* ah = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(mrows + PLANE_SLACK_ROWS, K)));
-        unsigned short* al = ah + (size_t)(arows + PLANE_SLACK_ROWS) * Kp;
-        int rc = split_planes(M, K, mrows, K, mh, ml, as_stream(stream)); if (rc) return rc;
-        rc = split_planes(Ar, K, arows, K, ah, al, as_stream(stream)); if (rc) return rc;
+        unsigned short* ml = mh + (size_t)ra * Kp;
+        unsigned short* ah = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + align256(planes_bytes(ra, K)));
+        unsigned short* al = ah + (size_t)rb * Kp;
+        int rc = split_planes(M, K, mrows, K, mh, ml, ra, as_stream(stream)); if (rc) return rc;
+        rc = split_planes(Ar, K, arows, K, ah, al, rb, as_stream(stream)); if (rc) return rc;
         PlaneGemmArgs c{};
-        c.Ah = mh; c.Al = ml; c.Bh = ah; c.Bl = al; c.lda = Kp; c.ldb = Kp;
-        c.sA1 = (int64_t)VQ * G * Kp; c.sB1 = (int64_t)A * Kp; c.nb1 = B; c.nb2 = 1;
+        c.Ah = mh; c.Al = ml; c.Bh = ah; c.Bl = al; c.rows_allocA = ra; c.rows_allocB = rb;
+        c.rA1 = (int64_t)VQ * G; c.rB1 = A; c.nb1 = B; c.nb2 = 1;
         c.M = VQ * G; c.N = A; c.Kp = Kp; c.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; c.epi = 3; c.gdiv = G;
         c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)VQ * A * G;
         return gemm_nt_planes(c, as_stream(stream));

@@ -81,22 +81,24 @@ struct GemmP {
 int gemm_nt_f32(const GemmP& p, hipStream_t st);
 
 // ---- the same GEMM on bf16 hi/lo planes (cti_gemm_bf16x3.hip) ----------------------------------------------------
+// Planes are CHUNK-MAJOR: element (row, k) at (k >> 5) * rows_alloc * 32 + row * 32 + (k & 31); see that file's header.
 struct PlaneGemmArgs {
     const unsigned short* Ah; const unsigned short* Al; const unsigned short* Bh; const unsigned short* Bl;
-    int64_t lda, ldb;                          // plane row strides in elements (multiples of 8)
-    int64_t sA1, sA2, sB1, sB2;                // batch strides of the operand planes (elements)
+    int64_t rows_allocA, rows_allocB;          // allocated rows (the chunk pitch is rows_alloc * 32 elements)
+    int64_t rA1, rA2, rB1, rB2;                // batch strides of the operands in ROWS
     int nb1, nb2;
     int M, N, Kp;
     int terms;                                 // 3 = bf16x3 (hi*hi + hi*lo + lo*hi), 1 = plain bf16 (hi planes only)
     int epi;                                   // 0 fp32 C, 1 hi/lo planes out, 3 fp32 C with G-interleaved rows
-    float* C; int64_t ldc_m, ldc_n, sC1, sC2;  // fp32 output (epi 0/3); sC1/sC2 are also the batch strides of Ph/Pl
-    unsigned short* Ph; unsigned short* Pl; int64_t ldp; int Np;     // planes output (epi 1)
+    float* C; int64_t ldc_m, ldc_n, sC1, sC2;  // fp32 output (epi 0/3); for epi 1 sC1/sC2 are batch strides in plane ROWS
+    unsigned short* Ph; unsigned short* Pl; int64_t rows_allocP; int Np;     // planes output (epi 1)
     int gdiv;                                  // epi 3
     const float* scale; int scale_div; const float* bias; int relu;
 };
 int planes_kp(int K);
 size_t planes_bytes(int64_t rows_alloc, int K);
-int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, hipStream_t st);
+int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
+                 hipStream_t st);
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
 constexpr int PLANE_SLACK_ROWS = 256;          // rows a GEMM tile may read past the last valid row
 

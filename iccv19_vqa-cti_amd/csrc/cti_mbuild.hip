@@ -21,7 +21,8 @@ template <int HR, bool PLANES>
 __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                            const float* __restrict__ Teff, float* __restrict__ Mf,
                                                            unsigned short* __restrict__ Mh, unsigned short* __restrict__ Ml,
-                                                           int V, int Q, int R, int G, int ldm /* row stride of M (elements) */,
+                                                           int V, int Q, int R, int G,
+                                                           int64_t ldm /* fp32: row stride of M; planes: chunk pitch (elements) */,
                                                            int rpb /* ranks per workgroup */) {
     constexpr int HH = HR * HR;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -94,11 +95,14 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
             const int64_t orow = (int64_t)b * rows + ((int64_t)lv * Q + lq) * G + lg;
             const int c0 = r * HR;
             if (PLANES) {
+                // chunk-major planes: column c of row orow lives at (c >> 5) * pitch + orow * 32 + (c & 31); the rows of one
+                // v are 64 B apart, so a wave's stores fall in a few contiguous KiB instead of 64 lines 1 KiB apart
                 unsigned short hb[HR], lb[HR];
 #pragma unroll
                 for (int k = 0; k < HR; ++k) { hb[k] = bf16_bits(acc[k]); lb[k] = bf16_bits(acc[k] - bf16_to_f32(hb[k])); }
-                unsigned short* ph = Mh + orow * ldm + c0;
-                unsigned short* pl = Ml + orow * ldm + c0;
+                const int64_t o = (int64_t)(c0 >> 5) * ldm + orow * 32 + (c0 & 31);
+                unsigned short* ph = Mh + o;
+                unsigned short* pl = Ml + o;
                 if (HR % 8 == 0) {
 #pragma unroll
                     for (int c8 = 0; c8 < HR / 8; ++c8) {
@@ -110,8 +114,11 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
                     *reinterpret_cast<uint2*>(ph) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
                     *reinterpret_cast<uint2*>(pl) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
                 }
-                if (r == R - 1) {                           // zero the K tail [K, ldm) of the planes (ldm = K rounded to 32)
-                    for (int c = K; c < ldm; ++c) { Mh[orow * ldm + c] = 0; Ml[orow * ldm + c] = 0; }
+                if (r == R - 1) {                           // zero the K tail [K, Kp) of the planes (Kp = K rounded up to 32)
+                    for (int c = K; c < ((K + 31) & ~31); ++c) {
+                        const int64_t oz = (int64_t)(c >> 5) * ldm + orow * 32 + (c & 31);
+                        Mh[oz] = 0; Ml[oz] = 0;
+                    }
                 }
             } else {
                 float* pf = Mf + orow * ldm + c0;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
 
 template <int HR, bool PLANES>
 int launch(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B, int V,
-           int Q, int R, int G, int ldm, size_t lds, hipStream_t st) {
+           int Q, int R, int G, int64_t ldm, size_t lds, hipStream_t st) {
     auto kern = mbuild_fast_kernel<HR, PLANES>;
     static thread_local int attr_dev = -1;
     int dev = 0;
@@ -153,7 +160,7 @@ int launch(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsig
 // returns CTI_E_UNSUPPORTED (without setting an error message the caller must surface) when the shape is outside the
 // fast path, so that the caller can take the generic kernel of cti_paralind.hip.
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
-                int V, int Q, int R, int hr, int G, int ldm, hipStream_t st) {
+                int V, int Q, int R, int hr, int G, int64_t ldm, hipStream_t st) {
     if (hr != 4 && hr != 8 && hr != 16) return CTI_E_UNSUPPORTED;
     if (B > 65535) return CTI_E_UNSUPPORTED;
     const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)V * hr + (size_t)hr * (Q | 1));

@@ -8,7 +8,7 @@
 
 namespace cti {
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
-                int V, int Q, int R, int hr, int G, int ldm, hipStream_t st);
+                int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 }
 using namespace cti;
 
@@ -24,11 +24,12 @@ struct Bump {
     }
 };
 
-struct Planes { unsigned short* hi; unsigned short* lo; int Kp; };
+struct Planes { unsigned short* hi; unsigned short* lo; int Kp; int64_t rows_alloc; };
 Planes take_planes(Bump& w, int64_t rows, int K) {
     const int Kp = planes_kp(K);
-    const size_t n = (size_t)(rows + PLANE_SLACK_ROWS) * Kp;
     Planes p;
+    p.rows_alloc = rows + PLANE_SLACK_ROWS;
+    const size_t n = (size_t)p.rows_alloc * Kp;
     p.hi = static_cast<unsigned short*>(w.take(2 * sizeof(unsigned short) * n));
     p.lo = p.hi ? p.hi + n : nullptr;
     p.Kp = Kp;
@@ -156,40 +157,39 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
 
     const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
     for (int s = 0; s < 3; ++s) {
-        rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, st); if (rc) return rc;
-        rc = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, st); if (rc) return rc;
-        rc = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, st); if (rc) return rc;
+        rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, st); if (rc) return rc;
+        rc = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
+        rc = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
     }
     const int Kh = planes_kp(h);
     for (int s = 0; s < 3; ++s) {
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
-        g.lda = p.xin[s].Kp; g.ldb = p.wt[s].Kp; g.nb1 = 1; g.nb2 = 1;
+        g.rows_allocA = p.xin[s].rows_alloc; g.rows_allocB = p.wt[s].rows_alloc; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
-        g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.ldp = Kh; g.Np = Kh;
+        g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.rows_allocP = p.tp[s].rows_alloc; g.Np = Kh;
         g.scale = p.scale_t[s]; g.scale_div = h; g.bias = tucker_b[s]; g.relu = relu;
         rc = gemm_nt_planes(g, st); if (rc) return rc;
         PlaneGemmArgs r{};                                   // packed rank nets: planes -> fp32 (v, q) or planes (a)
         r.Ah = p.tp[s].hi; r.Al = p.tp[s].lo; r.Bh = p.wr[s].hi; r.Bl = p.wr[s].lo;
-        r.lda = Kh; r.ldb = Kh; r.nb1 = 1; r.nb2 = 1;
+        r.rows_allocA = p.tp[s].rows_alloc; r.rows_allocB = p.wr[s].rows_alloc; r.nb1 = 1; r.nb2 = 1;
         r.M = (int)rows[s]; r.N = h; r.Kp = Kh; r.terms = terms;
         r.scale = p.scale_r[s]; r.scale_div = hr; r.bias = rank_b[s]; r.relu = relu;
         if (s < 2) { r.epi = 0; r.C = s == 0 ? p.Vr : p.Qr; r.ldc_m = h; r.ldc_n = 1; }
-        else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.ldp = Kh; r.Np = Kh; }
+        else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.rows_allocP = p.Arp.rows_alloc; r.Np = Kh; }
         rc = gemm_nt_planes(r, st); if (rc) return rc;
     }
-    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, Kh, st);
+    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 32, st);
     if (rc == CTI_E_UNSUPPORTED) {
-        // generic M build writes fp32 (B,V,Q,G,h) into the (larger) plane buffer's tail is not possible: use out as scratch
-        // only when it is big enough, else report.  out holds B*V*Q*A*G floats; M needs B*V*Q*G*h.
+        // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h)
         CTI_REQUIRE(A >= h, CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr);
         rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, stream); if (rc) return rc;
-        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, st);
+        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, st);
     }
     if (rc) return rc;
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;
-    c.lda = Kh; c.ldb = Kh; c.sA1 = mrows_per_b * Kh; c.sB1 = (int64_t)A * Kh; c.nb1 = B; c.nb2 = 1;
+    c.rows_allocA = p.Mp.rows_alloc; c.rows_allocB = p.Arp.rows_alloc; c.rA1 = mrows_per_b; c.rB1 = A; c.nb1 = B; c.nb2 = 1;
     c.M = (int)mrows_per_b; c.N = A; c.Kp = Kh; c.terms = terms; c.epi = 3; c.gdiv = G;
     c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)V * Q * A * G;
     if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
