@@ -47,12 +47,11 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* h) {
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, int Kp,
                                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                     int64_t pitch) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * (Kp >> 3)) return;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (row, 16-B piece) inside K chunk blockIdx.y
     const int c = (int)(idx & 3);
-    const int64_t t = idx >> 2;
-    const int64_t row = t % rows;
-    const int kc = (int)(t / rows);
+    const int64_t row = idx >> 2;
+    if (row >= rows) return;
+    const int kc = blockIdx.y;
     const int k0 = kc * 32 + c * 8;
     const float* src = x + row * ld + k0;
     float v[8];
@@ -383,8 +382,9 @@ size_t planes_bytes(int64_t rows_alloc, int K) { return 2 * sizeof(unsigned shor
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
                  hipStream_t st) {
     const int Kp = planes_kp(K);
-    const int64_t n = rows * (Kp >> 3);
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo, rows_alloc * 32);
+    const int64_t n = rows * 4;
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(Kp >> 5)), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo,
+                       rows_alloc * 32);
     return launch_status("split_planes");
 }
 

@@ -17,6 +17,9 @@ namespace {
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
+constexpr int MB_ITEMS = 4;      // step-1 work items per thread the fast path supports (HR^2*G*ceil(V/8) <= 4096)
+constexpr int MB_ROWS = 2;       // output rows per thread (V*Q*G <= 2048)
+
 template <int HR, bool PLANES>
 __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                            const float* __restrict__ Teff, float* __restrict__ Mf,
@@ -30,9 +33,10 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
     float* Ts = sm;                              // [HR][inner]
     float* Xs = Ts + HR * inner;                 // [V][G][HR(j)][HR(k)]
     float* Vs = Xs + (size_t)V * G * HH;         // [V][HR]
-    float* Qs = Vs + V * HR;                     // [HR(j)][Qpad]
+    float* Qs = Vs + (V + 8) * HR;               // [HR(j)][Qpad]  (8 slack rows behind Vs: step 1 reads v0..v0+7 unguarded)
     const int Qpad = Q | 1;
-    const int t = threadIdx.x, nthr = blockDim.x;
+    const int t = threadIdx.x;
+    constexpr int nthr = 1024;
     const int b = blockIdx.y;
     const int K = R * HR;
     const int rows = V * Q * G;
@@ -40,17 +44,68 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
     const float* qb = Qr + (int64_t)b * Q * K;
     const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
 
+    // ---- everything that does not depend on the rank is decoded ONCE (runtime integer divisions cost ~40 instructions
+    // each; inside the rank loop they outweighed the FMAs 7:1) -----------------------------------------------------------
+    // step-1 items: (column c of T_eff, chunk of 8 v)
+    const int nvc = (V + 7) / 8, nitems = inner * nvc;
+    int it_c[MB_ITEMS], it_v0[MB_ITEMS], it_x[MB_ITEMS];
+#pragma unroll
+    for (int n = 0; n < MB_ITEMS; ++n) {
+        const int it = t + n * nthr;
+        const int c = it % inner, v0 = (it / inner) * 8;
+        const int g = c % G, k = (c / G) % HR, j = c / (G * HR);
+        it_c[n] = it < nitems ? c : -1;
+        it_v0[n] = v0;
+        it_x[n] = (v0 * G + g) * HH + j * HR + k;              // X offset of (v0, g, j, k); +G*HH per v
+    }
+    // step-2 rows: lane order (v, g, q), q fastest: a 16-lane group shares its X row (LDS broadcast)
+    int row_x[MB_ROWS], row_q[MB_ROWS];
+    int64_t row_o[MB_ROWS];
+#pragma unroll
+    for (int n = 0; n < MB_ROWS; ++n) {
+        const int lr = t + n * nthr;
+        const int lq = lr % Q, lg = (lr / Q) % G, lv = lr / (Q * G);
+        row_q[n] = lr < rows ? lq : -1;
+        row_x[n] = (lv * G + lg) * HH;
+        row_o[n] = (int64_t)b * rows + ((int64_t)lv * Q + lq) * G + lg;     // output row in the (v,q,g) order of the mode-3 GEMM
+    }
+    // operand loads of one rank: T_eff[r] (HR*inner floats, float4 per thread and trip), Vr/Qr slices (<= 1 element each)
+    const int t4 = HR * inner / 4;                                             // float4 count of T_eff[r]
+    const int ve = t < V * HR ? (t / HR) * K + (t % HR) : -1;                  // + r*HR
+    const int qe = t < Q * HR ? (t / HR) * K + (t % HR) : -1;
+    const int qdst = (t % HR) * Qpad + (t / HR);
+    constexpr int T4MAX = 4;                                                    // HR*inner/4 <= 4096 float4 (HR=16, G<=4)
+    static_assert(T4MAX == 4, "the prefetch registers below are written out by hand");
+    float4 tp0 = make_float4(0.f, 0.f, 0.f, 0.f), tp1 = tp0, tp2 = tp0, tp3 = tp0;     // named registers, not an array
+    float vpre = 0.f, qpre = 0.f;
+#define CTI_MB_PREFETCH(rr)                                                                                   \
+    {                                                                                                         \
+        const float4* Tr_ = reinterpret_cast<const float4*>(Teff + (int64_t)(rr) * HR * inner);               \
+        if (t < t4) tp0 = Tr_[t];                                                                             \
+        if (t + nthr < t4) tp1 = Tr_[t + nthr];                                                               \
+        if (t + 2 * nthr < t4) tp2 = Tr_[t + 2 * nthr];                                                       \
+        if (t + 3 * nthr < t4) tp3 = Tr_[t + 3 * nthr];                                                       \
+        if (ve >= 0) vpre = vb[ve + (rr) * HR];                                                               \
+        if (qe >= 0) qpre = qb[qe + (rr) * HR];                                                               \
+    }
+    CTI_MB_PREFETCH(r_lo)
+
     for (int r = r_lo; r < r_hi; ++r) {
         __syncthreads();                                      // previous rank's readers are done with Ts/Xs/Vs/Qs
-        const float* Tr = Teff + (int64_t)r * HR * inner;
-        for (int e = t; e < HR * inner; e += nthr) Ts[e] = Tr[e];
-        for (int e = t; e < V * HR; e += nthr) Vs[e] = vb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
-        for (int e = t; e < Q * HR; e += nthr) Qs[(e % HR) * Qpad + (e / HR)] = qb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
+        if (t < t4) reinterpret_cast<float4*>(Ts)[t] = tp0;
+        if (t + nthr < t4) reinterpret_cast<float4*>(Ts)[t + nthr] = tp1;
+        if (t + 2 * nthr < t4) reinterpret_cast<float4*>(Ts)[t + 2 * nthr] = tp2;
+        if (t + 3 * nthr < t4) reinterpret_cast<float4*>(Ts)[t + 3 * nthr] = tp3;
+        if (ve >= 0) Vs[t] = vpre;
+        if (qe >= 0) Qs[qdst] = qpre;
         __syncthreads();
-        // step 1: work item = (column c of T_eff, chunk of 8 v):  X[v][g][j][k] = sum_i T_eff[r][i][j,k,g] * Vr[v][i]
-        const int nvc = (V + 7) / 8;
-        for (int it = t; it < inner * nvc; it += nthr) {
-            const int c = it % inner, v0 = (it / inner) * 8;
+        if (r + 1 < r_hi) CTI_MB_PREFETCH(r + 1)              // next rank's operands fly under this rank's FMAs
+        // step 1:  X[v][g][j][k] = sum_i T_eff[r][i][j,k,g] * Vr[v][i]
+#pragma unroll
+        for (int n = 0; n < MB_ITEMS; ++n) {
+            const int c = it_c[n];
+            if (c >= 0) {
+            const int v0 = it_v0[n];
             float x[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) x[u] = 0.f;
@@ -58,26 +113,30 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
             for (int i4 = 0; i4 < HR; i4 += 4) {
                 const float t0 = Ts[(i4 + 0) * inner + c], t1 = Ts[(i4 + 1) * inner + c];
                 const float t2 = Ts[(i4 + 2) * inner + c], t3 = Ts[(i4 + 3) * inner + c];
+                const float* vrow = Vs + v0 * HR + i4;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int v = min(v0 + u, V - 1);
-                    const float4 vv = *reinterpret_cast<const float4*>(Vs + v * HR + i4);
+                    // rows v0+u >= V read stale-but-in-bounds LDS (Vs is followed by Qs); their x[u] is never stored
+                    const float4 vv = *reinterpret_cast<const float4*>(vrow + u * HR);
                     x[u] = fmaf(t0, vv.x, fmaf(t1, vv.y, fmaf(t2, vv.z, fmaf(t3, vv.w, x[u]))));
                 }
             }
-            const int g = c % G, k = (c / G) % HR, j = c / (G * HR);
+            float* xo = Xs + it_x[n];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (v0 + u < V) Xs[((v0 + u) * G + g) * HH + j * HR + k] = x[u];
+                if (v0 + u < V) xo[u * G * HH] = x[u];
+            }
         }
         __syncthreads();
-        // step 2: one output row (v,q,g) per thread (lane order (v,g,q): a 16-lane group shares its X row), HR columns
-        for (int lr = t; lr < rows; lr += nthr) {
-            const int lq = lr % Q, lg = (lr / Q) % G, lv = lr / (Q * G);
+        // step 2: one output row (v,q,g) per thread and trip, HR columns
+#pragma unroll
+        for (int n = 0; n < MB_ROWS; ++n) {
+            const int lq = row_q[n];
+            if (lq >= 0) {
             float acc[HR];
 #pragma unroll
             for (int k = 0; k < HR; ++k) acc[k] = 0.f;
-            const float* xr = Xs + (lv * G + lg) * HH;
+            const float* xr = Xs + row_x[n];
 #pragma unroll 2
             for (int j = 0; j < HR; ++j) {
                 const float qv = Qs[j * Qpad + lq];
@@ -90,13 +149,11 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
                     acc[k4 + 3] = fmaf(qv, xx.w, acc[k4 + 3]);
                 }
             }
-            // output row id in the (v,q,g) order the mode-3 GEMM expects; HR columns starting at r*HR.  The same thread
-            // writes the neighbouring HR-column pieces of this row for the following ranks, so lines complete in L2.
-            const int64_t orow = (int64_t)b * rows + ((int64_t)lv * Q + lq) * G + lg;
+            const int64_t orow = row_o[n];
             const int c0 = r * HR;
             if (PLANES) {
                 // chunk-major planes: column c of row orow lives at (c >> 5) * pitch + orow * 32 + (c & 31); the rows of one
-                // v are 64 B apart, so a wave's stores fall in a few contiguous KiB instead of 64 lines 1 KiB apart
+                // v are 64 B apart, so a wave's stores fall in a few contiguous KiB
                 unsigned short hb[HR], lb[HR];
 #pragma unroll
                 for (int k = 0; k < HR; ++k) { hb[k] = bf16_bits(acc[k]); lb[k] = bf16_bits(acc[k] - bf16_to_f32(hb[k])); }
@@ -129,6 +186,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
 #pragma unroll
                     for (int k = 0; k < HR; ++k) pf[k] = acc[k];
                 }
+            }
             }
         }
     }
@@ -163,8 +221,10 @@ int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, 
                 int V, int Q, int R, int hr, int G, int64_t ldm, hipStream_t st) {
     if (hr != 4 && hr != 8 && hr != 16) return CTI_E_UNSUPPORTED;
     if (B > 65535) return CTI_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)V * hr + (size_t)hr * (Q | 1));
+    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)hr * (Q | 1));
     if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    if ((int64_t)hr * hr * G * ((V + 7) / 8) > 4096 || (int64_t)V * Q * G > 2048 || hr * hr * hr * G / 4 > 4096 || V * hr > 1024 || Q * hr > 1024)
+        return CTI_E_UNSUPPORTED;                           // per-thread item / row / prefetch budgets of the fast kernel
     const bool planes = Mh != nullptr;
 #define CTI_MB(H) (planes ? launch<H, true>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st) \
                           : launch<H, false>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st))
