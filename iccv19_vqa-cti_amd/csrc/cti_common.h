@@ -81,10 +81,10 @@ struct GemmP {
 int gemm_nt_f32(const GemmP& p, hipStream_t st);
 
 // ---- the same GEMM on bf16 hi/lo planes (cti_gemm_bf16x3.hip) ----------------------------------------------------
-// Planes are CHUNK-MAJOR: element (row, k) at (k >> 5) * rows_alloc * 32 + row * 32 + (k & 31); see that file's header.
+// Planes are CHUNK-MAJOR: element (row, k) at (k >> 4) * rows_alloc * 16 + row * 16 + (k & 15); see that file's header.
 struct PlaneGemmArgs {
     const unsigned short* Ah; const unsigned short* Al; const unsigned short* Bh; const unsigned short* Bl;
-    int64_t rows_allocA, rows_allocB;          // allocated rows (the chunk pitch is rows_alloc * 32 elements)
+    int64_t rows_allocA, rows_allocB;          // allocated rows (the chunk pitch is rows_alloc * 16 elements)
     int64_t rA1, rA2, rB1, rB2;                // batch strides of the operands in ROWS
     int nb1, nb2;
     int M, N, Kp;

@@ -6,19 +6,21 @@
 // <= 2^-16 relative).  Measured against the float64 oracle at the BASELINE config-1 shapes the whole TCNet.forward
 // stays at 1e-5 normalised max error (tolerance 1e-4), at 3/16 of the exact-fp32 MFMA issue cost.
 //
-// PLANE LAYOUT (chunk-major).  A plane of a (rows x K) operand is stored as [K/32 chunks][rows_alloc][32 elements]:
-// element (row, k) lives at (k >> 5) * pitch + row * 32 + (k & 31), pitch = rows_alloc * 32.  One K-step of a GEMM tile
-// (R rows x 32 k) is therefore ONE contiguous R*64-byte run, every LDS-DMA wave-instruction reads 1 KiB contiguous, and
-// neighbouring rows are 64 B apart (no power-of-two row pitch: no L2-channel camping).  The kernel was measured to be
+// PLANE LAYOUT (chunk-major).  A plane of a (rows x K) operand is stored as [K/16 chunks][rows_alloc][16 elements]:
+// element (row, k) lives at (k >> 4) * pitch + row * 16 + (k & 15), pitch = rows_alloc * 16.  One 16-deep K slice of a
+// GEMM tile (R rows) is therefore ONE contiguous R*32-byte run, every LDS-DMA wave-instruction reads 1 KiB contiguous
+// (32 rows), and neighbouring rows are 32 B apart (no power-of-two row pitch: no L2-channel camping).  The kernel was measured to be
 // bound by the L2 -> LDS DMA path (12 TB/s chip-wide with 64-B row segments, 16 TB/s with contiguous KiB), so layout and
 // tile size are chosen to minimise DMA requests and bytes; every producer (split kernel, GEMM epilogue, M build)
 // writes this layout directly.  K tails (K..Kp-1, Kp = K rounded up to 32) are zero-filled by the producer; rows beyond
 // the last valid one (up to PLANE_SLACK_ROWS) only feed discarded outputs.
 //
-// KERNEL.  Tile (WM*TM*32) x (WN*TN*32) x 32 per workgroup of WM*WN consumer waves (+ LW loader waves); a 2- or 3-slot
-// LDS ring filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS) with COUNTED vmcnt and one raw
-// s_barrier per K-step; the LDS image is lane-linear ([row][4 x 16 B]) and made bank-conflict-free for ds_read_b128 by
-// permuting the SOURCE chunk (c' = c ^ ((row >> 2) & 3)) and applying the same XOR on the read.
+// KERNEL.  Tile (WM*TM*32) x (WN*TN*32) per workgroup of WM*WN consumer waves (+ LW loader waves); an NST-slot LDS ring
+// of 16-deep K slices filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS) with COUNTED vmcnt;
+// SPB slices are consumed per raw s_barrier, NST - SPB slices stay in flight behind the MFMAs (the 256 x 256 tile keeps
+// three 32-KiB slices in flight: one 64-KiB K-step in flight was measured latency-bound).  The LDS image is lane-linear
+// ([row][2 x 16 B]) and made bank-conflict-free for ds_read_b128 by permuting the SOURCE chunk
+// (c' = c ^ ((row >> 3) & 1)) and applying the same XOR on the read.
 #include "cti_common.h"
 #include <type_traits>
 
@@ -30,8 +32,9 @@ namespace cti {
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int ROW_BYTES = BK * 2;                         // one tile row of one plane: 64 B = 4 chunks of 16 B
+constexpr int BK = 16;                                    // K depth of one ring slot = one MFMA 32x32x16 step
+constexpr int KPAD = 32;                                  // planes are zero-filled up to a multiple of 32 in K
+constexpr int ROW_BYTES = BK * 2;                         // one slot row of one plane: 32 B = 2 chunks of 16 B
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -42,8 +45,8 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* h) {
 }
 
 // ---- split: fp32 [rows, K] (row stride ld) -> chunk-major hi/lo planes --------------------------------------------
-// thread idx = (kc * rows + row) * 4 + c: consecutive threads write consecutive 16-B pieces (fully contiguous stores);
-// reads are 32 B per thread, 128 B contiguous per row.
+// grid.y = 32-wide K group; thread = (row, 16-B piece c of the group): piece c belongs to chunk 2*group + (c >> 1).
+// Reads are 32 B per thread, 128 B contiguous per row; stores 16 B per thread, 32 B contiguous per row and chunk.
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, int Kp,
                                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                     int64_t pitch) {
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     const int c = (int)(idx & 3);
     const int64_t row = idx >> 2;
     if (row >= rows) return;
-    const int kc = blockIdx.y;
-    const int k0 = kc * 32 + c * 8;
+    const int kg = blockIdx.y;
+    const int k0 = kg * 32 + c * 8;
     const float* src = x + row * ld + k0;
     float v[8];
     if (k0 + 8 <= K && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
         h[j] = bf16_bits(v[j]);
         l[j] = bf16_bits(v[j] - bf16_to_f32(h[j]));
     }
-    const int64_t o = (int64_t)kc * pitch + row * 32 + c * 8;
+    const int64_t o = (int64_t)(k0 >> 4) * pitch + row * 16 + (k0 & 15);
     *reinterpret_cast<uint4*>(hi + o) = pack8(h);
     *reinterpret_cast<uint4*>(lo + o) = pack8(l);
 }
@@ -91,15 +94,17 @@ struct PlaneGemmP {
 enum { EPI_F32 = 0, EPI_PLANES = 1, EPI_INTERLEAVE2 = 2, EPI_INTERLEAVE = 3 };
 
 __device__ __forceinline__ bf16x8 frag(const char* lds_plane, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(lds_plane + row * ROW_BYTES + ((chunk ^ ((row >> 2) & 3)) << 4));
+    return *reinterpret_cast<const bf16x8*>(lds_plane + row * ROW_BYTES + ((chunk ^ ((row >> 3) & 1)) << 4));
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Tile geometry: WM x WN consumer waves, each TM x TN MFMA tiles of 32 x 32; LW loader waves; NST ring slots.
-template <int WM_, int WN_, int TM_, int TN_, int LW_, int NST_>
+// Tile geometry: WM x WN consumer waves, each TM x TN MFMA tiles of 32 x 32; LW loader waves; NST ring slots (16-deep
+// K slices), SPB slots consumed per barrier.
+template <int WM_, int WN_, int TM_, int TN_, int LW_, int NST_, int SPB_>
 struct Geo {
-    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, LW = LW_, NST = NST_;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, LW = LW_, NST = NST_, SPB = SPB_;
+    static_assert(NST_ % SPB_ == 0 && NST_ > SPB_, "ring = whole groups of SPB slots, at least one group in flight");
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NCONS = WM * WN * 64, NTHR = NCONS + LW * 64;
     static constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
@@ -107,18 +112,21 @@ struct Geo {
     static constexpr int LDS = NST * STAGE;
 };
 
-// LDS-DMA of `npieces` 1-KiB pieces (16 rows x 64 B, contiguous in the chunk-major plane) of one plane tile: piece ids
-// first, first + stride, ...  LDS position p (chunk index) = (row = p >> 2, c' = p & 3) receives source chunk
-// c = c' ^ ((row >> 2) & 3) of that row.
-template <int NPIECES>
-__device__ __forceinline__ void dma_pieces(const unsigned short* __restrict__ gtile /* chunk kc, tile row 0 */, char* lds_plane,
-                                           int first, int stride, int lane) {
+// LDS-DMA of this wave's share of one operand's slice pair (hi plane rows, then lo plane rows: 2*ROWS/32 pieces of 1 KiB =
+// 32 rows x 32 B, each contiguous in the chunk-major plane): pieces first, first + stride, ...  LDS position p (16-B chunk
+// index inside the plane slice) = (row = p >> 1, c' = p & 1) receives source chunk c = c' ^ ((row >> 3) & 1) of that row.
+template <int ROWS, int NPIECES, bool BOTH>
+__device__ __forceinline__ void dma_pieces(const unsigned short* __restrict__ ghi, const unsigned short* __restrict__ glo,
+                                           char* lds_hi, int first, int stride, int lane) {
+    constexpr int PP = ROWS / 32;                                         // pieces per plane slice
 #pragma unroll
     for (int u = 0; u < NPIECES; ++u) {
-        const int pc = (first + u * stride) * 64 + lane;
-        const int row = pc >> 2, c = (pc & 3) ^ ((row >> 2) & 3);
-        const unsigned short* src = gtile + row * 32 + c * 8;
-        char* dst = lds_plane + (pc - lane) * 16;                       // wave-uniform base; the hardware adds lane * 16
+        const int pid = first + u * stride;                               // wave-uniform
+        const bool lo = BOTH && pid >= PP;
+        const int pc = (pid - (lo ? PP : 0)) * 64 + lane;
+        const int row = pc >> 1, c = (pc & 1) ^ ((row >> 3) & 1);
+        const unsigned short* src = (lo ? glo : ghi) + row * 16 + c * 8;
+        char* dst = lds_hi + (lo ? ROWS * ROW_BYTES : 0) + (pc - lane) * 16;   // wave-uniform base; the hardware adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -126,13 +134,17 @@ __device__ __forceinline__ void dma_pieces(const unsigned short* __restrict__ gt
 
 template <int TERMS, int EPI, class G>
 __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
-    constexpr int WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN, LW = G::LW, NST = G::NST;
-    constexpr int BM = G::BM, BN = G::BN, A_PLANE = G::A_PLANE, B_PLANE = G::B_PLANE, STAGE = G::STAGE;
+    constexpr int WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN, LW = G::LW, NST = G::NST, SPB = G::SPB;
+    constexpr int BM = G::BM, BN = G::BN, A_PLANE = G::A_PLANE, B_PLANE = G::B_PLANE, SLOT = G::STAGE;
+    constexpr int NG = NST / SPB;                                       // ring length in barrier groups
     constexpr int NW = LW > 0 ? LW : WM * WN;                           // waves that issue the DMA
-    constexpr int PA = BM / 16 / NW, PB = BN / 16 / NW;                 // pieces per issuing wave per A / B plane
-    static_assert((BM / 16) % NW == 0 && (BN / 16) % NW == 0, "issuing waves must divide the piece counts");
-    constexpr int NPL = (TERMS == 3 ? 2 : 1) * (PA + PB);               // DMA instructions per issuing wave per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];        // NST stages; reused by the staged epilogue
+    constexpr int NPLANE = TERMS == 3 ? 2 : 1;
+    constexpr int PAT = NPLANE * BM / 32, PBT = NPLANE * BN / 32;       // pieces per slot of the A / B operand (hi [+ lo])
+    constexpr bool EXACT = (PAT % NW == 0) && (PBT % NW == 0);          // every issuing wave issues the same count
+    constexpr int PA = (PAT + NW - 1) / NW, PB = (PBT + NW - 1) / NW;
+    constexpr int NPLG = SPB * (PA + PB);                               // DMA instructions per issuing wave per barrier group
+    static_assert(EXACT || TERMS == 1, "the fp32-grade configurations must split their pieces evenly over the issuing waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // NST slots; reused by the staged epilogue
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const bool loader = LW > 0 && wid >= WM * WN;
     const int wm = wid / WN, wn = wid % WN;
@@ -143,10 +155,10 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int b1 = z / p.nb2, b2 = z % p.nb2;
     const int64_t pitchA = p.pitchA, pitchB = p.pitchB;                 // locals: lambdas must not capture the argument struct
-    const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 32;
-    const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 32;
-    const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 32;
-    const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 32;
+    const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
+    const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
+    const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
+    const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -157,49 +169,59 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int iw = LW > 0 ? wid - WM * WN : wid;                        // index among the issuing waves
-    auto stage = [=](int slot, int kc) {
-        char* s = smem + slot * STAGE;
-        dma_pieces<PA>(Ah + kc * pitchA, s, iw, NW, lane);
-        dma_pieces<PB>(Bh + kc * pitchB, s + 2 * A_PLANE, iw, NW, lane);
-        if (TERMS == 3) {
-            dma_pieces<PA>(Al + kc * pitchA, s + A_PLANE, iw, NW, lane);
-            dma_pieces<PB>(Bl + kc * pitchB, s + 2 * A_PLANE + B_PLANE, iw, NW, lane);
+    // one barrier group = SPB consecutive 16-deep K slices; slot layout [A_hi | A_lo | B_hi | B_lo]
+    auto issue_group = [=](int ring_pos, int grp) {
+#pragma unroll
+        for (int s2 = 0; s2 < SPB; ++s2) {
+            char* s = smem + (ring_pos * SPB + s2) * SLOT;
+            const int64_t kc = (int64_t)grp * SPB + s2;
+            if (EXACT) {
+                dma_pieces<BM, PA, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw, NW, lane);
+                dma_pieces<BN, PB, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + 2 * A_PLANE, iw, NW, lane);
+            } else {                                                     // uneven split (plain-bf16 mode only): waves beyond the piece count idle
+#pragma unroll
+                for (int u = 0; u < PA; ++u) if (iw + u * NW < PAT) dma_pieces<BM, 1, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw + u * NW, NW, lane);
+#pragma unroll
+                for (int u = 0; u < PB; ++u) if (iw + u * NW < PBT) dma_pieces<BN, 1, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + 2 * A_PLANE, iw + u * NW, NW, lane);
+            }
         }
     };
 
-    // Ring protocol.  Step kt: the issuing waves retire tile kt with a COUNTED vmcnt (tiles kt+1 .. kt+NST-2 stay in
-    // flight), the raw barrier makes it visible to every wave and proves that slot (kt-1) % NST, read one step ago, is
-    // idle; then tile kt+NST-1 is issued into that slot and the consumers run their MFMAs.  No vmcnt(0) inside the loop
-    // (except for the last tiles), no __syncthreads() (it would drain the DMA queue).
-    const int nk = p.Kp / BK;
+    // Ring protocol.  Step g: the issuing waves retire group g with a COUNTED vmcnt (groups g+1 .. g+NG-2 stay in flight),
+    // the raw barrier makes it visible to every wave and proves that ring position (g-1) % NG, read one step ago, is idle;
+    // then group g+NG-1 is issued into that position and the consumers run their MFMAs.  No vmcnt(0) inside the loop
+    // (except for the last groups), no __syncthreads() (it would drain the DMA queue).
+    const int ngr = p.Kp / (BK * SPB);
     const bool issuer = LW == 0 || loader;
     if (issuer) {
 #pragma unroll
-        for (int i = 0; i < NST - 1; ++i) if (i < nk) stage(i, i);
+        for (int i = 0; i < NG - 1; ++i) if (i < ngr) issue_group(i, i);
     }
     const int r = lane & 31, h = lane >> 5;
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    int pos = 0;
+    for (int g = 0; g < ngr; ++g) {
         if (issuer) {
-            if (NST >= 3 && nk - 1 - kt >= NST - 2) wait_vmcnt<NPL*(NST - 2)>(); else wait_vmcnt<0>();
+            const int rem = ngr - 1 - g;                                 // groups issued after group g so far: min(NG-2, rem)
+            if (!EXACT) wait_vmcnt<0>();
+            else if (NG >= 3 && rem >= NG - 2) wait_vmcnt<(NG - 2) * NPLG>();
+            else if (NG >= 4 && rem == 1) wait_vmcnt<NPLG>();
+            else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        const int rslot = slot == 0 ? NST - 1 : slot - 1;
-        if (issuer && kt + NST - 1 < nk && !(CTI_ABL & 1)) stage(rslot, kt + NST - 1);
+        if (issuer && g + NG - 1 < ngr && !(CTI_ABL & 1)) issue_group(pos == 0 ? NG - 1 : pos - 1, g + NG - 1);
         if (!loader) {
-            const char* s = smem + slot * STAGE;
-            const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
-            const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
-            const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
-            const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int c = 2 * ks + h;
+            for (int s2 = 0; s2 < SPB; ++s2) {
+                const char* s = smem + (pos * SPB + s2) * SLOT;
+                const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
+                const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
+                const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
+                const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) { ah[i] = frag(sAh, i * 32 + r, c); if (TERMS == 3) al[i] = frag(sAl, i * 32 + r, c); }
+                for (int i = 0; i < TM; ++i) { ah[i] = frag(sAh, i * 32 + r, h); if (TERMS == 3) al[i] = frag(sAl, i * 32 + r, h); }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { bh[j] = frag(sBh, j * 32 + r, c); if (TERMS == 3) bl[j] = frag(sBl, j * 32 + r, c); }
+                for (int j = 0; j < TN; ++j) { bh[j] = frag(sBh, j * 32 + r, h); if (TERMS == 3) bl[j] = frag(sBl, j * 32 + r, h); }
 #if CTI_ABL & 2
 #pragma unroll
                 for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
 #endif
             }
         }
-        slot = slot == NST - 1 ? 0 : slot + 1;
+        pos = pos == NG - 1 ? 0 : pos + 1;
     }
     __syncthreads();                              // every wave is done reading the ring before the epilogue reuses it
     if (loader) return;
@@ -229,8 +251,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         // Staged epilogue, 64 columns of the wave's sub-tile at a time.  The wave parks a (TM*32) x 64 fp32 block in its own
         // slice of the (now idle) LDS ([row][16 slots of 16 B], slot ^= row & 1: conflict-free for the ds_write_b32 column
         // writes and the ds_read_b128 row reads); then every lane owns 8 consecutive columns of a row: scale/bias/ReLU and
-        // 16-B stores.  EPI_PLANES: lanes (row, chunk) of one 32-column group write 64 B per row, rows 64 B apart in the
-        // chunk-major plane, i.e. 512 contiguous bytes per 8 rows.
+        // 16-B stores.  EPI_PLANES: a lane's 8 columns are half a 16-wide chunk: 16 B per row and chunk, rows 32 B apart.
         float* stg = reinterpret_cast<float*>(smem) + wid * (TM * 32 * 64);
         const int c8 = lane & 7;
         const bool vecC = (EPI == EPI_F32) && (p.ldc_n == 1) && ((p.ldc_m & 3) == 0) && ((boff & 3) == 0) &&
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                     unsigned short hb[8], lb[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) { hb[u] = bf16_bits(x[u]); lb[u] = bf16_bits(x[u] - bf16_to_f32(hb[u])); }
-                    const int64_t o = (int64_t)(nb >> 5) * p.pitchP + (boff + m) * 32 + (nb & 31);
+                    const int64_t o = (int64_t)(nb >> 4) * p.pitchP + (boff + m) * 16 + (nb & 15);
                     *reinterpret_cast<uint4*>(p.Ph + o) = pack8(hb);
                     *reinterpret_cast<uint4*>(p.Pl + o) = pack8(lb);
                 } else {
@@ -343,10 +364,15 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #ifndef CTI_LW
 #define CTI_LW 0
 #endif
-// tile configurations: big (256 x 256, 2-slot ring), mid (256 x 128, 3-slot ring), small (128 x 128, 3-slot ring)
-using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 2>;
-using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 3>;
-using GeoSmall = Geo<2, 2, 2, 2, (CTI_LW > 2 ? 2 : CTI_LW), 3>;
+// tile configurations (ring slots are 16-deep K slices):
+//   big   256 x 256, 4 slots of 32 KiB, 1 per barrier (3 in flight);  mid 256 x 128, 6 slots of 24 KiB, 2 per barrier;
+//   small 128 x 128, 6 slots of 16 KiB, 2 per barrier
+#ifndef CTI_BIG_SPB
+#define CTI_BIG_SPB 1
+#endif
+using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
+using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;
+using GeoSmall = Geo<2, 2, 2, 2, (CTI_LW > 2 ? 2 : CTI_LW), 6, 2>;
 
 template <int TERMS, int EPI, class G>
 int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
@@ -376,7 +402,7 @@ int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_
 
 }  // namespace
 
-int planes_kp(int K) { return round_up(K, BK); }
+int planes_kp(int K) { return round_up(K, KPAD); }
 size_t planes_bytes(int64_t rows_alloc, int K) { return 2 * sizeof(unsigned short) * (size_t)rows_alloc * planes_kp(K); }
 
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
@@ -384,19 +410,19 @@ int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short
     const int Kp = planes_kp(K);
     const int64_t n = rows * 4;
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(Kp >> 5)), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo,
-                       rows_alloc * 32);
+                       rows_alloc * 16);
     return launch_status("split_planes");
 }
 
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     PlaneGemmP p{};
     p.Ah = a.Ah; p.Al = a.Al; p.Bh = a.Bh; p.Bl = a.Bl; p.C = a.C;
-    p.pitchA = a.rows_allocA * 32; p.pitchB = a.rows_allocB * 32; p.ldc_m = a.ldc_m; p.ldc_n = a.ldc_n;
+    p.pitchA = a.rows_allocA * 16; p.pitchB = a.rows_allocB * 16; p.ldc_m = a.ldc_m; p.ldc_n = a.ldc_n;
     p.rA1 = a.rA1; p.rA2 = a.rA2; p.rB1 = a.rB1; p.rB2 = a.rB2; p.sC1 = a.sC1; p.sC2 = a.sC2;
     p.nb2 = a.nb2; p.M = a.M; p.N = a.N; p.Kp = a.Kp;
     p.scale = a.scale; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.bias = a.bias; p.relu = a.relu;
-    p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 32; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
-    if (a.Kp % BK != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, BK);
+    p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
+    if (a.Kp % KPAD != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, KPAD);
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const long long nb = (long long)a.nb1 * a.nb2;
     // tile choice: the largest tile that still gives every CU a workgroup (operand bytes through the L2 -> LDS DMA path, the

@@ -152,12 +152,12 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
             const int64_t orow = row_o[n];
             const int c0 = r * HR;
             if (PLANES) {
-                // chunk-major planes: column c of row orow lives at (c >> 5) * pitch + orow * 32 + (c & 31); the rows of one
-                // v are 64 B apart, so a wave's stores fall in a few contiguous KiB
+                // chunk-major planes: column c of row orow lives at (c >> 4) * pitch + orow * 16 + (c & 15); the rows of one
+                // v are 32 B apart, so a wave's stores fall in a few contiguous KiB
                 unsigned short hb[HR], lb[HR];
 #pragma unroll
                 for (int k = 0; k < HR; ++k) { hb[k] = bf16_bits(acc[k]); lb[k] = bf16_bits(acc[k] - bf16_to_f32(hb[k])); }
-                const int64_t o = (int64_t)(c0 >> 5) * ldm + orow * 32 + (c0 & 31);
+                const int64_t o = (int64_t)(c0 >> 4) * ldm + orow * 16 + (c0 & 15);
                 unsigned short* ph = Mh + o;
                 unsigned short* pl = Ml + o;
                 if (HR % 8 == 0) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
                 }
                 if (r == R - 1) {                           // zero the K tail [K, Kp) of the planes (Kp = K rounded up to 32)
                     for (int c = K; c < ((K + 31) & ~31); ++c) {
-                        const int64_t oz = (int64_t)(c >> 5) * ldm + orow * 32 + (c & 31);
+                        const int64_t oz = (int64_t)(c >> 4) * ldm + orow * 16 + (c & 15);
                         Mh[oz] = 0; Ml[oz] = 0;
                     }
                 }
