@@ -6,7 +6,7 @@ import torch
 from . import _lib as L
 
 _PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
-_default_prec = "fp32"
+_default_prec = "bf16x3"     # fp32-grade (1e-5 vs float64 truth at the BASELINE shapes) at 3/16 of the exact-fp32 MFMA cost
 
 
 def set_precision(name):
