@@ -79,6 +79,31 @@ def cpu_baseline(c, state, seed, budget_s=20.0):
             "sample": "oracle.tcnet_forward (numpy fp32), %d samples of the C2 shapes in batches of %d, %.1f s" % (n, Bc, el)}
 
 
+def measure(step, steps, warmup, world, sync, dist=None, device="cpu"):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns the
+    MAX over ranks of the elapsed seconds (the contract's timing rule).  `sync` = torch.cuda.synchronize on a GPU."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(); barrier(); sync()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_rate(world, batch_per_rank, steps, elapsed):
+    """samples/s of the whole job: every rank processed batch_per_rank * steps samples in `elapsed` (max over ranks)."""
+    return world * batch_per_rank * steps / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,31 +140,19 @@ def main():
     net = cti_amd.TCNet(c["v_dim"], c["q_dim"], c["a_dim"], c["h_mm"], 1, c["rank"], c["glimpse"]).to(dev).eval()
     v, q, a = synth_inputs(c, c["B"], SEED + 1 + rank, dev)      # a different shard of the global batch per rank
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    res_holder = {}
+
+    def step():
+        res_holder["out"] = net(v, q, a)
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = net(v, q, a)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        cti_amd.ops.profile_start()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = net(v, q, a)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+            step()
+        cti_amd.ops.profile_start()                            # hipEvents around the kernels of the timed steps
+        el = measure(step, args.steps, 0, world, torch.cuda.synchronize, dist, dev)
         kt = cti_amd.ops.profile_stop()
+    out = res_holder["out"]
     assert out.shape == (c["B"], c["V"], c["Q"], c["A"], c["glimpse"]) and bool(torch.isfinite(out[0, 0, 0, 0]).all())
-    t = torch.tensor([el], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-
     if rank == 0:
         fl = flops_per_sample(c)
         core_ms = float(np.mean(kt.get("paralind_core", kt.get("tcnet_forward"))))
@@ -157,7 +170,7 @@ def main():
         mfma_per_flop = 3.0 if args.precision == "bf16x3" else 1.0
         res = {
             "metric": "CTI fused-forward samples/sec at B=256 (V=36x2048)",
-            "value": world * c["B"] * args.steps / el, "unit": "samples/s",
+            "value": whole_job_rate(world, c["B"], args.steps, el), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32 (bf16x3 split products, f32 accumulate)", "data": "synthetic",
