@@ -3,7 +3,7 @@
 Drop-in `nn.Module`s for the reference's TCNet / BCNet / BiAttention / TriAttention / FCNet / ModeProduct whose
 forward runs in hand-written gfx950 HIP kernels (csrc/) reached through the C ABI of include/cti_hip.h.
 The directory name carries a hyphen, so import it through the repo-root `cti_amd` module (or `dropin/src/*`)."""
-from . import _lib, ops                                        # noqa: F401
+from . import _lib, ops, autograd                              # noqa: F401
 from .fc import FCNet, WNLinear                                # noqa: F401
 from .tc import TCNet                                          # noqa: F401
 from .bc import BCNet                                          # noqa: F401

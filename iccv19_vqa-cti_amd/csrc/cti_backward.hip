@@ -1,0 +1,233 @@
+// cti_backward.hip -- primitives of the backward pass: fp32 transpose, batch sum, ReLU / bias backward, weight-norm
+// gradient, and the generic strided batched NT GEMM entry the gradient contractions are expressed with.
+// All byte movers: coalesced along the contiguous axis, LDS tile transpose, wave-shuffle + LDS-tree reductions.
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+// ---- dst[b][c][r] = src[b][r][c]  (32 x 32 tiles through LDS, +1 padding: conflict-free both ways) -----------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld_src, int64_t s_src,
+                                                        float* __restrict__ dst, int64_t ld_dst, int64_t s_dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const float* s = src + blockIdx.z * s_src;
+    float* d = dst + blockIdx.z * s_dst;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = s[(int64_t)r * ld_src + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) d[(int64_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ---- dst[i] = alpha * sum_b src[b][i] (+ beta * dst[i]) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_batches_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int64_t n,
+                                                          float alpha, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += src[(int64_t)b * n + i];
+    dst[i] = alpha * s + (beta != 0.f ? beta * dst[i] : 0.f);
+}
+
+// ---- dzs = scale[col/div] * dy * (y > 0) [relu] ; partial column sums of the UNSCALED dz for the bias gradient ---------
+// grid (ceil(n/64), row_chunks): each workgroup handles 64 columns x a chunk of rows; thread = (column, row lane 0..3).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, int scale_div, float* __restrict__ dzs,
+                                                      float* __restrict__ part_b, int64_t rows, int n, int relu, int64_t rows_per_chunk) {
+    __shared__ float sb[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int64_t r_lo = (int64_t)blockIdx.y * rows_per_chunk, r_hi = min(rows, r_lo + rows_per_chunk);
+    float ab = 0.f;
+    if (col < n) {
+        const float s = scale ? scale[col / scale_div] : 1.f;
+        for (int64_t r = r_lo + rl; r < r_hi; r += 4) {
+            float g = dy[r * n + col];
+            if (relu && !(y[r * n + col] > 0.f)) g = 0.f;
+            dzs[r * n + col] = g * s;
+            ab += g;
+        }
+    }
+    sb[rl][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        const int c = threadIdx.x & 63;
+        part_b[(int64_t)blockIdx.y * n + col] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+    }
+}
+
+// ---- weight-norm gradient of n_mats matrices stored back to back --------------------------------------------------------
+// W = s * V, s = g / ||V||, U = x V^T, pre-activation = s U + b.  Given G = (s dz)^T x (the gradient w.r.t. V through the
+// direct path, i.e. s times the gradient w.r.t. W):  dot = <G, V>;  dg = dot / g;  dV = G - (dot / ||V||^2) * V.
+// One workgroup per matrix: pass 1 dot and ||V||^2 (fixed tree), pass 2 writes dV.
+__global__ __launch_bounds__(1024) void wn_bwd_kernel(const float* __restrict__ dW, const float* __restrict__ V, const float* __restrict__ g,
+                                                      float* __restrict__ dV, float* __restrict__ dg, int64_t elems) {
+    __shared__ float p0[16], p1[16];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const float* w = dW + (int64_t)i * elems;
+    const float* v = V + (int64_t)i * elems;
+    float dot = 0.f, nn = 0.f;
+    for (int64_t j = t; j < elems; j += 1024) { dot = fmaf(w[j], v[j], dot); nn = fmaf(v[j], v[j], nn); }
+    dot = wave_sum(dot); nn = wave_sum(nn);
+    if ((t & 63) == 0) { p0[t >> 6] = dot; p1[t >> 6] = nn; }
+    __syncthreads();
+    float d = 0.f, n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { d += p0[k]; n2 += p1[k]; }
+    if (t == 0) dg[i] = d / g[i];
+    const float c = d / n2;
+    float* o = dV + (int64_t)i * elems;
+    for (int64_t j = t; j < elems; j += 1024) o[j] = fmaf(-c, v[j], w[j]);
+}
+
+// ---- dropout (nn.Dropout of src/fc.py:20-21,25-26 and src/bc.py:29): Philox-4x32-10 counter RNG, 4 elements per call -------
+__device__ __forceinline__ uint2 mulhilo(unsigned a, unsigned b) { const unsigned long long p = (unsigned long long)a * b; return make_uint2((unsigned)(p >> 32), (unsigned)p); }
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint2 m0 = mulhilo(0xD2511F53u, ctr.x), m1 = mulhilo(0xCD9E8D57u, ctr.z);
+        ctr = make_uint4(m1.x ^ ctr.y ^ key.x, m1.y, m0.x ^ ctr.w ^ key.y, m0.y);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+// y = x * keep / (1 - p), keep ~ Bernoulli(1 - p); mask byte stored for the backward.  backward: same kernel with x = dy, use_mask = 1.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                                      int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 4 elements
+    const int64_t i0 = q * 4;
+    if (i0 >= n) return;
+    const float inv = 1.f / (1.f - p);
+    uint4 rnd = make_uint4(0, 0, 0, 0);
+    if (!use_mask) {
+        const unsigned long long c = (unsigned long long)q + offset;
+        rnd = philox4x32_10(make_uint4((unsigned)c, (unsigned)(c >> 32), 0u, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    }
+    const unsigned rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+    const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i < n) {
+            const bool keep = use_mask ? mask[i] != 0 : rr[j] >= thr;
+            if (!use_mask) mask[i] = keep ? 1 : 0;
+            y[i] = keep ? x[i] * inv : 0.f;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
+                           void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(mask);
+    CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
+    const int64_t groups = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, mask, n, p,
+                       (unsigned long long)seed, (unsigned long long)offset, use_mask);
+    return launch_status("cti_dropout");
+}
+
+extern "C" int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,
+                                 int64_t batch_stride_dst, int rows, int cols, int batch, void* stream) {
+    CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst);
+    CTI_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && ld_src >= cols && ld_dst >= rows, CTI_E_SHAPE,
+                "cti_transpose_f32: rows=%d cols=%d batch=%d ld_src=%lld ld_dst=%lld", rows, cols, batch, (long long)ld_src, (long long)ld_dst);
+    CTI_REQUIRE((rows + 31) / 32 <= 65535, CTI_E_SHAPE, "cti_transpose_f32: rows=%d too large for grid.y", rows);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, as_stream(stream), src, ld_src, batch_stride_src, dst, ld_dst,
+                       batch_stride_dst, rows, cols);
+    return launch_status("cti_transpose_f32");
+}
+
+extern "C" int cti_sum_batches(const float* src, float* dst, int nb, int64_t n, float alpha, float beta, void* stream) {
+    CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst);
+    CTI_REQUIRE(nb > 0 && n > 0, CTI_E_SHAPE, "cti_sum_batches: nb=%d n=%lld", nb, (long long)n);
+    hipLaunchKernelGGL(sum_batches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, nb, n, alpha, beta);
+    return launch_status("cti_sum_batches");
+}
+
+static int act_chunks(int64_t rows) { int c = (int)((rows + 2047) / 2048); return c < 1 ? 1 : (c > 1024 ? 1024 : c); }
+
+extern "C" size_t cti_act_bwd_workspace_bytes(int64_t rows, int n) {
+    if (rows <= 0 || n <= 0) return 0;
+    return sizeof(float) * (size_t)act_chunks(rows) * n;
+}
+
+extern "C" int cti_act_bwd(const float* dy, const float* y, const float* scale, int scale_div, float* dzs, float* dbias, int64_t rows,
+                           int n, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(dy); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(dzs); CTI_REQUIRE_PTR(dbias); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(rows > 0 && n > 0 && (scale == nullptr || scale_div > 0), CTI_E_SHAPE, "cti_act_bwd: rows=%lld n=%d", (long long)rows, n);
+    CTI_REQUIRE(workspace_bytes >= cti_act_bwd_workspace_bytes(rows, n), CTI_E_WORKSPACE, "cti_act_bwd: workspace too small");
+    const int chunks = act_chunks(rows);
+    const int64_t rpc = (rows + chunks - 1) / chunks;
+    float* pb = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, scale ? scale_div : 1, dzs,
+                       pb, rows, n, act == CTI_ACT_RELU ? 1 : 0, rpc);
+    int rc = launch_status("cti_act_bwd"); if (rc) return rc;
+    return cti_sum_batches(pb, dbias, chunks, n, 1.f, 0.f, stream);
+}
+
+extern "C" int cti_wn_bwd(const float* G, const float* weight_v, const float* weight_g, float* dweight_v, float* dweight_g,
+                          int n_mats, int64_t elems, void* stream) {
+    CTI_REQUIRE_PTR(G); CTI_REQUIRE_PTR(weight_v); CTI_REQUIRE_PTR(weight_g); CTI_REQUIRE_PTR(dweight_v); CTI_REQUIRE_PTR(dweight_g);
+    CTI_REQUIRE(n_mats > 0 && elems > 0, CTI_E_SHAPE, "cti_wn_bwd: n_mats=%d elems=%lld", n_mats, (long long)elems);
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), G, weight_v, weight_g, dweight_v, dweight_g, elems);
+    return launch_status("cti_wn_bwd");
+}
+
+// ---- generic strided batched NT GEMM: C[z][m,n] = act(scale[n/div] * sum_k A[z][m,k] * B[z][n,k] + bias[n]) ---------------
+extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
+    if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + al(planes_bytes(rowsB_total + PLANE_SLACK_ROWS, K));
+}
+
+extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, int64_t rA2, const float* B, int64_t ldb,
+                           int64_t rowsB_total, int64_t rB1, int64_t rB2, float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC1, int64_t sC2,
+                           int nb1, int nb2, int M, int N, int K, const float* scale, int scale_div, const float* bias, int act, int prec,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    // A is ONE row-major matrix of rowsA_total rows x K (row stride lda); batch (b1,b2) uses rows [b1*rA1 + b2*rA2, +M).  Same for B / N.
+    CTI_REQUIRE_PTR(A); CTI_REQUIRE_PTR(B); CTI_REQUIRE_PTR(C);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0 && lda >= K && ldb >= K, CTI_E_SHAPE, "cti_gemm_nt: M=%d N=%d K=%d nb=%dx%d", M, N, K, nb1, nb2);
+    CTI_REQUIRE((int64_t)(nb1 - 1) * rA1 + (int64_t)(nb2 - 1) * rA2 + M <= rowsA_total && (int64_t)(nb1 - 1) * rB1 + (int64_t)(nb2 - 1) * rB2 + N <= rowsB_total,
+                CTI_E_SHAPE, "cti_gemm_nt: batches run past the operand rows");
+    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_gemm_nt: act=%d", act);
+    if (prec == CTI_PREC_F32) {
+        GemmP p{};
+        p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc_m = ldc_m; p.ldc_n = ldc_n;
+        p.sA1 = rA1 * lda; p.sA2 = rA2 * lda; p.sB1 = rB1 * ldb; p.sB2 = rB2 * ldb; p.sC1 = sC1; p.sC2 = sC2;
+        p.nb1 = nb1; p.nb2 = nb2; p.M = M; p.N = N; p.K = K;
+        p.scale = scale; p.scale_div = scale ? scale_div : 1; p.bias = bias; p.relu = act == CTI_ACT_RELU;
+        return gemm_nt_f32(p, as_stream(stream));
+    }
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_nt: prec=%d", prec);
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_nt_workspace_bytes(rowsA_total, rowsB_total, K, prec), CTI_E_WORKSPACE, "cti_gemm_nt: workspace too small");
+    const int Kp = planes_kp(K);
+    const int64_t ra = rowsA_total + PLANE_SLACK_ROWS, rb = rowsB_total + PLANE_SLACK_ROWS;
+    unsigned short* ah = static_cast<unsigned short*>(workspace);
+    unsigned short* al = ah + (size_t)ra * Kp;
+    unsigned short* bh = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255));
+    unsigned short* bl = bh + (size_t)rb * Kp;
+    int rc = split_planes(A, lda, rowsA_total, K, ah, al, ra, as_stream(stream)); if (rc) return rc;
+    rc = split_planes(B, ldb, rowsB_total, K, bh, bl, rb, as_stream(stream)); if (rc) return rc;
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb;
+    g.rA1 = rA1; g.rA2 = rA2; g.rB1 = rB1; g.rB2 = rB2; g.nb1 = nb1; g.nb2 = nb2;
+    g.M = M; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    g.C = C; g.ldc_m = ldc_m; g.ldc_n = ldc_n; g.sC1 = sC1; g.sC2 = sC2;
+    g.epi = (ldc_n == 1) ? 0 : 3; g.gdiv = 1;
+    g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = act == CTI_ACT_RELU;
+    return gemm_nt_planes(g, as_stream(stream));
+}

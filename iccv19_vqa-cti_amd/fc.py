@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 
 
 def _grad_guard(*tensors):
@@ -39,7 +40,8 @@ class WNLinear(nn.Module):
         return ops.wn_scale(self.weight_v, self.weight_g)
 
     def forward(self, x, relu=False):
-        _grad_guard(x, self.weight_v, self.weight_g, self.bias)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad or self.weight_g.requires_grad or self.bias.requires_grad):
+            return AG.WNLinearFn.apply(x, self.weight_v, self.weight_g, self.bias, relu, 1)
         return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu)
 
 
@@ -68,8 +70,7 @@ class FCNet(nn.Module):
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Dropout):
-                if self.training and m.p > 0:
-                    raise NotImplementedError("train-mode dropout of the CTI path is not built yet (eval mode only)")
+                x = AG.dropout(x, m.p, self.training)
                 i += 1
             elif isinstance(m, WNLinear):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None

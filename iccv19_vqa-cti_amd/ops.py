@@ -311,3 +311,118 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     L.check(L.lib().cti_bi_logits_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V,
                                       Q, D, _stream()), "cti_bi_logits_fwd")
     return out
+
+
+# ---- backward-pass primitives ---------------------------------------------------------------------------------------
+def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None, sC1=0, scale=None, scale_div=1, bias=None, relu=False,
+            prec=None):
+    """C[z][m,n] = act(scale * sum_k A[z*rA1 + m, k] * B[z*rB1 + n, k] + bias).  A (rowsA, K), B (rowsB, K) 2-D row-major."""
+    _req(A, "A"); _req(B, "B")
+    A2, lda = _rows2d(A); B2, ldb = _rows2d(B)
+    K = A2.shape[1]
+    assert B2.shape[1] == K
+    M = A2.shape[0] if M is None else M
+    N = B2.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty((nb1, M, N) if nb1 > 1 else (M, N), device=A.device, dtype=torch.float32)
+        ldc_m, ldc_n, sC1 = N, 1, M * N
+    else:
+        ldc_m, ldc_n = c_strides
+    pr = _prec(prec)
+    lib = L.lib()
+    wsb = lib.cti_gemm_nt_workspace_bytes(A2.shape[0], B2.shape[0], K, pr)
+    ws = torch.empty(wsb, device=A.device, dtype=torch.uint8) if wsb else None
+    L.check(lib.cti_gemm_nt(A2.data_ptr(), lda, A2.shape[0], rA1, 0, B2.data_ptr(), ldb, B2.shape[0], rB1, 0, out.data_ptr(), ldc_m, ldc_n,
+                            sC1, 0, nb1, 1, M, N, K, _ptr(scale), int(scale_div), _ptr(bias), L.ACT_RELU if relu else L.ACT_NONE, pr,
+                            _ptr(ws), wsb, _stream()), "cti_gemm_nt")
+    return out
+
+
+def transpose(src, rows, cols, batch=1, s_src=0, ld_src=None, dst=None, s_dst=0, ld_dst=None):
+    """dst[b][c][r] = src[b][r][c] for `batch` (rows x cols) matrices addressed with explicit strides."""
+    ld_src = cols if ld_src is None else ld_src
+    ld_dst = rows if ld_dst is None else ld_dst
+    if dst is None:
+        dst = torch.empty((batch, cols, rows), device=src.device, dtype=torch.float32)
+        s_dst = cols * rows
+    L.check(L.lib().cti_transpose_f32(src.data_ptr(), ld_src, s_src, dst.data_ptr(), ld_dst, s_dst, rows, cols, batch, _stream()),
+            "cti_transpose_f32")
+    return dst
+
+
+def sum_batches(src, nb, n, alpha=1.0, out=None, beta=0.0):
+    if out is None:
+        out = torch.empty(n, device=src.device, dtype=torch.float32)
+    L.check(L.lib().cti_sum_batches(src.data_ptr(), out.data_ptr(), nb, n, float(alpha), float(beta), _stream()), "cti_sum_batches")
+    return out
+
+
+def gemm_tn(a, b, prec=None):
+    """a (M, N), b (M, K) contiguous -> a^T b (N, K): the weight-gradient contraction over the ROW axis, as a split-K batched NT GEMM:
+    both operands are transposed chunk-wise ((S, Mc, .) -> (S, ., Mc)), S partial products are summed."""
+    _req(a, "a"); _req(b, "b")
+    M, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == M and a.is_contiguous() and b.is_contiguous()
+    S = max(1, min(128, M // 2048))
+    Mc = (M + S - 1) // S
+    Mc = (Mc + 31) // 32 * 32
+    S = (M + Mc - 1) // Mc
+    full, tail = M // Mc, M % Mc
+    alloc = torch.zeros if tail else torch.empty
+    aT = alloc((S, N, Mc), device=a.device, dtype=torch.float32)
+    bT = alloc((S, K, Mc), device=a.device, dtype=torch.float32)
+    if full:
+        transpose(a, Mc, N, full, Mc * N, N, aT, N * Mc, Mc)
+        transpose(b, Mc, K, full, Mc * K, K, bT, K * Mc, Mc)
+    if tail:
+        transpose(a[full * Mc:], tail, N, 1, 0, N, aT[full], 0, Mc)
+        transpose(b[full * Mc:], tail, K, 1, 0, K, bT[full], 0, Mc)
+    part = gemm_nt(aT.view(S * N, Mc), bT.view(S * K, Mc), nb1=S, rA1=N, rB1=K, M=N, N=K, prec=prec)
+    if S == 1:
+        return part.view(N, K)
+    return sum_batches(part, S, N * K).view(N, K)
+
+
+def act_bwd(dy, y, scale, scale_div, relu):
+    """dzs = scale[col // div] * dy * (y > 0); dbias = column sums of dy * (y > 0)."""
+    _req(dy, "dy"); _req(y, "y")
+    n = y.shape[-1]
+    dy2 = dy.contiguous().view(-1, n); y2 = y.contiguous().view(-1, n)
+    rows = y2.shape[0]
+    dzs = torch.empty_like(y2)
+    db = torch.empty(n, device=y.device, dtype=torch.float32)
+    lib = L.lib()
+    wsb = lib.cti_act_bwd_workspace_bytes(rows, n)
+    ws = torch.empty(wsb, device=y.device, dtype=torch.uint8)
+    L.check(lib.cti_act_bwd(dy2.data_ptr(), y2.data_ptr(), _ptr(scale), int(scale_div), dzs.data_ptr(), db.data_ptr(), rows, n,
+                            L.ACT_RELU if relu else L.ACT_NONE, ws.data_ptr(), wsb, _stream()), "cti_act_bwd")
+    return dzs, db
+
+
+def wn_bwd(G, weight_v, weight_g, n_mats):
+    G = G.contiguous(); wv = weight_v.contiguous(); g = weight_g.contiguous().view(-1)
+    dV = torch.empty_like(wv)
+    dg = torch.empty(n_mats, device=wv.device, dtype=torch.float32)
+    L.check(L.lib().cti_wn_bwd(G.data_ptr(), wv.data_ptr(), g.data_ptr(), dV.data_ptr(), dg.data_ptr(), n_mats, wv.numel() // n_mats,
+                               _stream()), "cti_wn_bwd")
+    return dV, dg
+
+
+_dropout_calls = [0]
+
+
+def dropout(x, p, mask=None):
+    """Forward (mask=None): returns (y, mask) with a fresh Philox stream keyed by torch's seed + a call counter.
+    Backward: pass the stored mask, returns dy * mask / (1-p)."""
+    _req(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if mask is None:
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
+        _dropout_calls[0] += 1
+        L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), seed, 0, 0, _stream()), "cti_dropout")
+        return y, mask
+    L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), 0, 0, 1, _stream()), "cti_dropout")
+    return y
