@@ -33,6 +33,13 @@ SIGNATURES = {
     "cti_act_bwd": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "cti_act_bwd_workspace_bytes": (_sz, [_i64, _int]),
     "cti_wn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "cti_paralind_mbuild_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_masked_softmax_tri_bwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
+    "cti_softmax_tri_bwd_workspace_bytes": (_sz, [_int, _int, _i64, _int]),
+    "cti_masked_softmax_bi_bwd": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
+    "cti_tri_pool_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_pool_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_logits_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _vp]),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),

@@ -7,8 +7,9 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 from .bc import BCNet
-from .tc import TCNet
+from .tc import TCNet, _needs_grad
 
 
 class BiAttention(nn.Module):
@@ -28,7 +29,10 @@ class BiAttention(nn.Module):
     def forward_all(self, v, q, v_mask=True):
         logits = self.logits(v, q)                                  # b x g x v x q
         mask = ops.zero_row_mask(v) if v_mask else None
-        p = ops.masked_softmax_bi_(logits, mask)
+        if _needs_grad(logits):
+            p = AG.BiSoftmaxFn.apply(logits, mask)
+        else:
+            p = ops.masked_softmax_bi_(logits, mask)
         return p, logits
 
 
@@ -44,7 +48,10 @@ class TriAttention(nn.Module):
             # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises
             raise RuntimeError("TriAttention needs glimpse >= 2 (the reference fails the same way: a 5-D mask is "
                                "expanded to the 4-D logits at src/attention.py:55)")
-        p = ops.masked_softmax_tri_(logits, mask)
+        if _needs_grad(logits):
+            p = AG.TriSoftmaxFn.apply(logits, mask)
+        else:
+            p = ops.masked_softmax_tri_(logits, mask)
         return p, logits
 
 

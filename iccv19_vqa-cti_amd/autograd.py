@@ -51,3 +51,134 @@ def dropout(x, p, training):
     if not training or p <= 0:
         return x
     return DropoutFn.apply(x, p)
+
+
+class TeffFn(torch.autograd.Function):
+    """T_g (1,R,hr,hr,hr,G,1) -> T_eff (R,hr,hr,hr,G): the index scramble of src/Tensor.py:6-8; backward = inverse scramble."""
+
+    @staticmethod
+    def forward(ctx, T_g):
+        ctx.shape = T_g.shape
+        return ops.teff_scramble(T_g[0, :, :, :, :, :, 0])
+
+    @staticmethod
+    def backward(ctx, dTeff):
+        return ops.teff_scramble(dTeff.contiguous(), inverse=True).view(ctx.shape)
+
+
+class MBuildFn(torch.autograd.Function):
+    """Modes 1+2 of Tensor.ModeProduct for all ranks (src/Tensor.py:6-13)."""
+
+    @staticmethod
+    def forward(ctx, Vr, Qr, Teff):
+        ctx.save_for_backward(Vr, Qr, Teff)
+        return ops.paralind_mbuild(Vr, Qr, Teff)
+
+    @staticmethod
+    def backward(ctx, dM):
+        Vr, Qr, Teff = ctx.saved_tensors
+        return ops.paralind_mbuild_bwd(dM, Vr, Qr, Teff)
+
+
+class CoreFn(torch.autograd.Function):
+    """Mode 3 + rank sum (src/Tensor.py:16-20, src/tc.py:50)."""
+
+    @staticmethod
+    def forward(ctx, M, Ar):
+        ctx.save_for_backward(M, Ar)
+        return ops.paralind_core(M, Ar)
+
+    @staticmethod
+    def backward(ctx, dout):
+        M, Ar = ctx.saved_tensors
+        return ops.paralind_core_bwd(dout, M, Ar)
+
+
+class TriSoftmaxFn(torch.autograd.Function):
+    """Masked softmax of TriAttention (src/attention.py:55-58).  The -inf fill happens on logits' DATA, untracked, exactly like the
+    reference's `logits.data.masked_fill_`; masked positions have p = 0 and receive a zero gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, mask):
+        p = ops.masked_softmax_tri_(logits.detach(), mask)            # in place on the shared storage
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        return ops.masked_softmax_tri_bwd(p, dp), None
+
+
+class BiSoftmaxFn(torch.autograd.Function):
+    """Masked softmax of BiAttention (src/attention.py:35-39)."""
+
+    @staticmethod
+    def forward(ctx, logits, mask):
+        p = ops.masked_softmax_bi_(logits.detach(), mask)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        return ops.masked_softmax_bi_bwd(p, dp), None
+
+
+class TriPoolFn(torch.autograd.Function):
+    """einsum('bdv,bvqa,bdqi,bdaj->bdij') of src/tc.py:59."""
+
+    @staticmethod
+    def forward(ctx, vt, qt, at, w):
+        ctx.save_for_backward(vt, qt, at, w)
+        return ops.tri_pool(vt, qt, at, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        vt, qt, at, w = ctx.saved_tensors
+        dvt, dqt, dat, dw = ops.tri_pool_bwd(dout, vt, qt, at, w, ctx.needs_input_grad[3])
+        return dvt, dqt, dat, dw
+
+
+class BiPoolFn(torch.autograd.Function):
+    """matmul pair + k-group sum-pool of src/bc.py:73-77 (w given) or the outer-product sum of src/bc.py:42-47 (w = None)."""
+
+    @staticmethod
+    def forward(ctx, vt, qt, w, k):
+        ctx.save_for_backward(vt, qt, w)
+        ctx.k = k
+        return ops.bi_pool(vt, qt, w, k)
+
+    @staticmethod
+    def backward(ctx, dout):
+        vt, qt, w = ctx.saved_tensors
+        dvt, dqt, dw = ops.bi_pool_bwd(dout, vt, qt, w, ctx.k, w is not None and ctx.needs_input_grad[2])
+        return dvt, dqt, dw, None
+
+
+class BiLogitsFn(torch.autograd.Function):
+    """logits[b,g,v,q] = s * sum_d vt h[g,d] qt + hb[g] (src/bc.py:52-58 / :63-68).  h_g is the weight-norm `g` of h (a 0-d
+    tensor) or None when h is a plain parameter."""
+
+    @staticmethod
+    def forward(ctx, vt, qt, h, h_g, h_bias):
+        G, D = h.shape[-3] if h.dim() == 4 else h.shape[0], h.shape[-1]
+        h2 = h.reshape(G, D)
+        scale = ops.wn_scale(h2.reshape(1, -1), h_g.reshape(1)) if h_g is not None else None
+        ctx.save_for_backward(vt, qt, h, h_g if h_g is not None else vt.new_empty(0), scale if scale is not None else vt.new_empty(0))
+        ctx.has_g = h_g is not None
+        ctx.hb_shape = None if h_bias is None else h_bias.shape
+        return ops.bi_logits(vt, qt, h2, scale, h_bias)
+
+    @staticmethod
+    def backward(ctx, dl):
+        vt, qt, h, h_g, scale = ctx.saved_tensors
+        G, D = (h.shape[-3] if h.dim() == 4 else h.shape[0]), h.shape[-1]
+        h2 = h.reshape(G, D)
+        dvt, dqt, Gh, dhb = ops.bi_logits_bwd(dl, vt, qt, h2, scale if ctx.has_g else None)
+        if ctx.has_g:
+            dh, dg = ops.wn_bwd(Gh, h2, h_g.reshape(1), 1)
+            dg = dg.view(h_g.shape)
+        else:
+            dh, dg = Gh, None
+        return dvt, dqt, dh.view(h.shape), dg, (None if ctx.hb_shape is None else dhb.view(ctx.hb_shape))

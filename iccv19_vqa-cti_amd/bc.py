@@ -3,12 +3,14 @@
 forward: the three h_out branches of src/bc.py:41-68; the `h_out <= 32` branch never materialises the
 (B,G,V,D) broadcast product of bc.py:55 (0.9 GB at B=256, G=8): the bilinear logits kernel folds h into the v row
 on the fly.  forward_with_weights (bc.py:70-78): two projections + one fused bilinear sum-pool (with the k-group
-sum-pooling of bc.py:75-77 inside)."""
+sum-pooling of bc.py:75-77 inside).  Under autograd the backward runs in HIP too (autograd.py)."""
 import torch
 import torch.nn as nn
 
 from . import ops
-from .fc import FCNet, WNLinear, _grad_guard
+from . import autograd as AG
+from .fc import FCNet, WNLinear
+from .tc import _needs_grad
 
 
 class BCNet(nn.Module):
@@ -44,34 +46,32 @@ class BCNet(nn.Module):
         self.h_mat_v = nn.Parameter(h.clone())
         return self
 
-    def _h(self):
-        if 'h_mat' in self._parameters:
-            return self.h_mat[0, :, 0, :], None
-        return self.h_mat_v[0, :, 0, :], ops.wn_scale(self.h_mat_v, self.h_mat_g)
-
-    def _attn_dropout(self, x):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("train-mode dropout of the CTI path is not built yet (eval mode only)")
-        return x
+    def _logits(self, v_, q_, h, h_g, h_bias):
+        if _needs_grad(v_, q_, h, h_g, h_bias):
+            return AG.BiLogitsFn.apply(v_, q_, h, h_g, h_bias)
+        G, D = (h.shape[-3] if h.dim() == 4 else h.shape[0]), h.shape[-1]
+        h2 = h.reshape(G, D)
+        scale = ops.wn_scale(h2.reshape(1, -1), h_g.reshape(1)) if h_g is not None else None
+        return ops.bi_logits(v_, q_, h2, scale, h_bias)
 
     def forward(self, v, q):
-        _grad_guard(v, q, *self.parameters())
         if None == self.h_out:
             v_ = self.v_net(v)
             q_ = self.q_net(q)
-            return ops.bi_pool(v_, q_, None, 1).unsqueeze(1)              # b x 1 x h_dim
-        elif self.h_out <= self.c:
-            v_ = self._attn_dropout(self.v_net(v))
-            q_ = self.q_net(q)
-            h, hs = self._h()
-            return ops.bi_logits(v_, q_, h, hs, self.h_bias)              # b x h_out x v x q
-        else:
-            v_ = self._attn_dropout(self.v_net(v))
-            q_ = self.q_net(q)
-            return ops.bi_logits(v_, q_, self.h_net.weight_v, self.h_net.scale(), self.h_net.bias)
+            out = AG.BiPoolFn.apply(v_, q_, None, 1) if _needs_grad(v_, q_) else ops.bi_pool(v_, q_, None, 1)
+            return out.unsqueeze(1)                                        # b x 1 x h_dim
+        v_ = AG.dropout(self.v_net(v), self.dropout.p, self.training)     # bc.py:53 / :64
+        q_ = self.q_net(q)
+        if self.h_out <= self.c:
+            if 'h_mat' in self._parameters:
+                return self._logits(v_, q_, self.h_mat, None, self.h_bias)             # b x h_out x v x q
+            return self._logits(v_, q_, self.h_mat_v, self.h_mat_g, self.h_bias)
+        return self._logits(v_, q_, self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias)
 
     def forward_with_weights(self, v, q, w):
-        _grad_guard(v, q, w, *self.parameters())
         v_ = self.v_net(v)
         q_ = self.q_net(q)
-        return ops.bi_pool(v_, q_, w.float(), self.k)
+        w = w.float()
+        if _needs_grad(v_, q_, w):
+            return AG.BiPoolFn.apply(v_, q_, w, self.k)
+        return ops.bi_pool(v_, q_, w, self.k)

@@ -8,22 +8,25 @@ namespace {
 
 // ---- dst[b][c][r] = src[b][r][c]  (32 x 32 tiles through LDS, +1 padding: conflict-free both ways) -----------------
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t ld_src, int64_t s_src,
-                                                        float* __restrict__ dst, int64_t ld_dst, int64_t s_dst, int rows, int cols) {
+                                                        float* __restrict__ dst, int64_t ld_dst, int64_t s_dst, int rows, int cols, int batch) {
     __shared__ float tile[32][33];
-    const float* s = src + blockIdx.z * s_src;
-    float* d = dst + blockIdx.z * s_dst;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int z = blockIdx.z; z < batch; z += gridDim.z) {
+        const float* s = src + (int64_t)z * s_src;
+        float* d = dst + (int64_t)z * s_dst;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * i][tx] = s[(int64_t)r * ld_src + c];
-    }
-    __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            if (r < rows && c < cols) tile[ty + 8 * i][tx] = s[(int64_t)r * ld_src + c];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (r < rows && c < cols) d[(int64_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;
+            if (r < rows && c < cols) d[(int64_t)c * ld_dst + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
     }
 }
 
@@ -141,12 +144,12 @@ extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, f
 extern "C" int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,
                                  int64_t batch_stride_dst, int rows, int cols, int batch, void* stream) {
     CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst);
-    CTI_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && ld_src >= cols && ld_dst >= rows, CTI_E_SHAPE,
+    CTI_REQUIRE(rows > 0 && cols > 0 && batch > 0 && ld_src >= cols && ld_dst >= rows, CTI_E_SHAPE,
                 "cti_transpose_f32: rows=%d cols=%d batch=%d ld_src=%lld ld_dst=%lld", rows, cols, batch, (long long)ld_src, (long long)ld_dst);
     CTI_REQUIRE((rows + 31) / 32 <= 65535, CTI_E_SHAPE, "cti_transpose_f32: rows=%d too large for grid.y", rows);
-    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch < 32768 ? batch : 32768);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, as_stream(stream), src, ld_src, batch_stride_src, dst, ld_dst,
-                       batch_stride_dst, rows, cols);
+                       batch_stride_dst, rows, cols, batch);
     return launch_status("cti_transpose_f32");
 }
 

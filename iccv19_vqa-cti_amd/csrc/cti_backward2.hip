@@ -1,0 +1,455 @@
+// cti_backward2.hip -- backward kernels of the non-GEMM ops: M build (modes 1+2), masked softmax (Tri / Bi), weighted
+// sum-pools (tri / bi) and bilinear attention logits.  fp32 VALU, lane axis = the contiguous axis, LDS column
+// accumulators (each thread owns its column: no synchronisation), wave-shuffle reductions where an output sums over d.
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+// =====================================================================================================================
+// M build backward.  Forward: X[v,j,k,g] = sum_i T[i,j,k,g] Vr[v,i];  M[v,q,g,k] = sum_j X[v,j,k,g] Qr[q,j]  (per b, r).
+//   dQr[q,j]   = sum_{v,g,k} dM[v,q,g,k] X[v,j,k,g]
+//   dX[v,j,k,g]= sum_q dM[v,q,g,k] Qr[q,j]
+//   dVr[v,i]   = sum_{j,k,g} dX[v,j,k,g] T[i,j,k,g]
+//   dT_b[i,j,k,g] = sum_v Vr[v,i] dX[v,j,k,g]        (per-sample partial; summed over b afterwards)
+// One 1024-thread workgroup per (b, rank group); LDS: T[r] | X then dX (same buffer) | Vr slice | Qr slice.
+// =====================================================================================================================
+template <int HR>
+__global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restrict__ dM, const float* __restrict__ Vr,
+                                                          const float* __restrict__ Qr, const float* __restrict__ Teff,
+                                                          float* __restrict__ dVr, float* __restrict__ dQr, float* __restrict__ dTpart,
+                                                          int V, int Q, int R, int G, int rpb) {
+    constexpr int HH = HR * HR;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int inner = HH * G;
+    float* Ts = sm;                              // [HR][inner]  (i, (j,k,g))
+    float* Xs = Ts + HR * inner;                 // [V][G][HR(j)][HR(k)]   X, later dX
+    float* Vs = Xs + (size_t)V * G * HH;         // [V + 8][HR]
+    float* Qs = Vs + (V + 8) * HR;               // [Q][HR]  (q, j)
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    constexpr int nthr = 1024;
+    const int b = blockIdx.y;
+    const int K = R * HR;
+    const float* vb = Vr + (int64_t)b * V * K;
+    const float* qb = Qr + (int64_t)b * Q * K;
+    const float* dmb = dM + (int64_t)b * V * Q * G * K;
+    const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
+    for (int r = r_lo; r < r_hi; ++r) {
+        __syncthreads();
+        const float* Tr = Teff + (int64_t)r * HR * inner;
+        for (int e = t; e < HR * inner; e += nthr) Ts[e] = Tr[e];
+        for (int e = t; e < V * HR; e += nthr) Vs[e] = vb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
+        for (int e = t; e < Q * HR; e += nthr) Qs[e] = qb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
+        __syncthreads();
+        // X[v][g][j][k] (as the forward's step 1)
+        for (int it = t; it < inner * V; it += nthr) {
+            const int c = it % inner, v = it / inner;
+            float x = 0.f;
+#pragma unroll
+            for (int i = 0; i < HR; ++i) x = fmaf(Ts[i * inner + c], Vs[v * HR + i], x);
+            const int g = c % G, k = (c / G) % HR, j = c / (G * HR);
+            Xs[(v * G + g) * HH + j * HR + k] = x;
+        }
+        __syncthreads();
+        // dQr[q][j] = sum_{v,g} sum_k dM[v,q,g,k] X[v,g,j,k]: P lanes split v, shuffle-reduced
+        {
+            const int nout = Q * HR;
+            int P = 1;
+            while (P * 2 * nout <= nthr && P < 16) P *= 2;
+            if (t < nout * P) {
+                const int o = t / P, part = t % P;
+                const int q = o / HR, j = o % HR;
+                float s = 0.f;
+                for (int v = part; v < V; v += P)
+                    for (int g = 0; g < G; ++g) {
+                        const float* dm = dmb + (((int64_t)v * Q + q) * G + g) * K + r * HR;
+                        const float* xr = Xs + (v * G + g) * HH + j * HR;
+#pragma unroll
+                        for (int k = 0; k < HR; ++k) s = fmaf(dm[k], xr[k], s);
+                    }
+                for (int off = P >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (part == 0) dQr[((int64_t)b * Q + q) * K + r * HR + j] = s;
+            }
+        }
+        __syncthreads();
+        // dX[v][g][j][k] = sum_q dM[v,q,g,k] Qr[q,j]  (overwrites X)
+        for (int it = t; it < V * G * HR; it += nthr) {
+            const int k = it % HR, g = (it / HR) % G, v = it / (HR * G);
+            float acc[HR];
+#pragma unroll
+            for (int j = 0; j < HR; ++j) acc[j] = 0.f;
+            for (int q = 0; q < Q; ++q) {
+                const float m = dmb[(((int64_t)v * Q + q) * G + g) * K + r * HR + k];
+#pragma unroll
+                for (int j = 0; j < HR; ++j) acc[j] = fmaf(m, Qs[q * HR + j], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < HR; ++j) Xs[(v * G + g) * HH + j * HR + k] = acc[j];
+        }
+        __syncthreads();
+        // dVr[v][i] = sum_{g,jk} dX[v][g][jk] T[i][(jk)*G + g]: one wave per (v,i) pair, lanes over (g,jk)
+        for (int pr = wid; pr < V * HR; pr += nthr / 64) {
+            const int v = pr / HR, i = pr % HR;
+            float s = 0.f;
+            for (int e = lane; e < inner; e += 64) {
+                const int g = e / HH, jk = e % HH;
+                s = fmaf(Xs[(v * G + g) * HH + jk], Ts[i * inner + jk * G + g], s);
+            }
+            s = wave_sum(s);
+            if (lane == 0) dVr[((int64_t)b * V + v) * K + r * HR + i] = s;
+        }
+        // dT_b[r][i][c] = sum_v Vr[v][i] dX[v][c]
+        for (int it = t; it < HR * inner; it += nthr) {
+            const int c = it % inner, i = it / inner;
+            const int g = c % G, jk = c / G;
+            float s = 0.f;
+            for (int v = 0; v < V; ++v) s = fmaf(Vs[v * HR + i], Xs[(v * G + g) * HH + jk], s);
+            dTpart[((int64_t)b * R + r) * HR * inner + it] = s;
+        }
+    }
+}
+
+// =====================================================================================================================
+// softmax backward: dl = p * (dp - sum p*dp) over the softmax axis.
+// =====================================================================================================================
+constexpr int GMAXB = 8;
+__global__ __launch_bounds__(256) void tri_sm_bwd_partial(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ part,
+                                                          int64_t N, int G, int64_t chunk_n, int nchunk) {
+    __shared__ float red[4][GMAXB];
+    const int b = blockIdx.y, c = blockIdx.x, t = threadIdx.x;
+    const int64_t lo = (int64_t)c * chunk_n, hi = min(N, lo + chunk_n);
+    const float* pp = p + (int64_t)b * N * G;
+    const float* dd = dp + (int64_t)b * N * G;
+    for (int g0 = 0; g0 < G; g0 += GMAXB) {
+        float s[GMAXB];
+#pragma unroll
+        for (int g = 0; g < GMAXB; ++g) s[g] = 0.f;
+        for (int64_t n = lo + t; n < hi; n += 256)
+#pragma unroll
+            for (int g = 0; g < GMAXB; ++g)
+                if (g0 + g < G) s[g] = fmaf(pp[n * G + g0 + g], dd[n * G + g0 + g], s[g]);
+#pragma unroll
+        for (int g = 0; g < GMAXB; ++g) s[g] = wave_sum(s[g]);
+        if ((t & 63) == 0)
+#pragma unroll
+            for (int g = 0; g < GMAXB; ++g) red[t >> 6][g] = s[g];
+        __syncthreads();
+        if (t < GMAXB && g0 + t < G) part[((int64_t)b * nchunk + c) * G + g0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void tri_sm_bwd_apply(const float* __restrict__ p, const float* __restrict__ dp, const float* __restrict__ part,
+                                                        float* __restrict__ dl, int64_t NG, int G, int nchunk) {
+    __shared__ float s[64];                                  // G <= 64 per pass
+    const int b = blockIdx.y;
+    for (int g = threadIdx.x; g < G && g < 64; g += 256) {
+        float a = 0.f;
+        for (int c = 0; c < nchunk; ++c) a += part[((int64_t)b * nchunk + c) * G + g];
+        s[g] = a;
+    }
+    __syncthreads();
+    const float* pp = p + (int64_t)b * NG;
+    const float* dd = dp + (int64_t)b * NG;
+    float* o = dl + (int64_t)b * NG;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < NG; f += stride) {
+        const int g = (int)(f % G);
+        o[f] = pp[f] * (dd[f] - s[g]);
+    }
+}
+__global__ __launch_bounds__(256) void bi_sm_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ dl,
+                                                        int rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pp = p + (int64_t)row * N;
+    const float* dd = dp + (int64_t)row * N;
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s = fmaf(pp[n], dd[n], s);
+    s = wave_sum(s);
+    for (int n = lane; n < N; n += 64) dl[(int64_t)row * N + n] = pp[n] * (dd[n] - s);
+}
+
+// =====================================================================================================================
+// tri pool backward.  out[b,d] = sum_v vt[v,d] sum_q qt[q,d] sum_a w[v,q,a] at[a,d]
+// kernel 1 (lane = d): dvt, dqt, dat;  kernel 2 (workgroup per (b,v)): dw[v,q,a] = sum_d do vt qt at
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void tri_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                           const float* __restrict__ at, const float* __restrict__ w, int64_t w_sb, int64_t w_sv,
+                                                           int64_t w_sq, int64_t w_sa, float* __restrict__ dvt, float* __restrict__ dqt,
+                                                           float* __restrict__ dat, int V, int Q, int A, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y, t = threadIdx.x, d = blockIdx.x * 256 + t;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float* qs = sm; float* as = qs + Q * 256; float* dq = as + A * 256; float* da = dq + Q * 256;
+    const float* qb = qt + (int64_t)b * Q * D; const float* ab = at + (int64_t)b * A * D; const float* vb = vt + (int64_t)b * V * D;
+    for (int q = 0; q < Q; ++q) { qs[q * 256 + t] = qb[(int64_t)q * D + dd]; dq[q * 256 + t] = 0.f; }
+    for (int a = 0; a < A; ++a) { as[a * 256 + t] = ab[(int64_t)a * D + dd]; da[a * 256 + t] = 0.f; }
+    const float g = dout[(int64_t)b * D + dd];
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int v = 0; v < V; ++v) {
+        const float x = vb[(int64_t)v * D + dd], gx = g * x;
+        float sv = 0.f;
+        for (int q = 0; q < Q; ++q) {
+            const float* wr = wb + v * w_sv + q * w_sq;
+            const float qq = qs[q * 256 + t];
+            float tq = 0.f;
+            for (int a = 0; a < A; ++a) {
+                const float ww = wr[a * w_sa];
+                tq = fmaf(ww, as[a * 256 + t], tq);
+                da[a * 256 + t] = fmaf(gx * qq, ww, da[a * 256 + t]);
+            }
+            sv = fmaf(qq, tq, sv);
+            dq[q * 256 + t] = fmaf(gx, tq, dq[q * 256 + t]);
+        }
+        if (live) dvt[((int64_t)b * V + v) * D + d] = g * sv;
+    }
+    if (live) {
+        for (int q = 0; q < Q; ++q) dqt[((int64_t)b * Q + q) * D + d] = dq[q * 256 + t];
+        for (int a = 0; a < A; ++a) dat[((int64_t)b * A + a) * D + d] = da[a * 256 + t];
+    }
+}
+// dw[b,v,q,a] = sum_d x[d] * qt[b,q,d] * at[b,a,d], x[d] = dout[b,d/kdiv] * vt[b,v,d]; also serves the bi pool (A = 1, at == NULL)
+constexpr int PQC = 4, PAC = 8;
+__global__ __launch_bounds__(256) void pool_dw_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                      const float* __restrict__ at, float* __restrict__ dw, int V, int Q, int A, int D, int kdiv) {
+    __shared__ float red[4][PQC * PAC];
+    const int bv = blockIdx.x, b = bv / V, t = threadIdx.x;
+    const float* vrow = vt + (int64_t)bv * D;
+    const float* qb = qt + (int64_t)b * Q * D;
+    const float* ab = at ? at + (int64_t)b * A * D : nullptr;
+    const float* go = dout + (int64_t)b * (D / kdiv);
+    for (int q0 = 0; q0 < Q; q0 += PQC)
+        for (int a0 = 0; a0 < A; a0 += PAC) {
+            float acc[PQC][PAC];
+#pragma unroll
+            for (int i = 0; i < PQC; ++i)
+#pragma unroll
+                for (int j = 0; j < PAC; ++j) acc[i][j] = 0.f;
+            for (int d = t; d < D; d += 256) {
+                const float x = go[d / kdiv] * vrow[d];
+                float av[PAC];
+#pragma unroll
+                for (int j = 0; j < PAC; ++j) av[j] = ab ? ((a0 + j < A) ? ab[(int64_t)(a0 + j) * D + d] : 0.f) : (j == 0 ? 1.f : 0.f);
+#pragma unroll
+                for (int i = 0; i < PQC; ++i) {
+                    const float xq = (q0 + i < Q) ? x * qb[(int64_t)(q0 + i) * D + d] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < PAC; ++j) acc[i][j] = fmaf(xq, av[j], acc[i][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PQC; ++i)
+#pragma unroll
+                for (int j = 0; j < PAC; ++j) {
+                    const float s = wave_sum(acc[i][j]);
+                    if ((t & 63) == 0) red[t >> 6][i * PAC + j] = s;
+                }
+            __syncthreads();
+            if (t < PQC * PAC) {
+                const int i = t / PAC, j = t % PAC;
+                if (q0 + i < Q && a0 + j < A) dw[((int64_t)bv * Q + q0 + i) * A + a0 + j] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            }
+            __syncthreads();
+        }
+}
+
+// bi pool backward (lane = d): out[b,n] = sum_{j<k} sum_v vt[v,nk+j] sum_q w[v,q] qt[q,nk+j]
+__global__ __launch_bounds__(256) void bi_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                          const float* __restrict__ w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                                                          float* __restrict__ dvt, float* __restrict__ dqt, int V, int Q, int D, int k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y, t = threadIdx.x, d = blockIdx.x * 256 + t;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float* qs = sm; float* dq = qs + Q * 256;
+    const float* qb = qt + (int64_t)b * Q * D; const float* vb = vt + (int64_t)b * V * D;
+    for (int q = 0; q < Q; ++q) { qs[q * 256 + t] = qb[(int64_t)q * D + dd]; dq[q * 256 + t] = 0.f; }
+    const int NO = D / k;
+    const float g = (dd / k < NO) ? dout[(int64_t)b * NO + dd / k] : 0.f;       // channels of a ragged tail get no gradient
+    if (w) {
+        const float* wb = w + (int64_t)b * w_sb;
+        for (int v = 0; v < V; ++v) {
+            const float gx = g * vb[(int64_t)v * D + dd];
+            float sv = 0.f;
+            for (int q = 0; q < Q; ++q) {
+                const float ww = wb[v * w_sv + q * w_sq];
+                sv = fmaf(ww, qs[q * 256 + t], sv);
+                dq[q * 256 + t] = fmaf(gx, ww, dq[q * 256 + t]);
+            }
+            if (live) dvt[((int64_t)b * V + v) * D + d] = g * sv;
+        }
+    } else {                                                   // w == 1
+        float sq = 0.f, sv = 0.f;
+        for (int q = 0; q < Q; ++q) sq += qs[q * 256 + t];
+        for (int v = 0; v < V; ++v) sv += vb[(int64_t)v * D + dd];
+        for (int v = 0; v < V; ++v) if (live) dvt[((int64_t)b * V + v) * D + d] = g * sq;
+        for (int q = 0; q < Q; ++q) dq[q * 256 + t] = g * sv;
+    }
+    if (live) for (int q = 0; q < Q; ++q) dqt[((int64_t)b * Q + q) * D + d] = dq[q * 256 + t];
+}
+
+// =====================================================================================================================
+// bilinear logits backward (lane = d).  logits[b,g,v,q] = hs * sum_d vt[v,d] h[g,d] qt[q,d] + hb[g]
+//   dvt[v,d] = hs sum_{g,q} dl h[g,d] qt[q,d];  dqt[q,d] = hs sum_{g,v} dl h[g,d] vt[v,d];
+//   dh_b[g,d] = hs sum_{v,q} dl vt[v,d] qt[q,d]   (per-sample partial of s * dL/dh_eff; summed over b afterwards)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void bi_logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                            const float* __restrict__ h, const float* __restrict__ h_scale,
+                                                            float* __restrict__ dvt, float* __restrict__ dqt, float* __restrict__ dhpart,
+                                                            int G, int V, int Q, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y, t = threadIdx.x, d = blockIdx.x * 256 + t;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float* vs = sm; float* qs = vs + V * 256; float* dv = qs + Q * 256; float* dq = dv + V * 256;
+    const float* vb = vt + (int64_t)b * V * D; const float* qb = qt + (int64_t)b * Q * D;
+    for (int v = 0; v < V; ++v) { vs[v * 256 + t] = vb[(int64_t)v * D + dd]; dv[v * 256 + t] = 0.f; }
+    for (int q = 0; q < Q; ++q) { qs[q * 256 + t] = qb[(int64_t)q * D + dd]; dq[q * 256 + t] = 0.f; }
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const float* dlb = dl + (int64_t)b * G * V * Q;
+    for (int g = 0; g < G; ++g) {
+        const float hh = h[(int64_t)g * D + dd] * hs;
+        float dh = 0.f;
+        for (int v = 0; v < V; ++v) {
+            const float x = vs[v * 256 + t];
+            float sv = 0.f;
+            for (int q = 0; q < Q; ++q) {
+                const float gl = dlb[((int64_t)g * V + v) * Q + q];
+                const float qq = qs[q * 256 + t];
+                sv = fmaf(gl, qq, sv);
+                dq[q * 256 + t] = fmaf(gl * hh, x, dq[q * 256 + t]);
+            }
+            dv[v * 256 + t] = fmaf(sv, hh, dv[v * 256 + t]);
+            dh = fmaf(sv, x, dh);
+        }
+        if (live) dhpart[((int64_t)b * G + g) * D + d] = dh * hs;
+    }
+    if (live) {
+        for (int v = 0; v < V; ++v) dvt[((int64_t)b * V + v) * D + d] = dv[v * 256 + t];
+        for (int q = 0; q < Q; ++q) dqt[((int64_t)b * Q + q) * D + d] = dq[q * 256 + t];
+    }
+}
+
+// out[r] = sum_c x[r, c]  (one wave per row)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += x[row * cols + c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+template <class K>
+int set_lds(K kern, size_t bytes, const char* what) {
+    if (bytes <= 64 * 1024) return CTI_OK;
+    if (bytes > 160 * 1024) return fail(CTI_E_SHAPE, "%s: needs %zu B of LDS (> 160 KiB)", what, bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? CTI_OK : fail((int)e, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
+                                       float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, void* stream) {
+    CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(dVr); CTI_REQUIRE_PTR(dQr); CTI_REQUIRE_PTR(dTeff_partial);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && R > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd: B=%d V=%d Q=%d R=%d G=%d", B, V, Q, R, G);
+    CTI_REQUIRE(hr == 4 || hr == 8 || hr == 16, CTI_E_UNSUPPORTED, "cti_paralind_mbuild_bwd: h/rank=%d (built for 4, 8, 16)", hr);
+    CTI_REQUIRE(Q * hr <= 1024, CTI_E_UNSUPPORTED, "cti_paralind_mbuild_bwd: Q*hr=%d > 1024", Q * hr);
+    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)Q * hr);
+    int groups = (256 + B - 1) / B; if (groups > R) groups = R;
+    const int rpb = (R + groups - 1) / groups;
+    dim3 grid((R + rpb - 1) / rpb, B);
+    int rc;
+#define CTI_MBB(H) rc = set_lds(mbuild_bwd_kernel<H>, lds, "cti_paralind_mbuild_bwd"); if (rc) return rc; \
+    hipLaunchKernelGGL(mbuild_bwd_kernel<H>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, G, rpb);
+    if (hr == 4) { CTI_MBB(4) } else if (hr == 8) { CTI_MBB(8) } else { CTI_MBB(16) }
+#undef CTI_MBB
+    return launch_status("cti_paralind_mbuild_bwd");
+}
+
+static void tri_chunks_b(int V, int64_t QA, int64_t* chunk_n, int* nchunk) {
+    const int64_t N = (int64_t)V * QA, c = 32768;
+    *nchunk = (int)((N + c - 1) / c); *chunk_n = c;
+}
+extern "C" size_t cti_softmax_tri_bwd_workspace_bytes(int B, int V, int64_t QA, int G) {
+    if (B <= 0 || V <= 0 || QA <= 0 || G <= 0) return 0;
+    int64_t cn; int nc; tri_chunks_b(V, QA, &cn, &nc);
+    return sizeof(float) * (size_t)B * nc * G;
+}
+extern "C" int cti_masked_softmax_tri_bwd(const float* p, const float* dp, float* dlogits, int B, int V, int64_t QA, int G, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(p); CTI_REQUIRE_PTR(dp); CTI_REQUIRE_PTR(dlogits); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && QA > 0 && G > 0 && G <= 64, CTI_E_SHAPE, "cti_masked_softmax_tri_bwd: B=%d V=%d QA=%lld G=%d", B, V, (long long)QA, G);
+    CTI_REQUIRE(workspace_bytes >= cti_softmax_tri_bwd_workspace_bytes(B, V, QA, G), CTI_E_WORKSPACE, "cti_masked_softmax_tri_bwd: workspace too small");
+    int64_t cn; int nc; tri_chunks_b(V, QA, &cn, &nc);
+    const int64_t N = (int64_t)V * QA, NG = N * G;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(tri_sm_bwd_partial, dim3(nc, B), dim3(256), 0, as_stream(stream), p, dp, part, N, G, cn, nc);
+    int rc = launch_status("cti_masked_softmax_tri_bwd/partial"); if (rc) return rc;
+    const int64_t nblk = (NG + 255) / 256;
+    hipLaunchKernelGGL(tri_sm_bwd_apply, dim3((unsigned)(nblk < 2048 ? nblk : 2048), B), dim3(256), 0, as_stream(stream), p, dp, part, dlogits, NG, G, nc);
+    return launch_status("cti_masked_softmax_tri_bwd/apply");
+}
+extern "C" int cti_masked_softmax_bi_bwd(const float* p, const float* dp, float* dlogits, int rows, int N, void* stream) {
+    CTI_REQUIRE_PTR(p); CTI_REQUIRE_PTR(dp); CTI_REQUIRE_PTR(dlogits);
+    CTI_REQUIRE(rows > 0 && N > 0, CTI_E_SHAPE, "cti_masked_softmax_bi_bwd: rows=%d N=%d", rows, N);
+    hipLaunchKernelGGL(bi_sm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), p, dp, dlogits, rows, N);
+    return launch_status("cti_masked_softmax_bi_bwd");
+}
+
+extern "C" int cti_tri_pool_bwd(const float* dout, const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                                int64_t w_sq, int64_t w_sa, float* dvt, float* dqt, float* dat, float* dw, int B, int V, int Q, int A, int D,
+                                void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w);
+    CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt); CTI_REQUIRE_PTR(dat);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && A > 0 && D > 0, CTI_E_SHAPE, "cti_tri_pool_bwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    const size_t lds = sizeof(float) * 256 * 2 * (size_t)(Q + A);
+    int rc = set_lds(tri_pool_bwd_kernel, lds, "cti_tri_pool_bwd"); if (rc) return rc;
+    hipLaunchKernelGGL(tri_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, at, w, w_sb, w_sv, w_sq, w_sa,
+                       dvt, dqt, dat, V, Q, A, D);
+    rc = launch_status("cti_tri_pool_bwd"); if (rc) return rc;
+    if (dw) {
+        hipLaunchKernelGGL(pool_dw_kernel, dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
+        rc = launch_status("cti_tri_pool_bwd/dw");
+    }
+    return rc;
+}
+
+extern "C" int cti_bi_pool_bwd(const float* dout, const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                               float* dvt, float* dqt, float* dw, int B, int V, int Q, int D, int k, void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && D > 0 && k > 0 && D >= k, CTI_E_SHAPE, "cti_bi_pool_bwd: B=%d V=%d Q=%d D=%d k=%d", B, V, Q, D, k);
+    const size_t lds = sizeof(float) * 256 * 2 * (size_t)Q;
+    int rc = set_lds(bi_pool_bwd_kernel, lds, "cti_bi_pool_bwd"); if (rc) return rc;
+    hipLaunchKernelGGL(bi_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, w, w_sb, w_sv, w_sq, dvt, dqt,
+                       V, Q, D, k);
+    rc = launch_status("cti_bi_pool_bwd"); if (rc) return rc;
+    if (dw && w) {
+        const int Du = (D / k) * k;                         // channels of a ragged tail take no part
+        hipLaunchKernelGGL(pool_dw_kernel, dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, (const float*)nullptr, dw, V, Q, 1, Du, k);
+        rc = launch_status("cti_bi_pool_bwd/dw");
+    }
+    return rc;
+}
+
+extern "C" int cti_bi_logits_bwd(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
+                                 float* dqt, float* dh_partial, float* dh_bias_partial, int B, int G, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(dlogits); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt);
+    CTI_REQUIRE_PTR(dh_partial); CTI_REQUIRE_PTR(dh_bias_partial);
+    CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_bwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
+    const size_t lds = sizeof(float) * 256 * 2 * (size_t)(V + Q);
+    int rc = set_lds(bi_logits_bwd_kernel, lds, "cti_bi_logits_bwd"); if (rc) return rc;
+    hipLaunchKernelGGL(bi_logits_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dlogits, vt, qt, h, h_scale, dvt, dqt,
+                       dh_partial, G, V, Q, D);
+    rc = launch_status("cti_bi_logits_bwd"); if (rc) return rc;
+    const int64_t rows = (int64_t)B * G;                    // dh_bias_partial[b,g] = sum_{v,q} dlogits[b,g,v,q]
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), dlogits, dh_bias_partial, rows, V * Q);
+    return launch_status("cti_bi_logits_bwd/bias");
+}

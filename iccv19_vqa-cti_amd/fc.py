@@ -15,12 +15,6 @@ from . import ops
 from . import autograd as AG
 
 
-def _grad_guard(*tensors):
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise NotImplementedError("the HIP backward kernels of the CTI path are not built yet: run under torch.no_grad() "
-                                  "(there is no eager-PyTorch fallback in this package)")
-
-
 class WNLinear(nn.Module):
     """weight_norm(nn.Linear(in, out), dim=None) as parameters only: bias (out), weight_g (), weight_v (out, in),
     registered in the order torch's weight_norm leaves them (bias, weight_g, weight_v)."""

@@ -426,3 +426,92 @@ def dropout(x, p, mask=None):
         return y, mask
     L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), 0, 0, 1, _stream()), "cti_dropout")
     return y
+
+
+def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
+    """-> dVr, dQr, dTeff (summed over the batch)."""
+    R, I, J, K, G = Teff.shape
+    B, V, _ = Vr.shape
+    Q = Qr.shape[1]
+    if not (I == J == K):
+        raise L.CtiError("M-build backward is built for cubic cores (hv = hq = ha)")
+    dM, Vr, Qr, Teff = dM.contiguous(), Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
+    dVr, dQr = torch.empty_like(Vr), torch.empty_like(Qr)
+    part = torch.empty((B,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
+    L.check(L.lib().cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
+                                            part.data_ptr(), B, V, Q, R, I, G, _stream()), "cti_paralind_mbuild_bwd")
+    dT = sum_batches(part, B, Teff.numel()).view(Teff.shape)
+    return dVr, dQr, dT
+
+
+def paralind_core_bwd(dout, M, Ar, prec=None):
+    """dout (B,V,Q,A,G), M (B,V,Q,G,K), Ar (B,A,K) -> dM, dAr: two batched NT GEMMs over transposed operands."""
+    B, V, Q, G, K = M.shape
+    A = Ar.shape[1]
+    VQG = V * Q * G
+    dout, M, Ar = dout.contiguous(), M.contiguous(), Ar.contiguous()
+    doutT = transpose(dout, A, G, B * V * Q, A * G)                       # (B*VQ, G, A): rows (vq,g), a contiguous
+    ArT = transpose(Ar, A, K, B, A * K)                                   # (B, K, A)
+    dM = gemm_nt(doutT.view(B * VQG, A), ArT.view(B * K, A), nb1=B, rA1=VQG, rB1=K, M=VQG, N=K, prec=prec)
+    dout2 = transpose(doutT, VQG, A, B, VQG * A)                          # (B, A, VQG)
+    Mt = transpose(M, VQG, K, B, VQG * K)                                 # (B, K, VQG)
+    dAr = gemm_nt(dout2.view(B * A, VQG), Mt.view(B * K, VQG), nb1=B, rA1=A, rB1=K, M=A, N=K, prec=prec)
+    return dM.view(B, V, Q, G, K), dAr.view(B, A, K)
+
+
+def masked_softmax_tri_bwd(p, dp):
+    B, V, Q, A, G = p.shape
+    p, dp = p.contiguous(), dp.contiguous()
+    dl = torch.empty_like(p)
+    lib = L.lib()
+    wsb = lib.cti_softmax_tri_bwd_workspace_bytes(B, V, Q * A, G)
+    ws = torch.empty(wsb, device=p.device, dtype=torch.uint8)
+    L.check(lib.cti_masked_softmax_tri_bwd(p.data_ptr(), dp.data_ptr(), dl.data_ptr(), B, V, Q * A, G, ws.data_ptr(), wsb, _stream()),
+            "cti_masked_softmax_tri_bwd")
+    return dl
+
+
+def masked_softmax_bi_bwd(p, dp):
+    B, G, V, Q = p.shape
+    p, dp = p.contiguous(), dp.contiguous()
+    dl = torch.empty_like(p)
+    L.check(L.lib().cti_masked_softmax_bi_bwd(p.data_ptr(), dp.data_ptr(), dl.data_ptr(), B * G, V * Q, _stream()), "cti_masked_softmax_bi_bwd")
+    return dl
+
+
+def tri_pool_bwd(dout, vt, qt, at, w, need_dw=True):
+    B, V, D = vt.shape
+    Q, A = qt.shape[1], at.shape[1]
+    dout, vt, qt, at = dout.contiguous(), vt.contiguous(), qt.contiguous(), at.contiguous()
+    dvt, dqt, dat = torch.empty_like(vt), torch.empty_like(qt), torch.empty_like(at)
+    dw = torch.empty((B, V, Q, A), device=vt.device, dtype=torch.float32) if need_dw else None
+    sb, sv, sq, sa = w.stride()
+    L.check(L.lib().cti_tri_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, dvt.data_ptr(),
+                                     dqt.data_ptr(), dat.data_ptr(), _ptr(dw), B, V, Q, A, D, _stream()), "cti_tri_pool_bwd")
+    return dvt, dqt, dat, dw
+
+
+def bi_pool_bwd(dout, vt, qt, w, k, need_dw=True):
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    dout, vt, qt = dout.contiguous(), vt.contiguous(), qt.contiguous()
+    dvt, dqt = torch.empty_like(vt), torch.empty_like(qt)
+    dw = torch.empty((B, V, Q), device=vt.device, dtype=torch.float32) if (need_dw and w is not None) else None
+    sb, sv, sq = w.stride() if w is not None else (0, 0, 0)
+    L.check(L.lib().cti_bi_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, dvt.data_ptr(), dqt.data_ptr(), _ptr(dw),
+                                    B, V, Q, D, k, _stream()), "cti_bi_pool_bwd")
+    return dvt, dqt, dw
+
+
+def bi_logits_bwd(dl, vt, qt, h, h_scale):
+    """-> dvt, dqt, G_h (G,D) = h_scale * dL/d(h_scale*h) summed over the batch, dh_bias (G,)."""
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    G = h.shape[0]
+    dl, vt, qt, h = dl.contiguous(), vt.contiguous(), qt.contiguous(), h.contiguous()
+    dvt, dqt = torch.empty_like(vt), torch.empty_like(qt)
+    hp = torch.empty((B, G, D), device=vt.device, dtype=torch.float32)
+    bp = torch.empty((B, G), device=vt.device, dtype=torch.float32)
+    L.check(L.lib().cti_bi_logits_bwd(dl.data_ptr(), vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), dvt.data_ptr(), dqt.data_ptr(),
+                                      hp.data_ptr(), bp.data_ptr(), B, G, V, Q, D, _stream()), "cti_bi_logits_bwd")
+    return dvt, dqt, sum_batches(hp, B, G * D).view(G, D), sum_batches(bp, B, G)

@@ -5,13 +5,20 @@ Same constructor / forward / forward_with_weights signatures, attributes and sta
 
 forward (src/tc.py:41-52): 3 Tucker projections (one MFMA GEMM each), the 3 x R rank nets as 3 packed h -> R*hr
 GEMMs with per-rank weight-norm scales in the epilogue, then T_eff scramble -> modes 1+2 (M build) -> mode 3 + rank
-sum as one batched MFMA GEMM.  ~700 torch launches of the reference become 12.
+sum as one batched MFMA GEMM.  Inference (no autograd, eval mode) is ONE C-ABI call (cti_tcnet_forward: ~700 torch
+launches of the reference become 24); under autograd the same kernels run op by op through autograd Functions whose
+backward is HIP as well.
 forward_with_weights (src/tc.py:54-61): 3 projections + one fused trilinear sum-pool kernel."""
 import torch
 import torch.nn as nn
 
 from . import ops
-from .fc import FCNet, _grad_guard
+from . import autograd as AG
+from .fc import FCNet
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
 
 class TCNet(nn.Module):
@@ -43,25 +50,35 @@ class TCNet(nn.Module):
         self.dropout = nn.Dropout(dropout[1])                 # constructed and unused, like tc.py:38
 
     # ---- packed rank nets: R x FCNet([h, hr]) == one (R*hr, h) GEMM with per-rank scale ---------------------------
+    @staticmethod
+    def _last_linear(net):
+        return net.main[-2] if isinstance(net.main[-1], nn.ReLU) else net.main[-1]
+
     def _rank_pack(self, nets):
-        lins = [n.main[-2] if isinstance(n.main[-1], nn.ReLU) else n.main[-1] for n in nets]
+        lins = [self._last_linear(n) for n in nets]
         wv = torch.cat([l.weight_v for l in lins], 0)                      # (R*hr, h)
         g = torch.stack([l.weight_g for l in lins])                        # (R,)
         b = torch.cat([l.bias for l in lins], 0)                           # (R*hr,)
         return wv, g, b
 
+    @staticmethod
+    def _drop_p(net):
+        return max([m.p for m in net.main if isinstance(m, nn.Dropout)] + [0.0])
+
     def _rank_proj(self, x, nets):
-        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in nets[0].main):
-            raise NotImplementedError("train-mode dropout of the CTI path is not built yet (eval mode only)")
         if self._act not in ('ReLU', ''):
             raise NotImplementedError("packed rank nets support act in {'ReLU', ''}")
+        relu = self._act == 'ReLU'
+        if self.training and self._drop_p(nets[0]) > 0:
+            # train mode: every rank net draws its OWN dropout mask on the shared input (src/fc.py:25-26 inside each of the R
+            # FCNets), so the R GEMMs cannot share one input; run them one by one (faithful, slower)
+            return torch.cat([n(x) for n in nets], -1)
         wv, g, b = self._rank_pack(nets)
+        if _needs_grad(x, wv, g, b):
+            return AG.WNLinearFn.apply(x, wv, g, b, relu, len(nets))
         hr = wv.shape[0] // len(nets)
         scale = ops.wn_scale(wv.view(len(nets), -1), g)
-        return ops.wn_linear(x, wv, scale, hr, b, relu=(self._act == 'ReLU'))
-
-    def _last_linear(self, net):
-        return net.main[-2] if isinstance(net.main[-1], nn.ReLU) else net.main[-1]
+        return ops.wn_linear(x, wv, scale, hr, b, relu)
 
     def _fused_args(self):
         """(tucker, rank) argument lists of ops.tcnet_forward; the packed rank weights are cached until a parameter
@@ -69,7 +86,8 @@ class TCNet(nn.Module):
         nets = (self.v_net, self.q_net, self.a_net)
         key = tuple((p.data_ptr(), p._version) for ns in nets for n in ns for p in n.parameters())
         if getattr(self, "_pack_key", None) != key:
-            self._pack = [tuple(t.detach() for t in self._rank_pack(ns)) for ns in nets]
+            with torch.no_grad():
+                self._pack = [tuple(t.detach() for t in self._rank_pack(ns)) for ns in nets]
             self._pack_key = key
         tucker = []
         for net in (self.v_tucker, self.q_tucker, self.a_tucker):
@@ -77,13 +95,12 @@ class TCNet(nn.Module):
             tucker.append((l.weight_v.detach(), l.weight_g.detach(), l.bias.detach()))
         return tucker, self._pack
 
-    def _fusable(self):
-        return (self._act in ('ReLU', '') and not self.training and all(len([m for m in n.main if hasattr(m, "weight_v")]) == 1
-                for n in (self.v_tucker, self.q_tucker, self.a_tucker)))
+    def _fusable(self, *inputs):
+        return (self._act in ('ReLU', '') and not self.training and not _needs_grad(*inputs, *self.parameters())
+                and all(len([m for m in n.main if hasattr(m, "weight_v")]) == 1 for n in (self.v_tucker, self.q_tucker, self.a_tucker)))
 
     def forward(self, v, q, a, _want_mask=False):
-        _grad_guard(v, q, a, self.T_g)
-        if self._fusable():
+        if self._fusable(v, q, a):
             tucker, rank = self._fused_args()
             res = ops.tcnet_forward(v.float(), q.float(), a.float(), tucker, rank, self.T_g.detach(), relu=(self._act == 'ReLU'),
                                     want_mask=_want_mask)
@@ -99,16 +116,23 @@ class TCNet(nn.Module):
         T = self.T_g
         if T.size(6) != 1:
             raise RuntimeError("TCNet.forward: h_out must be 1 (src/Tensor.py:6 cannot view the core otherwise)")
-        Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
-        M = ops.paralind_mbuild(Vr, Qr, Teff)
-        f_emb = ops.paralind_core(M, Ar)                       # (B,V,Q,A,G)
+        if _needs_grad(Vr, Qr, Ar, T):
+            Teff = AG.TeffFn.apply(T)
+            M = AG.MBuildFn.apply(Vr, Qr, Teff)
+            f_emb = AG.CoreFn.apply(M, Ar)
+        else:
+            Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
+            M = ops.paralind_mbuild(Vr, Qr, Teff)
+            f_emb = ops.paralind_core(M, Ar)                   # (B,V,Q,A,G)
         if _want_mask:
             return f_emb.squeeze(4), ops.zero_row_mask(v)
         return f_emb.squeeze(4)
 
     def forward_with_weights(self, v, q, a, w):
-        _grad_guard(v, q, a, w)
         v_ = self.v_tucker(v)                                  # b x v x d
         q_ = self.q_tucker(q)
         a_ = self.a_tucker(a)
-        return ops.tri_pool(v_, q_, a_, w.float())
+        w = w.float()
+        if _needs_grad(v_, q_, a_, w):
+            return AG.TriPoolFn.apply(v_, q_, a_, w)
+        return ops.tri_pool(v_, q_, a_, w)

@@ -184,6 +184,31 @@ int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uin
 int cti_wn_bwd(const float* G, const float* weight_v, const float* weight_g, float* dweight_v, float* dweight_g, int n_mats,
                int64_t elems, void* stream);
 
+/* Backward of cti_paralind_mbuild_fwd (hr = I = J = K in {4, 8, 16}).  dM (B,V,Q,G,R*hr); dVr (B,V,R*hr); dQr (B,Q,R*hr);
+ * dTeff_partial (B,R,hr,hr,hr,G): per-sample partials of dT_eff -- sum them with cti_sum_batches, then map to T_g's layout with
+ * cti_teff_scramble(inverse = 1). */
+int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
+                            float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, void* stream);
+
+/* Softmax backward, dlogits = p * (dp - sum_axis p * dp).  Tri: p, dp, dlogits (B, V*QA, G), axis = V*QA per (b,g).
+ * Bi: rows x N contiguous, axis = N.  Masked positions have p = 0 and therefore receive 0. */
+int cti_masked_softmax_tri_bwd(const float* p, const float* dp, float* dlogits, int B, int V, int64_t QA, int G, void* workspace,
+                               size_t workspace_bytes, void* stream);
+size_t cti_softmax_tri_bwd_workspace_bytes(int B, int V, int64_t QA, int G);
+int cti_masked_softmax_bi_bwd(const float* p, const float* dp, float* dlogits, int rows, int N, void* stream);
+
+/* Backward of cti_tri_pool_fwd: dvt (B,V,D), dqt (B,Q,D), dat (B,A,D), dw (B,V,Q,A) contiguous or NULL. */
+int cti_tri_pool_bwd(const float* dout, const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                     int64_t w_sq, int64_t w_sa, float* dvt, float* dqt, float* dat, float* dw, int B, int V, int Q, int A, int D,
+                     void* stream);
+/* Backward of cti_bi_pool_fwd: dout (B, D/k); dvt (B,V,D), dqt (B,Q,D), dw (B,V,Q) contiguous or NULL. */
+int cti_bi_pool_bwd(const float* dout, const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                    float* dvt, float* dqt, float* dw, int B, int V, int Q, int D, int k, void* stream);
+/* Backward of cti_bi_logits_fwd.  dvt (B,V,D), dqt (B,Q,D); dh_partial (B,G,D) = per-sample partials of h_scale * dL/d(h_scale*h)
+ * (sum over B = the `G` argument of cti_wn_bwd, or dL/dh itself when h_scale is NULL); dh_bias_partial (B,G). */
+int cti_bi_logits_bwd(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
+                      float* dqt, float* dh_partial, float* dh_bias_partial, int B, int G, int V, int Q, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

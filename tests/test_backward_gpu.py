@@ -84,3 +84,100 @@ def test_dropout_mask_statistics_and_backward():
     y2 = cti_amd.pkg.autograd.dropout(x, 0.3, True)                  # a fresh mask every call
     assert not torch.equal(y2 != 0, y != 0)
     assert cti_amd.pkg.autograd.dropout(x, 0.3, False) is x          # eval mode: identity
+
+
+def _tri(fx):
+    c = fx.cfg
+    return load_into(cti_amd.TriAttention(c["v_dim"], c["q_dim"], c["a_dim"], c["h_dim"], 1, c["rank"], c["glimpse"], c["k"]), fx.p)
+
+
+@pytest.mark.parametrize("name", ["g3_tcnet_small", "g3_tcnet_g3_odd"])
+def test_tcnet_forward_backward(name):
+    fx = gu.load(name)
+    m = _tri(fx)
+    v, q, a = T(fx.i["v"], True), T(fx.i["q"], True), T(fx.i["a"], True)
+    raw = m.TriAtt(v, q, a)
+    check(raw, fx.o["raw"], what=name + " forward under autograd")
+    (raw * T(fx.i["cot_raw"])).sum().backward()
+    for n_, t_ in (("v", v), ("q", q), ("a", a)):
+        check(t_.grad, fx.g[n_], what="%s d%s" % (name, n_))
+    check_param_grads(m, fx)
+
+
+def test_triattention_backward_through_softmax():
+    fx = gu.load("g8_triattention_grad")
+    m = _tri(fx)
+    v, q, a = T(fx.i["v"], True), T(fx.i["q"], True), T(fx.i["a"], True)
+    p, logits = m(v, q, a)
+    check(p, fx.o["p"], what="p under autograd")
+    assert np.array_equal(np.isneginf(logits.detach().cpu().numpy()), np.isneginf(fx.o["logits"]))
+    (p * T(fx.i["cot_p"])).sum().backward()
+    for n_, t_ in (("v", v), ("q", q), ("a", a)):
+        check(t_.grad, fx.g[n_], what="d%s" % n_)
+    check_param_grads(m, fx)
+
+
+@pytest.mark.parametrize("name", ["g5_tcnet_fww_k2", "g5_tcnet_fww_k1"])
+def test_tcnet_forward_with_weights_backward(name):
+    fx = gu.load(name)
+    c = fx.cfg
+    m = load_into(cti_amd.TCNet(c["v_dim"], c["q_dim"], c["a_dim"], c["h_dim"], 1, c["rank"], c["glimpse"], dropout=[.2, .5], k=c["k"]), fx.p)
+    v, q, a, att = T(fx.i["v"], True), T(fx.i["q"], True), T(fx.i["a"], True), T(fx.i["att"], True)
+    out = m.forward_with_weights(v, q, a, att[:, :, :, :, 1])
+    check(out, fx.o["out_g1"], what=name)
+    (out * T(fx.i["cot"])).sum().backward()
+    for n_, t_ in (("v", v), ("q", q), ("a", a), ("att", att)):
+        check(t_.grad, fx.g[n_], what="%s d%s" % (name, n_))
+    check_param_grads(m, fx)
+
+
+@pytest.mark.parametrize("name", ["g6_bcnet_hnone_k1", "g6_bcnet_h2_k3", "g6_bcnet_h40_k1"])
+def test_bcnet_backward(name):
+    fx = gu.load(name)
+    c = fx.cfg
+    m = load_into(cti_amd.BCNet(c["v_dim"], c["q_dim"], c["h_dim"], c["h_out"], k=c["k"]), fx.p)
+    v, q = T(fx.i["v"], True), T(fx.i["q"], True)
+    out = m(v, q)
+    check(out, fx.o["fwd"], what=name + " forward")
+    (out * T(fx.i["cot_fwd"])).sum().backward()
+    check(v.grad, fx.g["fwd/v"], what=name + " fwd dv")
+    check(q.grad, fx.g["fwd/q"], what=name + " fwd dq")
+    check_param_grads(m, fx, prefix="fwd/p/")
+    m.zero_grad()
+    v, q, w = T(fx.i["v"], True), T(fx.i["q"], True), T(fx.i["w"], True)
+    out = m.forward_with_weights(v, q, w[:, 1])
+    check(out, fx.o["fww"], what=name + " fww")
+    (out * T(fx.i["cot_fww"])).sum().backward()
+    check(v.grad, fx.g["fww/v"], what=name + " fww dv")
+    check(q.grad, fx.g["fww/q"], what=name + " fww dq")
+    check(w.grad, fx.g["fww/w"], what=name + " fww dw")
+    check_param_grads(m, fx, prefix="fww/p/")
+
+
+@pytest.mark.parametrize("name", ["g7_biattention_g2", "g7_biattention_g8", "g7_biattention_nomask"])
+def test_biattention_backward(name):
+    fx = gu.load(name)
+    c = fx.cfg
+    m = load_into(cti_amd.BiAttention(c["x_dim"], c["y_dim"], c["z_dim"], c["glimpse"]), fx.p)
+    v, q = T(fx.i["v"], True), T(fx.i["q"], True)
+    p, logits = m.forward_all(v, q, c["v_mask"])
+    check(p, fx.o["p"], what=name + " p")
+    (p * T(fx.i["cot_p"])).sum().backward()
+    check(v.grad, fx.g["v"], what=name + " dv")
+    check(q.grad, fx.g["q"], what=name + " dq")
+    check_param_grads(m, fx)
+
+
+def test_train_mode_runs_with_dropout_and_gives_gradients_to_every_parameter():
+    """The reference's Trainer raises if any trainable parameter has no gradient (src/FFOE/trainer.py:239-241)."""
+    fx = gu.load("g3_tcnet_small")
+    m = _tri(fx).train()
+    v, q, a = T(fx.i["v"]), T(fx.i["q"], True), T(fx.i["a"], True)
+    torch.manual_seed(0)
+    p, logits = m(v, q, a)
+    assert p.shape == fx.o["p"].shape
+    ok = ~torch.isnan(p)
+    p[ok].sum().backward() if False else (p.nan_to_num() * torch.randn_like(p)).sum().backward()
+    for n_, prm in m.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), n_
+    assert q.grad is not None and a.grad is not None

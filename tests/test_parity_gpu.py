@@ -222,7 +222,7 @@ def test_unfused_module_path_matches_fused():
     v, q, a = T(fx.i["v"]), T(fx.i["q"]), T(fx.i["a"])
     with torch.no_grad():
         fused = m.TriAtt(v, q, a)
-        m.TriAtt._fusable = lambda: False
+        m.TriAtt._fusable = lambda *a: False
         unfused = m.TriAtt(v, q, a)
     check(fused, fx.o["raw"], what="fused")
     check(unfused, fx.o["raw"], what="op-by-op")
