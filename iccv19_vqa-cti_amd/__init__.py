@@ -11,6 +11,7 @@ from .attention import BiAttention, TriAttention, StackedAttention   # noqa: F40
 from .Tensor import ModeProduct                                # noqa: F401
 from .ops import set_precision, get_precision                  # noqa: F401
 from ._lib import CtiError                                     # noqa: F401
+from .dp import FlatAdamaxDP                                   # noqa: F401
 
 __all__ = ["FCNet", "WNLinear", "TCNet", "BCNet", "BiAttention", "TriAttention", "StackedAttention", "ModeProduct",
-           "ops", "set_precision", "get_precision", "CtiError"]
+           "ops", "set_precision", "get_precision", "CtiError", "FlatAdamaxDP"]

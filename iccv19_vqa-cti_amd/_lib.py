@@ -40,6 +40,9 @@ SIGNATURES = {
     "cti_tri_pool_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_flat_scale_sumsq": (_int, [_vp, _i64, C.c_float, _vp, _vp]),
+    "cti_adamax_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _int, _vp, _vp]),
+    "cti_optim_workspace_bytes": (_sz, []),
     "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _vp]),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),

@@ -1,0 +1,83 @@
+"""Data-parallel training step for models built on the CTI modules.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  All trainable parameters, their gradients and the
+Adamax state live in FOUR flat fp32 buffers; `param.data` and `param.grad` are views into them, so
+  * backward accumulates straight into the flat gradient buffer (no pack / unpack copies: the reference's
+    _get_flat_grads / _set_flat_grads, src/FFOE/trainer.py:245-263, disappear),
+  * ONE all-reduce(sum) of that buffer is the only communication of the step,
+  * scale by 1/(world*update_freq), global-norm clip and the Adamax update are two HIP kernels with no host sync
+    (the reference blocks on grad_norm.item(), src/utils.py:324).
+Semantics restated from the reference: loss is divided by the LOCAL batch (trainer.py:189-190), gradients are summed over ranks
+and divided by world_size * update_freq, clip coefficient max_norm / (norm + 1e-6) applied only when < 1 (utils.py:323-328),
+Adamax with betas (0.9, 0.999), eps 1e-8, no weight decay (torch.optim.Adamax defaults, train.py:34)."""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+class FlatAdamaxDP:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_norm=0.25, update_freq=1, process_group=None):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise L.CtiError("FlatAdamaxDP runs on the GPU only (HIP update kernels, RCCL all-reduce)")
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise TypeError("all trainable parameters must be fp32 on one device")
+        self.n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(self.n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        self.exp_inf = torch.zeros(self.n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:                                   # named_parameters() order, like Trainer._get_flat_grads
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            off += k
+        lib = L.lib()
+        self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.lr, self.betas, self.eps, self.clip_norm, self.update_freq = lr, betas, eps, clip_norm, update_freq
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.step_count = 0
+
+    def broadcast_parameters(self, src=0):
+        """Identical initial parameters on every rank: one broadcast of the flat buffer."""
+        if self.world > 1:
+            dist.broadcast(self.flat_p, src=src, group=self.pg)
+
+    def zero_grad(self):
+        self.flat_g.zero_()                                     # grads stay views of the flat buffer (set_to_none would detach them)
+
+    def check_grads_are_views(self):
+        lo, hi = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.n
+        for p in self.params:
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                raise RuntimeError("a parameter's .grad left the flat buffer (zero_grad(set_to_none=True) or an optimizer touched it)")
+
+    def step(self):
+        """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm."""
+        self.check_grads_are_views()
+        if self.world > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
+        self.step_count += 1
+        st = torch.cuda.current_stream().cuda_stream
+        lib = L.lib()
+        L.check(lib.cti_flat_scale_sumsq(self.flat_g.data_ptr(), self.n, 1.0 / (self.world * self.update_freq), self.partial.data_ptr(), st),
+                "cti_flat_scale_sumsq")
+        L.check(lib.cti_adamax_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.n,
+                                    self.partial.data_ptr(), float(self.clip_norm), float(self.lr), self.betas[0], self.betas[1], self.eps,
+                                    self.step_count, self.grad_norm.data_ptr(), st), "cti_adamax_step")
+        return self.grad_norm
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_inf": self.exp_inf, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_inf.copy_(sd["exp_inf"]); self.lr = sd.get("lr", self.lr)

@@ -209,6 +209,18 @@ int cti_bi_pool_bwd(const float* dout, const float* vt, const float* qt, const f
 int cti_bi_logits_bwd(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
                       float* dqt, float* dh_partial, float* dh_bias_partial, int B, int G, int V, int Q, int D, void* stream);
 
+/* ---- data-parallel update -------------------------------------------------------------------------------
+ * What follows the single RCCL all-reduce of the flat gradient buffer; replaces Trainer._all_reduce_and_rescale + _opt
+ * (src/FFOE/trainer.py:221-269), utils.clip_grad_norm_ (src/utils.py:323-328) and torch.optim.Adamax.step (src/FFOE/train.py:34).
+ * grad *= inv_denom in place, partial[0..1023] = per-workgroup sums of squares (workspace of cti_optim_workspace_bytes()). */
+int cti_flat_scale_sumsq(float* grad, int64_t n, float inv_denom, float* partial, void* stream);
+/* norm = sqrt(sum partial); coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping); g' = coef * grad;
+ * exp_avg = b1*exp_avg + (1-b1)*g'; exp_inf = max(b2*exp_inf, |g'| + eps); param -= lr / (1 - b1^step) * exp_avg / exp_inf.
+ * grad_norm_out: NULL or one float (the pre-clip norm, for logging without a blocking .item() in the step). */
+int cti_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_inf, int64_t n, const float* partial, float max_norm,
+                    float lr, float beta1, float beta2, float eps, int step, float* grad_norm_out, void* stream);
+size_t cti_optim_workspace_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,138 @@
+"""Data-parallel training step on a small CTI model: flat buffers + fused HIP update vs the reference recipe
+(loss / B_local, flat grads / denom, clip max_norm/(norm+1e-6), torch.optim.Adamax), and N ranks == 1 rank on the whole batch.
+Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import cti_amd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class TinyCTI(nn.Module):
+    """The shape of CTIModel.forward (src/FFOE/base_model.py:112-136) without the language model: TriAttention, one t_net
+    pooling per glimpse with residual projections, sum, linear classifier (stock torch, outside the CTI path)."""
+
+    def __init__(self, vd=48, qd=40, ad=40, h=32, R=4, G=2, ncls=7):
+        super().__init__()
+        self.G = G
+        self.t_att = cti_amd.TriAttention(vd, qd, ad, h, 1, R, G, 1, dropout=[0.0, 0.0])
+        self.t_net = nn.ModuleList([cti_amd.TCNet(vd, qd, ad, qd // 2, 1, R, 1, k=2, dropout=[0.0, 0.0]) for _ in range(G)])
+        self.q_prj = nn.ModuleList([cti_amd.FCNet([qd, qd], "", 0.0) for _ in range(G)])
+        self.a_prj = nn.ModuleList([cti_amd.FCNet([qd, ad], "", 0.0) for _ in range(G)])
+        self.cls = nn.Linear(qd, ncls)
+
+    def forward(self, v, q, a):
+        att, _ = self.t_att(v, q, a)
+        for g in range(self.G):
+            b = self.t_net[g].forward_with_weights(v, q, a, att[:, :, :, :, g])
+            q = self.q_prj[g](b.unsqueeze(1)) + q
+            a = self.a_prj[g](b.unsqueeze(1)) + a
+        return self.cls(q.sum(1) + a.sum(1))
+
+
+def make_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(B, 6, 48, generator=g).abs()
+    v[:, 4:] = 0
+    q = torch.tanh(torch.randn(B, 5, 40, generator=g))
+    a = torch.tanh(torch.randn(B, 3, 40, generator=g))
+    y = (torch.rand(B, 7, generator=g) > 0.7).float()
+    return v, q, a, y
+
+
+def loss_fn(logits, y):
+    return nn.functional.binary_cross_entropy_with_logits(logits, y, reduction="sum") / logits.size(0)    # trainer.py:189-190
+
+
+def test_single_rank_matches_reference_recipe():
+    cti_amd.set_precision("fp32")
+    try:
+        torch.manual_seed(11)
+        m1 = TinyCTI().to(DEV)
+        m2 = TinyCTI().to(DEV)
+        m2.load_state_dict(m1.state_dict())
+        opt1 = cti_amd.FlatAdamaxDP(m1, lr=2e-3, clip_norm=0.25)
+        opt2 = torch.optim.Adamax(m2.parameters(), lr=2e-3)
+        for step in range(3):
+            v, q, a, y = (t.to(DEV) for t in make_batch(8, 100 + step))
+            opt1.zero_grad()
+            loss_fn(m1(v, q, a), y).backward()
+            gn = opt1.step()
+            opt2.zero_grad()
+            loss_fn(m2(v, q, a), y).backward()
+            flat = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+            norm = flat.norm()
+            coef = 0.25 / (norm + 1e-6)                                 # src/utils.py:323-328
+            if coef < 1:
+                for p in m2.parameters():
+                    p.grad.mul_(coef)
+            opt2.step()
+            assert abs(float(gn) - float(norm)) < 1e-4 * float(norm)
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert n1 == n2
+            assert torch.allclose(p1, p2, rtol=1e-4, atol=2e-6), n1
+    finally:
+        cti_amd.set_precision("bf16x3")
+
+
+def _rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)        # one GPU on the test box: gloo between two processes on cuda:0
+    import cti_amd as c
+    c.set_precision("fp32")
+    torch.manual_seed(11)
+    m = TinyCTI().to(DEV)
+    opt = c.FlatAdamaxDP(m, lr=2e-3, clip_norm=0.25)
+    opt.broadcast_parameters()
+    for step in range(2):
+        v, qq, a, y = make_batch(8, 100 + step)
+        sl = slice(rank * 4, rank * 4 + 4)                              # this rank's shard of the global batch
+        opt.zero_grad()
+        loss_fn(m(v[sl].to(DEV), qq[sl].to(DEV), a[sl].to(DEV)), y[sl].to(DEV)).backward()
+        opt.step()
+    q.put((rank, opt.flat_p.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_the_whole_batch():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict(q.get(timeout=240) for _ in range(2))
+    except Exception:
+        for p in procs:
+            p.kill()
+        pytest.skip("gloo cannot all-reduce device tensors between two processes on this box")
+    for p in procs:
+        p.join(timeout=60)
+    assert np.array_equal(res[0], res[1])                                # replicas stay bit-identical
+    cti_amd.set_precision("fp32")
+    try:
+        torch.manual_seed(11)
+        m = TinyCTI().to(DEV)
+        opt = cti_amd.FlatAdamaxDP(m, lr=2e-3, clip_norm=0.25)
+        for step in range(2):
+            v, qq, a, y = (t.to(DEV) for t in make_batch(8, 100 + step))
+            opt.zero_grad()
+            loss_fn(m(v, qq, a), y).backward()                            # whole batch, loss / B_global
+            opt.step()
+        one = opt.flat_p.cpu().numpy()
+    finally:
+        cti_amd.set_precision("bf16x3")
+    assert np.allclose(res[0], one, rtol=2e-4, atol=2e-6)                # equal up to fp32 reduction order
