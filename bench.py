@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
-    ap.add_argument("--precision", default=os.environ.get("CTI_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("CTI_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
                     help="bf16x3 (default): 3-term split-bf16 MFMA, fp32-grade (1e-5 vs the float64 oracle); fp32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -168,12 +168,15 @@ def main():
             tj = json.load(open(tf))
             traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         mfma_per_flop = 3.0 if args.precision == "bf16x3" else 1.0
+        if args.precision == "bf16":
+            res_note = "plain-bf16 mode is NOT the BASELINE metric (configs[1] is fp32): reported for reference only"
         res = {
             "metric": "CTI fused-forward samples/sec at B=256 (V=36x2048)",
             "value": whole_job_rate(world, c["B"], args.steps, el), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (bf16x3 split products, f32 accumulate)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 split products, f32 accumulate)", "bf16": "bf16 products, f32 accumulate"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: TCNet.forward fp32, B=%d/GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, "
                                    "h_mm=512, glimpse=2" % c["B"], "global_batch": world * c["B"], "precision": args.precision,
                        "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
@@ -189,7 +192,7 @@ def main():
             "whole_step_tflops": fl["total"] * c["B"] * args.steps / el / 1e12,
             "kernel_ms": kern,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(c, state, SEED, args.cpu_budget)
         print(json.dumps(res))

@@ -85,6 +85,7 @@ struct PlaneGemmP {
     int64_t sC1, sC2;                          // batch strides of C (elements) / of the output planes (rows)
     int nb2;
     int M, N, Kp;
+    int total_tiles;
     const float* scale; int scale_div; const float* bias; int relu;
     // EPI_PLANES: the result is written as chunk-major bf16 hi/lo planes (columns N..Np-1 zero-filled) instead of fp32
     unsigned short* Ph; unsigned short* Pl; int64_t pitchP; int Np;
@@ -150,8 +151,12 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int wm = wid / WN, wn = wid % WN;
     const int tiles_n = ((EPI == EPI_PLANES ? p.Np : p.N) + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
+    // Persistent tile loop: the grid is at most one workgroup per CU (a 128-KiB ring leaves room for one anyway); workgroup w
+    // walks tiles w, w + grid, ... -- with the grid a multiple of 8 these keep w's XCD, so tile_coords' L2 chunking holds.
+    // It removes the relaunch gap between consecutive tiles of a CU (52 tiles per CU on the mode-3 GEMM).
+    for (int vtile = blockIdx.x; vtile < p.total_tiles; vtile += gridDim.x) {
     int z, tm, tn;
-    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, z, tm, tn);
+    tile_coords(vtile, p.total_tiles, tiles_m, tiles_n, z, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int b1 = z / p.nb2, b2 = z % p.nb2;
     const int64_t pitchA = p.pitchA, pitchB = p.pitchB;                 // locals: lambdas must not capture the argument struct
@@ -244,9 +249,10 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         pos = pos == NG - 1 ? 0 : pos + 1;
     }
     __syncthreads();                              // every wave is done reading the ring before the epilogue reuses it
-    if (loader) return;
+    if (!loader) {
 
     const int64_t boff = b1 * p.sC1 + b2 * p.sC2;
+    do {
     if (EPI == EPI_PLANES || EPI == EPI_F32) {
         // Staged epilogue, 64 columns of the wave's sub-tile at a time.  The wave parks a (TM*32) x 64 fp32 block in its own
         // slice of the (now idle) LDS ([row][16 slots of 16 B], slot ^= row & 1: conflict-free for the ds_write_b32 column
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 }
             }
         }
-        return;
+        break;
     }
     float* C = p.C + boff;
     if (EPI == EPI_INTERLEAVE2) {
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 }
             }
         }
-        return;
+        break;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -357,6 +363,10 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             }
         }
     }
+    } while (0);
+    }                                             // !loader
+    __syncthreads();                              // the staged epilogue's LDS slices are free again before the next tile's DMA
+    }                                             // persistent tile loop
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -387,7 +397,17 @@ int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
     }
     const long long total = nb * ((p.M + G::BM - 1) / G::BM) * ((ncols + G::BN - 1) / G::BN);
     if (total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm_nt_planes: %lld tiles exceed the grid", total);
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(G::NTHR), G::LDS, st, p);
+    PlaneGemmP q = p;
+    q.total_tiles = (int)total;
+    static thread_local int n_cu = 0;
+    if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+#ifndef CTI_PERSIST
+#define CTI_PERSIST 1
+#endif
+    const int per_cu = G::LDS > 80 * 1024 ? 1 : 2;                      // workgroups that fit a CU's 160 KiB of LDS
+    long long grid = CTI_PERSIST ? (long long)n_cu * per_cu : total;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NTHR), G::LDS, st, q);
     return launch_status("gemm_nt_planes");
 }
 

@@ -17,8 +17,7 @@ namespace {
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-constexpr int MB_ITEMS = 4;      // step-1 work items per thread the fast path supports (HR^2*G*ceil(V/8) <= 4096)
-constexpr int MB_ROWS = 2;       // output rows per thread (V*Q*G <= 2048)
+constexpr int MB_ROWS = 2;       // step-2 work items (row pairs) per thread: V*G*ceil(Q/2) <= 2048
 
 template <int HR, bool PLANES>
 __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
@@ -34,7 +33,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
     float* Xs = Ts + HR * inner;                 // [V][G][HR(j)][HR(k)]
     float* Vs = Xs + (size_t)V * G * HH;         // [V][HR]
     float* Qs = Vs + (V + 8) * HR;               // [HR(j)][Qpad]  (8 slack rows behind Vs: step 1 reads v0..v0+7 unguarded)
-    const int Qpad = Q | 1;
+    const int Qpad = (Q + 1) | 1;
     const int t = threadIdx.x;
     constexpr int nthr = 1024;
     const int b = blockIdx.y;
@@ -46,26 +45,26 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
 
     // ---- everything that does not depend on the rank is decoded ONCE (runtime integer divisions cost ~40 instructions
     // each; inside the rank loop they outweighed the FMAs 7:1) -----------------------------------------------------------
-    // step-1 items: (column c of T_eff, chunk of 8 v)
-    const int nvc = (V + 7) / 8, nitems = inner * nvc;
-    int it_c[MB_ITEMS], it_v0[MB_ITEMS], it_x[MB_ITEMS];
-#pragma unroll
-    for (int n = 0; n < MB_ITEMS; ++n) {
-        const int it = t + n * nthr;
-        const int c = it % inner, v0 = (it / inner) * 8;
+    // step-1 item: (column c of T_eff, v range [v0, v0 + vspan)); the 1024 threads cover inner columns x nsplit v ranges
+    const int nsplit = max(1, nthr / inner), vspan = (V + nsplit - 1) / nsplit;
+    int it_c[1], it_v0[1], it_x[1];
+    {
+        const int c = t % inner, sp = t / inner;
         const int g = c % G, k = (c / G) % HR, j = c / (G * HR);
-        it_c[n] = it < nitems ? c : -1;
-        it_v0[n] = v0;
-        it_x[n] = (v0 * G + g) * HH + j * HR + k;              // X offset of (v0, g, j, k); +G*HH per v
+        it_c[0] = (sp < nsplit && sp * vspan < V) ? c : -1;
+        it_v0[0] = sp * vspan;
+        it_x[0] = (sp * vspan * G + g) * HH + j * HR + k;       // X offset of (v0, g, j, k); +G*HH per v
     }
-    // step-2 rows: lane order (v, g, q), q fastest: a 16-lane group shares its X row (LDS broadcast)
+    // step-2 work item: rows (v, q, g) and (v, q+1, g); lane order (v, g, q-pair), q-pair fastest: a 16-lane group mostly
+    // shares its X row (LDS broadcast)
+    const int QP = (Q + 1) / 2, items2 = V * G * QP;
     int row_x[MB_ROWS], row_q[MB_ROWS];
     int64_t row_o[MB_ROWS];
 #pragma unroll
     for (int n = 0; n < MB_ROWS; ++n) {
         const int lr = t + n * nthr;
-        const int lq = lr % Q, lg = (lr / Q) % G, lv = lr / (Q * G);
-        row_q[n] = lr < rows ? lq : -1;
+        const int lq = (lr % QP) * 2, lg = (lr / QP) % G, lv = lr / (QP * G);
+        row_q[n] = lr < items2 ? lq : -1;
         row_x[n] = (lv * G + lg) * HH;
         row_o[n] = (int64_t)b * rows + ((int64_t)lv * Q + lq) * G + lg;     // output row in the (v,q,g) order of the mode-3 GEMM
     }
@@ -100,76 +99,82 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
         if (qe >= 0) Qs[qdst] = qpre;
         __syncthreads();
         if (r + 1 < r_hi) CTI_MB_PREFETCH(r + 1)              // next rank's operands fly under this rank's FMAs
-        // step 1:  X[v][g][j][k] = sum_i T_eff[r][i][j,k,g] * Vr[v][i]
-#pragma unroll
-        for (int n = 0; n < MB_ITEMS; ++n) {
-            const int c = it_c[n];
+        // step 1:  X[v][g][j][k] = sum_i T_eff[r][i][j,k,g] * Vr[v][i].  A thread owns ONE column c = (j,k,g) of T_eff[r] (its HR
+        // values stay in registers) and half of the v range; Vr[v][0..HR) is wave-uniform, so it is read from global memory
+        // through the scalar path (s_load -> SGPR operands of the FMAs): no LDS broadcast traffic at all.
+        {
+            const int c = it_c[0];
             if (c >= 0) {
-            const int v0 = it_v0[n];
-            float x[8];
+                float tc[HR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = 0.f;
-#pragma unroll 1
-            for (int i4 = 0; i4 < HR; i4 += 4) {
-                const float t0 = Ts[(i4 + 0) * inner + c], t1 = Ts[(i4 + 1) * inner + c];
-                const float t2 = Ts[(i4 + 2) * inner + c], t3 = Ts[(i4 + 3) * inner + c];
-                const float* vrow = Vs + v0 * HR + i4;
+                for (int i = 0; i < HR; ++i) tc[i] = Ts[i * inner + c];
+                float* xo = Xs + it_x[0];
+                const int vlo = __builtin_amdgcn_readfirstlane(it_v0[0]), vhi = min(V, vlo + vspan);   // wave-uniform (inner % 64 == 0)
+                const float* vsrc = vb + r * HR;
+                for (int v = vlo; v < vhi; ++v) {
+                    const float* vr = vsrc + (int64_t)v * K;                  // uniform address
+                    float x = 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    // rows v0+u >= V read stale-but-in-bounds LDS (Vs is followed by Qs); their x[u] is never stored
-                    const float4 vv = *reinterpret_cast<const float4*>(vrow + u * HR);
-                    x[u] = fmaf(t0, vv.x, fmaf(t1, vv.y, fmaf(t2, vv.z, fmaf(t3, vv.w, x[u]))));
+                    for (int i = 0; i < HR; ++i) x = fmaf(tc[i], vr[i], x);
+                    xo[(v - vlo) * G * HH] = x;
                 }
-            }
-            float* xo = Xs + it_x[n];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (v0 + u < V) xo[u * G * HH] = x[u];
             }
         }
         __syncthreads();
-        // step 2: one output row (v,q,g) per thread and trip, HR columns
+        // step 2: output rows (v,q,g) and (v,q+1,g) per thread share the X row: HR columns each
 #pragma unroll
         for (int n = 0; n < MB_ROWS; ++n) {
             const int lq = row_q[n];
             if (lq >= 0) {
-            float acc[HR];
+            const bool two = lq + 1 < Q;
+            float acc[HR], acc2[HR];
 #pragma unroll
-            for (int k = 0; k < HR; ++k) acc[k] = 0.f;
+            for (int k = 0; k < HR; ++k) { acc[k] = 0.f; acc2[k] = 0.f; }
             const float* xr = Xs + row_x[n];
 #pragma unroll 2
             for (int j = 0; j < HR; ++j) {
                 const float qv = Qs[j * Qpad + lq];
+                const float qw = Qs[j * Qpad + lq + 1];                     // Qpad >= Q + 1 columns: in bounds, unused when !two
 #pragma unroll
                 for (int k4 = 0; k4 < HR; k4 += 4) {
                     const float4 xx = *reinterpret_cast<const float4*>(xr + j * HR + k4);
-                    acc[k4 + 0] = fmaf(qv, xx.x, acc[k4 + 0]);
-                    acc[k4 + 1] = fmaf(qv, xx.y, acc[k4 + 1]);
-                    acc[k4 + 2] = fmaf(qv, xx.z, acc[k4 + 2]);
-                    acc[k4 + 3] = fmaf(qv, xx.w, acc[k4 + 3]);
+                    acc[k4 + 0] = fmaf(qv, xx.x, acc[k4 + 0]); acc2[k4 + 0] = fmaf(qw, xx.x, acc2[k4 + 0]);
+                    acc[k4 + 1] = fmaf(qv, xx.y, acc[k4 + 1]); acc2[k4 + 1] = fmaf(qw, xx.y, acc2[k4 + 1]);
+                    acc[k4 + 2] = fmaf(qv, xx.z, acc[k4 + 2]); acc2[k4 + 2] = fmaf(qw, xx.z, acc2[k4 + 2]);
+                    acc[k4 + 3] = fmaf(qv, xx.w, acc[k4 + 3]); acc2[k4 + 3] = fmaf(qw, xx.w, acc2[k4 + 3]);
                 }
             }
-            const int64_t orow = row_o[n];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !two) break;
+            const float* av = half ? acc2 : acc;
+            const int64_t orow = row_o[n] + (half ? G : 0);                 // (v, q+1, g) is G rows further
             const int c0 = r * HR;
             if (PLANES) {
                 // chunk-major planes: column c of row orow lives at (c >> 4) * pitch + orow * 16 + (c & 15); the rows of one
                 // v are 32 B apart, so a wave's stores fall in a few contiguous KiB
-                unsigned short hb[HR], lb[HR];
-#pragma unroll
-                for (int k = 0; k < HR; ++k) { hb[k] = bf16_bits(acc[k]); lb[k] = bf16_bits(acc[k] - bf16_to_f32(hb[k])); }
                 const int64_t o = (int64_t)(c0 >> 4) * ldm + orow * 16 + (c0 & 15);
                 unsigned short* ph = Mh + o;
                 unsigned short* pl = Ml + o;
+                auto pk = [](float x0, float x1, unsigned& hi2, unsigned& lo2) {
+                    const unsigned short h0 = bf16_bits(x0), h1 = bf16_bits(x1);
+                    hi2 = h0 | ((unsigned)h1 << 16);
+                    lo2 = bf16_bits(x0 - bf16_to_f32(h0)) | ((unsigned)bf16_bits(x1 - bf16_to_f32(h1)) << 16);
+                };
                 if (HR % 8 == 0) {
 #pragma unroll
                     for (int c8 = 0; c8 < HR / 8; ++c8) {
-                        const unsigned short* hh = hb + c8 * 8; const unsigned short* ll = lb + c8 * 8;
-                        *reinterpret_cast<uint4*>(ph + c8 * 8) = make_uint4(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16), hh[4] | ((unsigned)hh[5] << 16), hh[6] | ((unsigned)hh[7] << 16));
-                        *reinterpret_cast<uint4*>(pl + c8 * 8) = make_uint4(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16), ll[4] | ((unsigned)ll[5] << 16), ll[6] | ((unsigned)ll[7] << 16));
+                        uint4 hq, lq4;
+                        pk(av[c8 * 8 + 0], av[c8 * 8 + 1], hq.x, lq4.x); pk(av[c8 * 8 + 2], av[c8 * 8 + 3], hq.y, lq4.y);
+                        pk(av[c8 * 8 + 4], av[c8 * 8 + 5], hq.z, lq4.z); pk(av[c8 * 8 + 6], av[c8 * 8 + 7], hq.w, lq4.w);
+                        *reinterpret_cast<uint4*>(ph + c8 * 8) = hq;
+                        *reinterpret_cast<uint4*>(pl + c8 * 8) = lq4;
                     }
                 } else {                                    // HR == 4: 8-byte pieces
-                    *reinterpret_cast<uint2*>(ph) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
-                    *reinterpret_cast<uint2*>(pl) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+                    uint2 hq, lq2;
+                    pk(av[0], av[1], hq.x, lq2.x); pk(av[2], av[3], hq.y, lq2.y);
+                    *reinterpret_cast<uint2*>(ph) = hq;
+                    *reinterpret_cast<uint2*>(pl) = lq2;
                 }
                 if (r == R - 1) {                           // zero the K tail [K, Kp) of the planes (Kp = K rounded up to 32)
                     for (int c = K; c < ((K + 31) & ~31); ++c) {
@@ -181,12 +186,13 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
                 float* pf = Mf + orow * ldm + c0;
                 if ((ldm & 3) == 0) {
 #pragma unroll
-                    for (int k4 = 0; k4 < HR; k4 += 4) *reinterpret_cast<float4*>(pf + k4) = make_float4(acc[k4], acc[k4 + 1], acc[k4 + 2], acc[k4 + 3]);
+                    for (int k4 = 0; k4 < HR; k4 += 4) *reinterpret_cast<float4*>(pf + k4) = make_float4(av[k4], av[k4 + 1], av[k4 + 2], av[k4 + 3]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < HR; ++k) pf[k] = acc[k];
+                    for (int k = 0; k < HR; ++k) pf[k] = av[k];
                 }
             }
+            }                                                             // half
             }
         }
     }
@@ -221,10 +227,10 @@ int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, 
                 int V, int Q, int R, int hr, int G, int64_t ldm, hipStream_t st) {
     if (hr != 4 && hr != 8 && hr != 16) return CTI_E_UNSUPPORTED;
     if (B > 65535) return CTI_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)hr * (Q | 1));
+    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)hr * ((Q + 1) | 1));
     if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
-    if ((int64_t)hr * hr * G * ((V + 7) / 8) > 4096 || (int64_t)V * Q * G > 2048 || hr * hr * hr * G / 4 > 4096 || V * hr > 1024 || Q * hr > 1024)
-        return CTI_E_UNSUPPORTED;                           // per-thread item / row / prefetch budgets of the fast kernel
+    if (hr * hr * G > 1024 || (int64_t)V * G * ((Q + 1) / 2) > 2048 || hr * hr * hr * G / 4 > 4096 || V * hr > 1024 || Q * hr > 1024)
+        return CTI_E_UNSUPPORTED;                           // per-thread column / row / prefetch budgets of the fast kernel
     const bool planes = Mh != nullptr;
 #define CTI_MB(H) (planes ? launch<H, true>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st) \
                           : launch<H, false>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st))
