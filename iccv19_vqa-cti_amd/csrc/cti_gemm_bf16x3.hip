@@ -24,6 +24,9 @@
 #include "cti_common.h"
 #include <type_traits>
 
+#ifndef CTI_PIPE
+#define CTI_PIPE 0
+#endif
 #ifndef CTI_ABL                 // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no epilogue stores
 #define CTI_ABL 0
 #endif
@@ -203,11 +206,46 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         for (int i = 0; i < NG - 1; ++i) if (i < ngr) issue_group(i, i);
     }
     const int r = lane & 31, h = lane >> 5;
+    // PIPE (SPB == 1, NG >= 4): fragments of slice g+1 are read from LDS at the END of step g (behind slice g's MFMAs), so
+    // every step opens with MFMAs instead of an exposed LDS round trip.  For that slot g+1 must already be visible after
+    // barrier g: the issuing waves retire one group more per step (NG-3 instead of NG-2 groups stay in flight).
+    constexpr bool PIPE = (CTI_PIPE != 0) && SPB == 1 && NG >= 4;
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    auto load_frags = [&](const char* s) {
+        const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
+        const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
+        const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
+        const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ah[i] = frag(sAh, i * 32 + r, h); if (TERMS == 3) al[i] = frag(sAl, i * 32 + r, h); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bh[j] = frag(sBh, j * 32 + r, h); if (TERMS == 3) bl[j] = frag(sBl, j * 32 + r, h); }
+    };
+    auto mfma_frags = [&]() {
+#if CTI_ABL & 2
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+#endif
+    };
     int pos = 0;
     for (int g = 0; g < ngr; ++g) {
         if (issuer) {
             const int rem = ngr - 1 - g;                                 // groups issued after group g so far: min(NG-2, rem)
             if (!EXACT) wait_vmcnt<0>();
+            else if (PIPE) { if (rem >= NG - 2) wait_vmcnt<(NG - 3) * NPLG>(); else wait_vmcnt<0>(); }   // groups <= g+1 landed
             else if (NG >= 3 && rem >= NG - 2) wait_vmcnt<(NG - 2) * NPLG>();
             else if (NG >= 4 && rem == 1) wait_vmcnt<NPLG>();
             else wait_vmcnt<0>();
@@ -215,35 +253,13 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         __builtin_amdgcn_s_barrier();
         if (issuer && g + NG - 1 < ngr && !(CTI_ABL & 1)) issue_group(pos == 0 ? NG - 1 : pos - 1, g + NG - 1);
         if (!loader) {
+            if (PIPE) {
+                if (g == 0) load_frags(smem + pos * SLOT);
+                mfma_frags();
+                if (g + 1 < ngr) load_frags(smem + (pos == NG - 1 ? 0 : pos + 1) * SLOT);
+            } else {
 #pragma unroll
-            for (int s2 = 0; s2 < SPB; ++s2) {
-                const char* s = smem + (pos * SPB + s2) * SLOT;
-                const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
-                const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
-                const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
-                const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) { ah[i] = frag(sAh, i * 32 + r, h); if (TERMS == 3) al[i] = frag(sAl, i * 32 + r, h); }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { bh[j] = frag(sBh, j * 32 + r, h); if (TERMS == 3) bl[j] = frag(sBl, j * 32 + r, h); }
-#if CTI_ABL & 2
-#pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
-#else
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (TERMS == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-#endif
+                for (int s2 = 0; s2 < SPB; ++s2) { load_frags(smem + (pos * SPB + s2) * SLOT); mfma_frags(); }
             }
         }
         pos = pos == NG - 1 ? 0 : pos + 1;
