@@ -84,6 +84,9 @@ int gemm_nt_f32(const GemmP& p, hipStream_t st);
 // Planes are CHUNK-MAJOR: element (row, k) at (k >> 4) * rows_alloc * 16 + row * 16 + (k & 15); see that file's header.
 struct PlaneGemmArgs {
     const unsigned short* Ah; const unsigned short* Al; const unsigned short* Bh; const unsigned short* Bl;
+    // Af != NULL: the A operand is the fp32 matrix itself (rows x Kreal, row stride ldaf, 16-B aligned rows, Kreal % 4 == 0):
+    // its rows are LDS-DMA'd as fp32 and split into hi/lo at fragment-read time (no split pass, no A planes); rA1/rA2 in rows.
+    const float* Af; int64_t ldaf; int Kreal;
     int64_t rows_allocA, rows_allocB;          // allocated rows (the chunk pitch is rows_alloc * 16 elements)
     int64_t rA1, rA2, rB1, rB2;                // batch strides of the operands in ROWS
     int nb1, nb2;

@@ -89,6 +89,7 @@ struct PlaneGemmP {
     int nb2;
     int M, N, Kp;
     int total_tiles;
+    const float* Af; int64_t ldaf; int Kreal;  // AF32 mode: the A operand is the fp32 matrix itself (rows x Kreal, row stride ldaf)
     const float* scale; int scale_div; const float* bias; int relu;
     // EPI_PLANES: the result is written as chunk-major bf16 hi/lo planes (columns N..Np-1 zero-filled) instead of fp32
     unsigned short* Ph; unsigned short* Pl; int64_t pitchP; int Np;
@@ -136,7 +137,26 @@ __device__ __forceinline__ void dma_pieces(const unsigned short* __restrict__ gh
     }
 }
 
-template <int TERMS, int EPI, class G>
+// LDS-DMA of fp32 A rows (AF32 mode): one piece = 16 rows x 64 B (16 floats) of the slice; LDS position p (16-B chunk index) =
+// (row = p >> 2, c' = p & 3) receives source chunk c = c' ^ ((row >> 2) & 3).  Chunks at or beyond K read the row start instead
+// (any finite data: the matching K-tail of the B planes is zero).  Unlike planes the caller's matrix has no slack rows.
+template <int NPIECES>
+__device__ __forceinline__ void dma_pieces_f32(const float* __restrict__ arow0, int64_t ld, int k0, int K, int rows_valid, char* lds,
+                                               int first, int stride, int lane) {
+#pragma unroll
+    for (int u = 0; u < NPIECES; ++u) {
+        const int pc = (first + u * stride) * 64 + lane;
+        const int row = pc >> 2, c = (pc & 3) ^ ((row >> 2) & 3);
+        const int k = k0 + c * 4;
+        const int rr = row < rows_valid ? row : rows_valid - 1;        // tile rows past the matrix re-read its last row (outputs discarded)
+        const float* src = arow0 + (int64_t)rr * ld + (k < K ? k : 0);
+        char* dst = lds + (pc - lane) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int TERMS, int EPI, class G, bool AF32 = false>
 __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     constexpr int WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN, LW = G::LW, NST = G::NST, SPB = G::SPB;
     constexpr int BM = G::BM, BN = G::BN, A_PLANE = G::A_PLANE, B_PLANE = G::B_PLANE, SLOT = G::STAGE;
@@ -165,6 +185,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int64_t pitchA = p.pitchA, pitchB = p.pitchB;                 // locals: lambdas must not capture the argument struct
     const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
     const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
+    const float* Af = AF32 ? p.Af + (b1 * p.rA1 + b2 * p.rA2 + m0) * p.ldaf : nullptr;
+    const int64_t ldaf = p.ldaf; const int Kreal = p.Kreal, rows_valid = p.M - m0;
     const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
     const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
 
@@ -184,7 +206,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             char* s = smem + (ring_pos * SPB + s2) * SLOT;
             const int64_t kc = (int64_t)grp * SPB + s2;
             if (EXACT) {
-                dma_pieces<BM, PA, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw, NW, lane);
+                if (AF32) dma_pieces_f32<PA>(Af, ldaf, (int)kc * 16, Kreal, rows_valid, s, iw, NW, lane);   // pieces of 16 rows x 64 B
+                else      dma_pieces<BM, PA, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw, NW, lane);
                 dma_pieces<BN, PB, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + 2 * A_PLANE, iw, NW, lane);
             } else {                                                     // uneven split (plain-bf16 mode only): waves beyond the piece count idle
 #pragma unroll
@@ -216,8 +239,27 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
         const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
         const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
+        if (AF32) {
+            // the slot's A region holds fp32 [row][16]: read this lane's 8 floats (two swizzled 16-B chunks) and split them
+            // here -- ~24 VALU per fragment pair, issued in the slots the MFMAs leave free
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * TM * 32 + i * 32 + r;
+                const char* rp = s + row * 64;
+                const float4 x0 = *reinterpret_cast<const float4*>(rp + (((2 * h) ^ ((row >> 2) & 3)) << 4));
+                const float4 x1 = *reinterpret_cast<const float4*>(rp + (((2 * h + 1) ^ ((row >> 2) & 3)) << 4));
+                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const __bf16 hv = static_cast<__bf16>(xs[e]);
+                    ah[i][e] = hv;
+                    al[i][e] = static_cast<__bf16>(xs[e] - static_cast<float>(hv));
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) { ah[i] = frag(sAh, i * 32 + r, h); if (TERMS == 3) al[i] = frag(sAl, i * 32 + r, h); }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) { bh[j] = frag(sBh, j * 32 + r, h); if (TERMS == 3) bl[j] = frag(sBl, j * 32 + r, h); }
     };
@@ -400,9 +442,9 @@ using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
 using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;
 using GeoSmall = Geo<2, 2, 2, 2, (CTI_LW > 2 ? 2 : CTI_LW), 6, 2>;
 
-template <int TERMS, int EPI, class G>
+template <int TERMS, int EPI, class G, bool AF32 = false>
 int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
-    auto kern = gemm_planes_kernel<TERMS, EPI, G>;
+    auto kern = gemm_planes_kernel<TERMS, EPI, G, AF32>;
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -429,6 +471,17 @@ int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
 
 template <int TERMS, int EPI>
 int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_t st) {
+    if (p.Af) {                                              // fp32 A operand: built for the fp32-grade mode and the row-major epilogues
+        if constexpr (TERMS == 3 && (EPI == 0 || EPI == 1)) {
+            switch (cfg) {
+                case 2: return launch_cfg<TERMS, EPI, GeoBig, true>(p, nb, ncols, st);
+                case 1: return launch_cfg<TERMS, EPI, GeoMid, true>(p, nb, ncols, st);
+                default: return launch_cfg<TERMS, EPI, GeoSmall, true>(p, nb, ncols, st);
+            }
+        } else {
+            return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: fp32 A operand with terms=%d epi=%d", TERMS, EPI);
+        }
+    }
     switch (cfg) {
         case 2: return launch_cfg<TERMS, EPI, GeoBig>(p, nb, ncols, st);
         case 1: return launch_cfg<TERMS, EPI, GeoMid>(p, nb, ncols, st);
@@ -458,6 +511,9 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.nb2 = a.nb2; p.M = a.M; p.N = a.N; p.Kp = a.Kp;
     p.scale = a.scale; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.bias = a.bias; p.relu = a.relu;
     p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
+    p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
+    if (a.Af && ((a.ldaf & 3) || (a.Kreal & 3) || (reinterpret_cast<uintptr_t>(a.Af) & 15)))
+        return fail(CTI_E_ALIGN, "gemm_nt_planes: fp32 A operand needs 16-B aligned rows and K %% 4 == 0 (ld=%lld K=%d)", (long long)a.ldaf, a.Kreal);
     if (a.Kp % KPAD != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, KPAD);
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const long long nb = (long long)a.nb1 * a.nb2;

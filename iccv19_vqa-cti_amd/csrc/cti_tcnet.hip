@@ -156,8 +156,17 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     }
 
     const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    bool af32[3];
     for (int s = 0; s < 3; ++s) {
-        rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, st); if (rc) return rc;
+        // Option (compile with -DCTI_AF32=1): feed the raw input to the Tucker GEMM as fp32 and split it at fragment-read time,
+        // skipping the HBM-bound split pass (2 GB of traffic for `a` at config 2).  MEASURED NEUTRAL on MI355X: the split pass
+        // (0.55 ms) disappears but the GEMMs slow down by the same amount (64-B row segments instead of contiguous KiB through
+        // the LDS-DMA path, conversions beside the MFMAs), so the default keeps the split pass.
+#ifndef CTI_AF32
+#define CTI_AF32 0
+#endif
+        af32[s] = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
+        if (!af32[s]) { rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, st); if (rc) return rc; }
         rc = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
         rc = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
     }
@@ -165,6 +174,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     for (int s = 0; s < 3; ++s) {
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
+        if (af32[s]) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
         g.rows_allocA = p.xin[s].rows_alloc; g.rows_allocB = p.wt[s].rows_alloc; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
         g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.rows_allocP = p.tp[s].rows_alloc; g.Np = Kh;
