@@ -11,7 +11,8 @@ _i64, _int, _vp, _sz = C.c_int64, C.c_int, C.c_void_p, C.c_size_t
 SIGNATURES = {
     "cti_abi_version": (_int, []),
     "cti_last_error_string": (C.c_char_p, []),
-    "cti_wn_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp]),
+    "cti_wn_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _sz, _vp]),
+    "cti_wn_scale_workspace_bytes": (_sz, [_int, _i64]),
     "cti_wn_linear_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_wn_linear_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "cti_zero_row_mask": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),

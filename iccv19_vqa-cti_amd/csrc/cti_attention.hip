@@ -231,16 +231,16 @@ __global__ __launch_bounds__(256) void bi_pool_kernel(const float* __restrict__ 
 
 // =====================================================================================================
 // bi logits: logits[b,g,v,q] = hs * sum_d vt[b,v,d] h[g,d] qt[b,q,d] + hb[g]               (bc.py:52-58)
-// One workgroup per (b, v); the d axis is split over the 256 lanes (coalesced reads of vt, h, qt rows), each
-// lane keeps a GC x QC block of partial sums, reduced by wave shuffles + a 4-wave LDS step.
+// ONE WAVE per (b, v): the 64 lanes split the d axis (coalesced reads of the vt row, of h and of the qt rows, the
+// latter two L2-resident), each lane keeps a GC x QC block of partial sums, reduced by wave shuffles.  A wave per
+// row keeps the ratio of shuffle-reduction work to FMAs at 1:4 (with 256 threads per row it was 1:1).
 // =====================================================================================================
 constexpr int GC = 8, QC = 16;
-__global__ __launch_bounds__(256) void bi_logits_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
-                                                        const float* __restrict__ h, const float* __restrict__ h_scale,
-                                                        const float* __restrict__ h_bias, float* __restrict__ logits,
-                                                        int G, int V, int Q, int D) {
-    __shared__ float red[4][GC * QC];
-    const int bv = blockIdx.x, b = bv / V, v = bv % V, t = threadIdx.x;
+__global__ __launch_bounds__(64) void bi_logits_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                       const float* __restrict__ h, const float* __restrict__ h_scale,
+                                                       const float* __restrict__ h_bias, float* __restrict__ logits,
+                                                       int G, int V, int Q, int D) {
+    const int bv = blockIdx.x, b = bv / V, v = bv % V, lane = threadIdx.x;
     const float* vrow = vt + (int64_t)bv * D;
     const float* qb = qt + (int64_t)b * Q * D;
     const float hs = h_scale ? h_scale[0] : 1.f;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void bi_logits_kernel(const float* __restrict_
             for (int g = 0; g < GC; ++g)
 #pragma unroll
                 for (int q = 0; q < QC; ++q) acc[g][q] = 0.f;
-            for (int d = t; d < D; d += 256) {
+            for (int d = lane; d < D; d += 64) {
                 const float x = vrow[d];
                 float qv[QC];
 #pragma unroll
@@ -268,18 +268,11 @@ __global__ __launch_bounds__(256) void bi_logits_kernel(const float* __restrict_
 #pragma unroll
                 for (int q = 0; q < QC; ++q) {
                     const float s = wave_sum(acc[g][q]);
-                    if ((t & 63) == 0) red[t >> 6][g * QC + q] = s;
+                    if (lane == 0 && g0 + g < G && q0 + q < Q) {
+                        const float hb = h_bias ? h_bias[g0 + g] : 0.f;
+                        logits[(((int64_t)b * G + g0 + g) * V + v) * Q + q0 + q] = s * hs + hb;
+                    }
                 }
-            __syncthreads();
-            if (t < GC * QC) {
-                const int g = t / QC, q = t % QC;
-                if (g0 + g < G && q0 + q < Q) {
-                    const float s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-                    const float hb = h_bias ? h_bias[g0 + g] : 0.f;
-                    logits[(((int64_t)b * G + g0 + g) * V + v) * Q + q0 + q] = s * hs + hb;
-                }
-            }
-            __syncthreads();
         }
     }
 }
@@ -369,7 +362,7 @@ extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* 
                                  float* logits, int B, int G, int V, int Q, int D, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
     CTI_REQUIRE(B > 0 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
-    hipLaunchKernelGGL(bi_logits_kernel, dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias,
+    hipLaunchKernelGGL(bi_logits_kernel, dim3((unsigned)(B * V)), dim3(64), 0, as_stream(stream), vt, qt, h, h_scale, h_bias,
                        logits, G, V, Q, D);
     return launch_status("cti_bi_logits_fwd");
 }

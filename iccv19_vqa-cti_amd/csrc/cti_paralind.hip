@@ -181,12 +181,25 @@ int wn_scale_batch(const WnBatch& d, float* partial, hipStream_t st) {
 }
 }  // namespace cti
 
-extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems,
-                            void* stream) {
+extern "C" size_t cti_wn_scale_workspace_bytes(int n_mats, int64_t elems) {
+    if (n_mats <= 0 || elems <= 0) return 0;
+    return sizeof(float) * (size_t)n_mats * (size_t)((elems + WN_CHUNK - 1) / WN_CHUNK);
+}
+
+extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     CTI_REQUIRE_PTR(weight_v); CTI_REQUIRE_PTR(weight_g); CTI_REQUIRE_PTR(scale);
     CTI_REQUIRE(n_mats > 0 && elems > 0, CTI_E_SHAPE, "cti_wn_scale: n_mats=%d elems=%lld", n_mats, (long long)elems);
-    hipLaunchKernelGGL(wn_scale_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), weight_v, weight_g, scale, elems);
-    return launch_status("cti_wn_scale");
+    if (elems <= WN_CHUNK || workspace == nullptr) {       // small matrices: one workgroup each is the fastest form
+        hipLaunchKernelGGL(wn_scale_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), weight_v, weight_g, scale, elems);
+        return launch_status("cti_wn_scale");
+    }
+    CTI_REQUIRE(workspace_bytes >= cti_wn_scale_workspace_bytes(n_mats, elems), CTI_E_WORKSPACE, "cti_wn_scale: workspace %zu < %zu",
+                workspace_bytes, cti_wn_scale_workspace_bytes(n_mats, elems));
+    WnBatch wb{};                                           // large matrices: 16,384-element chunks over many CUs, then a fixed-order sum
+    wb.n = 1; wb.wv[0] = weight_v; wb.g[0] = weight_g; wb.scale[0] = scale; wb.n_mats[0] = n_mats; wb.elems[0] = elems;
+    wn_batch_finish(wb);
+    return wn_scale_batch(wb, static_cast<float*>(workspace), as_stream(stream));
 }
 
 extern "C" int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream) {

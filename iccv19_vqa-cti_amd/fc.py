@@ -31,7 +31,13 @@ class WNLinear(nn.Module):
         return "in_features=%d, out_features=%d, weight_norm(dim=None)" % (self.in_features, self.out_features)
 
     def scale(self):
-        return ops.wn_scale(self.weight_v, self.weight_g)
+        """g / ||V||_F on the device, cached until weight_v / weight_g change (optimizer steps bump `_version`, .to() / load_state_dict
+        change the storage): in eval mode the norm of a 6M-element weight is computed once, not per forward."""
+        key = (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version)
+        if getattr(self, "_scale_key", None) != key:
+            self._scale_val = ops.wn_scale(self.weight_v.detach(), self.weight_g.detach())
+            self._scale_key = key
+        return self._scale_val
 
     def forward(self, x, relu=False):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad or self.weight_g.requires_grad or self.bias.requires_grad):

@@ -110,7 +110,10 @@ def wn_scale(weight_v, weight_g):
     wv = weight_v.contiguous()
     g = weight_g.contiguous().view(-1)
     out = torch.empty(n, device=wv.device, dtype=torch.float32)
-    L.check(L.lib().cti_wn_scale(wv.data_ptr(), g.data_ptr(), out.data_ptr(), n, wv.numel() // n, _stream()), "cti_wn_scale")
+    lib = L.lib()
+    wsb = lib.cti_wn_scale_workspace_bytes(n, wv.numel() // n)
+    ws = torch.empty(wsb, device=wv.device, dtype=torch.uint8) if wsb else None
+    L.check(lib.cti_wn_scale(wv.data_ptr(), g.data_ptr(), out.data_ptr(), n, wv.numel() // n, _ptr(ws), wsb, _stream()), "cti_wn_scale")
     return out
 
 

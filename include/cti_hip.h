@@ -59,7 +59,9 @@ int cti_event_elapsed_ms(void* begin, void* end, float* ms);
 /* scale[i] = g[i] / ||V_i||_F for n_mats matrices stored back to back, `elems` floats each.
  * Replaces the weight_norm pre-forward hook (torch `_weight_norm`: norm, div, mul over the whole weight) that
  * src/fc.py:22,27 installs; the scaled weight itself is never materialised (the scale is a GEMM-epilogue factor). */
-int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems, void* stream);
+int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems, void* workspace,
+                 size_t workspace_bytes, void* stream);
+size_t cti_wn_scale_workspace_bytes(int n_mats, int64_t elems);   /* workspace may be NULL (one workgroup per matrix: slow for >16K elements) */
 
 /* y[r, n] = act( scale[n / scale_div] * sum_k x[r, k] * w[n, k] + bias[n] )          (src/fc.py:33-34, nn.Linear)
  * x: rows x in_dim, row stride ldx;  w: out_dim x in_dim (weight_v), row stride ldw;  y: rows x out_dim, row stride ldy.

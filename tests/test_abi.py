@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_argument_errors_do_not_launch():
     lib = L.lib()
-    assert lib.cti_wn_scale(None, None, None, 1, 4, None) == -1          # CTI_E_NULL
+    assert lib.cti_wn_scale(None, None, None, 1, 4, None, 0, None) == -1  # CTI_E_NULL
     assert b"NULL" in lib.cti_last_error_string()
     assert lib.cti_zero_row_mask(1, 4, 1, 0, 4, None) == -2              # CTI_E_SHAPE (rows = 0) -- pointers not touched
     assert lib.cti_wn_linear_fwd(1, 4, 1, 4, None, 1, None, 1, 4, 2, 4, 4, 7, 0, None, 0, None) == -4   # bad act
