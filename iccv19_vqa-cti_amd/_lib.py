@@ -27,7 +27,7 @@ SIGNATURES = {
     "cti_tcnet_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _sz, _vp, _vp, _vp]),
     "cti_tcnet_forward_workspace_bytes": (_sz, [_int] * 11),
     "cti_gemm_nt": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int,
-                           _vp, _int, _vp, _int, _int, _vp, _sz, _vp]),
+                           _vp, _int, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "cti_transpose_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _int, _vp]),
     "cti_sum_batches": (_int, [_vp, _vp, _int, _i64, C.c_float, C.c_float, _vp]),
@@ -44,7 +44,7 @@ SIGNATURES = {
     "cti_flat_scale_sumsq": (_int, [_vp, _i64, C.c_float, _vp, _vp]),
     "cti_adamax_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _int, _vp, _vp]),
     "cti_optim_workspace_bytes": (_sz, []),
-    "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _vp]),
+    "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _i64, _vp]),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),
     "cti_masked_softmax_bi_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),

@@ -41,28 +41,34 @@ __global__ __launch_bounds__(256) void sum_batches_kernel(const float* __restric
 }
 
 // ---- dzs = scale[col/div] * dy * (y > 0) [relu] ; partial column sums of the UNSCALED dz for the bias gradient ---------
-// grid (ceil(n/64), row_chunks): each workgroup handles 64 columns x a chunk of rows; thread = (column, row lane 0..3).
+// A workgroup covers CW columns x a chunk of rows with 256/CW row lanes (CW = 16, 32 or 64, picked from n so that narrow
+// matrices -- the 16-column rank nets -- still use every lane); grid (ceil(n/CW), row_chunks).
+template <int CW>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       const float* __restrict__ scale, int scale_div, float* __restrict__ dzs,
                                                       float* __restrict__ part_b, int64_t rows, int n, int relu, int64_t rows_per_chunk) {
-    __shared__ float sb[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    constexpr int RL = 256 / CW;
+    __shared__ float sb[RL][CW];
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int col = blockIdx.x * CW + cl;
     const int64_t r_lo = (int64_t)blockIdx.y * rows_per_chunk, r_hi = min(rows, r_lo + rows_per_chunk);
     float ab = 0.f;
     if (col < n) {
         const float s = scale ? scale[col / scale_div] : 1.f;
-        for (int64_t r = r_lo + rl; r < r_hi; r += 4) {
+        for (int64_t r = r_lo + rl; r < r_hi; r += RL) {
             float g = dy[r * n + col];
             if (relu && !(y[r * n + col] > 0.f)) g = 0.f;
             dzs[r * n + col] = g * s;
             ab += g;
         }
     }
-    sb[rl][threadIdx.x & 63] = ab;
+    sb[rl][cl] = ab;
     __syncthreads();
     if (rl == 0 && col < n) {
-        const int c = threadIdx.x & 63;
-        part_b[(int64_t)blockIdx.y * n + col] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) t += sb[i][cl];
+        part_b[(int64_t)blockIdx.y * n + col] = t;
     }
 }
 
@@ -103,7 +109,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 }
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p); mask byte stored for the backward.  backward: same kernel with x = dy, use_mask = 1.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
-                                                      int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask) {
+                                                      int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask,
+                                                      int64_t period) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 4 elements
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         if (i < n) {
             const bool keep = use_mask ? mask[i] != 0 : rr[j] >= thr;
             if (!use_mask) mask[i] = keep ? 1 : 0;
-            y[i] = keep ? x[i] * inv : 0.f;
+            y[i] = keep ? x[period ? i % period : i] * inv : 0.f;
         }
     }
 }
@@ -132,12 +139,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 using namespace cti;
 
 extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
-                           void* stream) {
+                           int64_t period, void* stream) {
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(mask);
-    CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
+    CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f && period >= 0, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
     const int64_t groups = (n + 3) / 4;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, mask, n, p,
-                       (unsigned long long)seed, (unsigned long long)offset, use_mask);
+                       (unsigned long long)seed, (unsigned long long)offset, use_mask, period);
     return launch_status("cti_dropout");
 }
 
@@ -160,7 +167,7 @@ extern "C" int cti_sum_batches(const float* src, float* dst, int nb, int64_t n, 
     return launch_status("cti_sum_batches");
 }
 
-static int act_chunks(int64_t rows) { int c = (int)((rows + 2047) / 2048); return c < 1 ? 1 : (c > 1024 ? 1024 : c); }
+static int act_chunks(int64_t rows) { int c = (int)((rows + 255) / 256); return c < 1 ? 1 : (c > 1024 ? 1024 : c); }
 
 extern "C" size_t cti_act_bwd_workspace_bytes(int64_t rows, int n) {
     if (rows <= 0 || n <= 0) return 0;
@@ -175,8 +182,10 @@ extern "C" int cti_act_bwd(const float* dy, const float* y, const float* scale, 
     const int chunks = act_chunks(rows);
     const int64_t rpc = (rows + chunks - 1) / chunks;
     float* pb = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((n + 63) / 64, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, scale ? scale_div : 1, dzs,
-                       pb, rows, n, act == CTI_ACT_RELU ? 1 : 0, rpc);
+    const int relu = act == CTI_ACT_RELU ? 1 : 0, sdiv = scale ? scale_div : 1;
+    if (n <= 16)      hipLaunchKernelGGL(act_bwd_kernel<16>, dim3((n + 15) / 16, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
+    else if (n <= 32) hipLaunchKernelGGL(act_bwd_kernel<32>, dim3((n + 31) / 32, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
+    else              hipLaunchKernelGGL(act_bwd_kernel<64>, dim3((n + 63) / 64, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
     int rc = launch_status("cti_act_bwd"); if (rc) return rc;
     return cti_sum_batches(pb, dbias, chunks, n, 1.f, 0.f, stream);
 }
@@ -198,8 +207,8 @@ extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB
 
 extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, int64_t rA2, const float* B, int64_t ldb,
                            int64_t rowsB_total, int64_t rB1, int64_t rB2, float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC1, int64_t sC2,
-                           int nb1, int nb2, int M, int N, int K, const float* scale, int scale_div, const float* bias, int act, int prec,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+                           int nb1, int nb2, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs, const float* bias,
+                           int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream) {
     // A is ONE row-major matrix of rowsA_total rows x K (row stride lda); batch (b1,b2) uses rows [b1*rA1 + b2*rA2, +M).  Same for B / N.
     CTI_REQUIRE_PTR(A); CTI_REQUIRE_PTR(B); CTI_REQUIRE_PTR(C);
     CTI_REQUIRE(M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0 && lda >= K && ldb >= K, CTI_E_SHAPE, "cti_gemm_nt: M=%d N=%d K=%d nb=%dx%d", M, N, K, nb1, nb2);
@@ -212,6 +221,7 @@ extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int
         p.sA1 = rA1 * lda; p.sA2 = rA2 * lda; p.sB1 = rB1 * ldb; p.sB2 = rB2 * ldb; p.sC1 = sC1; p.sC2 = sC2;
         p.nb1 = nb1; p.nb2 = nb2; p.M = M; p.N = N; p.K = K;
         p.scale = scale; p.scale_div = scale ? scale_div : 1; p.bias = bias; p.relu = act == CTI_ACT_RELU;
+        p.scale_bs = scale_bs; p.bias_bs = bias_bs;
         return gemm_nt_f32(p, as_stream(stream));
     }
     CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_nt: prec=%d", prec);
@@ -232,5 +242,6 @@ extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int
     g.C = C; g.ldc_m = ldc_m; g.ldc_n = ldc_n; g.sC1 = sC1; g.sC2 = sC2;
     g.epi = (ldc_n == 1) ? 0 : 3; g.gdiv = 1;
     g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = act == CTI_ACT_RELU;
+    g.scale_bs = scale_bs; g.bias_bs = bias_bs;
     return gemm_nt_planes(g, as_stream(stream));
 }

@@ -74,9 +74,10 @@ struct GemmP {
     int64_t sA1, sA2, sB1, sB2, sC1, sC2;      // batch strides: z = b1 * nb2 + b2
     int nb1, nb2;
     int M, N, K;
-    const float* scale; int scale_div;         // epilogue: acc * scale[n / scale_div] (NULL = 1)
-    const float* bias;                         // + bias[n] (NULL = 0)
+    const float* scale; int scale_div;         // epilogue: acc * scale[b1*scale_bs + n / scale_div] (NULL = 1)
+    const float* bias;                         // + bias[b1*bias_bs + n] (NULL = 0)
     int relu;
+    int64_t scale_bs, bias_bs;                 // per-batch (b1) strides of scale / bias
 };
 int gemm_nt_f32(const GemmP& p, hipStream_t st);
 
@@ -97,6 +98,7 @@ struct PlaneGemmArgs {
     unsigned short* Ph; unsigned short* Pl; int64_t rows_allocP; int Np;     // planes output (epi 1)
     int gdiv;                                  // epi 3
     const float* scale; int scale_div; const float* bias; int relu;
+    int64_t scale_bs, bias_bs;                 // per-batch (b1) strides of scale / bias
 };
 int planes_kp(int K);
 size_t planes_bytes(int64_t rows_alloc, int K);

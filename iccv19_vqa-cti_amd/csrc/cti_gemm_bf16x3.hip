@@ -91,6 +91,7 @@ struct PlaneGemmP {
     int total_tiles;
     const float* Af; int64_t ldaf; int Kreal;  // AF32 mode: the A operand is the fp32 matrix itself (rows x Kreal, row stride ldaf)
     const float* scale; int scale_div; const float* bias; int relu;
+    int64_t scale_bs, bias_bs;                 // per-batch (b1) strides of scale / bias
     // EPI_PLANES: the result is written as chunk-major bf16 hi/lo planes (columns N..Np-1 zero-filled) instead of fp32
     unsigned short* Ph; unsigned short* Pl; int64_t pitchP; int Np;
     // EPI_INTERLEAVE: GEMM row m' = m*gdiv + g addresses C[(m'/gdiv)*ldc_m + (m'%gdiv) + n*ldc_n] (gdiv = G, ldc_n = G)
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             for (int u = 0; u < 8; ++u) {
                 const int n = nb + u;
                 const bool real = n < p.N;
-                sc[u] = (real && p.scale) ? p.scale[n / p.scale_div] : 1.f;
-                bi[u] = (real && p.bias) ? p.bias[n] : 0.f;
+                sc[u] = (real && p.scale) ? p.scale[b1 * p.scale_bs + n / p.scale_div] : 1.f;
+                bi[u] = (real && p.bias) ? p.bias[b1 * p.bias_bs + n] : 0.f;
             }
 #pragma unroll
             for (int it = 0; it < TM * 4; ++it) {
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (n >= p.N) continue;
-        const float sc = p.scale ? p.scale[n / p.scale_div] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
+        const float sc = p.scale ? p.scale[b1 * p.scale_bs + n / p.scale_div] : 1.f;
+        const float bi = p.bias ? p.bias[b1 * p.bias_bs + n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -510,6 +511,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.rA1 = a.rA1; p.rA2 = a.rA2; p.rB1 = a.rB1; p.rB2 = a.rB2; p.sC1 = a.sC1; p.sC2 = a.sC2;
     p.nb2 = a.nb2; p.M = a.M; p.N = a.N; p.Kp = a.Kp;
     p.scale = a.scale; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.bias = a.bias; p.relu = a.relu;
+    p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
     p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
     if (a.Af && ((a.ldaf & 3) || (a.Kreal & 3) || (reinterpret_cast<uintptr_t>(a.Af) & 15)))

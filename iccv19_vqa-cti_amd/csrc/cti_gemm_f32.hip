@@ -130,8 +130,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_f32_kernel(GemmP p) {
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= p.N) continue;
-        const float sc = p.scale ? p.scale[n / p.scale_div] : 1.f;
-        const float bi = p.bias ? p.bias[n] : 0.f;
+        const float sc = p.scale ? p.scale[b1 * p.scale_bs + n / p.scale_div] : 1.f;
+        const float bi = p.bias ? p.bias[b1 * p.bias_bs + n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll

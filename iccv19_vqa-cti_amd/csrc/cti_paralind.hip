@@ -163,6 +163,8 @@ __global__ __launch_bounds__(256) void mbuild_kernel(const float* __restrict__ V
 using namespace cti;
 
 namespace cti {
+int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
+                int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 size_t wn_batch_partials(const WnBatch& d) { return (size_t)d.chunk_begin[d.n]; }
 void wn_batch_finish(WnBatch& d) {
     int cb = 0, mb = 0;
@@ -226,6 +228,10 @@ extern "C" int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const f
     CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(M);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && I > 0 && J > 0 && K > 0 && G > 0, CTI_E_SHAPE,
                 "cti_paralind_mbuild_fwd: B=%d V=%d Q=%d R=%d I=%d J=%d K=%d G=%d", B, V, Q, R, I, J, K, G);
+    if (I == J && J == K) {                                 // cubic cores (every TCNet): the fast kernel of cti_mbuild.hip, fp32 output
+        const int rc = mbuild_fast(Vr, Qr, Teff, M, nullptr, nullptr, B, V, Q, R, I, G, (int64_t)R * K, as_stream(stream));
+        if (rc != CTI_E_UNSUPPORTED) return rc;
+    }
     const size_t lds = sizeof(float) * ((size_t)J * K * G + I + (size_t)Q * J);
     CTI_REQUIRE(lds <= 64 * 1024, CTI_E_SHAPE, "cti_paralind_mbuild_fwd: J*K*G + I + Q*J = %zu floats exceed 64 KiB of LDS",
                 lds / 4);

@@ -318,7 +318,7 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
 
 # ---- backward-pass primitives ---------------------------------------------------------------------------------------
 def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None, sC1=0, scale=None, scale_div=1, bias=None, relu=False,
-            prec=None):
+            prec=None, scale_bs=0, bias_bs=0):
     """C[z][m,n] = act(scale * sum_k A[z*rA1 + m, k] * B[z*rB1 + n, k] + bias).  A (rowsA, K), B (rowsB, K) 2-D row-major."""
     _req(A, "A"); _req(B, "B")
     A2, lda = _rows2d(A); B2, ldb = _rows2d(B)
@@ -336,8 +336,8 @@ def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None,
     wsb = lib.cti_gemm_nt_workspace_bytes(A2.shape[0], B2.shape[0], K, pr)
     ws = torch.empty(wsb, device=A.device, dtype=torch.uint8) if wsb else None
     L.check(lib.cti_gemm_nt(A2.data_ptr(), lda, A2.shape[0], rA1, 0, B2.data_ptr(), ldb, B2.shape[0], rB1, 0, out.data_ptr(), ldc_m, ldc_n,
-                            sC1, 0, nb1, 1, M, N, K, _ptr(scale), int(scale_div), _ptr(bias), L.ACT_RELU if relu else L.ACT_NONE, pr,
-                            _ptr(ws), wsb, _stream()), "cti_gemm_nt")
+                            sC1, 0, nb1, 1, M, N, K, _ptr(scale), int(scale_div), int(scale_bs), _ptr(bias), int(bias_bs),
+                            L.ACT_RELU if relu else L.ACT_NONE, pr, _ptr(ws), wsb, _stream()), "cti_gemm_nt")
     return out
 
 
@@ -415,19 +415,23 @@ def wn_bwd(G, weight_v, weight_g, n_mats):
 _dropout_calls = [0]
 
 
-def dropout(x, p, mask=None):
-    """Forward (mask=None): returns (y, mask) with a fresh Philox stream keyed by torch's seed + a call counter.
-    Backward: pass the stored mask, returns dy * mask / (1-p)."""
+def dropout(x, p, mask=None, copies=1):
+    """Forward (mask=None): returns (y, mask) with a fresh Philox stream keyed by torch's seed + a call counter; copies = R > 1
+    returns R independently masked copies of x stacked on a new leading axis.  Backward: pass the stored mask, returns
+    dy * mask / (1-p) (same shape as dy)."""
     _req(x, "x")
     x = x.contiguous()
-    y = torch.empty_like(x)
     if mask is None:
-        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        shape = ((copies,) + tuple(x.shape)) if copies > 1 else tuple(x.shape)
+        y = torch.empty(shape, device=x.device, dtype=torch.float32)
+        mask = torch.empty(shape, device=x.device, dtype=torch.uint8)
         seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
         _dropout_calls[0] += 1
-        L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), seed, 0, 0, _stream()), "cti_dropout")
+        L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), y.numel(), float(p), seed, 0, 0,
+                                    x.numel() if copies > 1 else 0, _stream()), "cti_dropout")
         return y, mask
-    L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), 0, 0, 1, _stream()), "cti_dropout")
+    y = torch.empty_like(x)
+    L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), 0, 0, 1, 0, _stream()), "cti_dropout")
     return y
 
 

@@ -69,11 +69,11 @@ class TCNet(nn.Module):
         if self._act not in ('ReLU', ''):
             raise NotImplementedError("packed rank nets support act in {'ReLU', ''}")
         relu = self._act == 'ReLU'
+        wv, g, b = self._rank_pack(nets)
         if self.training and self._drop_p(nets[0]) > 0:
             # train mode: every rank net draws its OWN dropout mask on the shared input (src/fc.py:25-26 inside each of the R
-            # FCNets), so the R GEMMs cannot share one input; run them one by one (faithful, slower)
-            return torch.cat([n(x) for n in nets], -1)
-        wv, g, b = self._rank_pack(nets)
+            # FCNets): R masked copies of the input, one batched GEMM
+            return AG.RankNetsDropFn.apply(x, wv, g, b, relu, len(nets), self._drop_p(nets[0]))
         if _needs_grad(x, wv, g, b):
             return AG.WNLinearFn.apply(x, wv, g, b, relu, len(nets))
         hr = wv.shape[0] // len(nets)

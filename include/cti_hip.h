@@ -152,13 +152,13 @@ int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const fl
  * autograd Functions of the host code (iccv19_vqa-cti_amd/autograd.py) are made of.  The reference has no explicit
  * backward code: torch.autograd differentiates src/fc.py, src/tc.py, src/bc.py, src/attention.py op by op. */
 
-/* C[z][m,n] = act(scale[n/scale_div] * sum_k A[z][m,k] * B[z][n,k] + bias[n]).  A is ONE row-major matrix of
+/* C[z][m,n] = act(scale[b1*scale_bs + n/scale_div] * sum_k A[z][m,k] * B[z][n,k] + bias[b1*bias_bs + n]).  A is ONE row-major matrix of
  * rowsA_total x K (row stride lda); batch z = (b1, b2), b1 < nb1, b2 < nb2 uses its rows [b1*rA1 + b2*rA2, +M); likewise B
  * with N rows.  C element (m,n) of batch z at C[b1*sC1 + b2*sC2 + m*ldc_m + n*ldc_n]. */
 int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, int64_t rA2, const float* B, int64_t ldb,
                 int64_t rowsB_total, int64_t rB1, int64_t rB2, float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC1,
-                int64_t sC2, int nb1, int nb2, int M, int N, int K, const float* scale, int scale_div, const float* bias,
-                int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
+                int64_t sC2, int nb1, int nb2, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
+                const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
 
 /* dst[b][c][r] = src[b][r][c] (fp32, `batch` matrices of rows x cols). */
@@ -177,8 +177,10 @@ size_t cti_act_bwd_workspace_bytes(int64_t rows, int n);
 
 /* nn.Dropout (src/fc.py:20-21,25-26; src/bc.py:29).  use_mask = 0: draw keep ~ Bernoulli(1-p) from Philox-4x32-10 keyed by
  * `seed`, counter = offset + element/4; store it in mask[i] (1 byte) and write y = x * keep / (1-p).  use_mask = 1: reuse the
- * stored mask (the backward pass: x = dy).  x == y is allowed. */
-int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask, void* stream);
+ * stored mask (the backward pass: x = dy).  x == y is allowed.  period > 0: x is read at i % period, i.e. y is n / period
+ * independently masked copies of x (the R rank nets of src/tc.py:29-31 each draw their own mask of the shared input). */
+int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
+                int64_t period, void* stream);
 
 /* Gradient through weight_norm(dim=None) (torch `_weight_norm` backward): W = g * V / ||V||_F = s * V.  Given
  * G = dzs^T x (n_mats matrices of `elems` floats, the gradient w.r.t. V through the direct path):

@@ -194,3 +194,34 @@ def test_train_mode_runs_with_dropout_and_gives_gradients_to_every_parameter():
     for n_, prm in m.named_parameters():
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), n_
     assert q.grad is not None and a.grad is not None
+
+
+def test_batched_rank_nets_under_dropout_match_a_manual_per_rank_evaluation():
+    """RankNetsDropFn (train mode) against the same masks applied rank by rank with the plain WNLinear Function."""
+    torch.manual_seed(5)
+    R, hr, h, rows = 4, 16, 64, 70
+    AG = cti_amd.pkg.autograd
+    x = torch.randn(5, 14, h, device=DEV, requires_grad=True)
+    wv = (torch.randn(R * hr, h, device=DEV) / 8).requires_grad_(True)
+    g = (torch.rand(R, device=DEV) + 0.5).requires_grad_(True)
+    b = (torch.randn(R * hr, device=DEV) / 10).requires_grad_(True)
+    y = AG.RankNetsDropFn.apply(x, wv, g, b, True, R, 0.5)
+    cot = torch.randn_like(y)
+    (y * cot).sum().backward()
+    got = [t.grad.clone() for t in (x, wv, g, b)]
+    # recover the masks from the saved expanded input: Xd = x * mask / (1-p)
+    Xd = y.grad_fn.saved_tensors[0].view(R, 5, 14, h)
+    for t in (x, wv, g, b):
+        t.grad = None
+    outs = []
+    for r in range(R):
+        m = (Xd[r] != 0).float() / 0.5
+        xr = x * m
+        outs.append(AG.WNLinearFn.apply(xr, wv[r * hr:(r + 1) * hr], g[r], b[r * hr:(r + 1) * hr], True, 1))
+    y2 = torch.cat(outs, -1)
+    check(y, y2.detach().cpu().numpy(), tol=2e-5, what="batched rank nets forward")
+    (y2 * cot).sum().backward()
+    for n_, a_, t in zip(("dx", "dwv", "dg", "db"), got, (x, wv, g, b)):
+        check(a_, t.grad.cpu().numpy(), tol=1e-4, what="batched rank nets " + n_)
+    keep = (Xd != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.02
