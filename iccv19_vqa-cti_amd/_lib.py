@@ -33,7 +33,8 @@ SIGNATURES = {
     "cti_sum_batches": (_int, [_vp, _vp, _int, _i64, C.c_float, C.c_float, _vp]),
     "cti_act_bwd": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "cti_act_bwd_workspace_bytes": (_sz, [_i64, _int]),
-    "cti_wn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "cti_wn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _sz, _vp]),
+    "cti_wn_bwd_workspace_bytes": (_sz, [_int, _i64]),
     "cti_paralind_mbuild_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_masked_softmax_tri_bwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_bwd_workspace_bytes": (_sz, [_int, _int, _i64, _int]),

@@ -133,6 +133,44 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
+// multi-workgroup form for large matrices: partial <G,V> and ||V||^2 per 16,384-element chunk, then every workgroup of the
+// apply pass re-reduces its matrix's partials in the same fixed order
+constexpr int64_t WNB_CHUNK = 16384;
+__global__ __launch_bounds__(256) void wn_bwd_partial_kernel(const float* __restrict__ G, const float* __restrict__ V, float* __restrict__ part,
+                                                             int64_t elems, int cpm) {
+    __shared__ float r0[4], r1[4];
+    const int mat = blockIdx.y, ch = blockIdx.x;
+    const float* w = G + (int64_t)mat * elems; const float* v = V + (int64_t)mat * elems;
+    const int64_t lo = (int64_t)ch * WNB_CHUNK, hi = min(elems, lo + WNB_CHUNK);
+    float d = 0.f, n = 0.f;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) { d = fmaf(w[j], v[j], d); n = fmaf(v[j], v[j], n); }
+    d = wave_sum(d); n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = d; r1[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((int64_t)mat * cpm + ch) * 2] = (r0[0] + r0[1]) + (r0[2] + r0[3]);
+        part[((int64_t)mat * cpm + ch) * 2 + 1] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    }
+}
+__global__ __launch_bounds__(256) void wn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ V, const float* __restrict__ g,
+                                                           const float* __restrict__ part, float* __restrict__ dV, float* __restrict__ dg,
+                                                           int64_t elems, int cpm) {
+    __shared__ float cs;
+    const int mat = blockIdx.y, ch = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float d = 0.f, n2 = 0.f;
+        for (int c = 0; c < cpm; ++c) { d += part[((int64_t)mat * cpm + c) * 2]; n2 += part[((int64_t)mat * cpm + c) * 2 + 1]; }
+        cs = d / n2;
+        if (ch == 0) dg[mat] = d / g[mat];
+    }
+    __syncthreads();
+    const float c = cs;
+    const int64_t lo = (int64_t)ch * WNB_CHUNK, hi = min(elems, lo + WNB_CHUNK);
+    const float* w = G + (int64_t)mat * elems; const float* v = V + (int64_t)mat * elems;
+    float* o = dV + (int64_t)mat * elems;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) o[j] = fmaf(-c, v[j], w[j]);
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -190,12 +228,27 @@ extern "C" int cti_act_bwd(const float* dy, const float* y, const float* scale, 
     return cti_sum_batches(pb, dbias, chunks, n, 1.f, 0.f, stream);
 }
 
+extern "C" size_t cti_wn_bwd_workspace_bytes(int n_mats, int64_t elems) {
+    if (n_mats <= 0 || elems <= WNB_CHUNK) return 0;
+    return sizeof(float) * 2 * (size_t)n_mats * (size_t)((elems + WNB_CHUNK - 1) / WNB_CHUNK);
+}
+
 extern "C" int cti_wn_bwd(const float* G, const float* weight_v, const float* weight_g, float* dweight_v, float* dweight_g,
-                          int n_mats, int64_t elems, void* stream) {
+                          int n_mats, int64_t elems, void* workspace, size_t workspace_bytes, void* stream) {
     CTI_REQUIRE_PTR(G); CTI_REQUIRE_PTR(weight_v); CTI_REQUIRE_PTR(weight_g); CTI_REQUIRE_PTR(dweight_v); CTI_REQUIRE_PTR(dweight_g);
-    CTI_REQUIRE(n_mats > 0 && elems > 0, CTI_E_SHAPE, "cti_wn_bwd: n_mats=%d elems=%lld", n_mats, (long long)elems);
-    hipLaunchKernelGGL(wn_bwd_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), G, weight_v, weight_g, dweight_v, dweight_g, elems);
-    return launch_status("cti_wn_bwd");
+    CTI_REQUIRE(n_mats > 0 && n_mats <= 65535 && elems > 0, CTI_E_SHAPE, "cti_wn_bwd: n_mats=%d elems=%lld", n_mats, (long long)elems);
+    if (elems <= WNB_CHUNK || workspace == nullptr) {
+        hipLaunchKernelGGL(wn_bwd_kernel, dim3(n_mats), dim3(1024), 0, as_stream(stream), G, weight_v, weight_g, dweight_v, dweight_g, elems);
+        return launch_status("cti_wn_bwd");
+    }
+    CTI_REQUIRE(workspace_bytes >= cti_wn_bwd_workspace_bytes(n_mats, elems), CTI_E_WORKSPACE, "cti_wn_bwd: workspace too small");
+    const int cpm = (int)((elems + WNB_CHUNK - 1) / WNB_CHUNK);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(wn_bwd_partial_kernel, dim3(cpm, n_mats), dim3(256), 0, as_stream(stream), G, weight_v, part, elems, cpm);
+    int rc = launch_status("cti_wn_bwd/partial"); if (rc) return rc;
+    hipLaunchKernelGGL(wn_bwd_apply_kernel, dim3(cpm, n_mats), dim3(256), 0, as_stream(stream), G, weight_v, weight_g, part, dweight_v, dweight_g,
+                       elems, cpm);
+    return launch_status("cti_wn_bwd/apply");
 }
 
 // ---- generic strided batched NT GEMM: C[z][m,n] = act(scale[n/div] * sum_k A[z][m,k] * B[z][n,k] + bias[n]) ---------------

@@ -34,6 +34,22 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restric
     const float* qb = Qr + (int64_t)b * Q * K;
     const float* dmb = dM + (int64_t)b * V * Q * G * K;
     const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
+    // rank-independent index decoding, done once (runtime integer divisions cost ~40 instructions each)
+    const int xc = t % inner, xsp = t / inner, xns = max(1, nthr / inner);            // X: column xc, v = xsp, xsp + xns, ...
+    const int xg = xc % G, xk = (xc / G) % HR, xj = xc / (G * HR);
+    const int x_off = xg * HH + xj * HR + xk;
+    const int nout = Q * HR;
+    int P = 1;
+    while (P * 2 * nout <= nthr && P < 16) P *= 2;
+    const int qo = t / P, qpart = t % P, qq = qo / HR, qj = qo % HR;                   // dQr: output (qq, qj), v split P ways
+    int dx_v[2], dx_g[2], dx_k[2];                                                      // dX items (v, g, k): <= 2 per thread
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int it = t + n * nthr;
+        dx_k[n] = it % HR; dx_g[n] = (it / HR) % G; dx_v[n] = it < V * G * HR ? it / (HR * G) : -1;
+    }
+    const int tc = t % inner, ti0 = t / inner, tistep = max(1, nthr / inner);          // dT: column tc, rows ti0, ti0 + tistep, ...
+    const int tg = tc % G, tjk = tc / G;
     for (int r = r_lo; r < r_hi; ++r) {
         __syncthreads();
         const float* Tr = Teff + (int64_t)r * HR * inner;
@@ -41,24 +57,23 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restric
         for (int e = t; e < V * HR; e += nthr) Vs[e] = vb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
         for (int e = t; e < Q * HR; e += nthr) Qs[e] = qb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
         __syncthreads();
-        // X[v][g][j][k] (as the forward's step 1)
-        for (int it = t; it < inner * V; it += nthr) {
-            const int c = it % inner, v = it / inner;
-            float x = 0.f;
+        // X[v][g][j][k] (as the forward's step 1): the thread's T_eff column in registers, v strided over the column groups
+        if (xsp < xns) {
+            float tcol[HR];
 #pragma unroll
-            for (int i = 0; i < HR; ++i) x = fmaf(Ts[i * inner + c], Vs[v * HR + i], x);
-            const int g = c % G, k = (c / G) % HR, j = c / (G * HR);
-            Xs[(v * G + g) * HH + j * HR + k] = x;
+            for (int i = 0; i < HR; ++i) tcol[i] = Ts[i * inner + xc];
+            for (int v = xsp; v < V; v += xns) {
+                float x = 0.f;
+#pragma unroll
+                for (int i = 0; i < HR; ++i) x = fmaf(tcol[i], Vs[v * HR + i], x);
+                Xs[v * G * HH + x_off] = x;
+            }
         }
         __syncthreads();
         // dQr[q][j] = sum_{v,g} sum_k dM[v,q,g,k] X[v,g,j,k]: P lanes split v, shuffle-reduced
         {
-            const int nout = Q * HR;
-            int P = 1;
-            while (P * 2 * nout <= nthr && P < 16) P *= 2;
             if (t < nout * P) {
-                const int o = t / P, part = t % P;
-                const int q = o / HR, j = o % HR;
+                const int part = qpart, q = qq, j = qj;
                 float s = 0.f;
                 for (int v = part; v < V; v += P)
                     for (int g = 0; g < G; ++g) {
@@ -73,8 +88,10 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restric
         }
         __syncthreads();
         // dX[v][g][j][k] = sum_q dM[v,q,g,k] Qr[q,j]  (overwrites X)
-        for (int it = t; it < V * G * HR; it += nthr) {
-            const int k = it % HR, g = (it / HR) % G, v = it / (HR * G);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = dx_k[n], g = dx_g[n], v = dx_v[n];
+            if (v < 0) continue;
             float acc[HR];
 #pragma unroll
             for (int j = 0; j < HR; ++j) acc[j] = 0.f;
@@ -99,12 +116,11 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restric
             if (lane == 0) dVr[((int64_t)b * V + v) * K + r * HR + i] = s;
         }
         // dT_b[r][i][c] = sum_v Vr[v][i] dX[v][c]
-        for (int it = t; it < HR * inner; it += nthr) {
-            const int c = it % inner, i = it / inner;
-            const int g = c % G, jk = c / G;
+        for (int i = ti0; i < HR; i += tistep) {
+            if (ti0 >= tistep) break;
             float s = 0.f;
-            for (int v = 0; v < V; ++v) s = fmaf(Vs[v * HR + i], Xs[(v * G + g) * HH + jk], s);
-            dTpart[((int64_t)b * R + r) * HR * inner + it] = s;
+            for (int v = 0; v < V; ++v) s = fmaf(Vs[v * HR + i], Xs[(v * G + tg) * HH + tjk], s);
+            dTpart[((int64_t)b * R + r) * HR * inner + i * inner + tc] = s;
         }
     }
 }
@@ -361,7 +377,8 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
     CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(dVr); CTI_REQUIRE_PTR(dQr); CTI_REQUIRE_PTR(dTeff_partial);
     CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && R > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd: B=%d V=%d Q=%d R=%d G=%d", B, V, Q, R, G);
     CTI_REQUIRE(hr == 4 || hr == 8 || hr == 16, CTI_E_UNSUPPORTED, "cti_paralind_mbuild_bwd: h/rank=%d (built for 4, 8, 16)", hr);
-    CTI_REQUIRE(Q * hr <= 1024, CTI_E_UNSUPPORTED, "cti_paralind_mbuild_bwd: Q*hr=%d > 1024", Q * hr);
+    CTI_REQUIRE(Q * hr <= 1024 && hr * hr * G <= 1024 && V * G * hr <= 2048, CTI_E_UNSUPPORTED,
+                "cti_paralind_mbuild_bwd: shape outside the kernel's per-thread budgets (Q*hr=%d, hr^2*G=%d, V*G*hr=%d)", Q * hr, hr * hr * G, V * G * hr);
     const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)Q * hr);
     int groups = (256 + B - 1) / B; if (groups > R) groups = R;
     const int rpb = (R + groups - 1) / groups;

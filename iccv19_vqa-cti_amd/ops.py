@@ -407,8 +407,11 @@ def wn_bwd(G, weight_v, weight_g, n_mats):
     G = G.contiguous(); wv = weight_v.contiguous(); g = weight_g.contiguous().view(-1)
     dV = torch.empty_like(wv)
     dg = torch.empty(n_mats, device=wv.device, dtype=torch.float32)
-    L.check(L.lib().cti_wn_bwd(G.data_ptr(), wv.data_ptr(), g.data_ptr(), dV.data_ptr(), dg.data_ptr(), n_mats, wv.numel() // n_mats,
-                               _stream()), "cti_wn_bwd")
+    lib = L.lib()
+    wsb = lib.cti_wn_bwd_workspace_bytes(n_mats, wv.numel() // n_mats)
+    ws = torch.empty(wsb, device=wv.device, dtype=torch.uint8) if wsb else None
+    L.check(lib.cti_wn_bwd(G.data_ptr(), wv.data_ptr(), g.data_ptr(), dV.data_ptr(), dg.data_ptr(), n_mats, wv.numel() // n_mats,
+                           _ptr(ws), wsb, _stream()), "cti_wn_bwd")
     return dV, dg
 
 

@@ -186,7 +186,8 @@ int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uin
  * G = dzs^T x (n_mats matrices of `elems` floats, the gradient w.r.t. V through the direct path):
  * dweight_g[i] = <G_i, V_i> / g_i;  dweight_v = G - (<G,V> / ||V||^2) * V. */
 int cti_wn_bwd(const float* G, const float* weight_v, const float* weight_g, float* dweight_v, float* dweight_g, int n_mats,
-               int64_t elems, void* stream);
+               int64_t elems, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_wn_bwd_workspace_bytes(int n_mats, int64_t elems);   /* 0 for matrices of <= 16,384 elements (one workgroup each) */
 
 /* Backward of cti_paralind_mbuild_fwd (hr = I = J = K in {4, 8, 16}).  dM (B,V,Q,G,R*hr); dVr (B,V,R*hr); dQr (B,Q,R*hr);
  * dTeff_partial (B,R,hr,hr,hr,G): per-sample partials of dT_eff -- sum them with cti_sum_batches, then map to T_g's layout with

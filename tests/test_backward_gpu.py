@@ -207,10 +207,10 @@ def test_batched_rank_nets_under_dropout_match_a_manual_per_rank_evaluation():
     b = (torch.randn(R * hr, device=DEV) / 10).requires_grad_(True)
     y = AG.RankNetsDropFn.apply(x, wv, g, b, True, R, 0.5)
     cot = torch.randn_like(y)
+    # recover the masks from the saved expanded input: Xd = x * mask / (1-p)  (before backward frees the saved tensors)
+    Xd = y.grad_fn.saved_tensors[0].clone().view(R, 5, 14, h)
     (y * cot).sum().backward()
     got = [t.grad.clone() for t in (x, wv, g, b)]
-    # recover the masks from the saved expanded input: Xd = x * mask / (1-p)
-    Xd = y.grad_fn.saved_tensors[0].view(R, 5, 14, h)
     for t in (x, wv, g, b):
         t.grad = None
     outs = []
