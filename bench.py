@@ -104,8 +104,69 @@ def whole_job_rate(world, batch_per_rank, steps, elapsed):
     return world * batch_per_rank * steps / elapsed
 
 
+class CTIFusionBlock(torch.nn.Module):
+    """The CTI fusion of CTIModel.forward (reference src/FFOE/base_model.py:128-135) at the VQA-2.0 shapes of BASELINE configs[3]/[4]:
+    TriAttention (h_mm 512, rank 32, glimpse 2), one TCNet(k=2) pooling + q_prj/a_prj residual per glimpse, sum, and a stock-torch
+    2-layer classifier (outside the CTI path).  Used by --mode train only."""
+
+    def __init__(self, cti, v_dim=2048, num_hid=1024, h_mm=512, rank=32, gamma=2, n_ans=3129):
+        super().__init__()
+        self.gamma = gamma
+        self.t_att = cti.TriAttention(v_dim, num_hid, num_hid, h_mm, 1, rank, gamma, 1, dropout=[.2, .5])
+        self.t_net = torch.nn.ModuleList([cti.TCNet(v_dim, num_hid, num_hid, h_mm, 1, rank, 1, dropout=[.2, .5], k=2) for _ in range(gamma)])
+        self.q_prj = torch.nn.ModuleList([cti.FCNet([num_hid, num_hid], '', .2) for _ in range(gamma)])
+        self.a_prj = torch.nn.ModuleList([cti.FCNet([num_hid, num_hid], '', .2) for _ in range(gamma)])
+        self.classifier = torch.nn.Sequential(torch.nn.Linear(num_hid, 2 * num_hid), torch.nn.ReLU(), torch.nn.Linear(2 * num_hid, n_ans))
+
+    def forward(self, v, q_emb, ans_emb):
+        att, _ = self.t_att(v, q_emb, ans_emb)
+        for g in range(self.gamma):
+            b_emb = self.t_net[g].forward_with_weights(v, q_emb, ans_emb, att[:, :, :, :, g])
+            q_emb = self.q_prj[g](b_emb.unsqueeze(1)) + q_emb
+            ans_emb = self.a_prj[g](b_emb.unsqueeze(1)) + ans_emb
+        return self.classifier(q_emb.sum(1) + ans_emb.sum(1))
+
+
+def run_train(args, world, rank, dev, dist):
+    """--mode train: data-parallel training step (BASELINE configs[4] shape: 256 rows per GPU) of the CTI fusion block:
+    forward + backward in HIP, ONE RCCL all-reduce of the flat gradient buffer, fused clip + Adamax.  Not the headline metric."""
+    import cti_amd
+    cti_amd.set_precision(args.precision)
+    torch.manual_seed(SEED)
+    model = CTIFusionBlock(cti_amd).to(dev).train()
+    opt = cti_amd.FlatAdamaxDP(model, lr=1e-3, clip_norm=0.25)
+    opt.broadcast_parameters()
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(SEED + 1 + rank)
+    v = torch.randn(B, 36, 2048, generator=g).abs_()
+    for b in range(B):
+        v[b, int(torch.randint(10, 37, (1,), generator=g)):] = 0
+    q = torch.tanh(torch.randn(B, 12, 1024, generator=g)).to(dev)
+    a = torch.tanh(torch.randn(B, 3, 1024, generator=g)).to(dev)
+    y = (torch.rand(B, 3129, generator=g) > 0.999).float().to(dev)
+    v = v.to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(v, q, a), y, reduction="sum") / B
+        loss.backward()
+        opt.step()
+
+    el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "CTI fusion-block data-parallel training samples/sec (256 rows/GPU, VQA-2.0 shapes)",
+                          "value": whole_job_rate(world, B, args.steps, el), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32 (bf16x3 split products)" if args.precision == "bf16x3" else args.precision,
+                          "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + classifier, "
+                                                 "train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
+                                     "global_batch": world * B, "parameters": opt.n, "parallelism": "dp%d" % world}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"], help="forward (the BASELINE metric) or train (DP step)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -133,6 +194,11 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.mode == "train":
+        run_train(args, world, rank, dev, dist)
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     import cti_amd
     cti_amd.set_precision(args.precision)
     c = dict(C2, B=args.batch)
