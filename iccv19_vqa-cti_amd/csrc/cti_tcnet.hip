@@ -106,7 +106,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
                                  const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                                  uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                  int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                                 void* ev_core_end, void* stream) {
+                                 void* ev_core_end, void* aux_stream, void* stream) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -156,30 +156,40 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     }
 
     const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
-    bool af32[3];
-    for (int s = 0; s < 3; ++s) {
-        // Option (compile with -DCTI_AF32=1): feed the raw input to the Tucker GEMM as fp32 and split it at fragment-read time,
-        // skipping the HBM-bound split pass (2 GB of traffic for `a` at config 2).  MEASURED NEUTRAL on MI355X: the split pass
-        // (0.55 ms) disappears but the GEMMs slow down by the same amount (64-B row segments instead of contiguous KiB through
-        // the LDS-DMA path, conversions beside the MFMAs), so the default keeps the split pass.
-#ifndef CTI_AF32
-#define CTI_AF32 0
-#endif
-        af32[s] = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
-        if (!af32[s]) { rc = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, st); if (rc) return rc; }
-        rc = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
-        rc = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
+    // Two independent chains feed the mode-3 GEMM: chain A (the a side: split, Tucker, rank nets -- 2.8 ms at config 2, opens with the
+    // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
+    // an auxiliary stream from the caller chain B runs beside chain A's split pass: fork/join with two events, no host sync.
+    hipStream_t sb = aux_stream ? as_stream(aux_stream) : st;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (aux_stream) {
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed");
+        (void)hipEventRecord(ev_fork, st);                  // scales, T_eff (and the mask) precede both chains
+        (void)hipStreamWaitEvent(sb, ev_fork, 0);
     }
+    auto finish = [&](int code) {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        return code;
+    };
+#ifndef CTI_AF32
+#define CTI_AF32 0       // option: fp32 A operand split at fragment-read time instead of the split pass (measured neutral on MI355X)
+#endif
     const int Kh = planes_kp(h);
-    for (int s = 0; s < 3; ++s) {
+    auto side = [&](int s, hipStream_t ss) -> int {
+        const bool af32 = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
+        int r_;
+        if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
+        r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
+        r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
-        if (af32[s]) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
+        if (af32) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
         g.rows_allocA = p.xin[s].rows_alloc; g.rows_allocB = p.wt[s].rows_alloc; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
         g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.rows_allocP = p.tp[s].rows_alloc; g.Np = Kh;
         g.scale = p.scale_t[s]; g.scale_div = h; g.bias = tucker_b[s]; g.relu = relu;
-        rc = gemm_nt_planes(g, st); if (rc) return rc;
+        r_ = gemm_nt_planes(g, ss); if (r_) return r_;
         PlaneGemmArgs r{};                                   // packed rank nets: planes -> fp32 (v, q) or planes (a)
         r.Ah = p.tp[s].hi; r.Al = p.tp[s].lo; r.Bh = p.wr[s].hi; r.Bl = p.wr[s].lo;
         r.rows_allocA = p.tp[s].rows_alloc; r.rows_allocB = p.wr[s].rows_alloc; r.nb1 = 1; r.nb2 = 1;
@@ -187,16 +197,23 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         r.scale = p.scale_r[s]; r.scale_div = hr; r.bias = rank_b[s]; r.relu = relu;
         if (s < 2) { r.epi = 0; r.C = s == 0 ? p.Vr : p.Qr; r.ldc_m = h; r.ldc_n = 1; }
         else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.rows_allocP = p.Arp.rows_alloc; r.Np = Kh; }
-        rc = gemm_nt_planes(r, st); if (rc) return rc;
-    }
-    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, st);
+        return gemm_nt_planes(r, ss);
+    };
+    // chain B on the auxiliary stream (or first, on the main stream)
+    rc = side(0, sb); if (rc) return finish(rc);
+    rc = side(1, sb); if (rc) return finish(rc);
+    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) {
         // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h)
-        CTI_REQUIRE(A >= h, CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr);
-        rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, stream); if (rc) return rc;
-        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, st);
+        if (A < h) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr));
+        rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, sb); if (rc) return finish(rc);
+        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, sb);
     }
-    if (rc) return rc;
+    if (rc) return finish(rc);
+    if (aux_stream) (void)hipEventRecord(ev_join, sb);
+    // chain A on the main stream
+    rc = side(2, st); if (rc) return finish(rc);
+    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;
     c.rows_allocA = p.Mp.rows_alloc; c.rows_allocB = p.Arp.rows_alloc; c.rA1 = mrows_per_b; c.rB1 = A; c.nb1 = B; c.nb2 = 1;
@@ -205,5 +222,5 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
     rc = gemm_nt_planes(c, st);
     if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
-    return rc;
+    return finish(rc);
 }

@@ -29,6 +29,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+import os as _os
+
+_aux = {}
+use_aux_stream = _os.environ.get("CTI_NO_AUX_STREAM", "0") != "1"
+
+
+def _aux_stream(device):
+    """One side stream per device for cti_tcnet_forward's second chain (None disables the overlap).  Buffers touched on it are
+    allocated on the current stream and only reused after the call's join event, so the caching allocator stays consistent."""
+    if not use_aux_stream:
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _aux:
+        _aux[key] = torch.cuda.Stream(device=device)
+    return _aux[key].cuda_stream
+
+
 # ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
 _prof = None
 
@@ -235,7 +252,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     with _timed("tcnet_forward"):
         L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                       _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
-                                      ws.data_ptr(), wsb, ev0, ev1, _stream()), "cti_tcnet_forward")
+                                      ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
     return (out, mask) if want_mask else out
 
 

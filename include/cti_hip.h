@@ -106,13 +106,15 @@ size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int
  * cti_zero_row_mask(v) (what TriAttention needs next).  All intermediates live in `workspace`
  * (cti_tcnet_forward_workspace_bytes); between MFMA GEMMs they stay bf16 hi/lo planes (no fp32 round trip).
  * ev_core_begin / ev_core_end: NULL, or hipEvent_t handles (cti_event_create) recorded on `stream` immediately before and
- * after the mode-3 GEMM launch -- how bench.py measures the dominant kernel inside the timed region. */
+ * after the mode-3 GEMM launch -- how bench.py measures the dominant kernel inside the timed region.
+ * aux_stream: NULL, or a second hipStream_t of the caller: the v/q-side chain + M build then run on it beside the a-side chain
+ * (fork/join by events inside the call; on return all work is ordered behind `stream` as usual). */
 int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                       const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                       const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                       uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                       int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                      void* ev_core_end, void* stream);
+                      void* ev_core_end, void* aux_stream, void* stream);
 size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                          int G, int prec);
 

@@ -65,6 +65,7 @@ def run(rounds=5, prec=1):
     ref = None
     times = {k: ([], []) for k in libs}
     st = torch.cuda.current_stream().cuda_stream
+    AUX = torch.cuda.Stream().cuda_stream if os.environ.get('CTI_TUNE_AUX', '0') == '1' else None
     for rnd in range(rounds + 1):
         for name, l in libs.items():
             wsb = l.cti_tcnet_forward_workspace_bytes(B, V, Q, A, c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, prec)
@@ -72,7 +73,7 @@ def run(rounds=5, prec=1):
             e = [l.cti_event_create() for _ in range(4)]
             l.cti_event_record(e[0], st)
             rc = l.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), *args6, Tg.data_ptr(), out.data_ptr(), None, B, V, Q, A,
-                                     c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, 1, prec, ws.data_ptr(), wsb, e[1], e[2], st)
+                                     c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, 1, prec, ws.data_ptr(), wsb, e[1], e[2], AUX, st)
             assert rc == 0, (name, rc, l.cti_last_error_string())
             l.cti_event_record(e[3], st)
             torch.cuda.synchronize()
