@@ -82,3 +82,41 @@ def c4_bi_case():
     for b, r in c["zero_from"].items():
         v[int(b), int(r):] = 0
     return fx, params, v, q
+
+
+def model_state(keys_shapes, seed):
+    """Parameters of the model-level fixtures (g9/g10/g12): identical copy of tests/golden/make_golden_models.py:model_state."""
+    rs = np.random.RandomState(seed)
+    shapes = {k: tuple(s) for k, s in keys_shapes}
+    new = {}
+
+    def normal(shape, scale):
+        return (rs.standard_normal(size=shape).astype(np.float32) * np.float32(scale)).reshape(shape)
+
+    for k, shape in keys_shapes:
+        shape = tuple(shape)
+        if ".rnn.weight" in k:
+            x = normal(shape, 1.0 / np.sqrt(shape[-1]))
+        elif ".rnn.bias" in k:
+            x = normal(shape, 0.1)
+        elif k.endswith("emb.weight") or k.endswith("emb_.weight"):
+            x = normal(shape, 0.5)
+        elif k.endswith("weight_v"):
+            x = normal(shape, 1.0 / np.sqrt(shape[-1]))
+        elif k.endswith("weight_g"):
+            x = np.float32((abs(rs.standard_normal()) + 0.5) * np.sqrt(shapes[k[:-1] + "v"][0]))
+        elif k.endswith("h_mat_g"):
+            x = np.float32(abs(rs.standard_normal()) + 0.5)
+        elif k.endswith("bias") and not k.endswith("h_bias"):
+            x = normal(shape, 0.1)
+        else:
+            x = normal(shape, 1.0)
+        new[k] = np.asarray(x, dtype=np.float32).reshape(shape)
+    return new
+
+
+def model_case(name):
+    """(fixture, params) of a model-level fixture: parameters regenerated from the (key, shape) list in its cfg."""
+    fx = load(name)
+    params = model_state([(k, tuple(s)) for k, s in fx.cfg["state_keys"]], fx.cfg["seed"])
+    return fx, params
