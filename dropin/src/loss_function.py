@@ -1,0 +1,3 @@
+"""Drop-in for the reference's src/loss_function.py: re-exports the MI355X implementation."""
+import cti_amd  # noqa: F401  (repo root on sys.path)
+from iccv19_vqa_cti_amd.loss_function import *  # noqa: F401,F403

@@ -45,6 +45,18 @@ SIGNATURES = {
     "cti_flat_scale_sumsq": (_int, [_vp, _i64, C.c_float, _vp, _vp]),
     "cti_adamax_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _int, _vp, _vp]),
     "cti_optim_workspace_bytes": (_sz, []),
+    "cti_embedding_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "cti_embedding_bwd": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _int, _i64, _i64, _vp]),
+    "cti_gru_gates_fwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp]),
+    "cti_gru_gates_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp]),
+    "cti_swish_fwd": (_int, [_vp, _vp, _i64, _vp]),
+    "cti_swish_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "cti_seq_sum": (_int, [_vp, _vp, _int, _int, _int, C.c_float, _vp]),
+    "cti_seq_bcast_add": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "cti_bce_logits_rows_fwd": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
+    "cti_bce_logits_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _i64, C.c_float, _vp]),
+    "cti_kd_rows_fwd": (_int, [_vp, _vp, _vp, _int, _int, C.c_float, _vp]),
+    "cti_kd_rows_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _int, _int, C.c_float, C.c_float, _vp]),
     "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _i64, _vp]),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),

@@ -223,3 +223,115 @@ class RankNetsDropFn(torch.autograd.Function):
             dXm = ops.dropout(dXd.view(R, rows, h), p, mask)
             dx = ops.sum_batches(dXm, R, rows * h).view(xshape)
         return dx, dV.view_as(wv), dg.view_as(g), db, None, None, None
+
+
+# ---- rows either side of the CTI path ------------------------------------------------------------------------
+class EmbeddingFn(torch.autograd.Function):
+    """WordEmbedding lookup (src/language_model.py:40-44): table1 is the frozen copy concatenated when 'c' in op."""
+
+    @staticmethod
+    def forward(ctx, tokens, table0, table1, padding_idx):
+        ctx.save_for_backward(tokens)
+        ctx.shape, ctx.pad = tuple(table0.shape), padding_idx
+        ctx.has1 = table1 is not None
+        return ops.embedding(tokens, table0, table1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        rows, dim = ctx.shape
+        d0 = ops.embedding_bwd(tokens, dout, 0, rows, dim, ctx.pad) if ctx.needs_input_grad[1] else None
+        d1 = ops.embedding_bwd(tokens, dout, dim, rows, dim, ctx.pad) if (ctx.has1 and ctx.needs_input_grad[2]) else None
+        return None, d0, d1, None
+
+
+class GRUFn(torch.autograd.Function):
+    """nn.GRU forward_all (src/language_model.py:91-96) with back-propagation through time in HIP kernels + MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        out, save, hps = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=True)
+        ctx.save_for_backward(x, w_ih, w_hh, save, hps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_ih, w_hh, save, hps = ctx.saved_tensors
+        dx, dW_ih, dW_hh, db_ih, db_hh = ops.gru_backward(dout, x, w_ih, w_hh, save, hps, need_dx=ctx.needs_input_grad[0])
+        return dx, dW_ih, dW_hh, db_ih, db_hh
+
+
+class SwishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.swish(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.swish_bwd(x, dy)
+
+
+class SeqSumFn(torch.autograd.Function):
+    """(B,L,H) -> (B,H), the `.sum(1)` of src/FFOE/base_model.py:66,134."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.L = x.shape[1]
+        return ops.seq_sum(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.seq_bcast_add(None, dout.contiguous(), ctx.L)
+
+
+class SeqBcastAddFn(torch.autograd.Function):
+    """x (B,L,H) + y (B,H)[:, None, :], the residual update of src/FFOE/base_model.py:61,131-132."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        return ops.seq_bcast_add(x, y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dy = ops.seq_sum(dout) if ctx.needs_input_grad[1] else None
+        return (dout if ctx.needs_input_grad[0] else None), dy
+
+
+class BCELogitsSumFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss(reduction='sum') (src/FFOE/train.py:28-33) -> 0-d tensor."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        ctx.save_for_backward(x, target)
+        rows = ops.bce_logits_sum(x, target)
+        return ops.sum_batches(rows, rows.numel(), 1).view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, target = ctx.saved_tensors
+        return ops.bce_logits_bwd(x, target, dl.contiguous(), 1.0).view_as(x), None
+
+
+class DistillationFn(torch.autograd.Function):
+    """Distillation_Loss.forward (src/loss_function.py:21-24): mean_b KL(softmax(k/T) || softmax(x/T)) * alpha*T*T + BCE_sum/B * (1-alpha)."""
+
+    @staticmethod
+    def forward(ctx, x, knowledge, target, T, alpha):
+        ctx.save_for_backward(x, knowledge, target)
+        ctx.T, ctx.alpha = T, alpha
+        B = x.shape[0]
+        kl = ops.kd_rows(x, knowledge, T)
+        bce = ops.bce_logits_sum(x, target)
+        out = ops.sum_batches(kl, kl.numel(), 1, alpha=alpha * T * T / B)
+        return ops.sum_batches(bce, bce.numel(), 1, alpha=(1.0 - alpha) / B, out=out, beta=1.0).view(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, knowledge, target = ctx.saved_tensors
+        B = x.shape[0]
+        dl = dl.contiguous()
+        dx = ops.kd_rows_bwd(x, knowledge, dl, ctx.alpha * ctx.T * ctx.T / B, ctx.T)
+        dx = ops.bce_logits_bwd(x, target, dl, (1.0 - ctx.alpha) / B, dx=dx, beta=1.0)
+        return dx.view_as(x), None, None, None, None

@@ -1,0 +1,241 @@
+"""Model forwards that call the CTI / BAN modules -- mirrors of the reference's
+src/FFOE/base_model.py:21-67 (BanModel), :92-136 (CTIModel), :139-160 (build_ban), :179-201 (build_cti) and of
+src/MC/base_model.py:19-77 (BanModel), :111-152 (TanModel), :155-203 (builders): same constructor arguments, attribute names
+(hence state_dict keys) and return values.
+
+Everything between the token ids and the logits runs in the HIP library: embedding gather, GRU, the CTI / BAN modules, the
+residual projections (`q_prj(b_emb.unsqueeze(1)) + q_emb` = one GEMM + one broadcast-add kernel, no (B,1,H) round trip
+through a generic broadcast), the sequence sums and the classifier.
+
+Outside the path (they raise): the counting module (`--use_counter`, src/counting.py) and the SAN baseline; tf-idf
+initialisation of the embeddings (`tfidf_loading`, src/utils.py) is data preparation -- load a checkpoint or call
+`WordEmbedding.init_embedding`."""
+import torch
+import torch.nn as nn
+
+from . import autograd as AG
+from . import ops
+from .attention import BiAttention, TriAttention
+from .bc import BCNet
+from .classifier import SimpleClassifier
+from .fc import FCNet
+from .language_model import QuestionEmbedding, WordEmbedding
+from .tc import TCNet, _needs_grad
+
+
+def _residual(prj, b_emb, seq):
+    """prj(b_emb.unsqueeze(1)) + seq  (src/FFOE/base_model.py:61,131-132): (B,H) through the FCNet, broadcast over the sequence."""
+    y = prj(b_emb)                                                           # (B, H)
+    if _needs_grad(y, seq):
+        return AG.SeqBcastAddFn.apply(seq, y)
+    return ops.seq_bcast_add(seq, y)
+
+
+def _joint(q_emb, ans_emb):
+    """q_emb.sum(1) + ans_emb.sum(1)  (src/FFOE/base_model.py:134)."""
+    if _needs_grad(q_emb, ans_emb):
+        return AG.SeqSumFn.apply(q_emb) + AG.SeqSumFn.apply(ans_emb)
+    return ops.seq_sum(ans_emb, out=ops.seq_sum(q_emb), beta=1.0)
+
+
+def _no_counter(counter):
+    if counter is not None:
+        raise NotImplementedError("the counting module (src/counting.py, --use_counter) is outside the CTI path; build with counter=None")
+
+
+class BanModel(nn.Module):
+    """FFOE BAN (src/FFOE/base_model.py:21-67)."""
+
+    def __init__(self, dataset, w_emb, q_emb, v_att, b_net, q_prj, c_prj, classifier, counter, op, glimpse):
+        super(BanModel, self).__init__()
+        _no_counter(counter)
+        self.dataset = dataset
+        self.op = op
+        self.glimpse = glimpse
+        self.w_emb = w_emb
+        self.q_emb = q_emb
+        self.v_att = v_att
+        self.b_net = nn.ModuleList(b_net)
+        self.q_prj = nn.ModuleList(q_prj)
+        self.classifier = classifier
+        self.counter = counter
+
+    def forward(self, v, b, q, labels):
+        """v: [batch, num_objs, obj_dim]; b: boxes (read by the counter only); q: [batch, seq_length] token ids.
+        return: logits (not probs), att"""
+        w_emb = self.w_emb(q)
+        q_emb = self.q_emb.forward_all(w_emb)                               # [batch, q_len, q_dim]
+        att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
+        total = None
+        for g in range(self.glimpse):
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :])
+            q_emb = _residual(self.q_prj[g], b_emb, q_emb)
+            # torch.stack(q_emb_list, 1).sum(1) then .sum(1): accumulate the per-glimpse sequence sums
+            if _needs_grad(q_emb):
+                s = AG.SeqSumFn.apply(q_emb)
+                total = s if total is None else total + s
+            else:
+                total = ops.seq_sum(q_emb, out=total, beta=1.0 if total is not None else 0.0)
+        logits = self.classifier(total)
+        return logits, att
+
+
+class _TriModel(nn.Module):
+    """The forward shared by FFOE CTIModel (src/FFOE/base_model.py:112-136) and MC TanModel (src/MC/base_model.py:128-152)."""
+
+    def _forward(self, t_att, v, q, ans):
+        q_emb = self.q_emb.forward_all(self.w_emb(q))                       # [batch, q_len, q_dim]
+        ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+        att, logits = t_att(v, q_emb, ans_emb)                              # b x v x q x a x g
+        for g in range(self.glimpse):
+            b_emb = self.t_net[g].forward_with_weights(v, q_emb, ans_emb, att[:, :, :, :, g])
+            q_emb = _residual(self.q_prj[g], b_emb, q_emb)
+            ans_emb = _residual(self.a_prj[g], b_emb, ans_emb)
+        return self.classifier(_joint(q_emb, ans_emb)), att
+
+
+class CTIModel(_TriModel):
+    def __init__(self, dataset, w_emb, q_emb, wa_emb, ans_emb, t_att, t_net, q_prj, a_prj, classifier, op, glimpse):
+        super(CTIModel, self).__init__()
+        self.dataset = dataset
+        self.op = op
+        self.glimpse = glimpse
+        self.w_emb = w_emb
+        self.q_emb = q_emb
+        self.wa_emb = wa_emb
+        self.ans_emb = ans_emb
+        self.t_att = t_att
+        self.t_net = nn.ModuleList(t_net)
+        self.q_prj = nn.ModuleList(q_prj)
+        self.a_prj = nn.ModuleList(a_prj)
+        self.classifier = classifier
+
+    def forward(self, v, q, ans):
+        """v: [batch, num_objs, obj_dim]; q, ans: token ids.  return: logits, not probs"""
+        return self._forward(self.t_att, v, q, ans)[0]
+
+
+class TanModel(_TriModel):
+    """MC (Visual7W) CTI model (src/MC/base_model.py:111-152): the TriAttention is called `v_att`, forward also returns att."""
+
+    def __init__(self, dataset, w_emb, q_emb, wa_emb, ans_emb, v_att, t_net, q_prj, a_prj, classifier, op, glimpse):
+        super(TanModel, self).__init__()
+        self.dataset = dataset
+        self.op = op
+        self.glimpse = glimpse
+        self.w_emb = w_emb
+        self.q_emb = q_emb
+        self.wa_emb = wa_emb
+        self.ans_emb = ans_emb
+        self.v_att = v_att
+        self.t_net = nn.ModuleList(t_net)
+        self.q_prj = nn.ModuleList(q_prj)
+        self.a_prj = nn.ModuleList(a_prj)
+        self.classifier = classifier
+
+    def forward(self, v, b, q, ans):
+        return self._forward(self.v_att, v, q, ans)
+
+
+class MCBanModel(nn.Module):
+    """MC BAN (src/MC/base_model.py:19-77): two bilinear attentions, image-question and image-answer."""
+
+    def __init__(self, dataset, w_emb, q_emb, wa_emb, ans_emb, v_att, b_net, va_att, tva_net, q_prj, a_prj, c_prj, classifier, counter,
+                 op, glimpse):
+        super(MCBanModel, self).__init__()
+        _no_counter(counter)
+        self.dataset = dataset
+        self.op = op
+        self.glimpse = glimpse
+        self.w_emb = w_emb
+        self.q_emb = q_emb
+        self.wa_emb = wa_emb
+        self.ans_emb = ans_emb
+        self.v_att = v_att
+        self.b_net = nn.ModuleList(b_net)
+        self.q_prj = nn.ModuleList(q_prj)
+        self.a_prj = nn.ModuleList(a_prj)
+        self.va_att = va_att
+        self.tva_net = nn.ModuleList(tva_net)
+        self.classifier = classifier
+        self.counter = counter
+
+    def forward(self, v, b, q, ans):
+        q_emb = self.q_emb.forward_all(self.w_emb(q))
+        ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+        att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
+        va_att, va_logits = self.va_att.forward_all(v, ans_emb)
+        for g in range(self.glimpse):
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :])
+            va_emb = self.tva_net[g].forward_with_weights(v, ans_emb, va_att[:, g, :, :])
+            q_emb = _residual(self.q_prj[g], b_emb, q_emb)
+            ans_emb = _residual(self.a_prj[g], va_emb, ans_emb)
+        return self.classifier(_joint(q_emb, ans_emb)), att
+
+
+def _embeddings(args, dataset, n):
+    """n x (WordEmbedding, QuestionEmbedding) exactly as src/FFOE/base_model.py:140-141,180-185 builds them."""
+    out = []
+    for _ in range(n):
+        out.append(WordEmbedding(dataset.dictionary.ntoken, 300, .0, args.op))
+        out.append(QuestionEmbedding(300 if 'c' not in args.op else 600, args.num_hid, 1, False, .0))
+    return out
+
+
+def build_ban(args, dataset):
+    """src/FFOE/base_model.py:139-160 (module construction order = the reference's, so the same seed gives the same parameters)."""
+    w_emb, q_emb = _embeddings(args, dataset, 1)
+    v_att = BiAttention(dataset.v_dim, args.num_hid, args.num_hid, args.gamma)
+    b_net, q_prj, c_prj = [], [], []
+    objects = 10                                                            # minimum number of boxes
+    for i in range(args.gamma):
+        b_net.append(BCNet(dataset.v_dim, args.num_hid, args.num_hid, None, k=1))
+        q_prj.append(FCNet([args.num_hid, args.num_hid], '', .2))
+        c_prj.append(FCNet([objects + 1, args.num_hid], 'ReLU', .0))        # built (RNG stream) but only kept with a counter
+    classifier = SimpleClassifier(args.num_hid, args.num_hid * 2, dataset.num_ans_candidates, args)
+    if getattr(args, 'use_counter', False):
+        _no_counter(True)
+    return BanModel(dataset, w_emb, q_emb, v_att, b_net, q_prj, c_prj, classifier, None, args.op, args.gamma)
+
+
+def _tri_parts(args, dataset, num_ans):
+    w_emb, q_emb, wa_emb, ans_emb = _embeddings(args, dataset, 2)
+    # the reference builds both WordEmbeddings first, then both GRUs in this order: w_emb, q_emb, wa_emb, ans_emb (lines 180-184)
+    t_att = TriAttention(dataset.v_dim, args.num_hid, args.num_hid, args.h_mm, 1, args.rank, args.gamma, args.k, dropout=[.2, .5])
+    t_net, q_prj, a_prj = [], [], []
+    for i in range(args.gamma):
+        t_net.append(TCNet(dataset.v_dim, args.num_hid, args.num_hid, args.h_mm, args.h_out, args.rank, 1, dropout=[.2, .5], k=2))
+        q_prj.append(FCNet([args.num_hid, args.num_hid], '', .2))
+        a_prj.append(FCNet([args.num_hid, args.num_hid], '', .2))
+    classifier = SimpleClassifier(args.num_hid, args.num_hid * 2, num_ans, args)
+    return w_emb, q_emb, wa_emb, ans_emb, t_att, t_net, q_prj, a_prj, classifier
+
+
+def build_cti(args, dataset):
+    """src/FFOE/base_model.py:179-201."""
+    return CTIModel(dataset, *_tri_parts(args, dataset, dataset.num_ans_candidates), args.op, args.gamma)
+
+
+def build_mc_cti(args, dataset):
+    """src/MC/base_model.py:180-203 (`build_cti` of the MC package): 2 output classes."""
+    return TanModel(dataset, *_tri_parts(args, dataset, 2), args.op, args.gamma)
+
+
+def build_mc_ban(args, dataset):
+    """src/MC/base_model.py:155-177 (`build_ban` of the MC package)."""
+    w_emb, q_emb, wa_emb, ans_emb = _embeddings(args, dataset, 2)
+    v_att = BiAttention(dataset.v_dim, args.num_hid, args.num_hid, args.gamma)
+    va_att = BiAttention(dataset.v_dim, args.num_hid, args.num_hid, args.gamma)
+    b_net, tva_net, a_prj, q_prj, c_prj = [], [], [], [], []
+    objects = 10
+    for i in range(args.gamma):
+        b_net.append(BCNet(dataset.v_dim, args.num_hid, args.num_hid, None, k=1))
+        tva_net.append(BCNet(dataset.v_dim, args.num_hid, args.num_hid, None, k=1))
+        q_prj.append(FCNet([args.num_hid, args.num_hid], '', .2))
+        a_prj.append(FCNet([args.num_hid, args.num_hid], '', .2))
+        c_prj.append(FCNet([objects + 1, args.num_hid], 'ReLU', .0))
+    classifier = SimpleClassifier(args.num_hid, args.num_hid * 2, 2, args)
+    if getattr(args, 'use_counter', False):
+        _no_counter(True)
+    return MCBanModel(dataset, w_emb, q_emb, wa_emb, ans_emb, v_att, b_net, va_att, tva_net, q_prj, a_prj, c_prj, classifier, None,
+                      args.op, args.gamma)

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
     // ---- everything that does not depend on the rank is decoded ONCE (runtime integer divisions cost ~40 instructions
     // each; inside the rank loop they outweighed the FMAs 7:1) -----------------------------------------------------------
     // step-1 item: (column c of T_eff, v range [v0, v0 + vspan)); the 1024 threads cover inner columns x nsplit v ranges
-    const int nsplit = max(1, nthr / inner), vspan = (V + nsplit - 1) / nsplit;
+    // (the v range of a thread is read through the scalar path, so it must be wave-uniform: with inner % 64 != 0 -- hr = 4 and
+    // G not a multiple of 4, test-sized models only -- a wave would straddle two v ranges, so those shapes do not split v)
+    const int nsplit = (inner % 64 == 0) ? max(1, nthr / inner) : 1, vspan = (V + nsplit - 1) / nsplit;
     int it_c[1], it_v0[1], it_x[1];
     {
         const int c = t % inner, sp = t / inner;

@@ -1,0 +1,299 @@
+// cti_model.hip -- the rows either side of the CTI path: word-embedding gather / scatter, the GRU's
+// gate arithmetic (its GEMMs are cti_gemm_nt), Swish, the residual broadcast-add / sequence sums of the model forwards, and
+// the two losses.  All of it is HBM-bound elementwise or row-reduction work: coalesced accesses, one pass over the data.
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// out[i, 0:dim] = table0[tok[i]], out[i, dim:2*dim] = table1[tok[i]] (when table1).  A token outside [0, rows) yields NaN.
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ t0, const float* __restrict__ t1,
+                                     float* __restrict__ out, int64_t n, int dim, int64_t rows) {
+    const int width = t1 ? 2 * dim : dim;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t k = tok[i];
+        const bool ok = k >= 0 && k < rows;
+        for (int c = threadIdx.x; c < width; c += blockDim.x) {
+            const float* src = c < dim ? t0 + k * dim + c : t1 + k * dim + (c - dim);
+            out[i * width + c] = ok ? *src : __builtin_nanf("");
+        }
+    }
+}
+
+// dtable[tok[i], c] += dout[i, col_off + c]; the padding row receives nothing (nn.Embedding(padding_idx))
+__global__ void embedding_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dout, int64_t ld, int col_off,
+                                     float* __restrict__ dtable, int64_t n, int dim, int64_t rows, int64_t pad) {
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t k = tok[i];
+        if (k < 0 || k >= rows || k == pad) continue;
+        for (int c = threadIdx.x; c < dim; c += blockDim.x) atomicAdd(dtable + k * dim + c, dout[i * ld + col_off + c]);
+    }
+}
+
+// One GRU step, gate order (r, z, n) as torch.nn.GRU.  gi = W_i x_t + b_i, gh = W_h h + b_h (both (B, 3H) rows).
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ gh,
+                                     const float* __restrict__ hprev, int64_t ld_hp, float* __restrict__ hout, int64_t ld_ho,
+                                     float* __restrict__ save, float* __restrict__ hps, int64_t ld_hps, int B, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), j = (int)(idx % H);
+    const float* gib = gi + (int64_t)b * ld_gi;
+    const float* ghb = gh + (int64_t)b * 3 * H;
+    const float hp = hprev ? hprev[(int64_t)b * ld_hp + j] : 0.f;
+    const float r = sigmoidf_(gib[j] + ghb[j]);
+    const float z = sigmoidf_(gib[H + j] + ghb[H + j]);
+    const float ghn = ghb[2 * H + j];
+    const float nn = tanhf(gib[2 * H + j] + r * ghn);
+    hout[(int64_t)b * ld_ho + j] = (1.f - z) * nn + z * hp;
+    if (save) {
+        float* s = save + (int64_t)b * 4 * H;
+        s[j] = r; s[H + j] = z; s[2 * H + j] = nn; s[3 * H + j] = ghn;
+    }
+    if (hps) hps[(int64_t)b * ld_hps + j] = hp;
+}
+
+// Backward of one step.  dh = dout + carry_a + carry_b;  writes the input-side and hidden-side pre-activation gradients and
+// the direct part of dh_prev (dh * z).
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ dout, int64_t ld_do, const float* __restrict__ ca,
+                                     const float* __restrict__ cb, const float* __restrict__ save, const float* __restrict__ hprev,
+                                     int64_t ld_hp, float* __restrict__ dgi, int64_t ld_dgi, float* __restrict__ dgh, int64_t ld_dgh,
+                                     float* __restrict__ carry, int B, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), j = (int)(idx % H);
+    float dh = dout ? dout[(int64_t)b * ld_do + j] : 0.f;
+    if (ca) dh += ca[idx];
+    if (cb) dh += cb[idx];
+    const float* s = save + (int64_t)b * 4 * H;
+    const float r = s[j], z = s[H + j], nn = s[2 * H + j], ghn = s[3 * H + j];
+    const float hp = hprev[(int64_t)b * ld_hp + j];
+    const float dan = dh * (1.f - z) * (1.f - nn * nn);
+    const float daz = dh * (hp - nn) * z * (1.f - z);
+    const float dar = dan * ghn * r * (1.f - r);
+    float* gi_ = dgi + (int64_t)b * ld_dgi;
+    float* gh_ = dgh + (int64_t)b * ld_dgh;
+    gi_[j] = dar; gi_[H + j] = daz; gi_[2 * H + j] = dan;
+    gh_[j] = dar; gh_[H + j] = daz; gh_[2 * H + j] = dan * r;
+    carry[idx] = dh * z;
+}
+
+__global__ void swish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * sigmoidf_(x[i]);
+}
+__global__ void swish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float s = sigmoidf_(x[i]); dx[i] = dy[i] * (s + x[i] * s * (1.f - s)); }
+}
+
+// out[b,h] = beta * out[b,h] + sum_l x[b,l,h]
+__global__ void seq_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int L, int H, float beta) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), h = (int)(idx % H);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += x[((int64_t)b * L + l) * H + h];
+    out[idx] = (beta != 0.f ? beta * out[idx] : 0.f) + s;
+}
+// out[b,l,h] = (x ? x[b,l,h] : 0) + y[b,h]
+__global__ void seq_bcast_add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int B, int L, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * L * H) return;
+    const int h = (int)(idx % H);
+    const int64_t b = idx / ((int64_t)L * H);
+    out[idx] = (x ? x[idx] : 0.f) + y[b * H + h];
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// row_loss[r] = sum_c max(x,0) - x*t + log1p(exp(-|x|))   (BCEWithLogitsLoss, reduction = sum, one row per workgroup)
+__global__ void bce_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ row_loss, int n) {
+    __shared__ float red[16];
+    const int64_t r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const float v = x[r * n + c];
+        s += fmaxf(v, 0.f) - v * t[r * n + c] + log1pf(__expf(-fabsf(v)));
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) row_loss[r] = s;
+}
+// dx = beta*dx + (sigmoid(x) - t) * coef * (*up)
+__global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ up, float coef,
+                               float* __restrict__ dx, int64_t n, float beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = coef * (up ? *up : 1.f);
+    dx[i] = (beta != 0.f ? beta * dx[i] : 0.f) + (sigmoidf_(x[i]) - t[i]) * c;
+}
+
+// row_kl[r] = sum_c pk * (log pk - log ps),  pk = softmax(k / T), ps = softmax(x / T)
+__global__ void kd_rows_fwd_kernel(const float* __restrict__ x, const float* __restrict__ k, float* __restrict__ row_kl, int n, float invT) {
+    __shared__ float red[16];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * n; const float* kr = k + r * n;
+    float mx = -INFINITY, mk = -INFINITY;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { mx = fmaxf(mx, xr[c] * invT); mk = fmaxf(mk, kr[c] * invT); }
+    mx = block_max(mx, red); mk = block_max(mk, red);
+    float sx = 0.f, sk = 0.f;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { sx += __expf(xr[c] * invT - mx); sk += __expf(kr[c] * invT - mk); }
+    sx = block_sum(sx, red); sk = block_sum(sk, red);
+    const float lsx = mx + __logf(sx), lsk = mk + __logf(sk);
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const float lk = kr[c] * invT - lsk, ls = xr[c] * invT - lsx;
+        acc += __expf(lk) * (lk - ls);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) row_kl[r] = acc;
+}
+// dx[r,c] = beta*dx + coef * (*up) * invT * (softmax(x/T) - softmax(k/T))
+__global__ void kd_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ k, const float* __restrict__ up, float coef,
+                                   float* __restrict__ dx, int n, float invT, float beta) {
+    __shared__ float red[16];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * n; const float* kr = k + r * n;
+    float mx = -INFINITY, mk = -INFINITY;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { mx = fmaxf(mx, xr[c] * invT); mk = fmaxf(mk, kr[c] * invT); }
+    mx = block_max(mx, red); mk = block_max(mk, red);
+    float sx = 0.f, sk = 0.f;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) { sx += __expf(xr[c] * invT - mx); sk += __expf(kr[c] * invT - mk); }
+    sx = block_sum(sx, red); sk = block_sum(sk, red);
+    const float cc = coef * (up ? *up : 1.f) * invT;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const float g = cc * (__expf(xr[c] * invT - mx) / sx - __expf(kr[c] * invT - mk) / sk);
+        dx[r * n + c] = (beta != 0.f ? beta * dx[r * n + c] : 0.f) + g;
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" {
+
+int cti_embedding_fwd(const int64_t* tokens, const float* table0, const float* table1, float* out, int64_t n, int dim, int64_t rows,
+                      void* stream) {
+    CTI_REQUIRE_PTR(tokens); CTI_REQUIRE_PTR(table0); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(n >= 0 && dim > 0 && rows > 0, CTI_E_SHAPE, "cti_embedding_fwd: n=%lld dim=%d rows=%lld", (long long)n, dim, (long long)rows);
+    if (n == 0) return CTI_OK;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, as_stream(stream), tokens, table0,
+                       table1, out, n, dim, rows);
+    return launch_status("cti_embedding_fwd");
+}
+
+int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout, int col_off, float* dtable, int64_t n, int dim,
+                      int64_t rows, int64_t padding_idx, void* stream) {
+    CTI_REQUIRE_PTR(tokens); CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(dtable);
+    CTI_REQUIRE(n >= 0 && dim > 0 && rows > 0 && col_off >= 0 && ld_dout >= col_off + dim, CTI_E_SHAPE,
+                "cti_embedding_bwd: n=%lld dim=%d rows=%lld col_off=%d ld=%lld", (long long)n, dim, (long long)rows, col_off, (long long)ld_dout);
+    if (n == 0) return CTI_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, as_stream(stream), tokens, dout,
+                       ld_dout, col_off, dtable, n, dim, rows, padding_idx);
+    return launch_status("cti_embedding_bwd");
+}
+
+int cti_gru_gates_fwd(const float* gi, int64_t ld_gi, const float* gh, const float* h_prev, int64_t ld_hprev, float* h_out,
+                      int64_t ld_hout, float* save, float* hprev_save, int64_t ld_hps, int B, int H, void* stream) {
+    CTI_REQUIRE_PTR(gi); CTI_REQUIRE_PTR(gh); CTI_REQUIRE_PTR(h_out);
+    CTI_REQUIRE(B >= 0 && H > 0 && ld_gi >= 3 * (int64_t)H && ld_hout >= H, CTI_E_SHAPE, "cti_gru_gates_fwd: B=%d H=%d ld_gi=%lld", B, H, (long long)ld_gi);
+    if (B == 0) return CTI_OK;
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), gi, ld_gi, gh, h_prev,
+                       ld_hprev, h_out, ld_hout, save, hprev_save, ld_hps, B, H);
+    return launch_status("cti_gru_gates_fwd");
+}
+
+int cti_gru_gates_bwd(const float* dout, int64_t ld_dout, const float* carry_a, const float* carry_b, const float* save,
+                      const float* h_prev, int64_t ld_hprev, float* dgi, int64_t ld_dgi, float* dgh, int64_t ld_dgh, float* carry_out,
+                      int B, int H, void* stream) {
+    CTI_REQUIRE_PTR(save); CTI_REQUIRE_PTR(h_prev); CTI_REQUIRE_PTR(dgi); CTI_REQUIRE_PTR(dgh); CTI_REQUIRE_PTR(carry_out);
+    CTI_REQUIRE(B >= 0 && H > 0 && ld_dgi >= 3 * (int64_t)H && ld_dgh >= 3 * (int64_t)H, CTI_E_SHAPE, "cti_gru_gates_bwd: B=%d H=%d", B, H);
+    if (B == 0) return CTI_OK;
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), dout, ld_dout, carry_a,
+                       carry_b, save, h_prev, ld_hprev, dgi, ld_dgi, dgh, ld_dgh, carry_out, B, H);
+    return launch_status("cti_gru_gates_bwd");
+}
+
+int cti_swish_fwd(const float* x, float* y, int64_t n, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y);
+    if (n <= 0) return CTI_OK;
+    hipLaunchKernelGGL(swish_fwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, y, n);
+    return launch_status("cti_swish_fwd");
+}
+int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(dy); CTI_REQUIRE_PTR(dx);
+    if (n <= 0) return CTI_OK;
+    hipLaunchKernelGGL(swish_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, dy, dx, n);
+    return launch_status("cti_swish_bwd");
+}
+
+int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B >= 0 && L >= 0 && H > 0, CTI_E_SHAPE, "cti_seq_sum: B=%d L=%d H=%d", B, L, H);
+    if (B == 0) return CTI_OK;
+    hipLaunchKernelGGL(seq_sum_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), x, out, B, L, H, beta);
+    return launch_status("cti_seq_sum");
+}
+int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream) {
+    CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B >= 0 && L >= 0 && H > 0, CTI_E_SHAPE, "cti_seq_bcast_add: B=%d L=%d H=%d", B, L, H);
+    if ((int64_t)B * L == 0) return CTI_OK;
+    hipLaunchKernelGGL(seq_bcast_add_kernel, dim3(blocks_for((int64_t)B * L * H, 256)), dim3(256), 0, as_stream(stream), x, y, out, B, L, H);
+    return launch_status("cti_seq_bcast_add");
+}
+
+int cti_bce_logits_rows_fwd(const float* x, const float* target, float* row_loss, int rows, int n, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(target); CTI_REQUIRE_PTR(row_loss);
+    CTI_REQUIRE(rows >= 0 && n > 0, CTI_E_SHAPE, "cti_bce_logits_rows_fwd: rows=%d n=%d", rows, n);
+    if (rows == 0) return CTI_OK;
+    hipLaunchKernelGGL(bce_rows_fwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), x, target, row_loss, n);
+    return launch_status("cti_bce_logits_rows_fwd");
+}
+int cti_bce_logits_bwd(const float* x, const float* target, const float* upstream, float coef, float* dx, int64_t n, float beta,
+                       void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(target); CTI_REQUIRE_PTR(dx);
+    if (n <= 0) return CTI_OK;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, target, upstream, coef, dx, n, beta);
+    return launch_status("cti_bce_logits_bwd");
+}
+int cti_kd_rows_fwd(const float* x, const float* knowledge, float* row_kl, int rows, int n, float T, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(knowledge); CTI_REQUIRE_PTR(row_kl);
+    CTI_REQUIRE(rows >= 0 && n > 0 && T > 0.f, CTI_E_SHAPE, "cti_kd_rows_fwd: rows=%d n=%d T=%g", rows, n, (double)T);
+    if (rows == 0) return CTI_OK;
+    hipLaunchKernelGGL(kd_rows_fwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), x, knowledge, row_kl, n, 1.f / T);
+    return launch_status("cti_kd_rows_fwd");
+}
+int cti_kd_rows_bwd(const float* x, const float* knowledge, const float* upstream, float coef, float* dx, int rows, int n, float T,
+                    float beta, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(knowledge); CTI_REQUIRE_PTR(dx);
+    CTI_REQUIRE(rows >= 0 && n > 0 && T > 0.f, CTI_E_SHAPE, "cti_kd_rows_bwd: rows=%d n=%d T=%g", rows, n, (double)T);
+    if (rows == 0) return CTI_OK;
+    hipLaunchKernelGGL(kd_rows_bwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), x, knowledge, upstream, coef, dx, n, 1.f / T, beta);
+    return launch_status("cti_kd_rows_bwd");
+}
+
+}  // extern "C"

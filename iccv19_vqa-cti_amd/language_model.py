@@ -1,0 +1,87 @@
+"""WordEmbedding / QuestionEmbedding -- drop-ins for the reference's src/language_model.py:11-98: same
+constructors, state_dict keys (`emb.weight`, `emb_.weight`, `rnn.weight_ih_l0`, ...) and RNG consumption at construction.
+
+The lookup is one gather kernel (both tables of the 'c' mode in the same pass); the GRU runs its input projection for all time
+steps as ONE MFMA GEMM and each step as one small GEMM + a fused gate kernel; backward (BPTT) runs in HIP kernels too."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import autograd as AG
+from . import ops
+
+
+class WordEmbedding(nn.Module):
+    """Word Embedding.  The ntoken-th row is the padding row (src/language_model.py:13-17)."""
+
+    def __init__(self, ntoken, emb_dim, dropout, op=''):
+        super(WordEmbedding, self).__init__()
+        self.op = op
+        self.emb = nn.Embedding(ntoken + 1, emb_dim, padding_idx=ntoken)
+        if 'c' in op:
+            self.emb_ = nn.Embedding(ntoken + 1, emb_dim, padding_idx=ntoken)
+            self.emb_.weight.requires_grad = False                      # the fixed copy (src/language_model.py:22)
+        self.dropout = nn.Dropout(dropout)
+        self.ntoken = ntoken
+        self.emb_dim = emb_dim
+
+    def init_embedding(self, np_file, tfidf=None, tfidf_weights=None):
+        """Host-side initialisation from a GloVe matrix (src/language_model.py:27-38): rows [0, ntoken) of `emb` take the file's
+        matrix; with 'c' in op the second table takes the same matrix, or its tf-idf re-weighting (then it becomes trainable)."""
+        init = torch.from_numpy(np.load(np_file))
+        if tuple(init.shape) != (self.ntoken, self.emb_dim):
+            raise AssertionError("embedding file has shape %s, expected %s" % (tuple(init.shape), (self.ntoken, self.emb_dim)))
+        dev = self.emb.weight.device
+        self.emb.weight.data[:self.ntoken] = init.to(dev)
+        second = init
+        if tfidf is not None:
+            if tfidf_weights is not None and 0 < tfidf_weights.size:
+                second = torch.cat([second, torch.from_numpy(tfidf_weights)], 0)
+            second = tfidf.matmul(second)
+            self.emb_.weight.requires_grad = True
+        if 'c' in self.op:
+            table = torch.zeros(init.shape)
+            table[:second.size(0)] = second
+            self.emb_.weight.data[:self.ntoken] = table.to(dev)
+
+    def forward(self, x):
+        second = self.emb_.weight if 'c' in self.op else None
+        if torch.is_grad_enabled() and (self.emb.weight.requires_grad or (second is not None and second.requires_grad)):
+            emb = AG.EmbeddingFn.apply(x, self.emb.weight, second, self.ntoken)
+        else:
+            emb = ops.embedding(x, self.emb.weight.detach(), None if second is None else second.detach())
+        return AG.dropout(emb, self.dropout.p, self.training)
+
+
+class QuestionEmbedding(nn.Module):
+    def __init__(self, in_dim, num_hid, nlayers, bidirect, dropout, rnn_type='GRU'):
+        """Module for question embedding (src/language_model.py:50-66).  `rnn` is an nn.GRU used as the parameter container only
+        (same keys and initial values as the reference); its arithmetic runs in the HIP library."""
+        super(QuestionEmbedding, self).__init__()
+        assert rnn_type == 'LSTM' or rnn_type == 'GRU'
+        rnn_cls = nn.LSTM if rnn_type == 'LSTM' else nn.GRU
+        self.rnn = rnn_cls(in_dim, num_hid, nlayers, bidirectional=bidirect, dropout=dropout, batch_first=True)
+        self.in_dim = in_dim
+        self.num_hid = num_hid
+        self.nlayers = nlayers
+        self.rnn_type = rnn_type
+        self.ndirections = 1 + int(bidirect)
+
+    def _check(self):
+        if self.rnn_type != 'GRU' or self.nlayers != 1 or self.ndirections != 1:
+            raise NotImplementedError("the MI355X path implements what the reference's builders construct: a 1-layer one-direction GRU "
+                                      "(src/FFOE/base_model.py:141,182,186); got %s, %d layer(s), %d direction(s)"
+                                      % (self.rnn_type, self.nlayers, self.ndirections))
+
+    def forward_all(self, x):
+        # x: [batch, sequence, in_dim] -> [batch, sequence, num_hid]
+        self._check()
+        r = self.rnn
+        ps = (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ps)):
+            return AG.GRUFn.apply(x, *ps)
+        return ops.gru_forward(x, *[p.detach() for p in ps])[0]
+
+    def forward(self, x):
+        # x: [batch, sequence, in_dim] -> the last hidden state [batch, num_hid]
+        return self.forward_all(x)[:, -1]

@@ -542,3 +542,165 @@ def bi_logits_bwd(dl, vt, qt, h, h_scale):
     L.check(L.lib().cti_bi_logits_bwd(dl.data_ptr(), vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), dvt.data_ptr(), dqt.data_ptr(),
                                       hp.data_ptr(), bp.data_ptr(), B, G, V, Q, D, _stream()), "cti_bi_logits_bwd")
     return dvt, dqt, sum_batches(hp, B, G * D).view(G, D), sum_batches(bp, B, G)
+
+
+# ---- rows either side of the CTI path: embedding, GRU, Swish, sequence sums, losses -------------------------
+def embedding(tokens, table0, table1=None):
+    """tokens (...,) int64 -> (..., dim) or (..., 2*dim) when a second table is concatenated."""
+    _req(tokens, "tokens", torch.int64); _req(table0, "table0")
+    tok = tokens.contiguous()
+    rows, dim = table0.shape
+    t0 = table0.contiguous()
+    t1 = None
+    if table1 is not None:
+        _req(table1, "table1")
+        if tuple(table1.shape) != (rows, dim):
+            raise ValueError("the two embedding tables differ in shape: %s vs %s" % (tuple(table0.shape), tuple(table1.shape)))
+        t1 = table1.contiguous()
+    out = torch.empty(tuple(tok.shape) + ((2 if t1 is not None else 1) * dim,), device=tok.device, dtype=torch.float32)
+    L.check(L.lib().cti_embedding_fwd(tok.data_ptr(), t0.data_ptr(), _ptr(t1), out.data_ptr(), tok.numel(), dim, rows, _stream()),
+            "cti_embedding_fwd")
+    return out
+
+
+def embedding_bwd(tokens, dout, col_off, rows, dim, padding_idx):
+    """-> dtable (rows, dim) = scatter-add of dout[..., col_off:col_off+dim] by token (the padding row stays zero)."""
+    tok = tokens.contiguous()
+    d2 = dout.contiguous().view(tok.numel(), -1)
+    dt = torch.zeros((rows, dim), device=dout.device, dtype=torch.float32)
+    L.check(L.lib().cti_embedding_bwd(tok.data_ptr(), d2.data_ptr(), d2.shape[1], int(col_off), dt.data_ptr(), tok.numel(), dim, rows,
+                                      int(padding_idx), _stream()), "cti_embedding_bwd")
+    return dt
+
+
+def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False):
+    """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H).
+    The input projection of all steps is one GEMM; each step is one (B,H)x(H,3H) GEMM + the fused gate kernel."""
+    _req(x, "x")
+    B, T, I = x.shape
+    H = w_hh.shape[1]
+    xc = x.contiguous()
+    out = torch.empty((B, T, H), device=x.device, dtype=torch.float32)
+    save = torch.empty((T, B, 4, H), device=x.device, dtype=torch.float32) if want_save else None
+    hps = torch.empty((B, T, H), device=x.device, dtype=torch.float32) if want_save else None
+    if B * T == 0:
+        return out, save, hps
+    gi = gemm_nt(xc.view(B * T, I), w_ih, bias=b_ih).view(B, T, 3 * H)
+    h0 = torch.zeros((B, H), device=x.device, dtype=torch.float32)
+    lib = L.lib()
+    for t in range(T):
+        hprev = out[:, t - 1] if t else h0
+        gh = gemm_nt(hprev, w_hh, bias=b_hh)                                  # (B, 3H)
+        L.check(lib.cti_gru_gates_fwd(gi[:, t].data_ptr(), T * 3 * H, gh.data_ptr(), hprev.data_ptr(), hprev.stride(0),
+                                      out[:, t].data_ptr(), T * H, _ptr(save[t]) if want_save else 0,
+                                      hps[:, t].data_ptr() if want_save else 0, T * H, B, H, _stream()), "cti_gru_gates_fwd")
+    return out, save, hps
+
+
+def gru_backward(dout, x, w_ih, w_hh, save, hps, need_dx=True):
+    """-> dx (or None), dW_ih, dW_hh, db_ih, db_hh."""
+    B, T, H = dout.shape
+    I = x.shape[2]
+    dout = dout.contiguous()
+    dgi = torch.empty((B, T, 3 * H), device=dout.device, dtype=torch.float32)
+    dgh = torch.empty((B, T, 3 * H), device=dout.device, dtype=torch.float32)
+    w_hh_t = transpose(w_hh.contiguous(), 3 * H, H).view(H, 3 * H)
+    lib = L.lib()
+    ca = cb = None
+    for t in range(T - 1, -1, -1):
+        carry = torch.empty((B, H), device=dout.device, dtype=torch.float32)
+        L.check(lib.cti_gru_gates_bwd(dout[:, t].data_ptr(), T * H, _ptr(ca), _ptr(cb), save[t].data_ptr(), hps[:, t].data_ptr(), T * H,
+                                      dgi[:, t].data_ptr(), T * 3 * H, dgh[:, t].data_ptr(), T * 3 * H, carry.data_ptr(), B, H,
+                                      _stream()), "cti_gru_gates_bwd")
+        ca = carry
+        cb = gemm_nt(dgh[:, t], w_hh_t) if t else None                          # (B, H) = dgh_t @ W_hh
+    dgi2, dgh2 = dgi.view(B * T, 3 * H), dgh.view(B * T, 3 * H)
+    dW_hh = gemm_tn(dgh2, hps.view(B * T, H))
+    dW_ih = gemm_tn(dgi2, x.contiguous().view(B * T, I))
+    db_hh = sum_batches(dgh2, B * T, 3 * H)
+    db_ih = sum_batches(dgi2, B * T, 3 * H)
+    dx = None
+    if need_dx:
+        w_ih_t = transpose(w_ih.contiguous(), 3 * H, I).view(I, 3 * H)
+        dx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
+    return dx, dW_ih, dW_hh, db_ih, db_hh
+
+
+def swish(x):
+    _req(x, "x")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    L.check(L.lib().cti_swish_fwd(xc.data_ptr(), y.data_ptr(), xc.numel(), _stream()), "cti_swish_fwd")
+    return y
+
+
+def swish_bwd(x, dy):
+    xc, dyc = x.contiguous(), dy.contiguous()
+    dx = torch.empty_like(xc)
+    L.check(L.lib().cti_swish_bwd(xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), _stream()), "cti_swish_bwd")
+    return dx
+
+
+def seq_sum(x, out=None, beta=0.0):
+    """x (B,L,H) -> (B,H) = beta*out + sum over L."""
+    _req(x, "x")
+    B, Lq, H = x.shape
+    xc = x.contiguous()
+    if out is None:
+        out = torch.empty((B, H), device=x.device, dtype=torch.float32)
+        beta = 0.0
+    L.check(L.lib().cti_seq_sum(xc.data_ptr(), out.data_ptr(), B, Lq, H, float(beta), _stream()), "cti_seq_sum")
+    return out
+
+
+def seq_bcast_add(x, y, Lq=None):
+    """x (B,L,H) or None, y (B,H) -> x + y[:, None, :]  (x None: y broadcast to (B,Lq,H))."""
+    _req(y, "y")
+    B, H = y.shape
+    if x is not None:
+        _req(x, "x")
+        Lq = x.shape[1]
+        x = x.contiguous()
+    out = torch.empty((B, Lq, H), device=y.device, dtype=torch.float32)
+    L.check(L.lib().cti_seq_bcast_add(_ptr(x), y.contiguous().data_ptr(), out.data_ptr(), B, Lq, H, _stream()), "cti_seq_bcast_add")
+    return out
+
+
+def bce_logits_sum(x, target):
+    """sum over every element of BCE-with-logits -> 0-d tensor."""
+    _req(x, "x"); _req(target, "target")
+    n = x.shape[-1]
+    x2, t2 = x.contiguous().view(-1, n), target.contiguous().view(-1, n)
+    rows = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    L.check(L.lib().cti_bce_logits_rows_fwd(x2.data_ptr(), t2.data_ptr(), rows.data_ptr(), x2.shape[0], n, _stream()), "cti_bce_logits_rows_fwd")
+    return rows
+
+
+def bce_logits_bwd(x, target, upstream, coef, dx=None, beta=0.0):
+    xc, tc = x.contiguous(), target.contiguous()
+    if dx is None:
+        dx = torch.empty_like(xc)
+        beta = 0.0
+    L.check(L.lib().cti_bce_logits_bwd(xc.data_ptr(), tc.data_ptr(), _ptr(upstream), float(coef), dx.data_ptr(), xc.numel(), float(beta),
+                                       _stream()), "cti_bce_logits_bwd")
+    return dx
+
+
+def kd_rows(x, knowledge, T):
+    _req(x, "x"); _req(knowledge, "knowledge")
+    n = x.shape[-1]
+    x2, k2 = x.contiguous().view(-1, n), knowledge.contiguous().view(-1, n)
+    rows = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+    L.check(L.lib().cti_kd_rows_fwd(x2.data_ptr(), k2.data_ptr(), rows.data_ptr(), x2.shape[0], n, float(T), _stream()), "cti_kd_rows_fwd")
+    return rows
+
+
+def kd_rows_bwd(x, knowledge, upstream, coef, T, dx=None, beta=0.0):
+    n = x.shape[-1]
+    xc, kc = x.contiguous(), knowledge.contiguous()
+    if dx is None:
+        dx = torch.empty_like(xc)
+        beta = 0.0
+    L.check(L.lib().cti_kd_rows_bwd(xc.data_ptr(), kc.data_ptr(), _ptr(upstream), float(coef), dx.data_ptr(), xc.numel() // n, n, float(T),
+                                    float(beta), _stream()), "cti_kd_rows_bwd")
+    return dx

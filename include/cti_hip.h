@@ -228,6 +228,49 @@ int cti_adamax_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, int step, float* grad_norm_out, void* stream);
 size_t cti_optim_workspace_bytes(void);
 
+/* ---- rows either side of the CTI path (N1 model forward, N3 GRU + word embedding, N4 classifier + losses) ----
+ * WordEmbedding.forward (src/language_model.py:40-46): out[i, 0:dim] = table0[tokens[i]], and out[i, dim:2*dim] =
+ * table1[tokens[i]] when table1 != NULL ('c' in op: the trainable and the frozen table, concatenated).  tokens: int64;
+ * tables: (rows, dim) contiguous; a token outside [0, rows) produces NaNs (torch raises IndexError there). */
+int cti_embedding_fwd(const int64_t* tokens, const float* table0, const float* table1, float* out, int64_t n, int dim, int64_t rows,
+                      void* stream);
+/* dtable[tokens[i], :] += dout[i, col_off : col_off + dim] (atomic adds; the caller zeroes dtable); row padding_idx receives
+ * nothing, like nn.Embedding(padding_idx = ntoken) (src/language_model.py:19). */
+int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout, int col_off, float* dtable, int64_t n, int dim,
+                      int64_t rows, int64_t padding_idx, void* stream);
+
+/* One step of nn.GRU (src/language_model.py:57-61, gate order r, z, n): gi = W_ih x_t + b_ih (row stride ld_gi), gh = W_hh h + b_hh
+ * ((B, 3H) contiguous), both produced by cti_gemm_nt.  h_out[b] = (1 - z) * n + z * h_prev[b]  (h_prev NULL = zero state).
+ * save (B, 4, H) = (r, z, n, W_hn h + b_hn) and hprev_save are written when not NULL (what the backward step needs). */
+int cti_gru_gates_fwd(const float* gi, int64_t ld_gi, const float* gh, const float* h_prev, int64_t ld_hprev, float* h_out,
+                      int64_t ld_hout, float* save, float* hprev_save, int64_t ld_hps, int B, int H, void* stream);
+/* Backward of one step: dh = dout (NULL = 0) + carry_a + carry_b (NULL = 0; (B,H) contiguous).  Writes dgi (gradient of gi),
+ * dgh (gradient of gh) and carry_out = dh * z, the direct part of dL/dh_prev; the caller adds dgh @ W_hh with cti_gemm_nt. */
+int cti_gru_gates_bwd(const float* dout, int64_t ld_dout, const float* carry_a, const float* carry_b, const float* save,
+                      const float* h_prev, int64_t ld_hprev, float* dgi, int64_t ld_dgi, float* dgh, int64_t ld_dgh, float* carry_out,
+                      int B, int H, void* stream);
+
+/* Swish (src/activation.py:17-22), the classifier's alternative activation (src/classifier.py:14). */
+int cti_swish_fwd(const float* x, float* y, int64_t n, void* stream);
+int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+
+/* out[b,h] = beta * out[b,h] + sum_l x[b,l,h]          (q_emb.sum(1), src/FFOE/base_model.py:66,134; x (B,L,H) contiguous) */
+int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, void* stream);
+/* out[b,l,h] = x[b,l,h] + y[b,h]  (x NULL = 0)         (q_prj(b_emb.unsqueeze(1)) + q_emb, src/FFOE/base_model.py:61,131-132) */
+int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream);
+
+/* nn.BCEWithLogitsLoss(reduction='sum') per row (src/FFOE/train.py:28-33, divided by the batch size at src/FFOE/trainer.py:189-190):
+ * row_loss[r] = sum_c max(x,0) - x*t + log(1 + exp(-|x|)); reduce the rows with cti_sum_batches.
+ * Backward: dx = beta * dx + coef * (*upstream) * (sigmoid(x) - t)   (upstream: device scalar or NULL = 1). */
+int cti_bce_logits_rows_fwd(const float* x, const float* target, float* row_loss, int rows, int n, void* stream);
+int cti_bce_logits_bwd(const float* x, const float* target, const float* upstream, float coef, float* dx, int64_t n, float beta,
+                       void* stream);
+/* Distillation term (src/loss_function.py:21-24): row_kl[r] = sum_c pk (log pk - log ps), pk = softmax(knowledge/T), ps = softmax(x/T).
+ * Backward: dx = beta * dx + coef * (*upstream) / T * (ps - pk). */
+int cti_kd_rows_fwd(const float* x, const float* knowledge, float* row_kl, int rows, int n, float T, void* stream);
+int cti_kd_rows_bwd(const float* x, const float* knowledge, const float* upstream, float coef, float* dx, int rows, int n, float T,
+                    float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

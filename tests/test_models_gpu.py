@@ -1,0 +1,240 @@
+"""Parity of the model-level rows (N1 model forwards, N3 GRU + word embedding, N4 classifier + losses) on an
+MI355X: HIP path vs the reference's outputs / gradients (tests/golden g9_*, g10_*, g12_*) and vs the oracle at larger shapes.
+Tolerance: normalised max error <= 1e-4 (fp32 arithmetic, fp32-grade GEMMs); gathers are bit-exact."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+from golden_util import load, model_case
+from oracle import cti_models as M
+from oracle.cti_oracle import norm_max_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+@pytest.fixture(params=["fp32", "bf16x3"], autouse=True)
+def precision(request):
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(request.param)
+    yield request.param
+    cti_amd.set_precision(old)
+
+
+class _DS:
+    def __init__(self, ntoken, v_dim, num_ans):
+        self.dictionary = types.SimpleNamespace(ntoken=ntoken)
+        self.v_dim = v_dim
+        self.num_ans_candidates = num_ans
+
+
+def T(x, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def load_into(m, params):
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+def check(x, ref, tol=TOL, what=""):
+    x = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    assert x.shape == tuple(np.shape(ref)), (what, x.shape, np.shape(ref))
+    e = norm_max_err(x, ref)
+    assert e < tol, "%s: normalised max error %.3g >= %.3g" % (what, e, tol)
+
+
+def build(name, builder):
+    fx, p = model_case(name)
+    c = fx.cfg
+    m = getattr(cti_amd, builder)(types.SimpleNamespace(**c["args"]), _DS(c["ntoken"], c["v_dim"], c["num_ans"]))
+    return fx, p, load_into(m, p)
+
+
+# ---- N3: word embedding, GRU ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["c", "none"])
+def test_word_embedding_forward_backward(op):
+    fx, p = model_case("g12_wordemb_op%s" % op)
+    w = load_into(cti_amd.WordEmbedding(fx.cfg["ntoken"], 300, 0.0, fx.cfg["op"]), p)
+    x = T(fx.i["x"])
+    with torch.no_grad():
+        out = w(x)
+    assert np.array_equal(out.cpu().numpy(), fx.o["out"])                   # gather: bit-exact
+    out = w(x)
+    (out * T(fx.i["cot"])).sum().backward()
+    check(w.emb.weight.grad, fx.g["emb.weight"], 1e-6, "d emb.weight")
+    assert float(w.emb.weight.grad[fx.cfg["ntoken"]].abs().sum()) == 0.0    # the padding row receives nothing
+    if op == "c":
+        assert w.emb_.weight.grad is None                                   # the frozen copy
+
+
+def test_word_embedding_bad_token_is_loud():
+    w = cti_amd.WordEmbedding(5, 300, 0.0, "").to(DEV)
+    with torch.no_grad():
+        out = w(torch.tensor([[0, 9]], device=DEV))
+    assert torch.isnan(out[0, 1]).all() and not torch.isnan(out[0, 0]).any()
+
+
+def test_gru_forward_and_bptt():
+    fx, p = model_case("g12_gru")
+    g = load_into(cti_amd.QuestionEmbedding(fx.cfg["in_dim"], fx.cfg["num_hid"], 1, False, 0.0), p)
+    with torch.no_grad():
+        check(g.forward_all(T(fx.i["x"])), fx.o["out_all"], TOL, "gru forward_all")
+        check(g(T(fx.i["x"])), fx.o["out_last"], TOL, "gru forward")
+    x = T(fx.i["x"], grad=True)
+    out = g.forward_all(x)
+    (out * T(fx.i["cot"])).sum().backward()
+    check(x.grad, fx.g["x"], TOL, "d x")
+    for k, prm in g.named_parameters():
+        check(prm.grad, fx.g[k], TOL, "d " + k)
+
+
+def test_gru_at_model_width_vs_oracle():
+    """B=64, T=14, in=600, H=1024 (the builders' widths, src/FFOE/base_model.py:141): vs the float64 oracle."""
+    rs = np.random.RandomState(5)
+    B, Tn, I, H = 64, 14, 600, 1024
+    g = cti_amd.QuestionEmbedding(I, H, 1, False, 0.0)
+    p = {k: (rs.standard_normal(size=tuple(v.shape)) * (0.1 if "bias" in k else 1.0 / np.sqrt(v.shape[-1]))).astype(np.float32)
+         for k, v in g.state_dict().items()}
+    load_into(g, p)
+    x = np.tanh(rs.standard_normal(size=(B, Tn, I))).astype(np.float32)
+    ref = M.gru_forward_all(x, p, "rnn.", dtype=np.float64)
+    with torch.no_grad():
+        check(g.forward_all(T(x)), ref, TOL, "gru 600->1024")
+
+
+# ---- N4: classifier, losses -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["relu", "swish"])
+def test_classifier_forward_backward(act):
+    fx, p = model_case("g12_classifier_%s" % act)
+    c = fx.cfg
+    m = load_into(cti_amd.SimpleClassifier(c["in_dim"], c["hid_dim"], c["out_dim"], types.SimpleNamespace(activation=act, dropout=0.5)), p)
+    with torch.no_grad():
+        check(m(T(fx.i["x"])), fx.o["out"], TOL, "classifier")
+    x = T(fx.i["x"], grad=True)
+    (m(x) * T(fx.i["cot"])).sum().backward()
+    check(x.grad, fx.g["x"], TOL, "d x")
+    got, ref = [], []
+    for k, prm in m.named_parameters():
+        if prm.dim() == 0:
+            got.append(float(prm.grad)); ref.append(float(fx.g[k]))
+        else:
+            check(prm.grad, fx.g[k], TOL, "d " + k)
+    check(np.array(got), np.array(ref), TOL, "d weight_g (as one vector)")
+
+
+def test_losses_forward_backward():
+    fx = load("g12_losses")
+    x = T(fx.i["x"], grad=True)
+    bce = cti_amd.BCEWithLogitsSum()(x, T(fx.i["target"]))
+    assert abs(float(bce) - float(fx.o["bce_sum"])) < 1e-5 * abs(float(fx.o["bce_sum"]))
+    bce.backward()
+    check(x.grad, fx.g["bce_x"], 1e-5, "d bce")
+    x.grad = None
+    kd = cti_amd.Distillation_Loss(fx.cfg["T"], fx.cfg["alpha"])(x, T(fx.i["knowledge"]), T(fx.i["target"]))
+    assert abs(float(kd) - float(fx.o["kd"])) < 1e-5 * abs(float(fx.o["kd"]))
+    (kd * 3.0).backward()                                                     # a non-unit upstream gradient
+    check(x.grad / 3.0, fx.g["kd_x"], 1e-5, "d kd")
+
+
+# ---- N1: model forwards -------------------------------------------------------------------------------------------------------
+def test_ffoe_cti_model():
+    fx, p, m = build("g9_ffoe_cti", "build_cti")
+    with torch.no_grad():
+        out = m(T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]))
+    check(out, fx.o["logits"], TOL, "FFOE CTI logits")
+
+
+def test_ffoe_ban_model():
+    fx, p, m = build("g9_ffoe_ban", "build_ban")
+    with torch.no_grad():
+        out, att = m(T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), None)
+    check(att, fx.o["att"], TOL, "FFOE BAN att")
+    check(out, fx.o["logits"], TOL, "FFOE BAN logits")
+
+
+def test_mc_tan_model():
+    fx, p, m = build("g9_mc_cti", "build_mc_cti")
+    with torch.no_grad():
+        out, att = m(T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), T(fx.i["ans"]))
+    check(att, fx.o["att"], TOL, "MC TAN att")
+    check(out, fx.o["logits"], TOL, "MC TAN logits")
+
+
+def test_mc_ban_model_vs_composed_oracle():
+    """MC BAN has no fixture of its own: compare with the oracle's modules composed as src/MC/base_model.py:41-77."""
+    from oracle import cti_oracle as O
+    c = load("g9_mc_cti").cfg
+    args = types.SimpleNamespace(**dict(c["args"], gamma=2))
+    torch.manual_seed(3)
+    m = cti_amd.build_mc_ban(args, _DS(c["ntoken"], c["v_dim"], 2))
+    p = {k: v.numpy().copy() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    fx = load("g9_mc_cti")
+    v, q, a = fx.i["v"], fx.i["q"], fx.i["ans"]
+    q_emb = M.gru_forward_all(M.word_embedding(q, p, "w_emb."), p, "q_emb.rnn.")
+    a_emb = M.gru_forward_all(M.word_embedding(a, p, "wa_emb."), p, "ans_emb.rnn.")
+    att, _ = O.bi_attention(v, q_emb, p, "v_att.")
+    va, _ = O.bi_attention(v, a_emb, p, "va_att.")
+    for g in range(2):
+        b = O.bcnet_forward_with_weights(v, q_emb, att[:, g], p, "b_net.%d." % g)
+        t = O.bcnet_forward_with_weights(v, a_emb, va[:, g], p, "tva_net.%d." % g)
+        q_emb = O.fcnet(b[:, None], p, "q_prj.%d." % g, act="") + q_emb
+        a_emb = O.fcnet(t[:, None], p, "a_prj.%d." % g, act="") + a_emb
+    ref = M.simple_classifier(q_emb.sum(1) + a_emb.sum(1), p, "classifier.")
+    with torch.no_grad():
+        out, att_h = m(T(v), T(fx.i["b"]), T(q), T(a))
+    check(att_h, att, TOL, "MC BAN att")
+    check(out, ref, TOL, "MC BAN logits")
+
+
+def test_ffoe_cti_train_step_matches_reference():
+    """G10: forward, BCE/B loss, backward through every HIP backward kernel (incl. GRU BPTT and the embedding scatter), gradient
+    norm before clipping, one clipped Adamax step (FlatAdamaxDP, world size 1), loss afterwards."""
+    fx, p, m = build("g10_ffoe_cti_step", "build_cti")
+    c = fx.cfg
+    v, q, a, tgt = T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]), T(fx.i["target"])
+    opt = cti_amd.FlatAdamaxDP(m, lr=c["lr"], clip_norm=c["clip_norm"])
+    opt.zero_grad()
+    out = m(v, q, a)
+    check(out, fx.o["logits"], TOL, "logits")
+    loss = cti_amd.BCEWithLogitsSum()(out, tgt) / c["B"]
+    assert abs(float(loss) - float(fx.o["loss"])) < 1e-4 * float(fx.o["loss"])
+    loss.backward()
+    named = dict(m.named_parameters())
+    prs = np.random.RandomState(c["proj_seed"])
+    proj = {}
+    for n, prm in m.named_parameters():
+        if prm.requires_grad:
+            proj[n] = prs.standard_normal(size=tuple(prm.shape)).astype(np.float32)
+    got_n = np.array([float(named[n].grad.norm()) for n in c["used"]])
+    got_p = np.array([float((named[n].grad.double().cpu() * torch.from_numpy(proj[n]).double()).sum()) for n in c["used"]])
+    ref_n, ref_p = fx.o["gnorm"], fx.o["gproj"]
+    assert np.max(np.abs(got_n - ref_n) / (ref_n + 1e-3 * ref_n.max())) < 2e-3, "per-parameter gradient norms"
+    assert np.max(np.abs(got_p - ref_p)) / np.max(np.abs(ref_p)) < 2e-3, "per-parameter gradient projections"
+    unused = [n for n, prm in m.named_parameters() if prm.requires_grad and n not in c["used"]]
+    for n in unused:                                                         # rank nets / T_g of the t_nets never see a gradient
+        assert float(named[n].grad.abs().max()) == 0.0, n
+    opt.step()
+    assert abs(float(opt.grad_norm) - float(fx.o["grad_norm"])) < 1e-3 * float(fx.o["grad_norm"])
+    with torch.no_grad():
+        loss2 = cti_amd.BCEWithLogitsSum()(m(v, q, a), tgt) / c["B"]
+    assert abs(float(loss2) - float(fx.o["loss_after"])) < 2e-3 * float(fx.o["loss_after"])
+
+
+def test_model_train_mode_runs_dropout_and_backward():
+    """train(): every Dropout draws from the Philox kernel; gradients reach the embeddings and the GRUs."""
+    fx, p, m = build("g9_ffoe_cti", "build_cti")
+    m.train()
+    torch.manual_seed(11)
+    out1 = m(T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]))
+    out2 = m(T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]))
+    assert torch.isfinite(out1).all() and not torch.equal(out1, out2)
+    out1.sum().backward()
+    assert m.w_emb.emb.weight.grad is not None and float(m.w_emb.emb.weight.grad.abs().sum()) > 0
+    assert float(m.q_emb.rnn.weight_hh_l0.grad.abs().sum()) > 0

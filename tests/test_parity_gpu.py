@@ -261,3 +261,24 @@ def test_plain_bf16_mode_within_its_own_tolerance():
         assert O.norm_max_err(lb.cpu().numpy(), fxb.o["logits"]) < 2e-2
     finally:
         cti_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("h,R,G", [(16, 4, 2), (64, 16, 2), (16, 4, 3), (16, 4, 4), (32, 4, 2), (32, 4, 3), (64, 4, 2), (128, 32, 2)])
+def test_tcnet_forward_rank_width_sweep(h, R, G):
+    """h/R in {4, 8, 16} x glimpse counts: the M-build kernel's column ownership changes with hr*hr*G (hr = 4 with G = 2 or 3 gives
+    fewer columns than a wavefront) -- fused path, op-by-op path and the autograd forward against the float64 oracle."""
+    torch.manual_seed(h * 100 + R * 10 + G)
+    vd, qd, ad, B, V, Q, A = 40, 32, 24, 5, 7, 5, 3
+    m = cti_amd.TCNet(vd, qd, ad, h, 1, R, G, k=1)
+    p = {k: x.numpy().copy() for k, x in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    rs = np.random.RandomState(h + R + G)
+    v = np.abs(rs.standard_normal((B, V, vd))).astype(np.float32)
+    q = rs.standard_normal((B, Q, qd)).astype(np.float32)
+    a = rs.standard_normal((B, A, ad)).astype(np.float32)
+    ref = O.tcnet_forward(v, q, a, p, dtype=np.float64)
+    with torch.no_grad():
+        check(m(T(v), T(q), T(a)), ref, what="fused hr=%d G=%d" % (h // R, G))
+        m._fusable = lambda *x: False
+        check(m(T(v), T(q), T(a)), ref, what="op-by-op hr=%d G=%d" % (h // R, G))
+    check(m(T(v).requires_grad_(True), T(q), T(a)), ref, what="autograd forward hr=%d G=%d" % (h // R, G))
