@@ -1,3 +1,12 @@
-"""Drop-in for the reference's src/loss_function.py: re-exports the MI355X implementation."""
-import cti_amd  # noqa: F401  (repo root on sys.path)
-from iccv19_vqa_cti_amd.loss_function import *  # noqa: F401,F403
+"""Drop-in replacement of the reference's src/loss_function.py: re-exports the MI355X-native implementation
+(see INTEGRATION.md).  Put `dropin/` (or a copy of this file inside the reference tree) ahead on sys.path."""
+import os
+import sys
+
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+import cti_amd as _c  # noqa: E402
+
+_m = __import__("iccv19_vqa_cti_amd.loss_function", fromlist=["*"])
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

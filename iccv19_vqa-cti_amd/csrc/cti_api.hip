@@ -46,7 +46,12 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t cti_wn_linear_workspace_bytes(int64_t rows, int in_dim, int out_dim, int prec) {
     if (prec == CTI_PREC_F32 || rows <= 0 || in_dim <= 0 || out_dim <= 0) return 0;
-    return align256(planes_bytes(rows + PLANE_SLACK_ROWS, in_dim)) + align256(planes_bytes(out_dim + PLANE_SLACK_ROWS, in_dim));
+    size_t n = align256(planes_bytes(rows + PLANE_SLACK_ROWS, in_dim)) + align256(planes_bytes(out_dim + PLANE_SLACK_ROWS, in_dim));
+    if (rows < (1ll << 31)) {                                               // split-K partials (skinny layers: rows = batch size)
+        const int S = plan_ksplit((int)rows, out_dim, planes_kp(in_dim), 1);
+        if (S > 1) n += align256(sizeof(float) * (size_t)S * (size_t)rows * (size_t)out_dim);
+    }
+    return n;
 }
 
 extern "C" int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* scale, int scale_div,
@@ -85,6 +90,11 @@ extern "C" int cti_wn_linear_fwd(const float* x, int64_t ldx, const float* w, in
         g.M = (int)rows; g.N = out_dim; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0;
         g.C = y; g.ldc_m = ldy; g.ldc_n = 1;
         g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = (act == CTI_ACT_RELU);
+        const int S = plan_ksplit((int)rows, out_dim, Kp, 1);
+        if (S > 1) {
+            g.ksplit = S;
+            g.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256(planes_bytes(ra, in_dim)) + align256(planes_bytes(rb, in_dim)));
+        }
         return gemm_nt_planes(g, as_stream(stream));
     }
 }

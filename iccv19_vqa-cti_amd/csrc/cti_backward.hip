@@ -255,7 +255,12 @@ extern "C" int cti_wn_bwd(const float* G, const float* weight_v, const float* we
 extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + al(planes_bytes(rowsB_total + PLANE_SLACK_ROWS, K));
+    size_t n = al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + al(planes_bytes(rowsB_total + PLANE_SLACK_ROWS, K));
+    if (rowsA_total < (1ll << 31) && rowsB_total < (1ll << 31)) {           // split-K partials of the unbatched call (M, N = all rows)
+        const int S = plan_ksplit((int)rowsA_total, (int)rowsB_total, planes_kp(K), 1);
+        if (S > 1) n += al(sizeof(float) * (size_t)S * (size_t)rowsA_total * (size_t)rowsB_total);
+    }
+    return n;
 }
 
 extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, int64_t rA2, const float* B, int64_t ldb,
@@ -296,5 +301,13 @@ extern "C" int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int
     g.epi = (ldc_n == 1) ? 0 : 3; g.gdiv = 1;
     g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = act == CTI_ACT_RELU;
     g.scale_bs = scale_bs; g.bias_bs = bias_bs;
+    if (nb1 == 1 && nb2 == 1 && M == rowsA_total && N == rowsB_total && ldc_n == 1) {
+        const int S = plan_ksplit(M, N, Kp, 1);
+        if (S > 1) {
+            g.ksplit = S;
+            g.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255) +
+                                                 ((planes_bytes(rb, K) + 255) & ~(size_t)255));
+        }
+    }
     return gemm_nt_planes(g, as_stream(stream));
 }

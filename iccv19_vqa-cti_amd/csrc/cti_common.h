@@ -99,7 +99,13 @@ struct PlaneGemmArgs {
     int gdiv;                                  // epi 3
     const float* scale; int scale_div; const float* bias; int relu;
     int64_t scale_bs, bias_bs;                 // per-batch (b1) strides of scale / bias
+    // split-K (skinny GEMMs: few output tiles, long K): ksplit > 1 runs ksplit K-ranges of Kp / ksplit as independent workgroups
+    // that write fp32 partials [ksplit][M][N] into `partial`; a reduce kernel sums them and applies scale / bias / act.
+    // Only for nb1 == nb2 == 1 and epi 0; pick ksplit with plan_ksplit().
+    int ksplit; float* partial;
+    int64_t kc2;                               // set by the split-K path itself: batch b2 starts kc2 * b2 K-chunks into both operands
 };
+int plan_ksplit(int M, int N, int Kp, long long nb);       // 1 = do not split
 int planes_kp(int K);
 size_t planes_bytes(int64_t rows_alloc, int K);
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,

@@ -85,6 +85,7 @@ struct PlaneGemmP {
     int64_t pitchA, pitchB;                    // chunk pitches (elements) of the operand planes
     int64_t ldc_m, ldc_n;
     int64_t rA1, rA2, rB1, rB2;                // batch strides of the operands, in ROWS
+    int64_t kc2;                               // split-K: batch b2 starts kc2 * b2 K-chunks (of 16) into both operands
     int64_t sC1, sC2;                          // batch strides of C (elements) / of the output planes (rows)
     int nb2;
     int M, N, Kp;
@@ -184,12 +185,12 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int b1 = z / p.nb2, b2 = z % p.nb2;
     const int64_t pitchA = p.pitchA, pitchB = p.pitchB;                 // locals: lambdas must not capture the argument struct
-    const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
-    const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16;
+    const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16 + b2 * p.kc2 * pitchA;
+    const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16 + b2 * p.kc2 * pitchA;
     const float* Af = AF32 ? p.Af + (b1 * p.rA1 + b2 * p.rA2 + m0) * p.ldaf : nullptr;
     const int64_t ldaf = p.ldaf; const int Kreal = p.Kreal, rows_valid = p.M - m0;
-    const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
-    const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16;
+    const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16 + b2 * p.kc2 * pitchB;
+    const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16 + b2 * p.kc2 * pitchB;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -428,6 +429,38 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     }                                             // persistent tile loop
 }
 
+// split-K reduce + epilogue: C[m, n] = act(scale[n / div] * sum_s part[s][m][n] + bias[n]); one float4 of a row per thread
+__global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ C,
+                                                            int64_t ldc_m, const float* __restrict__ scale, int scale_div,
+                                                            const float* __restrict__ bias, int relu) {
+    const int n4 = (N + 3) >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * n4) return;
+    const int m = (int)(idx / n4), n0 = (int)(idx % n4) * 4;
+    const int64_t MN = (int64_t)M * N;
+    const float* src = part + (int64_t)m * N + n0;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (N & 3) == 0;
+    for (int s = 0; s < S; ++s) {
+        if (vec) {
+            const float4 x = *reinterpret_cast<const float4*>(src + s * MN);
+            a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (n0 + u < N) a[u] += src[s * MN + u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u;
+        if (n < N) {
+            float x = a[u] * (scale ? scale[n / scale_div] : 1.f) + (bias ? bias[n] : 0.f);
+            if (relu) x = fmaxf(x, 0.f);
+            C[(int64_t)m * ldc_m + n] = x;
+        }
+    }
+}
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 #ifndef CTI_LW
@@ -493,6 +526,24 @@ int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_
 }  // namespace
 
 int planes_kp(int K) { return round_up(K, KPAD); }
+
+// Skinny GEMMs (the GRU's recurrent products, the classifier, the residual projections: M = batch size) give the 256 CUs only a
+// few dozen 128 x 128 tiles, each walking the whole K: split K so that about one workgroup per CU runs, each over >= 128 of K.
+int plan_ksplit(int M, int N, int Kp, long long nb) {
+#ifdef CTI_NO_KSPLIT
+    return 1;
+#endif
+    if (nb != 1 || Kp < 256) return 1;
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles > 96) return 1;
+    int best = 1;
+    for (int s = 2; s <= 16; ++s) {
+        if (Kp % (s * 32) != 0 || Kp / s < 128) continue;
+        if (tiles * s > 288) break;
+        best = s;
+    }
+    return best;
+}
 size_t planes_bytes(int64_t rows_alloc, int K) { return 2 * sizeof(unsigned short) * (size_t)rows_alloc * planes_kp(K); }
 
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
@@ -514,6 +565,22 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
     p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
+    if (a.ksplit > 1) {
+        if (a.nb1 != 1 || a.nb2 != 1 || a.epi != 0 || a.Af || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
+            return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
+        PlaneGemmArgs b = a;
+        b.ksplit = 1; b.partial = nullptr;
+        b.nb2 = a.ksplit; b.rA2 = 0; b.rB2 = 0; b.Kp = a.Kp / a.ksplit;
+        b.C = a.partial; b.ldc_m = a.N; b.ldc_n = 1; b.sC2 = (int64_t)a.M * a.N;
+        b.scale = nullptr; b.bias = nullptr; b.relu = 0;
+        b.kc2 = a.Kp / a.ksplit / 16;
+        int rc = gemm_nt_planes(b, st); if (rc) return rc;
+        const int64_t items = (int64_t)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL(ksplit_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a.partial, a.ksplit, a.M, a.N, a.C,
+                           a.ldc_m, a.scale, a.scale_div > 0 ? a.scale_div : 1, a.bias, a.relu);
+        return launch_status("gemm_nt_planes/ksplit_reduce");
+    }
+    p.kc2 = a.kc2;
     if (a.Af && ((a.ldaf & 3) || (a.Kreal & 3) || (reinterpret_cast<uintptr_t>(a.Af) & 15)))
         return fail(CTI_E_ALIGN, "gemm_nt_planes: fp32 A operand needs 16-B aligned rows and K %% 4 == 0 (ld=%lld K=%d)", (long long)a.ldaf, a.Kreal);
     if (a.Kp % KPAD != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, KPAD);
