@@ -47,8 +47,12 @@ SIGNATURES = {
     "cti_optim_workspace_bytes": (_sz, []),
     "cti_embedding_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
     "cti_embedding_bwd": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _int, _i64, _i64, _vp]),
-    "cti_gru_gates_fwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp]),
-    "cti_gru_gates_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _int, _vp]),
+    "cti_gru_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_gru_forward_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
+    "cti_gru_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_gru_backward_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "cti_col_sum": (_int, [_vp, _i64, _int, _vp, C.c_float, C.c_float, _vp, _sz, _vp]),
+    "cti_col_sum_workspace_bytes": (_sz, [_i64, _int]),
     "cti_swish_fwd": (_int, [_vp, _vp, _i64, _vp]),
     "cti_swish_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "cti_seq_sum": (_int, [_vp, _vp, _int, _int, _int, C.c_float, _vp]),

@@ -250,14 +250,14 @@ class GRUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
-        out, save, hps = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=True)
-        ctx.save_for_backward(x, w_ih, w_hh, save, hps)
+        out, save = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=True)
+        ctx.save_for_backward(x, w_ih, w_hh, save)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, w_ih, w_hh, save, hps = ctx.saved_tensors
-        dx, dW_ih, dW_hh, db_ih, db_hh = ops.gru_backward(dout, x, w_ih, w_hh, save, hps, need_dx=ctx.needs_input_grad[0])
+        x, w_ih, w_hh, save = ctx.saved_tensors
+        dx, dW_ih, dW_hh, db_ih, db_hh = ops.gru_backward(dout, x, w_ih, w_hh, save, need_dx=ctx.needs_input_grad[0])
         return dx, dW_ih, dW_hh, db_ih, db_hh
 
 

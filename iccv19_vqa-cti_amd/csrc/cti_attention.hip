@@ -192,6 +192,53 @@ __global__ __launch_bounds__(256) void tri_pool_kernel(const float* __restrict__
     if (live) out[(int64_t)b * D + d] = acc;
 }
 
+// Small-A variant (A <= 8: the 3..6 answer tokens of the model configurations).  The attention slice w[b] (V*Q*A floats, strided
+// in global memory: att[..., g]) is compacted into LDS once per workgroup as [v][q][AP] (AP = 4 or 8), so the inner loop is one
+// broadcast ds_read_b128 per (v,q) instead of A dependent scalar loads; the thread's at[., d] column lives in registers.
+template <int AP>
+__global__ __launch_bounds__(256) void tri_pool_small_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                             const float* __restrict__ at, const float* __restrict__ w,
+                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
+                                                             float* __restrict__ out, int V, int Q, int A, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int d = blockIdx.x * 256 + t;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float* wl = sm;                                     // [V*Q][AP]
+    float* qs = sm + (size_t)V * Q * AP;                // [Q][256]
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int i = t; i < V * Q * AP; i += 256) {
+        const int a = i % AP, vq = i / AP, q = vq % Q, v = vq / Q;
+        wl[i] = a < A ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+    }
+    const float* qb = qt + (int64_t)b * Q * D;
+    for (int q = 0; q < Q; ++q) qs[q * 256 + t] = qb[(int64_t)q * D + dd];
+    float ar[AP];
+#pragma unroll
+    for (int a = 0; a < AP; ++a) ar[a] = a < A ? at[((int64_t)b * A + a) * D + dd] : 0.f;
+    __syncthreads();
+    const float* vb = vt + (int64_t)b * V * D;
+    float acc = 0.f;
+    for (int v = 0; v < V; ++v) {
+        const float vv = vb[(int64_t)v * D + dd];
+        float sv = 0.f;
+        const float4* wr = reinterpret_cast<const float4*>(wl + (size_t)v * Q * AP);
+        for (int q = 0; q < Q; ++q) {
+            float sq;
+            const float4 w0 = wr[q * (AP / 4)];
+            sq = w0.x * ar[0] + w0.y * ar[1] + w0.z * ar[2] + w0.w * ar[3];
+            if (AP == 8) {
+                const float4 w1 = wr[q * 2 + 1];
+                sq += w1.x * ar[4] + w1.y * ar[5] + w1.z * ar[6] + w1.w * ar[7];
+            }
+            sv = fmaf(sq, qs[q * 256 + t], sv);
+        }
+        acc = fmaf(sv, vv, acc);
+    }
+    if (live) out[(int64_t)b * D + d] = acc;
+}
+
 // =====================================================================================================
 // bi pool: out[b,n] = sum_{j<k} sum_v vt[b,v,nk+j] * sum_q w[b,v,q] * qt[b,q,nk+j]        (bc.py:70-78)
 // One thread per pooled output n; its k channels' qt column is staged in LDS ([q][j][lane], conflict-free).
@@ -336,6 +383,15 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
                                 int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    if (A <= 8) {
+        const int AP = A <= 4 ? 4 : 8;
+        const size_t lds_s = sizeof(float) * ((size_t)V * Q * AP + 256 * (size_t)Q);
+        if (lds_s <= 64 * 1024) {
+            if (AP == 4) hipLaunchKernelGGL(tri_pool_small_kernel<4>, dim3((D + 255) / 256, B), dim3(256), lds_s, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D);
+            else         hipLaunchKernelGGL(tri_pool_small_kernel<8>, dim3((D + 255) / 256, B), dim3(256), lds_s, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D);
+            return launch_status("cti_tri_pool_fwd");
+        }
+    }
     size_t lds = sizeof(float) * 256 * (size_t)(Q + A);
     int stage_a = 1;
     if (lds > 64 * 1024) { stage_a = 0; lds = sizeof(float) * 256 * (size_t)Q; }

@@ -40,6 +40,21 @@ __global__ __launch_bounds__(256) void sum_batches_kernel(const float* __restric
     dst[i] = alpha * s + (beta != 0.f ? beta * dst[i] : 0.f);
 }
 
+// ---- column sums of a tall matrix: partial[g][c] = sum of rows [g*rpg, (g+1)*rpg) of column c; 64 columns x 4 row lanes per workgroup
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ src, float* __restrict__ part, int64_t rows, int n,
+                                                              int64_t rpg) {
+    __shared__ float sb[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int64_t r_lo = (int64_t)blockIdx.y * rpg, r_hi = min(rows, r_lo + rpg);
+    float a = 0.f;
+    if (col < n)
+        for (int64_t r = r_lo + rl; r < r_hi; r += 4) a += src[r * n + col];
+    sb[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && col < n) part[(int64_t)blockIdx.y * n + col] = sb[0][cl] + sb[1][cl] + sb[2][cl] + sb[3][cl];
+}
+
 // ---- dzs = scale[col/div] * dy * (y > 0) [relu] ; partial column sums of the UNSCALED dz for the bias gradient ---------
 // A workgroup covers CW columns x a chunk of rows with 256/CW row lanes (CW = 16, 32 or 64, picked from n so that narrow
 // matrices -- the 16-column rank nets -- still use every lane); grid (ceil(n/CW), row_chunks).
@@ -203,6 +218,26 @@ extern "C" int cti_sum_batches(const float* src, float* dst, int nb, int64_t n, 
     CTI_REQUIRE(nb > 0 && n > 0, CTI_E_SHAPE, "cti_sum_batches: nb=%d n=%lld", nb, (long long)n);
     hipLaunchKernelGGL(sum_batches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, nb, n, alpha, beta);
     return launch_status("cti_sum_batches");
+}
+
+static int col_groups(int64_t rows) { int64_t g = (rows + 31) / 32; return (int)(g < 1 ? 1 : (g > 256 ? 256 : g)); }
+
+extern "C" size_t cti_col_sum_workspace_bytes(int64_t rows, int n) {
+    if (rows <= 0 || n <= 0) return 0;
+    return sizeof(float) * (size_t)col_groups(rows) * n;
+}
+
+extern "C" int cti_col_sum(const float* src, int64_t rows, int n, float* dst, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(rows > 0 && n > 0, CTI_E_SHAPE, "cti_col_sum: rows=%lld n=%d", (long long)rows, n);
+    CTI_REQUIRE(workspace_bytes >= cti_col_sum_workspace_bytes(rows, n), CTI_E_WORKSPACE, "cti_col_sum: workspace too small");
+    const int groups = col_groups(rows);
+    const int64_t rpg = (rows + groups - 1) / groups;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3((n + 63) / 64, groups), dim3(256), 0, as_stream(stream), src, part, rows, n, rpg);
+    int rc = launch_status("cti_col_sum"); if (rc) return rc;
+    return cti_sum_batches(part, dst, groups, n, alpha, beta, stream);
 }
 
 static int act_chunks(int64_t rows) { int c = (int)((rows + 255) / 256); return c < 1 ? 1 : (c > 1024 ? 1024 : c); }

@@ -1,0 +1,251 @@
+// cti_gru.hip -- the question / answer GRU (reference src/language_model.py:57-61,91-96: nn.GRU(in, H, 1, batch_first=True) from a
+// zero state), forward over all steps and back-propagation through time, as ONE library call each: the time loop runs on the
+// host side of the C ABI, so a step costs two launches and no Python.
+//
+// Forward.  The input projection of every step is one plane GEMM (gi = x W_ih^T + b_ih).  The recurrent weights are split into
+// bf16 hi/lo planes ONCE; a step is  (1) the skinny GEMM h_{t-1} W_hh^T as split-K partials (M = batch: K ranges as extra
+// workgroups, cti_common.h plan_ksplit), (2) the gate kernel, which sums the partials, adds b_hh, applies the gates, writes
+// h_t to out[:, t] and -- as bf16 hi/lo planes -- straight into the A operand of the next step's GEMM (no split pass).
+// Backward mirrors it with W_hh^T planes: the gate-gradient kernel writes dgh_t as fp32 (for the weight gradients) and as planes
+// (the A operand of dh_{t-1} += dgh_t W_hh).
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ unsigned short bf16b(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
+__device__ __forceinline__ float bf16f(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// element (row, col) of a chunk-major plane pair: (col >> 4) * pitch + row * 16 + (col & 15)
+__device__ __forceinline__ void store_planes(unsigned short* hi, unsigned short* lo, int64_t pitch, int row, int col, float x) {
+    const int64_t o = (int64_t)(col >> 4) * pitch + (int64_t)row * 16 + (col & 15);
+    const unsigned short h = bf16b(x);
+    hi[o] = h;
+    lo[o] = bf16b(x - bf16f(h));
+}
+
+// gh = sum_s part[s][b][3H] + b_hh;  gate order (r, z, n).  save: (B,5,H) = r, z, n, gh_n, h_t.
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ part, int S,
+                                                           const float* __restrict__ b_hh, const float* __restrict__ hprev,
+                                                           float* __restrict__ out, int64_t ld_out, float* __restrict__ h_tm,
+                                                           float* __restrict__ save, unsigned short* __restrict__ ph,
+                                                           unsigned short* __restrict__ pl, int64_t pitch, int B, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), j = (int)(idx % H);
+    float g0 = b_hh[j], g1 = b_hh[H + j], g2 = b_hh[2 * H + j];
+    const int64_t BN = (int64_t)B * 3 * H;
+    for (int s = 0; s < S; ++s) {
+        const float* p = part + s * BN + (int64_t)b * 3 * H;
+        g0 += p[j]; g1 += p[H + j]; g2 += p[2 * H + j];
+    }
+    const float* gib = gi + (int64_t)b * ld_gi;
+    const float hp = hprev ? hprev[idx] : 0.f;
+    const float r = sigm(gib[j] + g0), z = sigm(gib[H + j] + g1);
+    const float n = tanhf(gib[2 * H + j] + r * g2);
+    const float h = (1.f - z) * n + z * hp;
+    out[(int64_t)b * ld_out + j] = h;
+    if (h_tm) h_tm[idx] = h;
+    if (save) {
+        float* sv = save + (int64_t)b * 5 * H;
+        sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = g2; sv[4 * H + j] = h;
+    }
+    if (ph) store_planes(ph, pl, pitch, b, j, h);
+}
+
+// dh = dout[b,t] + carry[b] + sum_s part[s][b];  writes dgi (row stride ld_dgi), dgh (fp32, contiguous (B,3H)), carry' = dh * z,
+// and dgh as planes (rows b, columns 3H) for the next GEMM.
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restrict__ dout, int64_t ld_do, const float* __restrict__ carry_in,
+                                                           const float* __restrict__ part, int S, const float* __restrict__ save,
+                                                           const float* __restrict__ save_prev, float* __restrict__ dgi, int64_t ld_dgi,
+                                                           float* __restrict__ dgh, float* __restrict__ carry_out,
+                                                           unsigned short* __restrict__ ph, unsigned short* __restrict__ pl, int64_t pitch,
+                                                           int B, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), j = (int)(idx % H);
+    float dh = dout[(int64_t)b * ld_do + j];
+    if (carry_in) dh += carry_in[idx];
+    for (int s = 0; s < S; ++s) dh += part[(int64_t)s * B * H + idx];
+    const float* sv = save + (int64_t)b * 5 * H;
+    const float r = sv[j], z = sv[H + j], n = sv[2 * H + j], ghn = sv[3 * H + j];
+    const float hp = save_prev ? save_prev[(int64_t)b * 5 * H + 4 * H + j] : 0.f;
+    const float dan = dh * (1.f - z) * (1.f - n * n);
+    const float daz = dh * (hp - n) * z * (1.f - z);
+    const float dar = dan * ghn * r * (1.f - r);
+    float* gi_ = dgi + (int64_t)b * ld_dgi;
+    float* gh_ = dgh + (int64_t)b * 3 * H;
+    gi_[j] = dar; gi_[H + j] = daz; gi_[2 * H + j] = dan;
+    gh_[j] = dar; gh_[H + j] = daz; gh_[2 * H + j] = dan * r;
+    carry_out[idx] = dh * z;
+    if (ph) {
+        store_planes(ph, pl, pitch, b, j, dar);
+        store_planes(ph, pl, pitch, b, H + j, daz);
+        store_planes(ph, pl, pitch, b, 2 * H + j, dan * r);
+    }
+}
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carve {
+    char* p; size_t used;
+    template <class T> T* take(size_t bytes) { T* r = reinterpret_cast<T*>(p + used); used += al256(bytes); return r; }
+};
+
+// the recurrent GEMM of one step: C_part[s] = A[:, ks] B[:, ks]^T  (A: M rows, B: N rows, both planes of depth Kp), S = plan or 1
+int step_gemm(const unsigned short* ah, const unsigned short* al, int64_t ra, const unsigned short* bh, const unsigned short* bl, int64_t rb,
+              int M, int N, int Kp, int S, int terms, float* part, hipStream_t st) {
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb;
+    g.nb1 = 1; g.nb2 = S; g.kc2 = S > 1 ? Kp / S / 16 : 0;
+    g.M = M; g.N = N; g.Kp = Kp / S; g.terms = terms; g.epi = 0;
+    g.C = part; g.ldc_m = N; g.ldc_n = 1; g.sC2 = (int64_t)M * N;
+    return gemm_nt_planes(g, st);
+}
+
+}  // namespace
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" {
+
+size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec) {
+    if (B <= 0 || T <= 0 || I <= 0 || H <= 0) return 0;
+    const size_t f = sizeof(float);
+    size_t n = al256(f * (size_t)B * T * 3 * H) + al256(f * (size_t)T * B * H);                 // gi, time-major h
+    if (prec == CTI_PREC_F32) return n + al256(f * (size_t)B * 3 * H);
+    const int S = plan_ksplit(B, 3 * H, planes_kp(H), 1);
+    n += al256(f * (size_t)S * B * 3 * H);
+    n += al256(planes_bytes((int64_t)B * T + PLANE_SLACK_ROWS, I)) + al256(planes_bytes(3 * (int64_t)H + PLANE_SLACK_ROWS, I));
+    n += al256(planes_bytes(3 * (int64_t)H + PLANE_SLACK_ROWS, H)) + 2 * al256(planes_bytes((int64_t)B + PLANE_SLACK_ROWS, H));
+    return n;
+}
+
+int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                    int B, int T, int I, int H, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(w_ih); CTI_REQUIRE_PTR(w_hh); CTI_REQUIRE_PTR(b_ih); CTI_REQUIRE_PTR(b_hh); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B > 0 && T > 0 && I > 0 && H > 0 && (int64_t)B * T < (1ll << 31), CTI_E_SHAPE, "cti_gru_forward: B=%d T=%d I=%d H=%d", B, T, I, H);
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gru_forward: prec=%d", prec);
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(workspace_bytes >= cti_gru_forward_workspace_bytes(B, T, I, H, prec), CTI_E_WORKSPACE, "cti_gru_forward: workspace too small");
+    hipStream_t st = as_stream(stream);
+    Carve ws{static_cast<char*>(workspace), 0};
+    const size_t f = sizeof(float);
+    const int H3 = 3 * H;
+    float* gi = ws.take<float>(f * (size_t)B * T * H3);                     // (B, T, 3H)
+    float* h_tm = ws.take<float>(f * (size_t)T * B * H);                    // (T, B, H): contiguous h_{t-1} for the fp32 GEMM
+    const unsigned nblk = (unsigned)(((int64_t)B * H + 255) / 256);
+    if (prec == CTI_PREC_F32) {
+        float* gh = ws.take<float>(f * (size_t)B * H3);
+        GemmP p{};
+        p.A = x; p.B = w_ih; p.C = gi; p.lda = I; p.ldb = I; p.ldc_m = H3; p.ldc_n = 1; p.nb1 = 1; p.nb2 = 1;
+        p.M = B * T; p.N = H3; p.K = I; p.scale_div = 1; p.bias = b_ih;
+        int rc = gemm_nt_f32(p, st); if (rc) return rc;
+        for (int t = 0; t < T; ++t) {
+            if (t) {
+                GemmP q{};
+                q.A = h_tm + (size_t)(t - 1) * B * H; q.B = w_hh; q.C = gh; q.lda = H; q.ldb = H; q.ldc_m = H3; q.ldc_n = 1; q.nb1 = 1; q.nb2 = 1;
+                q.M = B; q.N = H3; q.K = H; q.scale_div = 1;
+                rc = gemm_nt_f32(q, st); if (rc) return rc;
+            }
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(nblk), dim3(256), 0, st, gi + (size_t)t * H3, (int64_t)T * H3, gh, t ? 1 : 0, b_hh,
+                               t ? h_tm + (size_t)(t - 1) * B * H : nullptr, out + (size_t)t * H, (int64_t)T * H, h_tm + (size_t)t * B * H,
+                               save ? save + (size_t)t * B * 5 * H : nullptr, nullptr, nullptr, (int64_t)0, B, H);
+            rc = launch_status("cti_gru_forward/step"); if (rc) return rc;
+        }
+        return CTI_OK;
+    }
+    const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    const int KpI = planes_kp(I), KpH = planes_kp(H);
+    const int S = plan_ksplit(B, H3, KpH, 1);
+    float* part = ws.take<float>(f * (size_t)S * B * H3);
+    const int64_t rx = (int64_t)B * T + PLANE_SLACK_ROWS, rw = (int64_t)H3 + PLANE_SLACK_ROWS, rh = (int64_t)B + PLANE_SLACK_ROWS;
+    unsigned short* xh = ws.take<unsigned short>(planes_bytes(rx, I));   unsigned short* xl = xh + (size_t)rx * KpI;
+    unsigned short* wih = ws.take<unsigned short>(planes_bytes(rw, I));  unsigned short* wil = wih + (size_t)rw * KpI;
+    unsigned short* whh = ws.take<unsigned short>(planes_bytes(rw, H));  unsigned short* whl = whh + (size_t)rw * KpH;
+    unsigned short* hp_[2]; unsigned short* hl_[2];
+    for (int i = 0; i < 2; ++i) { hp_[i] = ws.take<unsigned short>(planes_bytes(rh, H)); hl_[i] = hp_[i] + (size_t)rh * KpH; }
+    int rc = split_planes(x, I, (int64_t)B * T, I, xh, xl, rx, st); if (rc) return rc;
+    rc = split_planes(w_ih, I, H3, I, wih, wil, rw, st); if (rc) return rc;
+    rc = split_planes(w_hh, H, H3, H, whh, whl, rw, st); if (rc) return rc;
+    if (KpH != H) {                                                       // K tail of the h planes stays zero (the kernel writes [0, H) only)
+        for (int i = 0; i < 2; ++i) { hipError_t e = hipMemsetAsync(hp_[i], 0, planes_bytes(rh, H), st); if (e != hipSuccess) return fail((int)e, "cti_gru_forward: memset"); }
+    }
+    {
+        PlaneGemmArgs g{};
+        g.Ah = xh; g.Al = xl; g.Bh = wih; g.Bl = wil; g.rows_allocA = rx; g.rows_allocB = rw; g.nb1 = 1; g.nb2 = 1;
+        g.M = B * T; g.N = H3; g.Kp = KpI; g.terms = terms; g.epi = 0; g.C = gi; g.ldc_m = H3; g.ldc_n = 1; g.scale_div = 1; g.bias = b_ih;
+        rc = gemm_nt_planes(g, st); if (rc) return rc;
+    }
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, prev = cur ^ 1;
+        if (t) { rc = step_gemm(hp_[prev], hl_[prev], rh, whh, whl, rw, B, H3, KpH, S, terms, part, st); if (rc) return rc; }
+        hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(nblk), dim3(256), 0, st, gi + (size_t)t * H3, (int64_t)T * H3, part, t ? S : 0, b_hh,
+                           t ? h_tm + (size_t)(t - 1) * B * H : nullptr, out + (size_t)t * H, (int64_t)T * H, h_tm + (size_t)t * B * H,
+                           save ? save + (size_t)t * B * 5 * H : nullptr, hp_[cur], hl_[cur], rh * 16, B, H);
+        rc = launch_status("cti_gru_forward/step"); if (rc) return rc;
+    }
+    return CTI_OK;
+}
+
+size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec) {
+    if (B <= 0 || T <= 0 || H <= 0) return 0;
+    const size_t f = sizeof(float);
+    size_t n = 2 * al256(f * (size_t)B * H);                                                   // carry ping-pong
+    if (prec == CTI_PREC_F32) return n + al256(f * (size_t)H * 3 * H) + al256(f * (size_t)B * H);
+    const int S = plan_ksplit(B, H, planes_kp(3 * H), 1);
+    n += al256(f * (size_t)S * B * H) + al256(f * (size_t)H * 3 * H);                          // partials, W_hh^T (fp32)
+    n += al256(planes_bytes((int64_t)H + PLANE_SLACK_ROWS, 3 * H)) + al256(planes_bytes((int64_t)B + PLANE_SLACK_ROWS, 3 * H));
+    return n;
+}
+
+int cti_gru_backward(const float* dout, const float* w_hh, const float* save, float* dgi, float* dgh, int B, int T, int H, int prec,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(w_hh); CTI_REQUIRE_PTR(save); CTI_REQUIRE_PTR(dgi); CTI_REQUIRE_PTR(dgh); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && T > 0 && H > 0, CTI_E_SHAPE, "cti_gru_backward: B=%d T=%d H=%d", B, T, H);
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gru_backward: prec=%d", prec);
+    CTI_REQUIRE(workspace_bytes >= cti_gru_backward_workspace_bytes(B, T, H, prec), CTI_E_WORKSPACE, "cti_gru_backward: workspace too small");
+    hipStream_t st = as_stream(stream);
+    Carve ws{static_cast<char*>(workspace), 0};
+    const size_t f = sizeof(float);
+    const int H3 = 3 * H;
+    float* carry[2] = {ws.take<float>(f * (size_t)B * H), ws.take<float>(f * (size_t)B * H)};
+    const unsigned nblk = (unsigned)(((int64_t)B * H + 255) / 256);
+    const bool planes = prec != CTI_PREC_F32;
+    const int KpW = planes_kp(H3);
+    const int S = planes ? plan_ksplit(B, H, KpW, 1) : 1;
+    float* part = ws.take<float>(f * (size_t)S * B * H);
+    float* wt = ws.take<float>(f * (size_t)H * H3);                         // W_hh^T (H, 3H): the contraction axis contiguous
+    int rc = cti_transpose_f32(w_hh, H, 0, wt, H3, 0, H3, H, 1, stream); if (rc) return rc;
+    unsigned short *wth = nullptr, *wtl = nullptr, *gh_ = nullptr, *gl_ = nullptr;
+    const int64_t rw = (int64_t)H + PLANE_SLACK_ROWS, rg = (int64_t)B + PLANE_SLACK_ROWS;
+    if (planes) {
+        wth = ws.take<unsigned short>(planes_bytes(rw, H3)); wtl = wth + (size_t)rw * KpW;
+        gh_ = ws.take<unsigned short>(planes_bytes(rg, H3)); gl_ = gh_ + (size_t)rg * KpW;
+        rc = split_planes(wt, H3, H, H3, wth, wtl, rw, st); if (rc) return rc;
+        if (KpW != H3) { hipError_t e = hipMemsetAsync(gh_, 0, planes_bytes(rg, H3), st); if (e != hipSuccess) return fail((int)e, "cti_gru_backward: memset"); }
+    }
+    const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t == T - 1;
+        float* dgh_t = dgh + (size_t)t * B * H3;                              // (T, B, 3H) time-major
+        hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(nblk), dim3(256), 0, st, dout + (size_t)t * H, (int64_t)T * H, last ? nullptr : carry[(t + 1) & 1],
+                           part, last ? 0 : S, save + (size_t)t * B * 5 * H, t ? save + (size_t)(t - 1) * B * 5 * H : nullptr,
+                           dgi + (size_t)t * H3, (int64_t)T * H3, dgh_t, carry[t & 1], gh_, gl_, rg * 16, B, H);
+        rc = launch_status("cti_gru_backward/step"); if (rc) return rc;
+        if (t == 0) break;
+        if (planes) {
+            rc = step_gemm(gh_, gl_, rg, wth, wtl, rw, B, H, KpW, S, terms, part, st); if (rc) return rc;
+        } else {
+            GemmP q{};
+            q.A = dgh_t; q.B = wt; q.C = part; q.lda = H3; q.ldb = H3; q.ldc_m = H; q.ldc_n = 1; q.nb1 = 1; q.nb2 = 1;
+            q.M = B; q.N = H; q.K = H3; q.scale_div = 1;
+            rc = gemm_nt_f32(q, st); if (rc) return rc;
+        }
+    }
+    return CTI_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
-// cti_model.hip -- the rows either side of the CTI path: word-embedding gather / scatter, the GRU's
-// gate arithmetic (its GEMMs are cti_gemm_nt), Swish, the residual broadcast-add / sequence sums of the model forwards, and
+// cti_model.hip -- the rows either side of the CTI path: word-embedding gather / scatter (the GRU is
+// cti_gru.hip), Swish, the residual broadcast-add / sequence sums of the model forwards, and
 // the two losses.  All of it is HBM-bound elementwise or row-reduction work: coalesced accesses, one pass over the data.
 #include "cti_common.h"
 
@@ -30,53 +30,6 @@ __global__ void embedding_bwd_kernel(const int64_t* __restrict__ tok, const floa
         if (k < 0 || k >= rows || k == pad) continue;
         for (int c = threadIdx.x; c < dim; c += blockDim.x) atomicAdd(dtable + k * dim + c, dout[i * ld + col_off + c]);
     }
-}
-
-// One GRU step, gate order (r, z, n) as torch.nn.GRU.  gi = W_i x_t + b_i, gh = W_h h + b_h (both (B, 3H) rows).
-__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ gh,
-                                     const float* __restrict__ hprev, int64_t ld_hp, float* __restrict__ hout, int64_t ld_ho,
-                                     float* __restrict__ save, float* __restrict__ hps, int64_t ld_hps, int B, int H) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * H) return;
-    const int b = (int)(idx / H), j = (int)(idx % H);
-    const float* gib = gi + (int64_t)b * ld_gi;
-    const float* ghb = gh + (int64_t)b * 3 * H;
-    const float hp = hprev ? hprev[(int64_t)b * ld_hp + j] : 0.f;
-    const float r = sigmoidf_(gib[j] + ghb[j]);
-    const float z = sigmoidf_(gib[H + j] + ghb[H + j]);
-    const float ghn = ghb[2 * H + j];
-    const float nn = tanhf(gib[2 * H + j] + r * ghn);
-    hout[(int64_t)b * ld_ho + j] = (1.f - z) * nn + z * hp;
-    if (save) {
-        float* s = save + (int64_t)b * 4 * H;
-        s[j] = r; s[H + j] = z; s[2 * H + j] = nn; s[3 * H + j] = ghn;
-    }
-    if (hps) hps[(int64_t)b * ld_hps + j] = hp;
-}
-
-// Backward of one step.  dh = dout + carry_a + carry_b;  writes the input-side and hidden-side pre-activation gradients and
-// the direct part of dh_prev (dh * z).
-__global__ void gru_gates_bwd_kernel(const float* __restrict__ dout, int64_t ld_do, const float* __restrict__ ca,
-                                     const float* __restrict__ cb, const float* __restrict__ save, const float* __restrict__ hprev,
-                                     int64_t ld_hp, float* __restrict__ dgi, int64_t ld_dgi, float* __restrict__ dgh, int64_t ld_dgh,
-                                     float* __restrict__ carry, int B, int H) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * H) return;
-    const int b = (int)(idx / H), j = (int)(idx % H);
-    float dh = dout ? dout[(int64_t)b * ld_do + j] : 0.f;
-    if (ca) dh += ca[idx];
-    if (cb) dh += cb[idx];
-    const float* s = save + (int64_t)b * 4 * H;
-    const float r = s[j], z = s[H + j], nn = s[2 * H + j], ghn = s[3 * H + j];
-    const float hp = hprev[(int64_t)b * ld_hp + j];
-    const float dan = dh * (1.f - z) * (1.f - nn * nn);
-    const float daz = dh * (hp - nn) * z * (1.f - z);
-    const float dar = dan * ghn * r * (1.f - r);
-    float* gi_ = dgi + (int64_t)b * ld_dgi;
-    float* gh_ = dgh + (int64_t)b * ld_dgh;
-    gi_[j] = dar; gi_[H + j] = daz; gi_[2 * H + j] = dan;
-    gh_[j] = dar; gh_[H + j] = daz; gh_[2 * H + j] = dan * r;
-    carry[idx] = dh * z;
 }
 
 __global__ void swish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -215,27 +168,6 @@ int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout,
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, as_stream(stream), tokens, dout,
                        ld_dout, col_off, dtable, n, dim, rows, padding_idx);
     return launch_status("cti_embedding_bwd");
-}
-
-int cti_gru_gates_fwd(const float* gi, int64_t ld_gi, const float* gh, const float* h_prev, int64_t ld_hprev, float* h_out,
-                      int64_t ld_hout, float* save, float* hprev_save, int64_t ld_hps, int B, int H, void* stream) {
-    CTI_REQUIRE_PTR(gi); CTI_REQUIRE_PTR(gh); CTI_REQUIRE_PTR(h_out);
-    CTI_REQUIRE(B >= 0 && H > 0 && ld_gi >= 3 * (int64_t)H && ld_hout >= H, CTI_E_SHAPE, "cti_gru_gates_fwd: B=%d H=%d ld_gi=%lld", B, H, (long long)ld_gi);
-    if (B == 0) return CTI_OK;
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), gi, ld_gi, gh, h_prev,
-                       ld_hprev, h_out, ld_hout, save, hprev_save, ld_hps, B, H);
-    return launch_status("cti_gru_gates_fwd");
-}
-
-int cti_gru_gates_bwd(const float* dout, int64_t ld_dout, const float* carry_a, const float* carry_b, const float* save,
-                      const float* h_prev, int64_t ld_hprev, float* dgi, int64_t ld_dgi, float* dgh, int64_t ld_dgh, float* carry_out,
-                      int B, int H, void* stream) {
-    CTI_REQUIRE_PTR(save); CTI_REQUIRE_PTR(h_prev); CTI_REQUIRE_PTR(dgi); CTI_REQUIRE_PTR(dgh); CTI_REQUIRE_PTR(carry_out);
-    CTI_REQUIRE(B >= 0 && H > 0 && ld_dgi >= 3 * (int64_t)H && ld_dgh >= 3 * (int64_t)H, CTI_E_SHAPE, "cti_gru_gates_bwd: B=%d H=%d", B, H);
-    if (B == 0) return CTI_OK;
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), dout, ld_dout, carry_a,
-                       carry_b, save, h_prev, ld_hprev, dgi, ld_dgi, dgh, ld_dgh, carry_out, B, H);
-    return launch_status("cti_gru_gates_bwd");
 }
 
 int cti_swish_fwd(const float* x, float* y, int64_t n, void* stream) {

@@ -573,52 +573,63 @@ def embedding_bwd(tokens, dout, col_off, rows, dim, padding_idx):
     return dt
 
 
-def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False):
-    """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H).
-    The input projection of all steps is one GEMM; each step is one (B,H)x(H,3H) GEMM + the fused gate kernel."""
+def col_sum(x2, alpha=1.0):
+    """(rows, n) contiguous -> (n,) column sums (two-stage reduction over row groups)."""
+    _req(x2, "x")
+    rows, n = x2.shape
+    out = torch.empty(n, device=x2.device, dtype=torch.float32)
+    if rows == 0:
+        return out.zero_()
+    lib = L.lib()
+    wsb = lib.cti_col_sum_workspace_bytes(rows, n)
+    ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
+    L.check(lib.cti_col_sum(x2.data_ptr(), rows, n, out.data_ptr(), float(alpha), 0.0, ws.data_ptr(), wsb, _stream()), "cti_col_sum")
+    return out
+
+
+def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None):
+    """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H), in ONE library
+    call (the time loop lives behind the C ABI).  want_save: also returns save (T,B,5,H) = (r, z, n, W_hn h + b_hn, h_t)."""
     _req(x, "x")
     B, T, I = x.shape
     H = w_hh.shape[1]
-    xc = x.contiguous()
     out = torch.empty((B, T, H), device=x.device, dtype=torch.float32)
-    save = torch.empty((T, B, 4, H), device=x.device, dtype=torch.float32) if want_save else None
-    hps = torch.empty((B, T, H), device=x.device, dtype=torch.float32) if want_save else None
+    save = torch.empty((T, B, 5, H), device=x.device, dtype=torch.float32) if want_save else None
     if B * T == 0:
-        return out, save, hps
-    gi = gemm_nt(xc.view(B * T, I), w_ih, bias=b_ih).view(B, T, 3 * H)
-    h0 = torch.zeros((B, H), device=x.device, dtype=torch.float32)
+        return out, save
+    pr = _prec(prec)
     lib = L.lib()
-    for t in range(T):
-        hprev = out[:, t - 1] if t else h0
-        gh = gemm_nt(hprev, w_hh, bias=b_hh)                                  # (B, 3H)
-        L.check(lib.cti_gru_gates_fwd(gi[:, t].data_ptr(), T * 3 * H, gh.data_ptr(), hprev.data_ptr(), hprev.stride(0),
-                                      out[:, t].data_ptr(), T * H, _ptr(save[t]) if want_save else 0,
-                                      hps[:, t].data_ptr() if want_save else 0, T * H, B, H, _stream()), "cti_gru_gates_fwd")
-    return out, save, hps
+    wsb = lib.cti_gru_forward_workspace_bytes(B, T, I, H, pr)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
+        L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                    b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
+                                    ws.data_ptr(), wsb, _stream()), "cti_gru_forward")
+    return out, save
 
 
-def gru_backward(dout, x, w_ih, w_hh, save, hps, need_dx=True):
-    """-> dx (or None), dW_ih, dW_hh, db_ih, db_hh."""
+def gru_backward(dout, x, w_ih, w_hh, save, need_dx=True, prec=None):
+    """-> dx (or None), dW_ih, dW_hh, db_ih, db_hh.  BPTT in one library call, then four weight-gradient contractions."""
     B, T, H = dout.shape
     I = x.shape[2]
-    dout = dout.contiguous()
-    dgi = torch.empty((B, T, 3 * H), device=dout.device, dtype=torch.float32)
-    dgh = torch.empty((B, T, 3 * H), device=dout.device, dtype=torch.float32)
-    w_hh_t = transpose(w_hh.contiguous(), 3 * H, H).view(H, 3 * H)
+    dev = dout.device
+    dgi = torch.empty((B, T, 3 * H), device=dev, dtype=torch.float32)
+    dgh = torch.empty((T, B, 3 * H), device=dev, dtype=torch.float32)
+    pr = _prec(prec)
     lib = L.lib()
-    ca = cb = None
-    for t in range(T - 1, -1, -1):
-        carry = torch.empty((B, H), device=dout.device, dtype=torch.float32)
-        L.check(lib.cti_gru_gates_bwd(dout[:, t].data_ptr(), T * H, _ptr(ca), _ptr(cb), save[t].data_ptr(), hps[:, t].data_ptr(), T * H,
-                                      dgi[:, t].data_ptr(), T * 3 * H, dgh[:, t].data_ptr(), T * 3 * H, carry.data_ptr(), B, H,
-                                      _stream()), "cti_gru_gates_bwd")
-        ca = carry
-        cb = gemm_nt(dgh[:, t], w_hh_t) if t else None                          # (B, H) = dgh_t @ W_hh
-    dgi2, dgh2 = dgi.view(B * T, 3 * H), dgh.view(B * T, 3 * H)
-    dW_hh = gemm_tn(dgh2, hps.view(B * T, H))
+    wsb = lib.cti_gru_backward_workspace_bytes(B, T, H, pr)
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    L.check(lib.cti_gru_backward(dout.contiguous().data_ptr(), w_hh.contiguous().data_ptr(), save.data_ptr(), dgi.data_ptr(), dgh.data_ptr(),
+                                 B, T, H, pr, ws.data_ptr(), wsb, _stream()), "cti_gru_backward")
+    dgi2, dgh2 = dgi.view(B * T, 3 * H), dgh.view(T * B, 3 * H)
+    if T > 1:
+        h_prev = save[:-1, :, 4, :].contiguous().view((T - 1) * B, H)           # h_0 .. h_{T-2}, time-major like dgh[1:]
+        dW_hh = gemm_tn(dgh2[B:], h_prev)
+    else:
+        dW_hh = torch.zeros((3 * H, H), device=dev, dtype=torch.float32)
     dW_ih = gemm_tn(dgi2, x.contiguous().view(B * T, I))
-    db_hh = sum_batches(dgh2, B * T, 3 * H)
-    db_ih = sum_batches(dgi2, B * T, 3 * H)
+    db_hh = col_sum(dgh2)
+    db_ih = col_sum(dgi2)
     dx = None
     if need_dx:
         w_ih_t = transpose(w_ih.contiguous(), 3 * H, I).view(I, 3 * H)

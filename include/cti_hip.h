@@ -170,6 +170,12 @@ int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch_stride_src
 /* dst[i] = alpha * sum_b src[b*n + i] + beta * dst[i]   (split-K partial sums, per-chunk column sums). */
 int cti_sum_batches(const float* src, float* dst, int nb, int64_t n, float alpha, float beta, void* stream);
 
+/* dst[c] = alpha * sum_r src[r, c] + beta * dst[c] for a tall contiguous (rows, n) matrix (bias gradients: the GRU's b_ih / b_hh),
+ * two stages over row groups; workspace of cti_col_sum_workspace_bytes(rows, n). */
+int cti_col_sum(const float* src, int64_t rows, int n, float* dst, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                void* stream);
+size_t cti_col_sum_workspace_bytes(int64_t rows, int n);
+
 /* Backward of y = act(scale * u + bias) w.r.t. u (src/fc.py:24,29 ReLU):  dzs[r,n] = scale[n/scale_div] * dy[r,n] * (y[r,n] > 0)
  * (act = RELU; without activation the (y > 0) factor is dropped);  dbias[n] = sum_r dy[r,n] * (y[r,n] > 0) (unscaled).
  * y, dy, dzs: rows x n contiguous. */
@@ -239,16 +245,19 @@ int cti_embedding_fwd(const int64_t* tokens, const float* table0, const float* t
 int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout, int col_off, float* dtable, int64_t n, int dim,
                       int64_t rows, int64_t padding_idx, void* stream);
 
-/* One step of nn.GRU (src/language_model.py:57-61, gate order r, z, n): gi = W_ih x_t + b_ih (row stride ld_gi), gh = W_hh h + b_hh
- * ((B, 3H) contiguous), both produced by cti_gemm_nt.  h_out[b] = (1 - z) * n + z * h_prev[b]  (h_prev NULL = zero state).
- * save (B, 4, H) = (r, z, n, W_hn h + b_hn) and hprev_save are written when not NULL (what the backward step needs). */
-int cti_gru_gates_fwd(const float* gi, int64_t ld_gi, const float* gh, const float* h_prev, int64_t ld_hprev, float* h_out,
-                      int64_t ld_hout, float* save, float* hprev_save, int64_t ld_hps, int B, int H, void* stream);
-/* Backward of one step: dh = dout (NULL = 0) + carry_a + carry_b (NULL = 0; (B,H) contiguous).  Writes dgi (gradient of gi),
- * dgh (gradient of gh) and carry_out = dh * z, the direct part of dL/dh_prev; the caller adds dgh @ W_hh with cti_gemm_nt. */
-int cti_gru_gates_bwd(const float* dout, int64_t ld_dout, const float* carry_a, const float* carry_b, const float* save,
-                      const float* h_prev, int64_t ld_hprev, float* dgi, int64_t ld_dgi, float* dgh, int64_t ld_dgh, float* carry_out,
-                      int B, int H, void* stream);
+/* nn.GRU(in, H, 1, batch_first=True) from a zero state (src/language_model.py:57-61,91-96; gate order r, z, n), every step in one
+ * call: x (B,T,I), w_ih (3H,I), w_hh (3H,H), b_ih / b_hh (3H) -> out (B,T,H) = all hidden states.  save: NULL, or (T,B,5,H) =
+ * (r, z, n, W_hn h + b_hn, h_t) per step, what cti_gru_backward needs.  The input projection is one GEMM over all steps; a step is
+ * one split-K GEMM against pre-split recurrent weights + one gate kernel that also emits h_t as the next GEMM's bf16 planes. */
+int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                    int B, int T, int I, int H, int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec);
+/* Back-propagation through time.  dout (B,T,H) contiguous; writes the pre-activation gradients dgi (B,T,3H) (input side: dx = dgi W_ih,
+ * dW_ih = dgi^T x, db_ih = column sums) and dgh (T,B,3H) (hidden side, time-major: dW_hh = sum_t dgh_t^T h_{t-1}, db_hh = column
+ * sums); the caller forms those products with cti_gemm_nt / cti_col_sum. */
+int cti_gru_backward(const float* dout, const float* w_hh, const float* save, float* dgi, float* dgh, int B, int T, int H, int prec,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec);
 
 /* Swish (src/activation.py:17-22), the classifier's alternative activation (src/classifier.py:14). */
 int cti_swish_fwd(const float* x, float* y, int64_t n, void* stream);
