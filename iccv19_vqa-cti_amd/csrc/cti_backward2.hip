@@ -125,6 +125,201 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_kernel(const float* __restric
     }
 }
 
+// Staged variant (the shapes of every model configuration: hr = 16, G = 2, V*Q*G <= 1024).  The generic kernel above reads its
+// dM slice straight from global memory inside the (v,g) and q loops -- short dependent loads at one workgroup per CU, i.e. pure
+// latency (2.7 ms at B = 256).  Here the rank's dM slice (V*Q*G rows x hr, 64 KiB) and T_eff[r] (32 KiB) are prefetched into
+// registers one rank ahead with 16-B loads and time-multiplexed through ONE LDS region: T for the X phase, the dM slice for the
+// dQr / dX phases (row pitch hr + 4 floats: the v-split lanes of dQr land in different banks), T again (still in registers) for
+// the dVr / dT phases.
+#ifndef CTI_MBB_SKIP
+#define CTI_MBB_SKIP 0        // timing-only ablation mask (tools/tune_mbuild.py): 1 X, 2 dQr, 4 dX, 8 dVr, 16 dT
+#endif
+template <int HR>
+__global__ __launch_bounds__(1024) void mbuild_bwd_staged_kernel(const float* __restrict__ dM, const float* __restrict__ Vr,
+                                                                 const float* __restrict__ Qr, const float* __restrict__ Teff,
+                                                                 float* __restrict__ dVr, float* __restrict__ dQr, float* __restrict__ dTpart,
+                                                                 int V, int Q, int R, int G, int rpb, int region_floats) {
+    constexpr int HH = HR * HR, HP = HR + 4, F4 = HR / 4;
+    const int TP = HH * G + 8;                   // row pitch of T in the region: rows 4 apart shift by 128 B (dVr phase: conflict-free)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int inner = HH * G;
+    float* Rg = sm;                              // T[r] ([HR][inner]) or the dM slice ([V*Q*G][HP])
+    float* Xs = Rg + region_floats;              // [V][G][HR(j)][HR(k)]   X, later dX
+    float* Vs = Xs + (size_t)V * G * HH;         // [V + 8][HR]
+    float* Qs = Vs + (V + 8) * HR;               // [Q][HR]  (q, j)
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    constexpr int nthr = 1024;
+    const int b = blockIdx.y;
+    const int K = R * HR;
+    const int rowsM = V * Q * G;
+    const float* vb = Vr + (int64_t)b * V * K;
+    const float* qb = Qr + (int64_t)b * Q * K;
+    const float* dmb = dM + (int64_t)b * rowsM * K;
+    const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
+    const int xc = t % inner, xsp = t / inner, xns = max(1, nthr / inner);
+    const int xg = xc % G, xk = (xc / G) % HR, xj = xc / (G * HR);
+    const int x_off = xg * HH + xj * HR + xk;
+    const int nout = Q * HR;
+    int P = 1;
+    while (P * 2 * nout <= nthr && P < 16) P *= 2;
+    const int qo = t / P, qpart = t % P, qq = qo / HR, qj = qo % HR;
+    int dx_v[2], dx_g[2], dx_k[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int it = t + n * nthr;
+        dx_k[n] = it % HR; dx_g[n] = (it / HR) % G; dx_v[n] = it < V * G * HR ? it / (HR * G) : -1;
+    }
+    int tistep = 1;                                                               // column groups of the dT phase: a power of two dividing HR
+    while (tistep * 2 <= HR && tistep * 2 * inner <= nthr) tistep *= 2;
+    const int tc = t % inner, ti0 = t / inner;
+    const int tg = tc % G, tjk = tc / G;
+    // prefetch registers: T[r] = HR*inner/4 float4 (<= 2 per thread), dM slice = rowsM*F4 float4 (<= 4 per thread)
+    const int t4n = HR * inner / 4, d4n = rowsM * F4;
+    int64_t d_off[4]; int d_dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int f = t + u * nthr;
+        const int row = f / F4, part = f % F4;
+        d_off[u] = f < d4n ? (int64_t)row * K + part * 4 : -1;
+        d_dst[u] = row * HP + part * 4;
+    }
+    const int tput0 = ((4 * t) / inner) * TP + (4 * t) % inner, tput1 = ((4 * (t + nthr)) / inner) * TP + (4 * (t + nthr)) % inner;
+    float4 tp0 = make_float4(0.f, 0.f, 0.f, 0.f), tp1 = tp0, dp0 = tp0, dp1 = tp0, dp2 = tp0, dp3 = tp0;
+#define CTI_MBB_PF_T(rr)                                                                              \
+    {                                                                                                 \
+        const float4* Tr_ = reinterpret_cast<const float4*>(Teff + (int64_t)(rr) * HR * inner);       \
+        if (t < t4n) tp0 = Tr_[t];                                                                    \
+        if (t + nthr < t4n) tp1 = Tr_[t + nthr];                                                      \
+    }
+#define CTI_MBB_PF_D(rr)                                                                              \
+    {                                                                                                 \
+        const float* s_ = dmb + (rr) * HR;                                                            \
+        if (d_off[0] >= 0) dp0 = *reinterpret_cast<const float4*>(s_ + d_off[0]);                     \
+        if (d_off[1] >= 0) dp1 = *reinterpret_cast<const float4*>(s_ + d_off[1]);                     \
+        if (d_off[2] >= 0) dp2 = *reinterpret_cast<const float4*>(s_ + d_off[2]);                     \
+        if (d_off[3] >= 0) dp3 = *reinterpret_cast<const float4*>(s_ + d_off[3]);                     \
+    }
+#define CTI_MBB_PUT_T()                                                                               \
+    {                                                                                                 \
+        if (t < t4n) *reinterpret_cast<float4*>(Rg + tput0) = tp0;                                    \
+        if (t + nthr < t4n) *reinterpret_cast<float4*>(Rg + tput1) = tp1;                             \
+    }
+    CTI_MBB_PF_T(r_lo)
+    CTI_MBB_PF_D(r_lo)
+    for (int r = r_lo; r < r_hi; ++r) {
+        __syncthreads();                                                        // previous rank's dVr / dT readers are done
+        CTI_MBB_PUT_T()
+        for (int e = t; e < V * HR; e += nthr) Vs[e] = vb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
+        for (int e = t; e < Q * HR; e += nthr) Qs[e] = qb[(int64_t)(e / HR) * K + r * HR + (e % HR)];
+        __syncthreads();
+        // X[v][g][j][k]: the thread's T_eff column in registers, v strided over the column groups
+        if (xsp < xns && !(CTI_MBB_SKIP & 1)) {
+            float tcol[HR];
+#pragma unroll
+            for (int i = 0; i < HR; ++i) tcol[i] = Rg[i * TP + xc];
+            for (int v = xsp; v < V; v += xns) {
+                float x = 0.f;
+#pragma unroll
+                for (int i = 0; i < HR; ++i) x = fmaf(tcol[i], Vs[v * HR + i], x);
+                Xs[v * G * HH + x_off] = x;
+            }
+        }
+        __syncthreads();                                                        // T readers done: the region becomes the dM slice
+        if (d_off[0] >= 0) *reinterpret_cast<float4*>(Rg + d_dst[0]) = dp0;
+        if (d_off[1] >= 0) *reinterpret_cast<float4*>(Rg + d_dst[1]) = dp1;
+        if (d_off[2] >= 0) *reinterpret_cast<float4*>(Rg + d_dst[2]) = dp2;
+        if (d_off[3] >= 0) *reinterpret_cast<float4*>(Rg + d_dst[3]) = dp3;
+        __syncthreads();
+        if (r + 1 < r_hi) CTI_MBB_PF_D(r + 1)                                   // next rank's slice flies under this rank's arithmetic
+        // dQr[q][j] = sum_{v,g} sum_k dM[v,q,g,k] X[v,g,j,k]: P lanes split v, shuffle-reduced
+        if (t < nout * P && !(CTI_MBB_SKIP & 2)) {
+            float s = 0.f;
+            for (int v = qpart; v < V; v += P)
+                for (int g = 0; g < G; ++g) {
+                    const float* dm = Rg + ((v * Q + qq) * G + g) * HP;
+                    const float* xr = Xs + (v * G + g) * HH + qj * HR;
+#pragma unroll
+                    for (int k4 = 0; k4 < HR; k4 += 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(dm + k4), x4 = *reinterpret_cast<const float4*>(xr + k4);
+                        s = fmaf(a.x, x4.x, s); s = fmaf(a.y, x4.y, s); s = fmaf(a.z, x4.z, s); s = fmaf(a.w, x4.w, s);
+                    }
+                }
+            for (int off = P >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (qpart == 0) dQr[((int64_t)b * Q + qq) * K + r * HR + qj] = s;
+        }
+        __syncthreads();
+        // dX[v][g][j][k] = sum_q dM[v,q,g,k] Qr[q,j]  (overwrites X)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = dx_k[n], g = dx_g[n], v = dx_v[n];
+            if (v >= 0 && !(CTI_MBB_SKIP & 4)) {
+                float acc[HR];
+#pragma unroll
+                for (int j = 0; j < HR; ++j) acc[j] = 0.f;
+                for (int q = 0; q < Q; ++q) {
+                    const float m = Rg[((v * Q + q) * G + g) * HP + k];
+#pragma unroll
+                    for (int j4 = 0; j4 < HR; j4 += 4) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(Qs + q * HR + j4);
+                        acc[j4] = fmaf(m, q4.x, acc[j4]); acc[j4 + 1] = fmaf(m, q4.y, acc[j4 + 1]);
+                        acc[j4 + 2] = fmaf(m, q4.z, acc[j4 + 2]); acc[j4 + 3] = fmaf(m, q4.w, acc[j4 + 3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < HR; ++j) Xs[(v * G + g) * HH + j * HR + k] = acc[j];
+            }
+        }
+        __syncthreads();                                                        // slice readers done: the region becomes T again
+        CTI_MBB_PUT_T()
+        __syncthreads();
+        if (r + 1 < r_hi) CTI_MBB_PF_T(r + 1)
+        // dVr[v][i] = sum_{g,jk} dX[v][g][jk] T[i][jk*G + g].  Item = (v pair, i quad, 1 of 8 interleaved column slices): 8
+        // accumulators per thread, 6 LDS reads per 8 FMAs, then a 3-step shuffle over the slice lanes (lane bits 0..2).
+        if (!(CTI_MBB_SKIP & 8)) {
+            const int slice = t & 7, iq = (t >> 3) & (HR / 4 - 1), vp = t / (8 * (HR / 4));
+            if (vp < (V + 1) / 2) {
+                const int v0 = 2 * vp, v1 = min(V - 1, v0 + 1), i0 = iq * 4;
+                float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int e = slice; e < inner; e += 8) {
+                    const int g = e / HH, jk = e - g * HH;
+                    const float x0 = Xs[(v0 * G + g) * HH + jk], x1 = Xs[(v1 * G + g) * HH + jk];
+                    const float* tr = Rg + i0 * TP + jk * G + g;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { const float tv = tr[n * TP]; a0[n] = fmaf(x0, tv, a0[n]); a1[n] = fmaf(x1, tv, a1[n]); }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int off = 4; off > 0; off >>= 1) { a0[n] += __shfl_xor(a0[n], off, 64); a1[n] += __shfl_xor(a1[n], off, 64); }
+                if (slice == 0) {
+                    float* o0 = dVr + ((int64_t)b * V + v0) * K + r * HR + i0;
+                    *reinterpret_cast<float4*>(o0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                    if (v0 + 1 < V) *reinterpret_cast<float4*>(o0 + K) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                }
+            }
+        }
+        // dT_b[r][i][c] = sum_v Vr[v][i] dX[v][c]: a thread owns column c and HR / tistep consecutive i: one X read feeds them all
+        if (!(CTI_MBB_SKIP & 16) && ti0 < tistep) {
+            const int ni = HR / tistep, i0 = ti0 * ni;                                   // tistep in {1, 2, 4, ...} divides HR
+            float acc[HR];
+#pragma unroll
+            for (int n = 0; n < HR; ++n) acc[n] = 0.f;
+            for (int v = 0; v < V; ++v) {
+                const float x = Xs[(v * G + tg) * HH + tjk];
+                const float* vr = Vs + v * HR + i0;
+#pragma unroll
+                for (int n = 0; n < HR; ++n) if (n < ni) acc[n] = fmaf(vr[n], x, acc[n]);
+            }
+            float* o = dTpart + ((int64_t)b * R + r) * HR * inner + (int64_t)i0 * inner + tc;
+#pragma unroll
+            for (int n = 0; n < HR; ++n) if (n < ni) o[(int64_t)n * inner] = acc[n];
+        }
+    }
+#undef CTI_MBB_PF_T
+#undef CTI_MBB_PF_D
+#undef CTI_MBB_PUT_T
+}
+
 // =====================================================================================================================
 // softmax backward: dl = p * (dp - sum p*dp) over the softmax axis.
 // =====================================================================================================================
@@ -384,6 +579,18 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
     const int rpb = (R + groups - 1) / groups;
     dim3 grid((R + rpb - 1) / rpb, B);
     int rc;
+    {   // staged variant when its prefetch-register and LDS budgets hold (every model configuration)
+        const int inner = hr * hr * G, rowsM = V * Q * G;
+        const int region = hr * (inner + 8) > rowsM * (hr + 4) ? hr * (inner + 8) : rowsM * (hr + 4);
+        const size_t lds_s = sizeof(float) * ((size_t)region + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)Q * hr);
+        if (hr * inner / 4 <= 2048 && rowsM * (hr / 4) <= 4096 && lds_s <= 160 * 1024) {
+#define CTI_MBS(H) rc = set_lds(mbuild_bwd_staged_kernel<H>, lds_s, "cti_paralind_mbuild_bwd"); if (rc) return rc; \
+    hipLaunchKernelGGL(mbuild_bwd_staged_kernel<H>, grid, dim3(1024), lds_s, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, G, rpb, region);
+            if (hr == 4) { CTI_MBS(4) } else if (hr == 8) { CTI_MBS(8) } else { CTI_MBS(16) }
+#undef CTI_MBS
+            return launch_status("cti_paralind_mbuild_bwd");
+        }
+    }
 #define CTI_MBB(H) rc = set_lds(mbuild_bwd_kernel<H>, lds, "cti_paralind_mbuild_bwd"); if (rc) return rc; \
     hipLaunchKernelGGL(mbuild_bwd_kernel<H>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, G, rpb);
     if (hr == 4) { CTI_MBB(4) } else if (hr == 8) { CTI_MBB(8) } else { CTI_MBB(16) }
