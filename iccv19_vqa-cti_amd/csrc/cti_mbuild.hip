@@ -19,6 +19,9 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builti
 
 constexpr int MB_ROWS = 2;       // step-2 work items (row pairs) per thread: V*G*ceil(Q/2) <= 2048
 
+#ifndef CTI_MBF_SKIP
+#define CTI_MBF_SKIP 0        // timing-only ablation mask (tools/tune_mbuild.py): 1 step 1, 2 step 2 arithmetic, 4 stores
+#endif
 template <int HR, bool PLANES>
 __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                            const float* __restrict__ Teff, float* __restrict__ Mf,
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
         // through the scalar path (s_load -> SGPR operands of the FMAs): no LDS broadcast traffic at all.
         {
             const int c = it_c[0];
-            if (c >= 0) {
+            if (c >= 0 && !(CTI_MBF_SKIP & 1)) {
                 float tc[HR];
 #pragma unroll
                 for (int i = 0; i < HR; ++i) tc[i] = Ts[i * inner + c];
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
             for (int k = 0; k < HR; ++k) { acc[k] = 0.f; acc2[k] = 0.f; }
             const float* xr = Xs + row_x[n];
 #pragma unroll 2
-            for (int j = 0; j < HR; ++j) {
+            for (int j = 0; j < ((CTI_MBF_SKIP & 2) ? 0 : HR); ++j) {
                 const float qv = Qs[j * Qpad + lq];
                 const float qw = Qs[j * Qpad + lq + 1];                     // Qpad >= Q + 1 columns: in bounds, unused when !two
 #pragma unroll
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(1024) void mbuild_fast_kernel(const float* __restri
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
             if (half == 1 && !two) break;
+            if ((CTI_MBF_SKIP & 4) && acc[0] != 12345.f) break;
             const float* av = half ? acc2 : acc;
             const int64_t orow = row_o[n] + (half ? G : 0);                 // (v, q+1, g) is G rows further
             const int c0 = r * HR;

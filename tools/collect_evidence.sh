@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round evidence on the GPU box: tests, bench lines, rocprofv3 kernel stats and the separate PMC passes of the same bench command.
+# Usage (through gpurun): bash tools/collect_evidence.sh   -> everything under gpurun_out/evidence/
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+E=gpurun_out/evidence; rm -rf $E; mkdir -p $E
+if [ "${1:-all}" != "pmc" ]; then
+python -m pytest tests -m gpu -q > $E/pytest_gpu.log 2>&1; tail -2 $E/pytest_gpu.log
+python bench.py > $E/bench_bf16x3.log 2>&1; tail -1 $E/bench_bf16x3.log | cut -c1-200
+python bench.py --precision fp32 --no-cpu-baseline > $E/bench_fp32.log 2>&1
+python bench.py --precision bf16 --no-cpu-baseline > $E/bench_bf16.log 2>&1
+python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.log | cut -c1-200
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/rocprof_stats.log 2>&1
+fi
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# one small counter group per pass (a group the hardware cannot collect together makes rocprofv3 abort and hang: bound every pass)
+i=0
+for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/pmc$i -o p -- $B > $E/pmc$i.log 2>&1 || echo "pmc pass $i ($grp) failed/timeout"
+done
+timeout 300 python tools/bench_model.py > $E/model_fwd.jsonl 2>$E/model_fwd.err
+timeout 300 python tools/bench_model.py --train > $E/model_train.jsonl 2>$E/model_train.err
+cat $E/model_fwd.jsonl $E/model_train.jsonl | cut -c1-120
+find $E -name "*.csv" | head -20; du -sh $E
