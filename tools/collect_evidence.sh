@@ -13,9 +13,10 @@ python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.l
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/rocprof_stats.log 2>&1
 fi
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-# one small counter group per pass (a group the hardware cannot collect together makes rocprofv3 abort and hang: bound every pass)
+# one small counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md counter budget); a group the
+# hardware cannot collect makes rocprofv3 abort and then hang, so every pass is bounded by `timeout`
 i=0
-for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/pmc$i -o p -- $B > $E/pmc$i.log 2>&1 || echo "pmc pass $i ($grp) failed/timeout"
 done
