@@ -87,7 +87,10 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.stale():
+    override = os.environ.get("CTI_HIP_LIB")           # kernel-variant A/B (tools/tune_gemm.py build ...): another build of the SAME library
+    if override:
+        path = override
+    elif _build.stale():
         try:
             _build.build()
         except Exception as e:  # no hipcc on this machine: use the prebuilt copy if there is one

@@ -277,6 +277,207 @@ __global__ __launch_bounds__(256) void bi_pool_kernel(const float* __restrict__ 
 }
 
 // =====================================================================================================
+// Streaming sum-pools (k = 1, D % 4 == 0, Q <= 16, A <= 8): the model configurations' K5 / K6.  These kernels are HBM-bound on
+// the vt stream (B*V*D floats); what limits a naive loop is memory-level parallelism, not bandwidth.  Here a thread owns FOUR
+// consecutive channels (16-B loads), a workgroup of 128 threads one 512-channel slab of one sample; the qt (and at) columns
+// live in registers, the attention slice is compacted into LDS once, and the vt rows are fetched VC at a time -- VC independent
+// 16-B loads in flight per thread (~24 KiB per workgroup, several workgroups per CU) -- before any of them is consumed.
+// TRI: out[b,d] = sum_v vt[v,d] * sum_q qt[q,d] * sum_a w[v,q,a] at[a,d];   BI: out[b,d] = sum_v vt[v,d] * sum_q w[v,q] qt[q,d].
+// =====================================================================================================
+template <bool TRI, int AP, int NG, int QX>
+__global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                          const float* __restrict__ at, const float* __restrict__ w,
+                                                          int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
+                                                          float* __restrict__ out, int V, int Q, int A, int D) {
+#ifndef CTI_POOL_VC
+#define CTI_POOL_VC 9
+#endif
+    // QX = the exact Q (12 or 14: no guards in the unrolled q loops, so the LDS reads of a whole v are issued together) or 0 = any Q <= 16
+    constexpr int VC = CTI_POOL_VC, QM = 16, QL = QX ? QX : QM;
+    const int Qn = QX ? QX : Q;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // TRI: [V*Q][AP]   BI: [V][QM]
+    // NG groups of 128 threads split the v range of the slab (more wavefronts in flight: the arithmetic of the tri pool is not
+    // negligible -- V*Q*(A+1) FMAs per channel); their partial sums meet in LDS
+    const int b = blockIdx.y, tt = threadIdx.x, t = tt & 127, grp = tt >> 7;
+    const int d = (blockIdx.x * 128 + t) * 4;
+    const bool live = d < D;
+    const int dd = live ? d : 0;
+    constexpr int NT = 128 * NG;
+    if (w) {
+        const float* wb = w + (int64_t)b * w_sb;
+        if (TRI) {
+            for (int i = tt; i < V * Q * AP; i += NT) {
+                const int a = i % AP, vq = i / AP, q = vq % Q, v = vq / Q;
+                sm[i] = a < A ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+            }
+        } else {
+            for (int i = tt; i < V * QM; i += NT) {
+                const int q = i % QM, v = i / QM;
+                sm[i] = q < Q ? wb[v * w_sv + q * w_sq] : 0.f;
+            }
+        }
+    } else {
+        for (int i = tt; i < V * QM; i += NT) sm[i] = (i % QM) < Q ? 1.f : 0.f;      // BCNet.forward with h_out = None: w == 1
+    }
+    float4 qr[QM];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < QM; ++q) qr[q] = (q < QL && q < Qn) ? *reinterpret_cast<const float4*>(qt + ((int64_t)b * Q + q) * D + dd) : z4;
+    float4 ar[AP];
+    if (TRI) {
+#pragma unroll
+        for (int a = 0; a < AP; ++a) ar[a] = a < A ? *reinterpret_cast<const float4*>(at + ((int64_t)b * A + a) * D + dd) : z4;
+    }
+    __syncthreads();
+    const float* vb = vt + (int64_t)b * V * D + dd;
+    float4 acc = z4;
+    const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
+    for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
+        float4 vr[VC];
+#pragma unroll
+        for (int u = 0; u < VC; ++u) vr[u] = v0 + u < v_hi ? *reinterpret_cast<const float4*>(vb + (int64_t)(v0 + u) * D) : z4;
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int v = v0 + u;
+            if (v < v_hi) {
+                float4 sv = z4;
+                if (TRI) {
+                    const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * Q * AP);
+#pragma unroll
+                    for (int q = 0; q < QL; ++q) {
+                        if (QX || q < Q) {
+                            const float4 w0 = wr[q * (AP / 4)];
+                            float4 sq;
+                            sq.x = w0.x * ar[0].x + w0.y * ar[1].x + w0.z * ar[2].x + w0.w * ar[3].x;
+                            sq.y = w0.x * ar[0].y + w0.y * ar[1].y + w0.z * ar[2].y + w0.w * ar[3].y;
+                            sq.z = w0.x * ar[0].z + w0.y * ar[1].z + w0.z * ar[2].z + w0.w * ar[3].z;
+                            sq.w = w0.x * ar[0].w + w0.y * ar[1].w + w0.z * ar[2].w + w0.w * ar[3].w;
+                            if (AP == 8) {
+                                const float4 w1 = wr[q * 2 + 1];
+                                sq.x += w1.x * ar[AP - 4].x + w1.y * ar[AP - 3].x + w1.z * ar[AP - 2].x + w1.w * ar[AP - 1].x;
+                                sq.y += w1.x * ar[AP - 4].y + w1.y * ar[AP - 3].y + w1.z * ar[AP - 2].y + w1.w * ar[AP - 1].y;
+                                sq.z += w1.x * ar[AP - 4].z + w1.y * ar[AP - 3].z + w1.z * ar[AP - 2].z + w1.w * ar[AP - 1].z;
+                                sq.w += w1.x * ar[AP - 4].w + w1.y * ar[AP - 3].w + w1.z * ar[AP - 2].w + w1.w * ar[AP - 1].w;
+                            }
+                            sv.x = fmaf(sq.x, qr[q].x, sv.x); sv.y = fmaf(sq.y, qr[q].y, sv.y);
+                            sv.z = fmaf(sq.z, qr[q].z, sv.z); sv.w = fmaf(sq.w, qr[q].w, sv.w);
+                        }
+                    }
+                } else {
+                    const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * QM);
+#pragma unroll
+                    for (int q4 = 0; q4 < (QL + 3) / 4; ++q4) {
+                        if (QX || q4 * 4 < Q) {
+                            const float4 ww = wr[q4];
+                            sv.x += ww.x * qr[q4 * 4].x + ww.y * qr[q4 * 4 + 1].x + ww.z * qr[q4 * 4 + 2].x + ww.w * qr[q4 * 4 + 3].x;
+                            sv.y += ww.x * qr[q4 * 4].y + ww.y * qr[q4 * 4 + 1].y + ww.z * qr[q4 * 4 + 2].y + ww.w * qr[q4 * 4 + 3].y;
+                            sv.z += ww.x * qr[q4 * 4].z + ww.y * qr[q4 * 4 + 1].z + ww.z * qr[q4 * 4 + 2].z + ww.w * qr[q4 * 4 + 3].z;
+                            sv.w += ww.x * qr[q4 * 4].w + ww.y * qr[q4 * 4 + 1].w + ww.z * qr[q4 * 4 + 2].w + ww.w * qr[q4 * 4 + 3].w;
+                        }
+                    }
+                }
+                acc.x = fmaf(sv.x, vr[u].x, acc.x); acc.y = fmaf(sv.y, vr[u].y, acc.y);
+                acc.z = fmaf(sv.z, vr[u].z, acc.z); acc.w = fmaf(sv.w, vr[u].w, acc.w);
+            }
+        }
+    }
+    if (NG > 1) {
+        __syncthreads();                                               // the attention slice is dead: reuse LDS for the partials
+        float4* red = reinterpret_cast<float4*>(sm);
+        if (grp > 0) red[(grp - 1) * 128 + t] = acc;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < NG; ++g) { const float4 o = red[(g - 1) * 128 + t]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        }
+    }
+    if (live && grp == 0) *reinterpret_cast<float4*>(out + (int64_t)b * D + d) = acc;
+}
+
+// Tri pool, product-table form (exact Q*A known at compile time: 36, 42 -- the A = 3 answer tokens of the FFOE model).  The arithmetic of the tri pool is V*Q*A FMAs per
+// channel -- 13.6 flop per HBM byte, near the fp32 VALU ridge -- so the instruction count decides.  A thread owns TWO channels and
+// first forms P[q,a] = qt[q,d] * at[a,d] (Q*A float2 registers); every v is then ONE dot product of the compacted attention row
+// w[v, 0:QA] (LDS, broadcast ds_read_b128) with P: QA packed FMAs per v and channel pair, no padding of A, no per-q re-association.
+template <int QA, int NG>
+__global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                                  const float* __restrict__ at, const float* __restrict__ w,
+                                                                  int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
+                                                                  float* __restrict__ out, int V, int Q, int A, int D) {
+    constexpr int QAP = (QA + 3) & ~3, VC = 9;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [V][QAP]
+    const int b = blockIdx.y, tt = threadIdx.x, t = tt & 127, grp = tt >> 7;
+    const int d = (blockIdx.x * 128 + t) * 2;
+    const bool live = d < D;
+    const int dd = live ? d : 0;
+    constexpr int NT = 128 * NG;
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int i = tt; i < V * QAP; i += NT) {
+        const int qa = i % QAP, v = i / QAP, q = qa / A, a = qa - q * A;
+        sm[i] = qa < QA ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+    }
+    float2 P[QAP];
+    {
+        float2 ar[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) ar[a] = a < A ? *reinterpret_cast<const float2*>(at + ((int64_t)b * A + a) * D + dd) : make_float2(0.f, 0.f);
+        int q = 0, a = 0;
+#pragma unroll
+        for (int i = 0; i < QAP; ++i) {
+            if (i < QA) {
+                const float2 qv = *reinterpret_cast<const float2*>(qt + ((int64_t)b * Q + q) * D + dd);
+                float2 av = ar[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) if (u == a) av = ar[u];
+                P[i] = make_float2(qv.x * av.x, qv.y * av.y);
+                if (++a == A) { a = 0; ++q; }
+            } else {
+                P[i] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    const float* vb = vt + (int64_t)b * V * D + dd;
+    float2 acc = make_float2(0.f, 0.f);
+    const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
+    for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
+        float2 vr[VC];
+#pragma unroll
+        for (int u = 0; u < VC; ++u) vr[u] = v0 + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + u) * D) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int v = v0 + u;
+            if (v < v_hi) {
+                const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * QAP);
+                float2 s0 = make_float2(0.f, 0.f), s1 = s0;
+#pragma unroll
+                for (int i4 = 0; i4 < QAP / 4; ++i4) {
+                    const float4 ww = wr[i4];
+                    s0.x = fmaf(ww.x, P[i4 * 4].x, s0.x);     s0.y = fmaf(ww.x, P[i4 * 4].y, s0.y);
+                    s1.x = fmaf(ww.y, P[i4 * 4 + 1].x, s1.x); s1.y = fmaf(ww.y, P[i4 * 4 + 1].y, s1.y);
+                    s0.x = fmaf(ww.z, P[i4 * 4 + 2].x, s0.x); s0.y = fmaf(ww.z, P[i4 * 4 + 2].y, s0.y);
+                    s1.x = fmaf(ww.w, P[i4 * 4 + 3].x, s1.x); s1.y = fmaf(ww.w, P[i4 * 4 + 3].y, s1.y);
+                }
+                acc.x = fmaf(s0.x + s1.x, vr[u].x, acc.x);
+                acc.y = fmaf(s0.y + s1.y, vr[u].y, acc.y);
+            }
+        }
+    }
+    if (NG > 1) {
+        __syncthreads();
+        float2* red = reinterpret_cast<float2*>(sm);
+        if (grp > 0) red[(grp - 1) * 128 + t] = acc;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < NG; ++g) { const float2 o = red[(g - 1) * 128 + t]; acc.x += o.x; acc.y += o.y; }
+        }
+    }
+    if (live && grp == 0) *reinterpret_cast<float2*>(out + (int64_t)b * D + d) = acc;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// =====================================================================================================
 // bi logits: logits[b,g,v,q] = hs * sum_d vt[b,v,d] h[g,d] qt[b,q,d] + hb[g]               (bc.py:52-58)
 // ONE WAVE per (b, v): the 64 lanes split the d axis (coalesced reads of the vt row, of h and of the qt rows, the
 // latter two L2-resident), each lane keeps a GC x QC block of partial sums, reduced by wave shuffles.  A wave per
@@ -383,6 +584,43 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
                                 int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+#ifndef CTI_TRI_TABLE
+#define CTI_TRI_TABLE 1
+#endif
+#ifndef CTI_TRI_TABLE_NG
+#define CTI_TRI_TABLE_NG 1
+#endif
+    if (CTI_TRI_TABLE && A <= 8 && D % 4 == 0 && aligned16(vt) && aligned16(qt) && aligned16(at) && aligned16(out)) {
+        const int QA = Q * A;
+        constexpr int NGT = CTI_TRI_TABLE_NG;
+        const dim3 grid((D / 2 + 127) / 128, B);
+        size_t lds_t = sizeof(float) * (size_t)V * ((QA + 3) & ~3);
+        if (lds_t < sizeof(float2) * 128 * (NGT - 1)) lds_t = sizeof(float2) * 128 * (NGT - 1);
+#define CTI_TT(QAv) hipLaunchKernelGGL((tri_pool_table_kernel<QAv, NGT>), grid, dim3(128 * NGT), lds_t, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
+        if (lds_t <= 64 * 1024) {
+            // measured at B = 256, D = 1024 (rocprofv3): QA = 42: 27.1 us (stream form 31.6); QA = 72: 53 us (stream form 46.5, kept there)
+            if (QA == 42) { CTI_TT(42); return launch_status("cti_tri_pool_fwd"); }
+            if (QA == 36) { CTI_TT(36); return launch_status("cti_tri_pool_fwd"); }
+        }
+#undef CTI_TT
+    }
+    if (A <= 8 && Q <= 16 && D % 4 == 0 && aligned16(vt) && aligned16(qt) && aligned16(at) && aligned16(out)) {
+        const int AP = A <= 4 ? 4 : 8;
+#ifndef CTI_POOL_NG
+#define CTI_POOL_NG 2
+#endif
+        constexpr int NG = CTI_POOL_NG;
+        size_t lds_p = sizeof(float) * (size_t)V * Q * AP;
+        if (lds_p < sizeof(float4) * 128 * (NG - 1)) lds_p = sizeof(float4) * 128 * (NG - 1);
+        if (lds_p <= 64 * 1024) {
+            const dim3 grid((D / 4 + 127) / 128, B);
+#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
+            if (AP == 4) { if (Q == 14) CTI_TP(4, 14); else if (Q == 12) CTI_TP(4, 12); else CTI_TP(4, 0); }
+            else         { if (Q == 14) CTI_TP(8, 14); else if (Q == 12) CTI_TP(8, 12); else CTI_TP(8, 0); }
+#undef CTI_TP
+            return launch_status("cti_tri_pool_fwd");
+        }
+    }
     if (A <= 8) {
         const int AP = A <= 4 ? 4 : 8;
         const size_t lds_s = sizeof(float) * ((size_t)V * Q * AP + 256 * (size_t)Q);
@@ -406,6 +644,19 @@ extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w,
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && D > 0 && k > 0 && B <= 65535, CTI_E_SHAPE, "cti_bi_pool_fwd: B=%d V=%d Q=%d D=%d k=%d", B, V, Q, D, k);
     CTI_REQUIRE(D >= k, CTI_E_SHAPE, "cti_bi_pool_fwd: D=%d < k=%d", D, k);
+    if (k == 1 && Q <= 16 && D % 4 == 0 && (size_t)V * 16 * sizeof(float) <= 64 * 1024 && aligned16(vt) && aligned16(qt) && aligned16(out)) {
+#ifndef CTI_POOL_NG_BI
+#define CTI_POOL_NG_BI 2
+#endif
+        constexpr int NGB = CTI_POOL_NG_BI;
+        size_t lds_b = sizeof(float) * (size_t)V * 16;
+        if (lds_b < sizeof(float4) * 128 * (NGB - 1)) lds_b = sizeof(float4) * 128 * (NGB - 1);
+#define CTI_BP(QXv) hipLaunchKernelGGL((pool_stream_kernel<false, 4, NGB, QXv>), dim3((D / 4 + 127) / 128, B), dim3(128 * NGB), lds_b, as_stream(stream), \
+                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D)
+        if (Q == 14) CTI_BP(14); else if (Q == 12) CTI_BP(12); else CTI_BP(0);
+#undef CTI_BP
+        return launch_status("cti_bi_pool_fwd");
+    }
     const size_t lds = sizeof(float) * 256 * (size_t)Q * k;
     CTI_REQUIRE(lds <= 64 * 1024, CTI_E_SHAPE, "cti_bi_pool_fwd: Q*k=%d too large for the LDS staging (<= 64)", Q * k);
     const int NO = D / k;                                   // AvgPool1d(k, stride=k) drops a ragged tail, like torch

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""HBM-roofline check of the path's memory-bound kernels (weighted sum-pools K5/K6, masked softmax K4, BiAttention
+logits K7, zero-row mask) at B = 256: achieved GB/s = algorithmic bytes (inputs read once + outputs written once) / kernel time
+(torch events around back-to-back launches), as a fraction of the 8 TB/s HBM3E peak.  One JSON line per kernel.
+
+    python tools/bench_pools.py [reps]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import cti_amd  # noqa: E402
+from cti_amd import ops  # noqa: E402
+
+DEV = "cuda"
+PEAK = 8000.0      # GB/s
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3       # us
+
+
+def report(name, us, nbytes, **kw):
+    gbs = nbytes / us / 1e3
+    print(json.dumps(dict(kernel=name, us=round(us, 2), MB=round(nbytes / 1e6, 2), GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK, 3), **kw)), flush=True)
+
+
+def main(reps=20):
+    torch.manual_seed(0)
+    B, V, D = 256, 36, 1024
+    f = 4
+    for (Q, A) in ((14, 3), (12, 6)):
+        vt = torch.randn(B, V, D, device=DEV); qt = torch.randn(B, Q, D, device=DEV); at = torch.randn(B, A, D, device=DEV)
+        att = torch.softmax(torch.randn(B, V * Q * A, 2, device=DEV), 1).view(B, V, Q, A, 2)
+        w = att[..., 0]
+        report("tri_pool (TCNet.forward_with_weights pool)", timeit(lambda: ops.tri_pool(vt, qt, at, w), reps),
+               f * B * (V * D + Q * D + A * D + V * Q * A + D), Q=Q, A=A, D=D)
+    Q = 14
+    vt = torch.randn(B, V, D, device=DEV); qt = torch.randn(B, Q, D, device=DEV)
+    att = torch.softmax(torch.randn(B, 8, V * Q, device=DEV), 2).view(B, 8, V, Q)
+    report("bi_pool k=1 (BCNet.forward_with_weights)", timeit(lambda: ops.bi_pool(vt, qt, att[:, 0], 1), reps), f * B * (V * D + Q * D + V * Q + D), Q=Q, D=D)
+    D3 = 3072
+    vt3 = torch.randn(B, V, D3, device=DEV); qt3 = torch.randn(B, Q, D3, device=DEV)
+    report("bi_pool k=3", timeit(lambda: ops.bi_pool(vt3, qt3, att[:, 0], 3), reps), f * B * (V * D3 + Q * D3 + V * Q + D3 // 3), Q=Q, D=D3)
+    h = torch.randn(8, D3, device=DEV); hb = torch.randn(8, device=DEV); hs = torch.ones(1, device=DEV)
+    report("bi_logits G=8 (BiAttention logits)", timeit(lambda: ops.bi_logits(vt3, qt3, h, hs, hb), reps),
+           f * (B * (V * D3 + Q * D3 + 8 * V * Q) + 8 * D3), Q=Q, D=D3, G=8)
+    v = torch.randn(B, V, 2048, device=DEV).abs(); v[:, 30:] = 0
+    report("zero_row_mask", timeit(lambda: ops.zero_row_mask(v), reps), f * B * V * 2048 + B * V)
+    mask = ops.zero_row_mask(v)
+    lg = torch.randn(B, 8, V, Q, device=DEV)
+    report("masked_softmax_bi G=8", timeit(lambda: ops.masked_softmax_bi_(lg.clone(), mask), reps), 2 * f * B * 8 * V * Q, note="includes a clone of the logits")
+    for (Q, A, tag) in ((14, 3, "C4"), (14, 3129, "C2")):
+        Bc = B if A < 100 else 64
+        lg = torch.randn(Bc, V, Q, A, 2, device=DEV)
+        m = ops.zero_row_mask(v[:Bc])
+        buf = torch.empty_like(lg)
+
+        def run():
+            buf.copy_(lg)
+            ops.masked_softmax_tri_(buf, m)
+        t_all = timeit(run, reps)
+        t_copy = timeit(lambda: buf.copy_(lg), reps)
+        report("masked_softmax_tri %s" % tag, t_all - t_copy, 2 * f * lg.numel(), B=Bc, A=A, note="copy time subtracted; bytes = read logits + write p")
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20)
