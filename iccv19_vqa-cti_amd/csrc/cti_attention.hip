@@ -525,6 +525,84 @@ __global__ __launch_bounds__(64) void bi_logits_kernel(const float* __restrict__
     }
 }
 
+// =====================================================================================================
+// bi logits on the MFMA (fp32-grade, 3 bf16 products): per sample a (V x D) . (G*Q x D)^T contraction whose right operand
+// h[g,d] * qt[b,q,d] is formed on the fly.  Both operands have the contraction axis d contiguous in memory, and an MFMA
+// 32x32x16 fragment is "8 consecutive k of one row" per lane -- so every lane loads its fragments STRAIGHT from global
+// memory as two 16-B loads (no LDS, no layout pass), multiplies / splits them into bf16 hi + lo in registers and issues
+// al*bh + ah*bl + ah*bh.  One 512-thread workgroup per (sample, half of D): its 8 waves own the (m-tile, n-tile) pairs;
+// the two D halves meet by atomicAdd (two addends: order-independent).  716 us -> ~60 us at B=256, G=8, D=3072.
+// =====================================================================================================
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+typedef float lf32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split8(const float4 a, const float4 b, lbf16x8& hi, lbf16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = static_cast<__bf16>(x[e]);
+        hi[e] = h;
+        lo[e] = static_cast<__bf16>(x[e] - static_cast<float>(h));
+    }
+}
+
+__global__ __launch_bounds__(512) void bi_logits_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                             const float* __restrict__ h, const float* __restrict__ h_scale,
+                                                             const float* __restrict__ h_bias, float* __restrict__ logits,
+                                                             int G, int V, int Q, int D, int MT, int NT, int dper) {
+    const int b = blockIdx.x, ks = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int N = G * Q;
+    const int d_lo = ks * dper, d_hi = min(D, d_lo + dper);
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tile = wid; tile < MT * NT; tile += 8) {
+        const int mt = tile % MT, nt = tile / MT;
+        const int v = mt * 32 + r, c = nt * 32 + r;
+        const bool vok = v < V, cok = c < N;
+        const int g = cok ? c / Q : 0, q = cok ? c - g * Q : 0;
+        const float* ap = vt + ((int64_t)b * V + (vok ? v : 0)) * D + kg * 8;
+        const float* hp = h + (int64_t)g * D + kg * 8;
+        const float* qp = qt + ((int64_t)b * Q + q) * D + kg * 8;
+        lf32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        float4 a0 = z4, a1 = z4, h0 = z4, h1 = z4, q0 = z4, q1 = z4;
+        if (d_lo < d_hi) {
+            if (vok) { a0 = *reinterpret_cast<const float4*>(ap + d_lo); a1 = *reinterpret_cast<const float4*>(ap + d_lo + 4); }
+            if (cok) { h0 = *reinterpret_cast<const float4*>(hp + d_lo); h1 = *reinterpret_cast<const float4*>(hp + d_lo + 4);
+                       q0 = *reinterpret_cast<const float4*>(qp + d_lo); q1 = *reinterpret_cast<const float4*>(qp + d_lo + 4); }
+        }
+        for (int d0 = d_lo; d0 < d_hi; d0 += 16) {
+            const float4 ca0 = a0, ca1 = a1;
+            const float4 p0 = make_float4(h0.x * q0.x, h0.y * q0.y, h0.z * q0.z, h0.w * q0.w);
+            const float4 p1 = make_float4(h1.x * q1.x, h1.y * q1.y, h1.z * q1.z, h1.w * q1.w);
+            const int dn = d0 + 16;
+            if (dn < d_hi) {                                                   // next slice's raw fragments fly under this slice's arithmetic
+                if (vok) { a0 = *reinterpret_cast<const float4*>(ap + dn); a1 = *reinterpret_cast<const float4*>(ap + dn + 4); }
+                if (cok) { h0 = *reinterpret_cast<const float4*>(hp + dn); h1 = *reinterpret_cast<const float4*>(hp + dn + 4);
+                           q0 = *reinterpret_cast<const float4*>(qp + dn); q1 = *reinterpret_cast<const float4*>(qp + dn + 4); }
+            }
+            lbf16x8 ah, al, bh, bl;
+            split8(ca0, ca1, ah, al);
+            split8(p0, p1, bh, bl);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+        if (cok) {
+            const float hb = (h_bias && ks == 0) ? h_bias[g] : 0.f;
+            float* o = logits + (((int64_t)b * G + g) * V) * Q + q;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int vv = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                if (vv < V) atomicAdd(o + (int64_t)vv * Q, acc[e] * hs + hb);
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -672,4 +750,19 @@ extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* 
     hipLaunchKernelGGL(bi_logits_kernel, dim3((unsigned)(B * V)), dim3(64), 0, as_stream(stream), vt, qt, h, h_scale, h_bias,
                        logits, G, V, Q, D);
     return launch_status("cti_bi_logits_fwd");
+}
+
+extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                                      float* logits, int B, int G, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
+    CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_mfma_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
+    if (D % 16 != 0 || !aligned16(vt) || !aligned16(qt) || !aligned16(h))
+        return CTI_E_UNSUPPORTED;                                          // the caller takes cti_bi_logits_fwd (no message: not an error)
+    const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;
+    const int KS = D >= 1024 ? 2 : 1;
+    const int dper = ((D / 16 + KS - 1) / KS) * 16;
+    hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)B * G * V * Q, as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "cti_bi_logits_mfma_fwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(bi_logits_mfma_kernel, dim3(B, KS), dim3(512), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, MT, NT, dper);
+    return launch_status("cti_bi_logits_mfma_fwd");
 }

@@ -328,8 +328,15 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     vt, qt, h = vt.contiguous(), qt.contiguous(), h.contiguous()
     hb = h_bias.contiguous().view(-1) if h_bias is not None else None
     out = torch.empty((B, G, V, Q), device=vt.device, dtype=torch.float32)
-    L.check(L.lib().cti_bi_logits_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V,
-                                      Q, D, _stream()), "cti_bi_logits_fwd")
+    lib = L.lib()
+    if get_precision() != "fp32":                       # fp32-grade MFMA form; the exact-fp32 mode keeps the fp32 VALU kernel
+        rc = lib.cti_bi_logits_mfma_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D,
+                                        _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_bi_logits_mfma_fwd")
+            return out
+    L.check(lib.cti_bi_logits_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V,
+                                  Q, D, _stream()), "cti_bi_logits_fwd")
     return out
 
 

@@ -148,6 +148,11 @@ int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w, int64_t w_
  * h_bias: (G) or NULL.  The (B,G,V,D) intermediate of src/bc.py:55 is never materialised. */
 int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                       float* logits, int B, int G, int V, int Q, int D, void* stream);
+/* The same logits on the MFMA in the fp32-grade 3-product bf16 mode (h[g,d] * qt[b,q,d] formed on the fly, fragments loaded straight
+ * from global memory).  Returns CTI_E_UNSUPPORTED without a message when D % 16 != 0 or an operand is not 16-B aligned: call
+ * cti_bi_logits_fwd then. */
+int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                           float* logits, int B, int G, int V, int Q, int D, void* stream);
 
 /* ---- backward-pass primitives ----------------------------------------------------------------------------------------
  * The gradient contractions of every layer are NT GEMMs of transposed operands; these entry points are what the
