@@ -18,7 +18,7 @@ from . import ops
 from .attention import BiAttention, TriAttention
 from .bc import BCNet
 from .classifier import SimpleClassifier
-from .fc import FCNet
+from .fc import FCNet, HoistedProjection
 from .language_model import QuestionEmbedding, WordEmbedding
 from .tc import TCNet, _needs_grad
 
@@ -59,6 +59,7 @@ class BanModel(nn.Module):
         self.q_prj = nn.ModuleList(q_prj)
         self.classifier = classifier
         self.counter = counter
+        self._v_hoist = HoistedProjection([n.v_net for n in self.b_net])   # N1: one batched GEMM for the glimpses' v projections
 
     def forward(self, v, b, q, labels):
         """v: [batch, num_objs, obj_dim]; b: boxes (read by the counter only); q: [batch, seq_length] token ids.
@@ -66,9 +67,10 @@ class BanModel(nn.Module):
         w_emb = self.w_emb(q)
         q_emb = self.q_emb.forward_all(w_emb)                               # [batch, q_len, q_dim]
         att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
+        vp = self._v_hoist.maybe(v)
         total = None
         for g in range(self.glimpse):
-            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :])
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :], _v_proj=None if vp is None else vp[g])
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             # torch.stack(q_emb_list, 1).sum(1) then .sum(1): accumulate the per-glimpse sequence sums
             if _needs_grad(q_emb):
@@ -87,8 +89,11 @@ class _TriModel(nn.Module):
         q_emb = self.q_emb.forward_all(self.w_emb(q))                       # [batch, q_len, q_dim]
         ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
         att, logits = t_att(v, q_emb, ans_emb)                              # b x v x q x a x g
+        if not hasattr(self, "_v_hoist"):
+            object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net]))
+        vp = self._v_hoist.maybe(v)                                         # N1: the glimpses' v projections as one batched GEMM
         for g in range(self.glimpse):
-            b_emb = self.t_net[g].forward_with_weights(v, q_emb, ans_emb, att[:, :, :, :, g])
+            b_emb = self.t_net[g].forward_with_weights(v, q_emb, ans_emb, att[:, :, :, :, g], _v_proj=None if vp is None else vp[g])
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             ans_emb = _residual(self.a_prj[g], b_emb, ans_emb)
         return self.classifier(_joint(q_emb, ans_emb)), att
@@ -165,9 +170,13 @@ class MCBanModel(nn.Module):
         ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
         att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
         va_att, va_logits = self.va_att.forward_all(v, ans_emb)
+        if not hasattr(self, "_v_hoist"):
+            object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_net for n in self.b_net] + [n.v_net for n in self.tva_net]))
+        vp = self._v_hoist.maybe(v)
+        G = self.glimpse
         for g in range(self.glimpse):
-            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :])
-            va_emb = self.tva_net[g].forward_with_weights(v, ans_emb, va_att[:, g, :, :])
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :], _v_proj=None if vp is None else vp[g])
+            va_emb = self.tva_net[g].forward_with_weights(v, ans_emb, va_att[:, g, :, :], _v_proj=None if vp is None else vp[G + g])
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             ans_emb = _residual(self.a_prj[g], va_emb, ans_emb)
         return self.classifier(_joint(q_emb, ans_emb)), att

@@ -84,3 +84,49 @@ class FCNet(nn.Module):
                 x = m(x)
                 i += 1
         return x
+
+
+class HoistedProjection:
+    """Model-level fusion of SURVEY.md 8f row N1: several single-layer FCNets `[Dropout, WNLinear(in, out), ReLU]` that read the SAME
+    input (the `v_net` / `v_tucker` of every glimpse's pooling network read `v`, src/FFOE/base_model.py:57,130) run as ONE batched
+    GEMM -- the input is split into bf16 planes once instead of once per network, and the launch has n times the tiles.
+    Inference only (in train mode every network draws its own input-dropout mask, and autograd needs the per-network graph):
+    `maybe(...)` returns None whenever the fusion does not apply and the caller takes the per-network path.
+    The concatenated weights are cached until a parameter changes (`_version` / `data_ptr`)."""
+
+    def __init__(self, nets):
+        self.nets = list(nets)
+        self._key = None
+
+    def _layers(self):
+        out = []
+        for n in self.nets:
+            mods = [m for m in n.main if not isinstance(m, nn.Dropout)]
+            if len(mods) != 2 or not isinstance(mods[0], WNLinear) or not isinstance(mods[1], nn.ReLU):
+                return None
+            out.append(mods[0])
+        if len({(l.in_features, l.out_features) for l in out}) != 1:
+            return None
+        return out
+
+    def maybe(self, x):
+        """x (..., in) -> list of (..., out) tensors, one per network, or None."""
+        if len(self.nets) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets for p in n.parameters())):
+            return None
+        if any(n.training for n in self.nets):
+            return None
+        layers = self._layers()
+        if layers is None:
+            return None
+        key = tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
+        if key != self._key:
+            with torch.no_grad():
+                self._w = torch.cat([l.weight_v.detach() for l in layers], 0).contiguous()
+                self._b = torch.cat([l.bias.detach() for l in layers], 0).contiguous()
+                self._s = torch.cat([l.scale().view(1) for l in layers], 0).contiguous()
+            self._key = key
+        n, out_dim = len(layers), layers[0].out_features
+        x2 = x.reshape(-1, x.shape[-1])
+        y = ops.gemm_nt(x2, self._w, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, scale=self._s, scale_div=out_dim, scale_bs=1,
+                        bias=self._b, bias_bs=out_dim, relu=True)
+        return [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
