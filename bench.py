@@ -83,7 +83,7 @@ def measure(step, steps, warmup, world, sync, dist=None, device="cpu"):
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns the
     MAX over ranks of the elapsed seconds (the contract's timing rule).  `sync` = torch.cuda.synchronize on a GPU."""
     def barrier():
-        if world > 1:
+        if dist is not None and dist.is_initialized():
             dist.barrier()
     for _ in range(warmup):
         step()
@@ -94,9 +94,22 @@ def measure(step, steps, warmup, world, sync, dist=None, device="cpu"):
     sync(); barrier(); sync()
     el = time.perf_counter() - t0
     t = torch.tensor([el], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    el = float(t.item())
+    flush_c_stdio()
+    return el
+
+
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when the first communicator is created; on a pipe it would sit in libc's buffer until
+    exit and land AFTER the JSON line.  Push it out now so that the JSON line is the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
 
 
 def whole_job_rate(world, batch_per_rank, steps, elapsed):
@@ -153,6 +166,9 @@ def run_train(args, world, rank, dev, dist):
         opt.step()
 
     el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+    if dist.is_initialized():                                   # tear RCCL down first: the JSON line must be the last line of stdout
+        dist.barrier(); dist.destroy_process_group()
+    flush_c_stdio()
     if rank == 0:
         print(json.dumps({"metric": "CTI fusion-block data-parallel training samples/sec (256 rows/GPU, VQA-2.0 shapes)",
                           "value": whole_job_rate(world, B, args.steps, el), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -185,8 +201,11 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     import torch.distributed as dist
-    if world > 1:
+    # CTI_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the N > 1 code path -- init, barrier, max-reduce -- on a 1-GPU box)
+    if world > 1 or os.environ.get("CTI_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -196,7 +215,7 @@ def main():
 
     if args.mode == "train":
         run_train(args, world, rank, dev, dist)
-        if world > 1:
+        if dist is not None and dist.is_initialized():
             dist.barrier(); dist.destroy_process_group()
         return
     import cti_amd
@@ -261,10 +280,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(c, state, SEED, args.cpu_budget)
-        print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():                                    # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
