@@ -70,7 +70,8 @@ class BanModel(nn.Module):
         vp = self._v_hoist.maybe(v)
         total = None
         for g in range(self.glimpse):
-            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :], _v_proj=None if vp is None else vp[g])
+            w_g = att[:, g, :, :]
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, w_g) if vp is None else self.b_net[g]._pool_projected(vp[g], q_emb, w_g)
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             # torch.stack(q_emb_list, 1).sum(1) then .sum(1): accumulate the per-glimpse sequence sums
             if _needs_grad(q_emb):
@@ -93,7 +94,9 @@ class _TriModel(nn.Module):
             object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net]))
         vp = self._v_hoist.maybe(v)                                         # N1: the glimpses' v projections as one batched GEMM
         for g in range(self.glimpse):
-            b_emb = self.t_net[g].forward_with_weights(v, q_emb, ans_emb, att[:, :, :, :, g], _v_proj=None if vp is None else vp[g])
+            w_g = att[:, :, :, :, g]
+            b_emb = (self.t_net[g].forward_with_weights(v, q_emb, ans_emb, w_g) if vp is None
+                     else self.t_net[g]._pool_projected(vp[g], q_emb, ans_emb, w_g))
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             ans_emb = _residual(self.a_prj[g], b_emb, ans_emb)
         return self.classifier(_joint(q_emb, ans_emb)), att
@@ -175,8 +178,11 @@ class MCBanModel(nn.Module):
         vp = self._v_hoist.maybe(v)
         G = self.glimpse
         for g in range(self.glimpse):
-            b_emb = self.b_net[g].forward_with_weights(v, q_emb, att[:, g, :, :], _v_proj=None if vp is None else vp[g])
-            va_emb = self.tva_net[g].forward_with_weights(v, ans_emb, va_att[:, g, :, :], _v_proj=None if vp is None else vp[G + g])
+            w_g = att[:, g, :, :]
+            b_emb = self.b_net[g].forward_with_weights(v, q_emb, w_g) if vp is None else self.b_net[g]._pool_projected(vp[g], q_emb, w_g)
+            wa_g = va_att[:, g, :, :]
+            va_emb = (self.tva_net[g].forward_with_weights(v, ans_emb, wa_g) if vp is None
+                      else self.tva_net[g]._pool_projected(vp[G + g], ans_emb, wa_g))
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             ans_emb = _residual(self.a_prj[g], va_emb, ans_emb)
         return self.classifier(_joint(q_emb, ans_emb)), att

@@ -68,8 +68,11 @@ class BCNet(nn.Module):
             return self._logits(v_, q_, self.h_mat_v, self.h_mat_g, self.h_bias)
         return self._logits(v_, q_, self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias)
 
-    def forward_with_weights(self, v, q, w, _v_proj=None):
-        v_ = self.v_net(v) if _v_proj is None else _v_proj     # _v_proj: v_net(v) computed by the model's hoisted projection
+    def forward_with_weights(self, v, q, w):
+        return self._pool_projected(self.v_net(v), q, w)
+
+    def _pool_projected(self, v_, q, w):
+        """forward_with_weights given v_ = v_net(v) (the model forwards compute it for all glimpses in one batched GEMM)."""
         q_ = self.q_net(q)
         w = w.float()
         if _needs_grad(v_, q_, w):

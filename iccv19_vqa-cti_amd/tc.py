@@ -128,8 +128,11 @@ class TCNet(nn.Module):
             return f_emb.squeeze(4), ops.zero_row_mask(v)
         return f_emb.squeeze(4)
 
-    def forward_with_weights(self, v, q, a, w, _v_proj=None):
-        v_ = self.v_tucker(v) if _v_proj is None else _v_proj  # b x v x d (_v_proj: computed by the model's hoisted projection)
+    def forward_with_weights(self, v, q, a, w):
+        return self._pool_projected(self.v_tucker(v), q, a, w)
+
+    def _pool_projected(self, v_, q, a, w):
+        """forward_with_weights given v_ = v_tucker(v), b x v x d (the model forwards compute it for all glimpses in one batched GEMM)."""
         q_ = self.q_tucker(q)
         a_ = self.a_tucker(a)
         w = w.float()
