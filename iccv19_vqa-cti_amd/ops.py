@@ -162,6 +162,8 @@ def zero_row_mask(v):
     _req(v, "v")
     x2, ld = _rows2d(v)
     mask = torch.empty(v.shape[:-1], device=v.device, dtype=torch.uint8)
+    if mask.numel() == 0:
+        return mask
     L.check(L.lib().cti_zero_row_mask(x2.data_ptr(), ld, mask.data_ptr(), x2.shape[0], v.shape[-1], _stream()), "cti_zero_row_mask")
     return mask
 
@@ -185,6 +187,8 @@ def paralind_mbuild(Vr, Qr, Teff):
     assert Vr.shape[2] == R * I and Qr.shape[2] == R * J and Qr.shape[0] == B
     Vr, Qr, Teff = Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
     M = torch.empty((B, V, Q, G, R * K), device=Vr.device, dtype=torch.float32)
+    if M.numel() == 0:
+        return M
     with _timed("paralind_mbuild"):
       L.check(L.lib().cti_paralind_mbuild_fwd(Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), M.data_ptr(), B, V, Q, R, I, J, K, G,
                                             _stream()), "cti_paralind_mbuild_fwd")
@@ -199,6 +203,8 @@ def paralind_core(M, Ar, prec=None):
     assert Ar.shape[0] == B and Ar.shape[2] == K
     M, Ar = M.contiguous(), Ar.contiguous()
     out = torch.empty((B, V, Q, A, G), device=M.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
     pr = _prec(prec)
     lib = L.lib()
     wsb = lib.cti_paralind_core_workspace_bytes(B, V * Q, A, G, K, pr)
@@ -241,6 +247,8 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     Tg = T_g.contiguous()
     out = torch.empty((B, V, Q, A, G), device=v.device, dtype=torch.float32)
     mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
+    if out.numel() == 0:                                   # empty batch (or a zero-length axis): nothing to launch
+        return (out, mask) if want_mask else out
     pr = _prec(prec)
     lib = L.lib()
     wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
@@ -262,6 +270,8 @@ def masked_softmax_tri_(logits, mask):
     assert logits.is_contiguous() and mask.is_contiguous()
     B, V, Q, A, G = logits.shape
     p = torch.empty_like(logits)
+    if p.numel() == 0:
+        return p
     lib = L.lib()
     wsb = lib.cti_softmax_tri_workspace_bytes(B, V, Q * A, G)
     ws = torch.empty(wsb, device=logits.device, dtype=torch.uint8)
@@ -279,6 +289,8 @@ def masked_softmax_bi_(logits, mask):
         _req(mask, "mask", torch.uint8)
     B, G, V, Q = logits.shape
     p = torch.empty_like(logits)
+    if p.numel() == 0:
+        return p
     L.check(L.lib().cti_masked_softmax_bi_fwd(logits.data_ptr(), _ptr(mask), p.data_ptr(), B, G, V, Q, _stream()),
             "cti_masked_softmax_bi_fwd")
     return p
@@ -294,6 +306,10 @@ def tri_pool(vt, qt, at, w):
         raise ValueError("w must be (B,V,Q,A) = %s, got %s" % ((B, V, Q, A), tuple(w.shape)))
     vt, qt, at = vt.contiguous(), qt.contiguous(), at.contiguous()
     out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
+    if B == 0:
+        return out
+    if V * Q * A == 0:
+        return out.zero_()
     sb, sv, sq, sa = w.stride()
     L.check(L.lib().cti_tri_pool_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
                                      B, V, Q, A, D, _stream()), "cti_tri_pool_fwd")
@@ -314,6 +330,10 @@ def bi_pool(vt, qt, w, k=1):
     else:
         sb = sv = sq = 0
     out = torch.empty((B, D // k), device=vt.device, dtype=torch.float32)
+    if B == 0:
+        return out
+    if V * Q == 0:
+        return out.zero_()
     L.check(L.lib().cti_bi_pool_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, out.data_ptr(), B, V, Q, D, k, _stream()),
             "cti_bi_pool_fwd")
     return out
@@ -328,6 +348,8 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     vt, qt, h = vt.contiguous(), qt.contiguous(), h.contiguous()
     hb = h_bias.contiguous().view(-1) if h_bias is not None else None
     out = torch.empty((B, G, V, Q), device=vt.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
     lib = L.lib()
     if get_precision() != "fp32":                       # fp32-grade MFMA form; the exact-fp32 mode keeps the fp32 VALU kernel
         rc = lib.cti_bi_logits_mfma_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D,

@@ -1,0 +1,118 @@
+"""Edge cases of the path on an MI355X against the oracle: degenerate sizes (one sample / object / token / candidate), feature widths
+that are not multiples of the GEMM's K padding or tile sizes, ragged row counts around the tile boundaries, an empty batch, and
+non-contiguous inputs.  Random-init modules; reference = the float64 oracle on the module's own state_dict."""
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+from oracle import cti_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+@pytest.fixture(params=["fp32", "bf16x3"], autouse=True)
+def precision(request):
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(request.param)
+    yield request.param
+    cti_amd.set_precision(old)
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def sd(m):
+    return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+
+
+def check(x, ref, what, tol=TOL):
+    x = x.detach().cpu().numpy()
+    assert x.shape == ref.shape, (what, x.shape, ref.shape)
+    if x.size:
+        e = O.norm_max_err(x, ref)
+        assert e < tol, "%s: %.3g" % (what, e)
+
+
+SHAPES = [
+    # B, V, Q, A, v_dim, q_dim, a_dim, h, R, G
+    (1, 1, 1, 1, 8, 8, 8, 16, 4, 2),            # everything degenerate
+    (2, 3, 2, 5, 33, 17, 9, 32, 4, 2),          # feature widths not multiples of 4 / 16 / 32
+    (3, 36, 14, 4, 100, 60, 30, 64, 4, 3),      # odd glimpse count, K tails
+    (5, 7, 3, 130, 24, 24, 20, 32, 2, 2),       # A just past a 128-column tile
+    (2, 37, 14, 3, 40, 40, 40, 128, 32, 2),     # V*Q*G past the 1024 rows of one 256-row tile group
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_triattention_and_pool_shapes(shape):
+    B, V, Q, A, vd, qd, ad, h, R, G = shape
+    torch.manual_seed(sum(shape))
+    att = cti_amd.TriAttention(vd, qd, ad, h, 1, R, G, 1).to(DEV).eval()
+    net = cti_amd.TCNet(vd, qd, ad, h, 1, R, 1, k=2).to(DEV).eval()
+    rs = np.random.RandomState(sum(shape))
+    v = np.abs(rs.standard_normal((B, V, vd))).astype(np.float32)
+    if V > 2:
+        v[0, V - 1] = 0                                          # one masked object
+    q = rs.standard_normal((B, Q, qd)).astype(np.float32)
+    a = rs.standard_normal((B, A, ad)).astype(np.float32)
+    with torch.no_grad():
+        p, logits = att(T(v), T(q), T(a))
+        pooled = net.forward_with_weights(T(v), T(q), T(a), p[..., 0])
+    p_ref, l_ref = O.tri_attention(v, q, a, sd(att), dtype=np.float64)
+    fin = np.isfinite(l_ref)
+    assert np.array_equal(np.isfinite(logits.cpu().numpy()), fin)
+    check(torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits)), np.where(fin, l_ref, 0), "logits")
+    check(p, p_ref, "p")
+    check(pooled, O.tcnet_forward_with_weights(v, q, a, p_ref[..., 0], sd(net), dtype=np.float64), "pooled")
+
+
+@pytest.mark.parametrize("B,V,Q,vd,qd,hd,G", [(1, 1, 1, 8, 8, 8, 1), (2, 5, 3, 33, 17, 20, 3), (3, 36, 14, 100, 60, 48, 8), (2, 36, 12, 64, 64, 256, 8)])
+def test_biattention_and_pool_shapes(B, V, Q, vd, qd, hd, G):
+    torch.manual_seed(B + V + Q + G)
+    att = cti_amd.BiAttention(vd, qd, hd, G).to(DEV).eval()
+    net = cti_amd.BCNet(vd, qd, hd, None, k=1).to(DEV).eval()
+    rs = np.random.RandomState(B * 7 + V)
+    v = np.abs(rs.standard_normal((B, V, vd))).astype(np.float32)
+    if V > 2:
+        v[0, 1] = 0
+    q = rs.standard_normal((B, Q, qd)).astype(np.float32)
+    with torch.no_grad():
+        p, logits = att.forward_all(T(v), T(q))
+        pooled = net.forward_with_weights(T(v), T(q), p[:, 0])
+    p_ref, l_ref = O.bi_attention(v, q, sd(att), dtype=np.float64)
+    fin = np.isfinite(l_ref)
+    assert np.array_equal(np.isfinite(logits.cpu().numpy()), fin)
+    check(torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits)), np.where(fin, l_ref, 0), "logits", 1.5e-4)
+    check(p, p_ref, "p", 1.5e-4)
+    check(pooled, O.bcnet_forward_with_weights(v, q, p_ref[:, 0], sd(net), dtype=np.float64), "pooled")
+
+
+def test_empty_batch_returns_empty_tensors():
+    att = cti_amd.TriAttention(16, 16, 16, 16, 1, 4, 2, 1).to(DEV).eval()
+    net = cti_amd.TCNet(16, 16, 16, 16, 1, 4, 1, k=2).to(DEV).eval()
+    bi = cti_amd.BiAttention(16, 16, 16, 2).to(DEV).eval()
+    v, q, a = torch.zeros(0, 5, 16, device=DEV), torch.zeros(0, 3, 16, device=DEV), torch.zeros(0, 2, 16, device=DEV)
+    with torch.no_grad():
+        p, logits = att(v, q, a)
+        assert tuple(p.shape) == (0, 5, 3, 2, 2) and tuple(logits.shape) == (0, 5, 3, 2, 2)
+        assert tuple(net.forward_with_weights(v, q, a, p[..., 0]).shape) == (0, 32)
+        pb, lb = bi.forward_all(v, q)
+        assert tuple(pb.shape) == (0, 2, 5, 3)
+
+
+def test_non_contiguous_inputs():
+    torch.manual_seed(3)
+    att = cti_amd.TriAttention(24, 16, 16, 32, 1, 4, 2, 1).to(DEV).eval()
+    rs = np.random.RandomState(9)
+    vbig = np.abs(rs.standard_normal((3, 10, 48))).astype(np.float32)
+    qbig = rs.standard_normal((3, 4, 2, 16)).astype(np.float32)
+    a = rs.standard_normal((3, 2, 16)).astype(np.float32)
+    v_t, q_t = T(vbig)[:, ::2, 12:36], T(qbig)[:, :, 1, :]                 # strided rows, offset columns
+    with torch.no_grad():
+        p, _ = att(v_t, q_t, T(a))
+    p_ref, _ = O.tri_attention(vbig[:, ::2, 12:36], qbig[:, :, 1, :], a, sd(att), dtype=np.float64)
+    check(p, p_ref, "p (non-contiguous inputs)")
