@@ -18,6 +18,7 @@ SIGNATURES = {
     "cti_zero_row_mask": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),
     "cti_teff_scramble": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_paralind_mbuild_planes_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _i64, _vp]),
     "cti_paralind_core_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_paralind_core_workspace_bytes": (_sz, [_int, _int, _int, _int, _int, _int]),
     "cti_event_create": (_vp, []),

@@ -249,3 +249,169 @@ int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, 
 }
 
 }  // namespace cti
+
+// =====================================================================================================================
+// M build on the MFMA (fp32-grade 3-product bf16 mode; hr = 16, G = 2, V <= 51, Q <= 16, even R: every model configuration).
+// Both contractions of a rank are K = 16 GEMMs -- ONE 32x32x16 MFMA step each:
+//   step 1  X[v, c=(j,k,g)] = sum_i Vr[v,i] T[i,c]        rows v (two 32-row tiles), 16 column tiles (j = tile index)
+//   step 2  Mt[(g,k), q]    = sum_j X[v,(j,k,g)] Qr[q,j]  one tile per v: rows (g,k) = 32, columns q
+// Fragments are "8 consecutive k of one row", and Vr / Qr / the PRE-TRANSPOSED core Tt[r][c][i] have the contraction axis
+// contiguous in global memory, so their fragments are two 16-B global loads per lane (issued one rank ahead); only X changes
+// hands through LDS ([v][g][k][j], pitch 20 floats: conflict-free b128 fragment reads).  Step 2 is oriented so that a lane's
+// accumulator holds 4 CONSECUTIVE k of one output row (v,q,g): the hi/lo plane stores are 8 B each, no output staging.
+// The VALU kernel above spends ~29k cycles per rank and workgroup; this one is bounded by the hi/lo splits (~5k).
+// =====================================================================================================================
+namespace cti {
+namespace {
+
+typedef __bf16 mb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float mb_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void mb_split8(const float4 a, const float4 b, mb_bf16x8& hi, mb_bf16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = static_cast<__bf16>(x[e]);
+        hi[e] = h;
+        lo[e] = static_cast<__bf16>(x[e] - static_cast<float>(h));
+    }
+}
+
+#ifndef CTI_MM_SKIP
+#define CTI_MM_SKIP 0     // timing-only ablation mask: 1 plane stores, 2 X2 writes, 4 step-2 MFMAs + splits, 8 step-1 MFMAs
+#endif
+__device__ __forceinline__ uint4 mb_pack8(const unsigned short* h) {
+    uint4 r;
+    r.x = h[0] | ((unsigned)h[1] << 16); r.y = h[2] | ((unsigned)h[3] << 16);
+    r.z = h[4] | ((unsigned)h[5] << 16); r.w = h[6] | ((unsigned)h[7] << 16);
+    return r;
+}
+constexpr int MB_SP = 36;                       // pitch of the wave-private output patch [q][32 rho + 4 pad]
+constexpr int MB_XP = 20;                       // X row pitch in floats (16 j + 4 pad: 80-B rows, 16-B aligned, conflict-free)
+
+__global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
+                                                           const float* __restrict__ Tt, unsigned short* __restrict__ Mh,
+                                                           unsigned short* __restrict__ Ml, int V, int Q, int R, int64_t pitchM) {
+    constexpr int HR = 16, G = 2, INNER = HR * HR * G;          // 512 columns c = (j*16 + k)*2 + g
+    extern __shared__ __attribute__((aligned(16))) float X2[];  // [V][G][HR(k)][MB_XP], then 16 output patches [16][MB_SP]
+    float* stage = X2 + (size_t)V * G * HR * MB_XP;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;  // 16 waves
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int K = R * HR;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vb = Vr + (int64_t)b * V * K + kg * 8;
+    const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
+    const int v0 = l31, v1 = 32 + l31;                          // step-1 A rows of the two tiles
+    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
+    const int c1 = wid * 32 + l31;                              // step-1 column of this lane: j = wid, (k, g) = (l31 >> 1, l31 & 1)
+    const int xk = l31 >> 1, xg = l31 & 1;
+    const int64_t rows_b = (int64_t)b * V * Q * G;
+    // fragments of rank r, loaded one rank ahead
+    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
+#define CTI_MM_LOAD(rr)                                                                                             \
+    {                                                                                                               \
+        const int o_ = (rr) * HR;                                                                                   \
+        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
+        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
+        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_); q1 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_ + 4); } \
+        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
+        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
+    }
+    CTI_MM_LOAD(0)
+    for (int r = 0; r < R; ++r) {
+        // ---- step 1: this wave's column tile (j = wid) for both row tiles ------------------------------------------------
+        mb_bf16x8 ah0, al0, ah1, al1, th, tl, qh, ql;
+        mb_split8(a00, a01, ah0, al0);
+        mb_split8(a10, a11, ah1, al1);
+        mb_split8(t0, t1, th, tl);
+        mb_split8(q0, q1, qh, ql);
+        if (r + 1 < R) CTI_MM_LOAD(r + 1)
+        mb_f32x16 x0, x1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
+        if (!(CTI_MM_SKIP & 8)) {
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, th, x0, 0, 0, 0);
+        }
+        if (V > 32 && !(CTI_MM_SKIP & 8)) {
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
+        }
+        __syncthreads();                                        // step-2 readers of the previous rank are done with X2
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int vv = (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (CTI_MM_SKIP & 2) { if (x0[e] == 12345.f) X2[e] = x1[e]; continue; }
+            if (vv < V) X2[((vv * G + xg) * HR + xk) * MB_XP + wid] = x0[e];
+            if (vv + 32 < V) X2[(((vv + 32) * G + xg) * HR + xk) * MB_XP + wid] = x1[e];
+        }
+        __syncthreads();
+        // ---- step 2: one tile per v: rows rho = g*16 + k, columns q ------------------------------------------------------
+        const int sg = l31 >> 4, sk = l31 & 15;
+        for (int v = wid; v < ((CTI_MM_SKIP & 4) ? 0 : V); v += 16) {
+            const float* xr = X2 + ((v * G + sg) * HR + sk) * MB_XP + kg * 8;
+            mb_bf16x8 xh, xl;
+            mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
+            mb_f32x16 m;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = 0.f;
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, qh, m, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ql, m, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, qh, m, 0, 0, 0);
+            // The tile goes through a wave-private LDS patch [q][rho] so that the stores are whole 64-B lines: the hi (or lo) bytes
+            // of output rows (v,q,0) and (v,q,1) of this rank's chunk are contiguous (2 x 16 bf16), i.e. rho = g*16 + k in order.
+            // 4 lanes x 16 B per (v,q): one store instruction per plane and tile (8-B pieces cost 8x the L2 write transactions).
+            float* stg = stage + wid * (16 * MB_SP);
+            if (qok) {
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg)
+                    *reinterpret_cast<float4*>(stg + l31 * MB_SP + 8 * eg + 4 * kg) = make_float4(m[eg * 4], m[eg * 4 + 1], m[eg * 4 + 2], m[eg * 4 + 3]);
+            }
+            // (same wave writes and reads: LDS operations of one wave complete in order)
+            const int sq = lane >> 2, sp = lane & 3;
+            if (sq < Q && !((CTI_MM_SKIP & 1) && m[0] != 12345.f)) {
+                const float4 y0 = *reinterpret_cast<const float4*>(stg + sq * MB_SP + sp * 8);
+                const float4 y1 = *reinterpret_cast<const float4*>(stg + sq * MB_SP + sp * 8 + 4);
+                const float ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+                unsigned short hb[8], lb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { hb[u] = bf16_bits(ys[u]); lb[u] = bf16_bits(ys[u] - bf16_to_f32(hb[u])); }
+                const int64_t row = rows_b + ((int64_t)v * Q + sq) * G;                       // row of g = 0; g = 1 is the next row
+                const int64_t o = (int64_t)r * pitchM + row * 16 + sp * 8;
+                *reinterpret_cast<uint4*>(Mh + o) = mb_pack8(hb);
+                *reinterpret_cast<uint4*>(Ml + o) = mb_pack8(lb);
+            }
+        }
+    }
+#undef CTI_MM_LOAD
+}
+
+}  // namespace
+
+// Tt: the core pre-transposed to [r][c][i] (cti_transpose_f32 of T_eff[r] (i x c) for every r).  CTI_E_UNSUPPORTED = take mbuild_fast.
+int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, int B, int V, int Q, int R,
+                int hr, int G, int64_t pitchM, hipStream_t st) {
+#ifdef CTI_NO_MBUILD_MFMA
+    return CTI_E_UNSUPPORTED;
+#endif
+    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || !Mh || !Ml) return CTI_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + 16 * 16 * MB_SP);
+    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    auto kern = mbuild_mfma_kernel;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "mbuild_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, V, Q, R, pitchM);
+    return launch_status("mbuild_mfma");
+}
+
+}  // namespace cti

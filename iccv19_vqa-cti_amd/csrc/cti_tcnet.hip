@@ -7,6 +7,8 @@
 #include "cti_common.h"
 
 namespace cti {
+int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, int B, int V, int Q, int R,
+                int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 }
@@ -40,7 +42,7 @@ struct Dims { int B, V, Q, A, vd, qd, ad, h, R, G; };
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
-    float* scale_t[3]; float* scale_r[3]; float* Teff; float* wn_partial;
+    float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* wn_partial;
     // fp32 mode
     float* t32[3]; float* r32[3]; float* M32;
     // planes mode
@@ -57,6 +59,7 @@ Plan carve(const Dims& d, int prec, void* ws) {
     const int in[3] = {d.vd, d.qd, d.ad};
     for (int s = 0; s < 3; ++s) { p.scale_t[s] = static_cast<float*>(w.take(sizeof(float))); p.scale_r[s] = static_cast<float*>(w.take(sizeof(float) * d.R)); }
     p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
+    p.Tt = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [r][c][i]: the MFMA M build's B operand
     {
         size_t chunks = 0;
         for (int s = 0; s < 3; ++s) chunks += (size_t)(((int64_t)d.h * in[s] + WN_CHUNK - 1) / WN_CHUNK) + (size_t)d.R * (((int64_t)hr * d.h + WN_CHUNK - 1) / WN_CHUNK);
@@ -137,6 +140,10 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         rc = wn_scale_batch(wb, p.wn_partial, st); if (rc) return rc;
     }
     rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, stream); if (rc) return rc;
+    if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
+        rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * G, (int64_t)hr * hr * hr * G, p.Tt, hr, (int64_t)hr * hr * hr * G, hr, hr * hr * G, R, stream);
+        if (rc) return rc;
+    }
     const int64_t mrows_per_b = (int64_t)V * Q * G;
 
     if (prec == CTI_PREC_F32) {
@@ -202,7 +209,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     // chain B on the auxiliary stream (or first, on the main stream)
     rc = side(0, sb); if (rc) return finish(rc);
     rc = side(1, sb); if (rc) return finish(rc);
-    rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
+    rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
+    if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) {
         // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h)
         if (A < h) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr));

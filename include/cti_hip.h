@@ -89,6 +89,11 @@ int cti_teff_scramble(const float* src, float* dst, int R, int I, int J, int K, 
  * Vr: (B,V,R*I), Qr: (B,Q,R*J) contiguous (outputs of the packed rank nets); M: (B,V,Q,G,R*K) contiguous. */
 int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const float* Teff, float* M, int B, int V, int Q,
                             int R, int I, int J, int K, int G, void* stream);
+/* The same M, written directly as the bf16 hi/lo operand planes of the mode-3 GEMM (chunk-major [R*hr/16][rows_alloc][16], see
+ * DESIGN.md section 3; R*hr must be a multiple of 32, rows_alloc >= B*V*Q*G + 256).  Teff_t: NULL, or T_eff with the two inner
+ * axes swapped to [r][(j,k,g)][i] (cti_transpose_f32 per r) -- with it, hr = 16, G = 2, V <= 51, Q <= 16 run on the MFMA. */
+int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, const float* Teff, const float* Teff_t, unsigned short* Mh,
+                                   unsigned short* Ml, int B, int V, int Q, int R, int hr, int G, int64_t rows_alloc, void* stream);
 
 /* out[b,vq,a,g] = sum_K M[b,vq,g,K] * Ar[b,a,K]   (mode-3 product + the sum over ranks, src/Tensor.py:16-20 and the
  * running `+ f_emb` of src/tc.py:50).  M: (B,VQ,G,K); Ar: (B,A,K); out: (B,VQ,A,G) contiguous = the logical

@@ -46,24 +46,39 @@ def main(rounds=5):
         def fwd(l=l, M=M):
             rc = l.cti_paralind_mbuild_fwd(Vr.data_ptr(), Qr.data_ptr(), Te.data_ptr(), M.data_ptr(), B, V, Q, R, hr, hr, hr, G, st)
             assert rc == 0, l.cti_last_error_string()
-        bwd(); fwd(); torch.cuda.synchronize()
+        rows_alloc = B * V * Q * G + 256
+        Mh = torch.zeros(K // 16, rows_alloc, 16, device=dev, dtype=torch.int16); Ml = torch.zeros_like(Mh)
+        Tt = Te.view(R, hr, hr * hr * G).transpose(1, 2).contiguous()
+
+        def planes(l=l, Mh=Mh, Ml=Ml, Tt=Tt):
+            rc = l.cti_paralind_mbuild_planes_fwd(Vr.data_ptr(), Qr.data_ptr(), Te.data_ptr(), Tt.data_ptr(), Mh.data_ptr(), Ml.data_ptr(), B, V, Q, R, hr, G,
+                                                  rows_alloc, st)
+            assert rc == 0, l.cti_last_error_string()
+        bwd(); fwd(); planes(); torch.cuda.synchronize()
+        # planes -> fp32 (hi + lo) in the (B,V,Q,G,K) layout, against the fp32 M of the same library
+        def unplane(P):
+            x = (P.to(torch.int32) & 0xFFFF) << 16
+            return x.view(torch.float32)[:, :B * V * Q * G, :].permute(1, 0, 2).reshape(B, V, Q, G, K)
+        Mp = unplane(Mh) + unplane(Ml)
+        print("%-12s planes vs fp32 M: %.2e" % (name, float((Mp - M).abs().max() / M.abs().max())))
         outs = [dVr.clone(), dQr.clone(), dT.sum(0), M.clone()]
         if ref is None:
             ref = outs
         else:
             print("%-12s max diff vs first: dVr %.2e dQr %.2e dT %.2e M %.2e" % ((name,) + tuple(float((a - b).abs().max() / b.abs().max()) for a, b in zip(outs, ref))))
-        res[name] = (bwd, fwd, [], [])
+        res[name] = (bwd, fwd, planes, [], [], [])
     for _ in range(rounds):
-        for name, (bwd, fwd, tb, tf) in res.items():
-            for fn, acc in ((bwd, tb), (fwd, tf)):
+        for name, (bwd, fwd, planes, tb, tf, tp) in res.items():
+            for fn, acc in ((bwd, tb), (fwd, tf), (planes, tp)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(5):
                     fn()
                 e1.record(); torch.cuda.synchronize()
                 acc.append(e0.elapsed_time(e1) / 5)
-    for name, (_, _, tb, tf) in res.items():
-        print("%-12s bwd median %.3f ms (min %.3f)   fwd median %.3f ms (min %.3f)" % (name, statistics.median(tb), min(tb), statistics.median(tf), min(tf)))
+    for name, (_, _, _, tb, tf, tp) in res.items():
+        print("%-12s bwd median %.3f ms (min %.3f)   fwd median %.3f ms (min %.3f)   planes fwd median %.3f ms (min %.3f)"
+              % (name, statistics.median(tb), min(tb), statistics.median(tf), min(tf), statistics.median(tp), min(tp)))
 
 
 if __name__ == "__main__":
