@@ -95,6 +95,77 @@ __global__ __launch_bounds__(SM_THREADS) void tri_partial_kernel(float* __restri
     }
 }
 
+// G = 2 fast path of the partial pass (every TriAttention of the reference's models): a thread handles TWO positions per 16-B load,
+// the owning object v = n / QA is tracked incrementally (the generic kernel pays a 64-bit division per element), and max / sum are
+// accumulated in ONE sweep (thread-local running maximum, rescaled when it moves), so the chunk is read once.
+__global__ __launch_bounds__(SM_THREADS) void tri_partial_g2_kernel(float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                                    float* __restrict__ part, int V, int64_t QA, int64_t chunk_n, int nchunk) {
+    __shared__ float red[2][SM_THREADS / 64][2];
+    const int b = blockIdx.y, c = blockIdx.x, t = threadIdx.x;
+    const int64_t N = (int64_t)V * QA;
+    const int64_t n_lo = (int64_t)c * chunk_n, n_hi = min(N, n_lo + chunk_n);
+    float* x = logits + (int64_t)b * N * 2;
+    const uint8_t* mk = mask + (int64_t)b * V;
+    float m0 = neg_inf(), m1 = neg_inf(), s0 = 0.f, s1 = 0.f;
+    auto upd = [](float v, float& m, float& sacc) {
+        if (v > m) { sacc = sacc * __expf(m - v) + 1.f; m = v; }           // m = -inf: exp(-inf) = 0
+        else if (v != neg_inf()) sacc += __expf(v - m);
+    };
+    // positions n, n+1 per thread and trip (n even: n_lo and chunk_n are even, N even or the tail is handled below)
+    int64_t n = n_lo + 2 * t;
+    int64_t vcur = n < n_hi ? n / QA : 0;
+    int64_t bound = (vcur + 1) * QA;                                       // first position of the next object
+    for (; n + 1 < n_hi; n += 2 * SM_THREADS) {
+        while (n >= bound) { ++vcur; bound += QA; }
+        const bool ma = mk[vcur] != 0;
+        const bool mb = (n + 1 >= bound) ? (mk[vcur + 1] != 0) : ma;
+        float4 v4 = *reinterpret_cast<const float4*>(x + n * 2);
+        if (ma) { v4.x = neg_inf(); v4.y = neg_inf(); }
+        if (mb) { v4.z = neg_inf(); v4.w = neg_inf(); }
+        if (ma || mb) *reinterpret_cast<float4*>(x + n * 2) = v4;
+        upd(v4.x, m0, s0); upd(v4.y, m1, s1); upd(v4.z, m0, s0); upd(v4.w, m1, s1);
+    }
+    if (n < n_hi) {                                                        // odd tail: one position
+        while (n >= bound) { ++vcur; bound += QA; }
+        float2 v2 = *reinterpret_cast<const float2*>(x + n * 2);
+        if (mk[vcur] != 0) { v2.x = neg_inf(); v2.y = neg_inf(); *reinterpret_cast<float2*>(x + n * 2) = v2; }
+        upd(v2.x, m0, s0); upd(v2.y, m1, s1);
+    }
+    // combine the threads: common maximum, rescaled sums
+    const float w0 = wave_max(m0), w1 = wave_max(m1);
+    s0 = wave_sum(m0 == neg_inf() ? 0.f : s0 * __expf(m0 - w0));
+    s1 = wave_sum(m1 == neg_inf() ? 0.f : s1 * __expf(m1 - w1));
+    if ((t & 63) == 0) { red[0][t >> 6][0] = w0; red[0][t >> 6][1] = w1; red[1][t >> 6][0] = s0; red[1][t >> 6][1] = s1; }
+    __syncthreads();
+    if (t < 2) {
+        float m = red[0][0][t];
+#pragma unroll
+        for (int w = 1; w < SM_THREADS / 64; ++w) m = fmaxf(m, red[0][w][t]);
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < SM_THREADS / 64; ++w) if (red[0][w][t] != neg_inf()) sacc += red[1][w][t] * __expf(red[0][w][t] - m);
+        float* o = part + (((int64_t)b * nchunk + c) * 2 + t) * 2;
+        o[0] = m; o[1] = sacc;
+    }
+}
+
+// p = exp(x - m_g) / s_g, four elements per thread when G divides 4 (g of element u is u % G: the float4 starts at a multiple of 4)
+__global__ __launch_bounds__(256) void tri_normalise_v4_kernel(const float* __restrict__ logits, const float* __restrict__ stats,
+                                                               float* __restrict__ p, int64_t NG4, int G) {
+    const int b = blockIdx.y;
+    const float4* x = reinterpret_cast<const float4*>(logits) + (int64_t)b * NG4;
+    float4* y = reinterpret_cast<float4*>(p) + (int64_t)b * NG4;
+    const float* st = stats + (int64_t)b * G * 2;
+    float m[4], inv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { m[u] = st[(u % G) * 2]; inv[u] = 1.f / st[(u % G) * 2 + 1]; }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < NG4; f += stride) {
+        const float4 v = x[f];
+        y[f] = make_float4(__expf(v.x - m[0]) * inv[0], __expf(v.y - m[1]) * inv[1], __expf(v.z - m[2]) * inv[2], __expf(v.w - m[3]) * inv[3]);
+    }
+}
+
 __global__ __launch_bounds__(64) void tri_combine_kernel(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */,
                                                          int G, int nchunk) {
     const int b = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
@@ -634,6 +705,10 @@ extern "C" int cti_masked_softmax_tri_fwd(float* logits, const uint8_t* mask, fl
     float* stats = part + (size_t)B * nc * G * 2;
     hipStream_t st = as_stream(stream);
     dim3 grid(nc, B);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(p)) & 15) == 0;
+    const bool fast2 = G == 2 && al16 && (((int64_t)V * QA) & 1) == 0 && (cn & 1) == 0;       // even position counts: every sample starts 16-B aligned
+    if (fast2) hipLaunchKernelGGL(tri_partial_g2_kernel, grid, dim3(SM_THREADS), 0, st, logits, mask, part, V, QA, cn, nc);
+    else
     switch (G) {
 #define CTI_CASE(g) case g: hipLaunchKernelGGL(tri_partial_kernel<g>, grid, dim3(SM_THREADS), 0, st, logits, mask, part, V, QA, G, cn, nc); break;
         CTI_CASE(1) CTI_CASE(2) CTI_CASE(3) CTI_CASE(4) CTI_CASE(8)
@@ -646,7 +721,12 @@ extern "C" int cti_masked_softmax_tri_fwd(float* logits, const uint8_t* mask, fl
     const int64_t NG = (int64_t)V * QA * G;
     const int64_t nblk = (NG + 255) / 256;
     const unsigned gx = (unsigned)(nblk < 2048 ? nblk : 2048);
-    hipLaunchKernelGGL(tri_normalise_kernel, dim3(gx, B), dim3(256), 0, st, logits, stats, p, NG, G);
+    if (al16 && (G == 1 || G == 2 || G == 4) && (NG & 3) == 0) {
+        const int64_t nb4 = (NG / 4 + 255) / 256;
+        hipLaunchKernelGGL(tri_normalise_v4_kernel, dim3((unsigned)(nb4 < 4096 ? nb4 : 4096), B), dim3(256), 0, st, logits, stats, p, NG / 4, G);
+    } else {
+        hipLaunchKernelGGL(tri_normalise_kernel, dim3(gx, B), dim3(256), 0, st, logits, stats, p, NG, G);
+    }
     return launch_status("cti_masked_softmax_tri_fwd/normalise");
 }
 

@@ -251,7 +251,7 @@ int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, 
 }  // namespace cti
 
 // =====================================================================================================================
-// M build on the MFMA (fp32-grade 3-product bf16 mode; hr = 16, G = 2, V <= 51, Q <= 16, even R: every model configuration).
+// M build on the MFMA (fp32-grade 3-product bf16 mode; hr = 16, G = 2, V <= 48, Q <= 16, even R: every model configuration).
 // Both contractions of a rank are K = 16 GEMMs -- ONE 32x32x16 MFMA step each:
 //   step 1  X[v, c=(j,k,g)] = sum_i Vr[v,i] T[i,c]        rows v (two 32-row tiles), 16 column tiles (j = tile index)
 //   step 2  Mt[(g,k), q]    = sum_j X[v,(j,k,g)] Qr[q,j]  one tile per v: rows (g,k) = 32, columns q

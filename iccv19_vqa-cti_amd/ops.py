@@ -195,6 +195,27 @@ def paralind_mbuild(Vr, Qr, Teff):
     return M
 
 
+def paralind_mbuild_planes(Vr, Qr, Teff, use_mfma=True):
+    """The same M as bf16 hi/lo operand planes of the mode-3 GEMM: returns (Mh, Ml) int16 tensors (K/16, rows_alloc, 16) with
+    rows_alloc = B*V*Q*G + 256, element (row, k) at [k >> 4, row, k & 15].  This is what the fused TCNet.forward feeds its last GEMM."""
+    _req(Vr, "Vr"); _req(Qr, "Qr"); _req(Teff, "Teff")
+    R, I, J, K, G = Teff.shape
+    if not (I == J == K):
+        raise ValueError("the plane-writing M build needs a cubic core, got %s" % (tuple(Teff.shape),))
+    B, V, _ = Vr.shape
+    Q = Qr.shape[1]
+    if (R * K) % 32:
+        raise ValueError("R*hr = %d must be a multiple of 32 (the planes' K padding)" % (R * K))
+    Vr, Qr, Teff = Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
+    rows_alloc = B * V * Q * G + 256
+    Mh = torch.zeros((R * K // 16, rows_alloc, 16), device=Vr.device, dtype=torch.int16)
+    Ml = torch.zeros_like(Mh)
+    Tt = transpose(Teff, I, J * K * G, batch=R, s_src=I * J * K * G, ld_src=J * K * G, s_dst=I * J * K * G, ld_dst=I).view(R, J * K * G, I) if use_mfma else None
+    L.check(L.lib().cti_paralind_mbuild_planes_fwd(Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), _ptr(Tt), Mh.data_ptr(), Ml.data_ptr(), B, V, Q, R, I, G,
+                                                   rows_alloc, _stream()), "cti_paralind_mbuild_planes_fwd")
+    return Mh, Ml
+
+
 def paralind_core(M, Ar, prec=None):
     """M (B,V,Q,G,K), Ar (B,A,K) -> out (B,V,Q,A,G) contiguous."""
     _req(M, "M"); _req(Ar, "Ar")

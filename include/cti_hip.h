@@ -91,7 +91,7 @@ int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const float* Teff,
                             int R, int I, int J, int K, int G, void* stream);
 /* The same M, written directly as the bf16 hi/lo operand planes of the mode-3 GEMM (chunk-major [R*hr/16][rows_alloc][16], see
  * DESIGN.md section 3; R*hr must be a multiple of 32, rows_alloc >= B*V*Q*G + 256).  Teff_t: NULL, or T_eff with the two inner
- * axes swapped to [r][(j,k,g)][i] (cti_transpose_f32 per r) -- with it, hr = 16, G = 2, V <= 51, Q <= 16 run on the MFMA. */
+ * axes swapped to [r][(j,k,g)][i] (cti_transpose_f32 per r) -- with it, hr = 16, G = 2, V <= 48, Q <= 16 run on the MFMA. */
 int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, const float* Teff, const float* Teff_t, unsigned short* Mh,
                                    unsigned short* Ml, int B, int V, int Q, int R, int hr, int G, int64_t rows_alloc, void* stream);
 

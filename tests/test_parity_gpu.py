@@ -282,3 +282,24 @@ def test_tcnet_forward_rank_width_sweep(h, R, G):
         m._fusable = lambda *x: False
         check(m(T(v), T(q), T(a)), ref, what="op-by-op hr=%d G=%d" % (h // R, G))
     check(m(T(v).requires_grad_(True), T(q), T(a)), ref, what="autograd forward hr=%d G=%d" % (h // R, G))
+
+
+@pytest.mark.parametrize("B,V,Q,R,use_mfma", [(5, 36, 14, 32, True), (3, 7, 3, 4, True), (2, 51, 16, 2, True), (3, 36, 20, 4, True), (4, 36, 14, 32, False)])
+def test_mbuild_planes_vs_fp32_m(B, V, Q, R, use_mfma):
+    """The plane-writing M build (MFMA kernel for hr = 16, G = 2, Q <= 16; VALU kernel otherwise) against the fp32 M of the generic
+    kernel and a float64 einsum: hi + lo planes carry M to 2^-16 relative."""
+    hr, G = 16, 2
+    rs = np.random.RandomState(B * 100 + V + Q + R)
+    Vr = rs.standard_normal((B, V, R * hr)).astype(np.float32)
+    Qr = rs.standard_normal((B, Q, R * hr)).astype(np.float32)
+    Te = rs.standard_normal((R, hr, hr, hr, G)).astype(np.float32)
+    ref = np.einsum("rijkg,bvri,bqrj->bvqgrk", Te.astype(np.float64), Vr.reshape(B, V, R, hr), Qr.reshape(B, Q, R, hr)).reshape(B, V, Q, G, R * hr)
+    Mh, Ml = cti_amd.ops.paralind_mbuild_planes(T(Vr), T(Qr), T(Te), use_mfma=use_mfma)
+
+    def unplane(P):
+        x = ((P.to(torch.int32) & 0xFFFF) << 16).view(torch.float32)
+        return x[:, :B * V * Q * G, :].permute(1, 0, 2).reshape(B, V, Q, G, R * hr)
+    check(unplane(Mh) + unplane(Ml), ref, tol=3e-5, what="M from planes")
+    assert float(unplane(Mh)[..., 0].abs().sum()) > 0
+    # rows past B*V*Q*G (the tile over-read slack) stay zero
+    assert int(Mh[:, B * V * Q * G:, :].abs().sum()) == 0
