@@ -177,7 +177,7 @@ def run_train(args, world, rank, dev, dist):
                           "data": "synthetic",
                           "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + classifier, "
                                                  "train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
-                                     "global_batch": world * B, "parameters": opt.n, "parallelism": "dp%d" % world}}))
+                                     "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world}}))
 
 
 def main():

@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void tri_pool_bwd_kernel(const float* __restri
     }
 }
 // dw[b,v,q,a] = sum_d x[d] * qt[b,q,d] * at[b,a,d], x[d] = dout[b,d/kdiv] * vt[b,v,d]; also serves the bi pool (A = 1, at == NULL)
-constexpr int PQC = 4, PAC = 8;
+// (PQC, PAC) = the per-lane block of (q, a) accumulators: (4, 8) for the tri pool, (16, 1) for the bi pool -- one sweep over D covers
+// every q there, and no FMA is spent on padded answers
+template <int PQC, int PAC>
 __global__ __launch_bounds__(256) void pool_dw_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
                                                       const float* __restrict__ at, float* __restrict__ dw, int V, int Q, int A, int D, int kdiv) {
     __shared__ float red[4][PQC * PAC];
@@ -640,7 +642,7 @@ extern "C" int cti_tri_pool_bwd(const float* dout, const float* vt, const float*
                        dvt, dqt, dat, V, Q, A, D);
     rc = launch_status("cti_tri_pool_bwd"); if (rc) return rc;
     if (dw) {
-        hipLaunchKernelGGL(pool_dw_kernel, dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
+        hipLaunchKernelGGL((pool_dw_kernel<4, 8>), dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
         rc = launch_status("cti_tri_pool_bwd/dw");
     }
     return rc;
@@ -657,7 +659,7 @@ extern "C" int cti_bi_pool_bwd(const float* dout, const float* vt, const float* 
     rc = launch_status("cti_bi_pool_bwd"); if (rc) return rc;
     if (dw && w) {
         const int Du = (D / k) * k;                         // channels of a ragged tail take no part
-        hipLaunchKernelGGL(pool_dw_kernel, dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, (const float*)nullptr, dw, V, Q, 1, Du, k);
+        hipLaunchKernelGGL((pool_dw_kernel<16, 1>), dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, (const float*)nullptr, dw, V, Q, 1, Du, k);
         rc = launch_status("cti_bi_pool_bwd/dw");
     }
     return rc;

@@ -17,6 +17,8 @@ from . import _lib as L
 
 
 class FlatAdamaxDP:
+    ALIGN = 64                                                  # floats: 256-B parameter alignment inside the flat buffers
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_norm=0.25, update_freq=1, process_group=None):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
@@ -27,8 +29,12 @@ class FlatAdamaxDP:
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise TypeError("all trainable parameters must be fp32 on one device")
-        self.n = sum(p.numel() for p in self.params)
-        self.flat_p = torch.empty(self.n, device=dev, dtype=torch.float32)
+        # every parameter starts on a 256-B boundary of the flat buffers: the kernels' 16-B load paths (plane splits, MFMA fragment
+        # loads) test the pointer alignment of their operands, and a packed layout would send most weights down the scalar paths.
+        # The padding stays zero in all four buffers (zero gradient -> zero Adamax update), so norms and updates are unaffected.
+        self.n_params = sum(p.numel() for p in self.params)
+        self.n = sum((p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN for p in self.params)
+        self.flat_p = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.exp_inf = torch.zeros(self.n, device=dev, dtype=torch.float32)
@@ -38,7 +44,7 @@ class FlatAdamaxDP:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
-            off += k
+            off += (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         lib = L.lib()
         self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
