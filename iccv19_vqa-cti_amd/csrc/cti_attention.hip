@@ -674,6 +674,96 @@ __global__ __launch_bounds__(512) void bi_logits_mfma_kernel(const float* __rest
     }
 }
 
+// =====================================================================================================
+// Tri pool on the MFMA (fp32-grade 3-product bf16 mode; A = 3 or 6, Q <= 16, V <= 64, D % 32 == 0).  Per sample:
+//   U[v, d] = sum_{(q,a)} w[v,(q,a)] * P[(q,a), d],  P = qt[q,d] * at[a,d];     out[d] = sum_v vt[v,d] * U[v,d]
+// The V*Q*A FMAs per channel that bound the VALU forms (27 % of the HBM roofline) become Q*A/16 MFMA steps per 32 x 32 tile.
+// M = v (the compacted attention rows, fragments from LDS, loaded ONCE per wave and reused for all its channel tiles),
+// N = d: lane = channel, so qt / at / vt are read as coalesced 128-B rows and P is formed per lane; with rows = v in the
+// accumulator the Hadamard with vt and the sum over v are in-lane (+ one exchange between the two k-halves).
+// =====================================================================================================
+template <int A_, int KS>
+__global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+                                                            const float* __restrict__ at, const float* __restrict__ w,
+                                                            int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
+                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave) {
+    constexpr int QAP = KS * 16, MT = 2, WP = QAP + 4;             // W row pitch: +4 floats keeps b128 alignment and spreads the banks
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // Wc[64][WP]
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int QA = Q * A_;
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int i = t; i < 64 * QAP; i += 256) {
+        const int qa = i % QAP, v = i / QAP, q = qa / A_, a = qa - q * A_;
+        sm[v * WP + qa] = (v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+    }
+    __syncthreads();
+    lbf16x8 wh[MT][KS], wl[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* wr = sm + (mt * 32 + l31) * WP + ks * 16 + kg * 8;
+            split8(*reinterpret_cast<const float4*>(wr), *reinterpret_cast<const float4*>(wr + 4), wh[mt][ks], wl[mt][ks]);
+        }
+    const bool two = V > 32;
+    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    const int ntile = min(tiles_per_wave, D / 32 - tile0);
+    // The per-tile operands (Q + A + up to 20 vt values per lane, all coalesced 128-B rows) are loaded one tile AHEAD into the other
+    // register set: a wave's loads, P formation, MFMA chain and Hadamard would otherwise run strictly one after the other.
+    float qA[16], aA[A_], vA[16], wA[16], qB[16], aB[A_], vB[16], wB[16];
+#define CTI_TPM_LOAD(qr_, ar_, v0_, v1_, tile_)                                                                  \
+    {                                                                                                            \
+        const int d_ = (tile_) * 32 + l31;                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) qr_[q] = q < Q ? qt[((int64_t)b * Q + q) * D + d_] : 0.f; \
+        _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = at[((int64_t)b * A_ + a) * D + d_];              \
+        const float* vb_ = vt + (int64_t)b * V * D + d_;                                                         \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                         \
+            const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;                                                       \
+            v0_[e] = v < V ? vb_[(int64_t)v * D] : 0.f;                                                          \
+            v1_[e] = (two && v + 32 < V) ? vb_[(int64_t)(v + 32) * D] : 0.f;                                     \
+        }                                                                                                        \
+    }
+#define CTI_TPM_COMPUTE(qr_, ar_, v0_, v1_, tile_)                                                               \
+    {                                                                                                            \
+        lf32x16 u0, u1;                                                                                          \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) { u0[e] = 0.f; u1[e] = 0.f; }                             \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                      \
+            float p0[8], p1[8];                                                                                  \
+            _Pragma("unroll") for (int uu = 0; uu < 8; ++uu) {                                                   \
+                const int k0 = ks * 16 + uu, k1 = ks * 16 + 8 + uu;                                              \
+                p0[uu] = (k0 / A_ < 16) ? qr_[(k0 / A_) & 15] * ar_[k0 % A_] : 0.f;                              \
+                p1[uu] = (k1 / A_ < 16) ? qr_[(k1 / A_) & 15] * ar_[k1 % A_] : 0.f;                              \
+            }                                                                                                    \
+            const float4 pa = kg ? make_float4(p1[0], p1[1], p1[2], p1[3]) : make_float4(p0[0], p0[1], p0[2], p0[3]); \
+            const float4 pb = kg ? make_float4(p1[4], p1[5], p1[6], p1[7]) : make_float4(p0[4], p0[5], p0[6], p0[7]); \
+            lbf16x8 ph, pl;                                                                                      \
+            split8(pa, pb, ph, pl);                                                                              \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[0][ks], ph, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[1][ks], ph, u1, 0, 0, 0);                   \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][ks], pl, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], pl, u1, 0, 0, 0);                   \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][ks], ph, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], ph, u1, 0, 0, 0);                   \
+        }                                                                                                        \
+        float acc = 0.f;                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc = fmaf(u0[e], v0_[e], acc); acc = fmaf(u1[e], v1_[e], acc); } \
+        acc += __shfl_xor(acc, 32, 64);                                                                          \
+        if (kg == 0) out[(int64_t)b * D + (tile_) * 32 + l31] = acc;                                             \
+    }
+    if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)
+    for (int ti = 0; ti < ntile; ti += 2) {
+        if (ti + 1 < ntile) CTI_TPM_LOAD(qB, aB, vB, wB, tile0 + ti + 1)
+        CTI_TPM_COMPUTE(qA, aA, vA, wA, tile0 + ti)
+        if (ti + 1 < ntile) {
+            if (ti + 2 < ntile) CTI_TPM_LOAD(qA, aA, vA, wA, tile0 + ti + 2)
+            CTI_TPM_COMPUTE(qB, aB, vB, wB, tile0 + ti + 1)
+        }
+    }
+#undef CTI_TPM_LOAD
+#undef CTI_TPM_COMPUTE
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -845,4 +935,29 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
     if (e != hipSuccess) return fail((int)e, "cti_bi_logits_mfma_fwd: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(bi_logits_mfma_kernel, dim3(B, KS), dim3(512), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, MT, NT, dper);
     return launch_status("cti_bi_logits_mfma_fwd");
+}
+
+extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
+    CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    // measured at B = 256, D = 1024 (rocprofv3): A = 6: 35.4 us here vs 46.5 us in the streaming VALU form; A = 3: 29.1 us here vs 27.1 us in the
+    // product-table VALU form -- so A = 3 stays there (CTI_TRI_MFMA_A3 builds it in for experiments)
+#ifndef CTI_TRI_MFMA_A3
+#define CTI_TRI_MFMA_A3 0
+#endif
+    if (!(A == 6 || (A == 3 && CTI_TRI_MFMA_A3)) || Q > 16 || V > 64 || D % 32 != 0) return CTI_E_UNSUPPORTED;   // the caller takes cti_tri_pool_fwd
+    const int KS = (Q * A + 15) / 16;
+    const int tiles = D / 32;
+#ifndef CTI_TPM_TPW
+#define CTI_TPM_TPW 4
+#endif
+    const int tpw = tiles >= 32 ? CTI_TPM_TPW : 1;
+    const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
+    const size_t lds = sizeof(float) * 64 * (size_t)(KS * 16 + 4);
+#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw)
+    if (A == 3) { if (KS <= 2) CTI_TM(3, 2); else CTI_TM(3, 3); }
+    else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
+#undef CTI_TM
+    return launch_status("cti_tri_pool_mfma_fwd");
 }

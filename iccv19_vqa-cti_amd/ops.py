@@ -332,8 +332,15 @@ def tri_pool(vt, qt, at, w):
     if V * Q * A == 0:
         return out.zero_()
     sb, sv, sq, sa = w.stride()
-    L.check(L.lib().cti_tri_pool_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
-                                     B, V, Q, A, D, _stream()), "cti_tri_pool_fwd")
+    lib = L.lib()
+    if get_precision() != "fp32" and _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") != "1":      # fp32-grade MFMA form; exact-fp32 mode keeps the VALU kernels
+        rc = lib.cti_tri_pool_mfma_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(), B, V, Q, A, D,
+                                       _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_tri_pool_mfma_fwd")
+            return out
+    L.check(lib.cti_tri_pool_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
+                                 B, V, Q, A, D, _stream()), "cti_tri_pool_fwd")
     return out
 
 
