@@ -1,6 +1,9 @@
-"""SimpleClassifier -- drop-in for the reference's src/classifier.py:11-28: weight-normalised
-Linear -> relu | swish -> Dropout -> weight-normalised Linear, state_dict keys `main.0.*`, `main.3.*`.  Both Linears are the
-MFMA GEMM with the weight-norm scale, bias (and ReLU) in the epilogue."""
+"""SimpleClassifier -- drop-in for the reference's src/classifier.py:11-28.
+
+Layout kept for checkpoint compatibility: `main` is an nn.Sequential whose slots 0 and 3 are the two weight-normalised Linears
+(state_dict keys `main.0.*`, `main.3.*`), slot 1 the activation, slot 2 the Dropout.  Arithmetic: both Linears are the path's MFMA GEMM
+with the weight-norm scale and bias (and, for relu, the activation) in the epilogue -- split-K at batch-sized M; Swish and the
+dropout are HIP kernels with their own backward."""
 import torch.nn as nn
 
 from . import autograd as AG
@@ -8,33 +11,33 @@ from .fc import WNLinear
 
 
 class Swish(nn.Module):
-    """x * sigmoid(x) (src/activation.py:17-22)."""
+    """x * sigmoid(x), the reference's alternative classifier activation (src/activation.py:17-22)."""
 
     def forward(self, x):
         return AG.SwishFn.apply(x)
 
 
+_ACTIVATIONS = {"relu": nn.ReLU, "swish": Swish}
+
+
 class SimpleClassifier(nn.Module):
     def __init__(self, in_dim, hid_dim, out_dim, args):
         super(SimpleClassifier, self).__init__()
-        activation_dict = {'relu': nn.ReLU(), 'swish': Swish()}
-        try:
-            activation_func = activation_dict[args.activation]
-        except Exception:
-            raise AssertionError(str(getattr(args, 'activation', None)) + " is not supported yet!")
-        layers = [
-            WNLinear(in_dim, hid_dim),
-            activation_func,
-            nn.Dropout(args.dropout),
-            WNLinear(hid_dim, out_dim),
-        ]
-        self.main = nn.Sequential(*layers)
+        kind = getattr(args, "activation", None)
+        if kind not in _ACTIVATIONS:
+            raise AssertionError("%s is not supported yet!" % (kind,))
+        # construction order = RNG order of the reference: first Linear, then the second
+        hidden = WNLinear(in_dim, hid_dim)
+        act = _ACTIVATIONS[kind]()
+        drop = nn.Dropout(args.dropout)
+        head = WNLinear(hid_dim, out_dim)
+        self.main = nn.Sequential(hidden, act, drop, head)
 
     def forward(self, x):
-        first, act, drop, last = self.main
-        if isinstance(act, nn.ReLU):
-            h = first(x, relu=True)
-        else:
-            h = act(first(x))
-        h = AG.dropout(h, drop.p, self.training)
-        return last(h)
+        hidden, act, drop, head = self.main[0], self.main[1], self.main[2], self.main[3]
+        fused_relu = isinstance(act, nn.ReLU)
+        y = hidden(x, relu=fused_relu)
+        if not fused_relu:
+            y = act(y)
+        y = AG.dropout(y, drop.p, self.training)
+        return head(y)

@@ -12,18 +12,22 @@ from . import ops
 
 
 class WordEmbedding(nn.Module):
-    """Word Embedding.  The ntoken-th row is the padding row (src/language_model.py:13-17)."""
+    """Token ids -> word vectors; row `ntoken` of each table is the padding row (src/language_model.py:13-17).  With 'c' in `op` a second,
+    frozen table `emb_` is looked up in the same kernel pass and concatenated (src/language_model.py:20-22,43-44)."""
 
     def __init__(self, ntoken, emb_dim, dropout, op=''):
         super(WordEmbedding, self).__init__()
-        self.op = op
-        self.emb = nn.Embedding(ntoken + 1, emb_dim, padding_idx=ntoken)
-        if 'c' in op:
-            self.emb_ = nn.Embedding(ntoken + 1, emb_dim, padding_idx=ntoken)
-            self.emb_.weight.requires_grad = False                      # the fixed copy (src/language_model.py:22)
+        self.ntoken, self.emb_dim, self.op = ntoken, emb_dim, op
+        rows = ntoken + 1
+        self.emb = nn.Embedding(rows, emb_dim, padding_idx=ntoken)
+        if self._concat:
+            self.emb_ = nn.Embedding(rows, emb_dim, padding_idx=ntoken)
+            self.emb_.weight.requires_grad_(False)                      # the fixed copy
         self.dropout = nn.Dropout(dropout)
-        self.ntoken = ntoken
-        self.emb_dim = emb_dim
+
+    @property
+    def _concat(self):
+        return 'c' in self.op
 
     def init_embedding(self, np_file, tfidf=None, tfidf_weights=None):
         """Host-side initialisation from a GloVe matrix (src/language_model.py:27-38): rows [0, ntoken) of `emb` take the file's
@@ -39,13 +43,13 @@ class WordEmbedding(nn.Module):
                 second = torch.cat([second, torch.from_numpy(tfidf_weights)], 0)
             second = tfidf.matmul(second)
             self.emb_.weight.requires_grad = True
-        if 'c' in self.op:
+        if self._concat:
             table = torch.zeros(init.shape)
             table[:second.size(0)] = second
             self.emb_.weight.data[:self.ntoken] = table.to(dev)
 
     def forward(self, x):
-        second = self.emb_.weight if 'c' in self.op else None
+        second = self.emb_.weight if self._concat else None
         if torch.is_grad_enabled() and (self.emb.weight.requires_grad or (second is not None and second.requires_grad)):
             emb = AG.EmbeddingFn.apply(x, self.emb.weight, second, self.ntoken)
         else:
@@ -54,18 +58,18 @@ class WordEmbedding(nn.Module):
 
 
 class QuestionEmbedding(nn.Module):
+    """GRU over the word vectors (src/language_model.py:50-98).  `rnn` is a torch nn.GRU / nn.LSTM used ONLY as the parameter container
+    (same keys `rnn.weight_ih_l0` ... and the same initial values as the reference); the arithmetic runs in the HIP library."""
+
+    _CELLS = {'GRU': nn.GRU, 'LSTM': nn.LSTM}
+
     def __init__(self, in_dim, num_hid, nlayers, bidirect, dropout, rnn_type='GRU'):
-        """Module for question embedding (src/language_model.py:50-66).  `rnn` is an nn.GRU used as the parameter container only
-        (same keys and initial values as the reference); its arithmetic runs in the HIP library."""
         super(QuestionEmbedding, self).__init__()
-        assert rnn_type == 'LSTM' or rnn_type == 'GRU'
-        rnn_cls = nn.LSTM if rnn_type == 'LSTM' else nn.GRU
-        self.rnn = rnn_cls(in_dim, num_hid, nlayers, bidirectional=bidirect, dropout=dropout, batch_first=True)
-        self.in_dim = in_dim
-        self.num_hid = num_hid
-        self.nlayers = nlayers
-        self.rnn_type = rnn_type
-        self.ndirections = 1 + int(bidirect)
+        if rnn_type not in self._CELLS:
+            raise AssertionError("rnn_type must be 'LSTM' or 'GRU', got %r" % (rnn_type,))
+        self.in_dim, self.num_hid, self.nlayers, self.rnn_type = in_dim, num_hid, nlayers, rnn_type
+        self.ndirections = 2 if bidirect else 1
+        self.rnn = self._CELLS[rnn_type](in_dim, num_hid, nlayers, bidirectional=bool(bidirect), dropout=dropout, batch_first=True)
 
     def _check(self):
         if self.rnn_type != 'GRU' or self.nlayers != 1 or self.ndirections != 1:
