@@ -3,7 +3,10 @@
 one training step (forward + loss + backward + clipped Adamax through FlatAdamaxDP) of the FFOE CTI model, the FFOE BAN model
 (gamma = 8) and the MC CTI model, B = 256, random-init weights, synthetic inputs.  One JSON line per case.
 
-    python tools/bench_model.py [ffoe_cti ffoe_ban mc_cti] [--train] [--steps 20]
+    python tools/bench_model.py [ffoe_cti ffoe_ban mc_cti] [--train] [--steps 20] [--precision bf16x3|bf16|fp32]
+
+`--precision bf16` = plain bf16 products with fp32 accumulation (BASELINE configs[2], [3] name bf16): 1 MFMA per product instead of 3;
+its own tolerance is in tests/test_parity_gpu.py::test_plain_bf16_mode_within_its_own_tolerance.
 """
 import json
 import os
@@ -99,5 +102,7 @@ def run(name, train, steps, warmup=5, B=256, ntoken=20000):
 if __name__ == "__main__":
     names = [x for x in sys.argv[1:] if x in CASES] or list(CASES)
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
+    if "--precision" in sys.argv:
+        cti_amd.set_precision(sys.argv[sys.argv.index("--precision") + 1])
     for n in names:
         run(n, "--train" in sys.argv, steps)

@@ -22,5 +22,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
 done
 timeout 300 python tools/bench_model.py > $E/model_fwd.jsonl 2>$E/model_fwd.err
 timeout 300 python tools/bench_model.py --train > $E/model_train.jsonl 2>$E/model_train.err
+timeout 300 python tools/bench_model.py --precision bf16 > $E/model_fwd_bf16.jsonl 2>/dev/null
+timeout 300 python tools/bench_model.py --precision bf16 --train > $E/model_train_bf16.jsonl 2>/dev/null
+timeout 300 python tools/bench_pools.py 30 2>/dev/null | grep kernel > $E/hbm_kernels.jsonl
 cat $E/model_fwd.jsonl $E/model_train.jsonl | cut -c1-120
 find $E -name "*.csv" | head -20; du -sh $E
