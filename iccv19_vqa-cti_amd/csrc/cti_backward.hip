@@ -125,7 +125,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p); mask byte stored for the backward.  backward: same kernel with x = dy, use_mask = 1.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
                                                       int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask,
-                                                      int64_t period) {
+                                                      int64_t period, int vec) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 4 elements
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -137,6 +137,20 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
     const unsigned rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
     const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);
+    // fast path: the whole group of 4 is in range and 16-B / 4-B aligned in x, y and mask (period a multiple of 4: the group does not
+    // straddle two copies): one 16-B load, one 16-B store, one 4-B mask access, one 64-bit modulo per group instead of per element
+    const int64_t s0 = period ? i0 % period : i0;
+    if (vec && i0 + 4 <= n) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + s0);
+        uchar4 mk;
+        if (use_mask) mk = *reinterpret_cast<const uchar4*>(mask + i0);
+        else {
+            mk = make_uchar4(rr[0] >= thr, rr[1] >= thr, rr[2] >= thr, rr[3] >= thr);
+            *reinterpret_cast<uchar4*>(mask + i0) = mk;
+        }
+        *reinterpret_cast<float4*>(y + i0) = make_float4(mk.x ? xv.x * inv : 0.f, mk.y ? xv.y * inv : 0.f, mk.z ? xv.z * inv : 0.f, mk.w ? xv.w * inv : 0.f);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t i = i0 + j;
@@ -196,8 +210,10 @@ extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, f
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(mask);
     CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f && period >= 0, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
     const int64_t groups = (n + 3) / 4;
+    const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0 &&
+                    (period & 3) == 0;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, mask, n, p,
-                       (unsigned long long)seed, (unsigned long long)offset, use_mask, period);
+                       (unsigned long long)seed, (unsigned long long)offset, use_mask, period, vec);
     return launch_status("cti_dropout");
 }
 
