@@ -303,6 +303,48 @@ extern "C" int cti_wn_bwd(const float* G, const float* weight_v, const float* we
 }
 
 // ---- generic strided batched NT GEMM: C[z][m,n] = act(scale[n/div] * sum_k A[z][m,k] * B[z][n,k] + bias[n]) ---------------
+// C (N x K) = a^T b for a (M x N), b (M x K) row-major: the weight-gradient contraction over the ROW axis.  Both operands go
+// straight to transposed bf16 planes (split_planes_t), the M axis is cut into S ranges that run as extra workgroups, a reduce kernel
+// sums the S partials.  (The previous route wrote transposed fp32 copies of both operands first.)
+static void tn_plan(int64_t M, int N, int K, int* S, int64_t* Mp) {
+    *S = plan_ksplit_tn(M, N, K);
+    const int64_t q = 32 * (int64_t)*S;
+    *Mp = (M + q - 1) / q * q;
+}
+extern "C" size_t cti_gemm_tn_workspace_bytes(int64_t M, int N, int K, int prec) {
+    if (prec == CTI_PREC_F32 || M <= 0 || N <= 0 || K <= 0) return 0;
+    int S; int64_t Mp; tn_plan(M, N, K, &S, &Mp);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t pa = 2 * sizeof(unsigned short) * (size_t)(N + PLANE_SLACK_ROWS) * Mp, pb = 2 * sizeof(unsigned short) * (size_t)(K + PLANE_SLACK_ROWS) * Mp;
+    return al(pa) + al(pb) + (S > 1 ? al(sizeof(float) * (size_t)S * N * K) : 0);
+}
+extern "C" int cti_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* C, int64_t M, int N, int K, int prec, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(b); CTI_REQUIRE_PTR(C); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= N && ldb >= K, CTI_E_SHAPE, "cti_gemm_tn: M=%lld N=%d K=%d", (long long)M, N, K);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_tn: prec=%d (the exact-fp32 mode contracts transposed fp32 copies with cti_gemm_nt)", prec);
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_tn_workspace_bytes(M, N, K, prec), CTI_E_WORKSPACE, "cti_gemm_tn: workspace too small");
+    int S; int64_t Mp; tn_plan(M, N, K, &S, &Mp);
+    CTI_REQUIRE(Mp / 16 <= 65535, CTI_E_SHAPE, "cti_gemm_tn: M=%lld exceeds the split grid", (long long)M);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int64_t ra = (int64_t)N + PLANE_SLACK_ROWS, rb = (int64_t)K + PLANE_SLACK_ROWS;
+    char* w = static_cast<char*>(workspace);
+    unsigned short* ah = reinterpret_cast<unsigned short*>(w);            unsigned short* al_ = ah + (size_t)ra * Mp;
+    w += al(2 * sizeof(unsigned short) * (size_t)ra * Mp);
+    unsigned short* bh = reinterpret_cast<unsigned short*>(w);            unsigned short* bl = bh + (size_t)rb * Mp;
+    w += al(2 * sizeof(unsigned short) * (size_t)rb * Mp);
+    float* part = reinterpret_cast<float*>(w);
+    hipStream_t st = as_stream(stream);
+    int rc = split_planes_t(a, lda, M, N, Mp, ah, al_, ra, st); if (rc) return rc;
+    rc = split_planes_t(b, ldb, M, K, Mp, bh, bl, rb, st); if (rc) return rc;
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
+    g.M = N; g.N = K; g.Kp = (int)Mp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0;
+    g.C = C; g.ldc_m = K; g.ldc_n = 1; g.scale_div = 1;
+    if (S > 1) { g.ksplit = S; g.partial = part; }
+    return gemm_nt_planes(g, st);
+}
+
 extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

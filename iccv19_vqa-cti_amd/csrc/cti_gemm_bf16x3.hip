@@ -79,6 +79,26 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     *reinterpret_cast<uint4*>(lo + o) = pack8(l);
 }
 
+// Transposing split: x is (M x n) row-major; the planes hold x^T, i.e. rows = the n columns of x, depth = M (zero-filled up to Mp).
+// A thread owns one column: its 16 loads (one per row of the chunk) are coalesced across the workgroup, and its 16 values are one
+// contiguous 32-B run of each plane.  This is the weight-gradient operand layout (dW = dz^T x contracts over the ROW axis) without
+// a transposed fp32 copy.
+__global__ __launch_bounds__(256) void split_t_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int n, unsigned short* __restrict__ hi,
+                                                      unsigned short* __restrict__ lo, int64_t pitch) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= n) return;
+    const int64_t m0 = (int64_t)blockIdx.y * 16;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (m0 + j < M) ? x[(m0 + j) * ld + col] : 0.f;
+    unsigned short h[16], l[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { h[j] = bf16_bits(v[j]); l[j] = bf16_bits(v[j] - bf16_to_f32(h[j])); }
+    const int64_t o = (int64_t)blockIdx.y * pitch + (int64_t)col * 16;
+    *reinterpret_cast<uint4*>(hi + o) = pack8(h);     *reinterpret_cast<uint4*>(hi + o + 8) = pack8(h + 8);
+    *reinterpret_cast<uint4*>(lo + o) = pack8(l);     *reinterpret_cast<uint4*>(lo + o + 8) = pack8(l + 8);
+}
+
 struct PlaneGemmP {
     const unsigned short* Ah; const unsigned short* Al; const unsigned short* Bh; const unsigned short* Bl;
     float* C;
@@ -553,6 +573,23 @@ int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(Kp >> 5)), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo,
                        rows_alloc * 16);
     return launch_status("split_planes");
+}
+
+int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
+                   hipStream_t st) {
+    if (Mp % 16 != 0 || Mp / 16 > 65535) return fail(CTI_E_SHAPE, "split_planes_t: depth %lld", (long long)Mp);
+    hipLaunchKernelGGL(split_t_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(Mp / 16)), dim3(256), 0, st, x, ld, M, n, hi, lo, rows_alloc * 16);
+    return launch_status("split_planes_t");
+}
+
+// K ranges for C = a^T b (contraction over the M rows): about two workgroups per CU, at least 256 of depth each
+int plan_ksplit_tn(int64_t M, int N, int K) {
+    const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+    long long s = 512 / (tiles > 0 ? tiles : 1);
+    const long long smax = (M + 255) / 256;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
 }
 
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {

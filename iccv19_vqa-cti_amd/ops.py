@@ -441,6 +441,15 @@ def gemm_tn(a, b, prec=None):
     M, N = a.shape
     K = b.shape[1]
     assert b.shape[0] == M and a.is_contiguous() and b.is_contiguous()
+    pr = _prec(prec)
+    if pr != L.PREC_F32 and M > 0 and _os.environ.get("CTI_GEMM_TN_LEGACY", "0") != "1":
+        # straight to transposed operand planes + split-K over the rows, all behind one C-ABI call
+        out = torch.empty((N, K), device=a.device, dtype=torch.float32)
+        lib = L.lib()
+        wsb = lib.cti_gemm_tn_workspace_bytes(M, N, K, pr)
+        ws = torch.empty(wsb, device=a.device, dtype=torch.uint8)
+        L.check(lib.cti_gemm_tn(a.data_ptr(), N, b.data_ptr(), K, out.data_ptr(), M, N, K, pr, ws.data_ptr(), wsb, _stream()), "cti_gemm_tn")
+        return out
     S = max(1, min(128, M // 2048))
     Mc = (M + S - 1) // S
     Mc = (Mc + 31) // 32 * 32

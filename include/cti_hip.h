@@ -177,6 +177,14 @@ int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, i
                 const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
 
+/* C (N x K, contiguous) = a^T b for a (M x N, row stride lda) and b (M x K, row stride ldb): the weight-gradient contraction over the
+ * ROW axis (dW = dz^T x; src/fc.py:22-29 under autograd).  Both operands are written straight to transposed bf16 hi/lo planes, the M axis
+ * is split over extra workgroups and a reduce kernel sums the partials.  prec = BF16X3 or BF16 (the exact-fp32 mode uses
+ * cti_transpose_f32 + cti_gemm_nt). */
+int cti_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* C, int64_t M, int N, int K, int prec, void* workspace,
+                size_t workspace_bytes, void* stream);
+size_t cti_gemm_tn_workspace_bytes(int64_t M, int N, int K, int prec);
+
 /* dst[b][c][r] = src[b][r][c] (fp32, `batch` matrices of rows x cols). */
 int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,
                       int64_t batch_stride_dst, int rows, int cols, int batch, void* stream);

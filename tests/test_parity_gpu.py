@@ -303,3 +303,14 @@ def test_mbuild_planes_vs_fp32_m(B, V, Q, R, use_mfma):
     assert float(unplane(Mh)[..., 0].abs().sum()) > 0
     # rows past B*V*Q*G (the tile over-read slack) stay zero
     assert int(Mh[:, B * V * Q * G:, :].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(37, 16, 16), (1000, 33, 70), (5000, 512, 300), (20000, 130, 64)])
+def test_gemm_tn_row_contraction_vs_float64(M, N, K, precision):
+    """a^T b (the weight-gradient contraction over the row axis): transposed operand planes + split-K over the rows (fp32-grade mode), or
+    transposed fp32 copies + the exact MFMA (fp32 mode)."""
+    rs = np.random.RandomState(M + N + K)
+    a = rs.standard_normal((M, N)).astype(np.float32)
+    b = rs.standard_normal((M, K)).astype(np.float32)
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    check(cti_amd.ops.gemm_tn(T(a), T(b)), ref, what="a^T b %dx%dx%d" % (M, N, K))
