@@ -68,7 +68,9 @@ def run(rounds=5, prec=1):
     ref = None
     times = {k: ([], []) for k in libs}
     st = torch.cuda.current_stream().cuda_stream
-    AUX = torch.cuda.Stream().cuda_stream if os.environ.get('CTI_TUNE_AUX', '0') == '1' else None
+    # the auxiliary stream of cti_tcnet_forward: on by default like the product path (CTI_TUNE_AUX=0 disables, CTI_TUNE_AUX_PRIO=-1 = high priority)
+    aux_obj = torch.cuda.Stream(priority=int(os.environ.get('CTI_TUNE_AUX_PRIO', '0'))) if os.environ.get('CTI_TUNE_AUX', '1') == '1' else None
+    AUX = aux_obj.cuda_stream if aux_obj is not None else None
     for rnd in range(rounds + 1):
         for name, l in libs.items():
             wsb = l.cti_tcnet_forward_workspace_bytes(B, V, Q, A, c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, prec)
