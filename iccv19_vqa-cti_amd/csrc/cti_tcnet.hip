@@ -128,24 +128,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     const int64_t rows[3] = {(int64_t)B * V, (int64_t)B * Q, (int64_t)B * A};
     const int relu = act == CTI_ACT_RELU;
 
-    // Two-stream layout (planes modes, with an auxiliary stream from the caller): the auxiliary stream takes the weight-norm scales, T_eff and
-    // chain B; the main stream opens straight away with the HBM-bound split of `a` and waits for the scales only before its first GEMM.
-    hipStream_t sb = (aux_stream && prec != CTI_PREC_F32) ? as_stream(aux_stream) : st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre = nullptr;
-    auto finish = [&](int code) {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (ev_pre) (void)hipEventDestroy(ev_pre);
-        return code;
-    };
-    if (sb != st) {
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) != hipSuccess)
-            return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed"));
-        (void)hipEventRecord(ev_fork, st);                  // whatever the caller queued before this call precedes both streams
-        (void)hipStreamWaitEvent(sb, ev_fork, 0);
-    }
-    if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return finish(rc); }
+    if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
     {
         WnBatch wb{};
         wb.n = 6;
@@ -154,14 +137,13 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
             wb.wv[3 + s] = rank_wv[s]; wb.g[3 + s] = rank_g[s]; wb.scale[3 + s] = p.scale_r[s]; wb.n_mats[3 + s] = R; wb.elems[3 + s] = (int64_t)hr * h;
         }
         wn_batch_finish(wb);
-        rc = wn_scale_batch(wb, p.wn_partial, sb); if (rc) return finish(rc);
+        rc = wn_scale_batch(wb, p.wn_partial, st); if (rc) return rc;
     }
-    rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, sb); if (rc) return finish(rc);
+    rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, stream); if (rc) return rc;
     if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
-        rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * G, (int64_t)hr * hr * hr * G, p.Tt, hr, (int64_t)hr * hr * hr * G, hr, hr * hr * G, R, sb);
-        if (rc) return finish(rc);
+        rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * G, (int64_t)hr * hr * hr * G, p.Tt, hr, (int64_t)hr * hr * hr * G, hr, hr * hr * G, R, stream);
+        if (rc) return rc;
     }
-    if (ev_pre) (void)hipEventRecord(ev_pre, sb);             // scales + T_eff are ready
     const int64_t mrows_per_b = (int64_t)V * Q * G;
 
     if (prec == CTI_PREC_F32) {
@@ -184,17 +166,29 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     // Two independent chains feed the mode-3 GEMM: chain A (the a side: split, Tucker, rank nets -- 2.8 ms at config 2, opens with the
     // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
     // an auxiliary stream from the caller chain B runs beside chain A's split pass: fork/join with two events, no host sync.
+    hipStream_t sb = aux_stream ? as_stream(aux_stream) : st;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (aux_stream) {
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+            return fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed");
+        (void)hipEventRecord(ev_fork, st);                  // scales, T_eff (and the mask) precede both chains
+        (void)hipStreamWaitEvent(sb, ev_fork, 0);
+    }
+    auto finish = [&](int code) {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        return code;
+    };
 #ifndef CTI_AF32
 #define CTI_AF32 0       // option: fp32 A operand split at fragment-read time instead of the split pass (measured neutral on MI355X)
 #endif
     const int Kh = planes_kp(h);
-    auto side = [&](int s, hipStream_t ss, hipEvent_t scales_ready) -> int {
+    auto side = [&](int s, hipStream_t ss) -> int {
         const bool af32 = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
         int r_;
         if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
         r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
         r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
-        if (scales_ready) (void)hipStreamWaitEvent(ss, scales_ready, 0);     // the GEMM epilogues read the weight-norm scales
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
         if (af32) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
@@ -213,8 +207,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         return gemm_nt_planes(r, ss);
     };
     // chain B on the auxiliary stream (or first, on the main stream)
-    rc = side(0, sb, nullptr); if (rc) return finish(rc);
-    rc = side(1, sb, nullptr); if (rc) return finish(rc);
+    rc = side(0, sb); if (rc) return finish(rc);
+    rc = side(1, sb); if (rc) return finish(rc);
     rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) {
@@ -224,10 +218,10 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, sb);
     }
     if (rc) return finish(rc);
-    if (ev_join) (void)hipEventRecord(ev_join, sb);
+    if (aux_stream) (void)hipEventRecord(ev_join, sb);
     // chain A on the main stream
-    rc = side(2, st, ev_pre); if (rc) return finish(rc);
-    if (ev_join) (void)hipStreamWaitEvent(st, ev_join, 0);
+    rc = side(2, st); if (rc) return finish(rc);
+    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;
     c.rows_allocA = p.Mp.rows_alloc; c.rows_allocB = p.Arp.rows_alloc; c.rA1 = mrows_per_b; c.rB1 = A; c.nb1 = B; c.nb2 = 1;
