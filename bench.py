@@ -184,8 +184,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="forward", choices=["forward", "train"], help="forward (the BASELINE metric) or train (DP step)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (the default run takes well under a minute on the GPU + ~20 s of CPU baseline)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps: allocator growth, one-time kernel attributes, clock ramp")
     ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
     ap.add_argument("--precision", default=os.environ.get("CTI_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
                     help="bf16x3 (default): 3-term split-bf16 MFMA, fp32-grade (1e-5 vs the float64 oracle); fp32: exact fp32 MFMA")
