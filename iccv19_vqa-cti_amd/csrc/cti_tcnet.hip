@@ -51,11 +51,11 @@ struct Plan {
     size_t bytes;
 };
 
-Plan carve(const Dims& d, int prec, void* ws) {
-    Plan p{};
-    Bump w{static_cast<char*>(ws), 0, 0};
+// The batch-independent part of the plan -- weight-norm scales, T_eff (+ its transposed copy), the weights' operand planes: carved
+// either at the head of the per-call workspace (and recomputed every call) or in a caller-kept "prepared" block (cti_tcnet_prepare:
+// computed once per parameter update, the way inference holds its weights).
+void carve_prep(const Dims& d, int prec, Bump& w, Plan& p) {
     const int hr = d.h / d.R;
-    const int64_t rows[3] = {(int64_t)d.B * d.V, (int64_t)d.B * d.Q, (int64_t)d.B * d.A};
     const int in[3] = {d.vd, d.qd, d.ad};
     for (int s = 0; s < 3; ++s) { p.scale_t[s] = static_cast<float*>(w.take(sizeof(float))); p.scale_r[s] = static_cast<float*>(w.take(sizeof(float) * d.R)); }
     p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
@@ -65,6 +65,16 @@ Plan carve(const Dims& d, int prec, void* ws) {
         for (int s = 0; s < 3; ++s) chunks += (size_t)(((int64_t)d.h * in[s] + WN_CHUNK - 1) / WN_CHUNK) + (size_t)d.R * (((int64_t)hr * d.h + WN_CHUNK - 1) / WN_CHUNK);
         p.wn_partial = static_cast<float*>(w.take(sizeof(float) * chunks));
     }
+    if (prec != CTI_PREC_F32)
+        for (int s = 0; s < 3; ++s) { p.wt[s] = take_planes(w, d.h, in[s]); p.wr[s] = take_planes(w, d.h, d.h); }
+}
+
+Plan carve(const Dims& d, int prec, void* ws) {
+    Plan p{};
+    Bump w{static_cast<char*>(ws), 0, 0};
+    const int64_t rows[3] = {(int64_t)d.B * d.V, (int64_t)d.B * d.Q, (int64_t)d.B * d.A};
+    const int in[3] = {d.vd, d.qd, d.ad};
+    carve_prep(d, prec, w, p);
     const int64_t mrows = (int64_t)d.B * d.V * d.Q * d.G;
     if (prec == CTI_PREC_F32) {
         for (int s = 0; s < 3; ++s) {
@@ -75,8 +85,6 @@ Plan carve(const Dims& d, int prec, void* ws) {
     } else {
         for (int s = 0; s < 3; ++s) {
             p.xin[s] = take_planes(w, rows[s], in[s]);
-            p.wt[s] = take_planes(w, d.h, in[s]);
-            p.wr[s] = take_planes(w, d.h, d.h);
             p.tp[s] = take_planes(w, rows[s], d.h);
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
@@ -95,7 +103,59 @@ int check_dims(const Dims& d) {
     return CTI_OK;
 }
 
+// scales of the six weight-normalised layers, T_eff (and its transposed copy), and -- planes modes -- the weights' operand planes
+int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tucker_wv, const float* const* tucker_g, const float* const* rank_wv,
+                const float* const* rank_g, const float* T_g, bool weight_planes, void* stream) {
+    const int hr = d.h / d.R;
+    const int in[3] = {d.vd, d.qd, d.ad};
+    hipStream_t st = as_stream(stream);
+    WnBatch wb{};
+    wb.n = 6;
+    for (int s = 0; s < 3; ++s) {
+        wb.wv[s] = tucker_wv[s]; wb.g[s] = tucker_g[s]; wb.scale[s] = p.scale_t[s]; wb.n_mats[s] = 1; wb.elems[s] = (int64_t)d.h * in[s];
+        wb.wv[3 + s] = rank_wv[s]; wb.g[3 + s] = rank_g[s]; wb.scale[3 + s] = p.scale_r[s]; wb.n_mats[3 + s] = d.R; wb.elems[3 + s] = (int64_t)hr * d.h;
+    }
+    wn_batch_finish(wb);
+    int rc = wn_scale_batch(wb, p.wn_partial, st); if (rc) return rc;
+    rc = cti_teff_scramble(T_g, p.Teff, d.R, hr, hr, hr, d.G, 0, stream); if (rc) return rc;
+    if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
+        rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * d.G, (int64_t)hr * hr * hr * d.G, p.Tt, hr, (int64_t)hr * hr * hr * d.G, hr, hr * hr * d.G, d.R, stream);
+        if (rc) return rc;
+        if (weight_planes)
+            for (int s = 0; s < 3; ++s) {
+                rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
+                rc = split_planes(rank_wv[s], d.h, d.h, d.h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
+            }
+    }
+    return CTI_OK;
+}
+
 }  // namespace
+
+extern "C" size_t cti_tcnet_prepared_bytes(int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec) {
+    if (v_dim <= 0 || q_dim <= 0 || a_dim <= 0 || h <= 0 || R <= 0 || G <= 0 || h % R) return 0;
+    Dims d{1, 1, 1, 1, v_dim, q_dim, a_dim, h, R, G};
+    Plan p{};
+    Bump w{nullptr, 0, 0};
+    carve_prep(d, prec, w, p);
+    return (w.off + 255) & ~(size_t)255;
+}
+
+extern "C" int cti_tcnet_prepare(const float* const* tucker_wv, const float* const* tucker_g, const float* const* rank_wv, const float* const* rank_g,
+                                 const float* T_g, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec, void* prepared, size_t prepared_bytes,
+                                 void* stream) {
+    CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(T_g); CTI_REQUIRE_PTR(prepared);
+    Dims d{1, 1, 1, 1, v_dim, q_dim, a_dim, h, R, G};
+    int rc = check_dims(d); if (rc) return rc;
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_tcnet_prepare: prec=%d", prec);
+    CTI_REQUIRE(prepared_bytes >= cti_tcnet_prepared_bytes(v_dim, q_dim, a_dim, h, R, G, prec), CTI_E_WORKSPACE, "cti_tcnet_prepare: block too small");
+    for (int s = 0; s < 3; ++s)
+        CTI_REQUIRE(tucker_wv[s] && tucker_g[s] && rank_wv[s] && rank_g[s], CTI_E_NULL, "cti_tcnet_prepare: weight pointer %d is NULL", s);
+    Plan p{};
+    Bump w{static_cast<char*>(prepared), 0, 0};
+    carve_prep(d, prec, w, p);
+    return run_prepare(d, prec, p, tucker_wv, tucker_g, rank_wv, rank_g, T_g, true, stream);
+}
 
 extern "C" size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                                     int G, int prec) {
@@ -108,7 +168,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                                  const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                                  uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
-                                 int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                 int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                                  void* ev_core_end, void* aux_stream, void* stream) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
@@ -119,8 +179,12 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_tcnet_forward: prec=%d", prec);
     for (int s = 0; s < 3; ++s)
         CTI_REQUIRE(tucker_wv[s] && tucker_g[s] && tucker_b[s] && rank_wv[s] && rank_g[s] && rank_b[s], CTI_E_NULL, "cti_tcnet_forward: weight pointer %d is NULL", s);
-    const Plan p = carve(d, prec, workspace);
+    Plan p = carve(d, prec, workspace);
     CTI_REQUIRE(workspace_bytes >= p.bytes, CTI_E_WORKSPACE, "cti_tcnet_forward: workspace %zu < %zu", workspace_bytes, p.bytes);
+    if (prepared) {                                             // scales, T_eff and weight planes come from cti_tcnet_prepare
+        Bump wp{static_cast<char*>(const_cast<void*>(prepared)), 0, 0};
+        carve_prep(d, prec, wp, p);
+    }
     hipStream_t st = as_stream(stream);
     const int hr = h / R;
     const float* x[3] = {v, q, a};
@@ -129,21 +193,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     const int relu = act == CTI_ACT_RELU;
 
     if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
-    {
-        WnBatch wb{};
-        wb.n = 6;
-        for (int s = 0; s < 3; ++s) {
-            wb.wv[s] = tucker_wv[s]; wb.g[s] = tucker_g[s]; wb.scale[s] = p.scale_t[s]; wb.n_mats[s] = 1; wb.elems[s] = (int64_t)h * in[s];
-            wb.wv[3 + s] = rank_wv[s]; wb.g[3 + s] = rank_g[s]; wb.scale[3 + s] = p.scale_r[s]; wb.n_mats[3 + s] = R; wb.elems[3 + s] = (int64_t)hr * h;
-        }
-        wn_batch_finish(wb);
-        rc = wn_scale_batch(wb, p.wn_partial, st); if (rc) return rc;
-    }
-    rc = cti_teff_scramble(T_g, p.Teff, R, hr, hr, hr, G, 0, stream); if (rc) return rc;
-    if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
-        rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * G, (int64_t)hr * hr * hr * G, p.Tt, hr, (int64_t)hr * hr * hr * G, hr, hr * hr * G, R, stream);
-        if (rc) return rc;
-    }
+    if (!prepared) { rc = run_prepare(d, prec, p, tucker_wv, tucker_g, rank_wv, rank_g, T_g, false, stream); if (rc) return rc; }
     const int64_t mrows_per_b = (int64_t)V * Q * G;
 
     if (prec == CTI_PREC_F32) {
@@ -187,8 +237,10 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         const bool af32 = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
         int r_;
         if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
-        r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
-        r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
+        if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
+            r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
+            r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
+        }
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
         if (af32) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }

@@ -236,10 +236,40 @@ def paralind_core(M, Ar, prec=None):
     return out
 
 
-def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None):
-    """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
-    the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  Returns out (B,V,Q,A,G) [, mask (B,V)]."""
+def _weight_arrays(tucker, rank):
     import ctypes as C
+    keep = []
+
+    def arr(ts):
+        ts = [_req(t, "weight").contiguous() for t in ts]
+        keep.extend(ts)
+        return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    return (arr([t[0] for t in tucker]), arr([t[1] for t in tucker]), arr([t[2] for t in tucker]),
+            arr([t[0] for t in rank]), arr([t[1] for t in rank]), arr([t[2] for t in rank]), keep)
+
+
+def tcnet_prepare(tucker, rank, T_g, prec=None):
+    """The batch-independent part of tcnet_forward (weight-norm scales, T_eff, the weights' operand planes) as one device block: compute it
+    once per parameter update and pass it as `prepared=`.  Returns (block, precision code it was built for)."""
+    _req(T_g, "T_g")
+    h = tucker[0][0].shape[0]
+    R = rank[0][1].numel()
+    G = T_g.shape[5]
+    vd, qd, ad = (tucker[s][0].shape[1] for s in range(3))
+    pr = _prec(prec)
+    lib = L.lib()
+    nb = lib.cti_tcnet_prepared_bytes(vd, qd, ad, h, R, G, pr)
+    block = torch.empty(nb, device=T_g.device, dtype=torch.uint8)
+    twv, tg, tb, rwv, rg, rb, keep = _weight_arrays(tucker, rank)
+    L.check(lib.cti_tcnet_prepare(twv, tg, rwv, rg, T_g.contiguous().data_ptr(), vd, qd, ad, h, R, G, pr, block.data_ptr(), nb, _stream()),
+            "cti_tcnet_prepare")
+    return block, pr
+
+
+def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None):
+    """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
+    the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  prepared: the (block, precision) pair of tcnet_prepare for
+    these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)]."""
     for t, n in ((v, "v"), (q, "q"), (a, "a"), (T_g, "T_g")):
         _req(t, n)
     v, q, a = v.contiguous(), q.contiguous(), a.contiguous()
@@ -253,24 +283,21 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     G = T_g.shape[5]
     if T_g.shape[6] != 1:
         raise RuntimeError("TCNet.forward: h_out must be 1 (src/Tensor.py:6 cannot view the core otherwise)")
-    keep = []
-
-    def arr(ts):
-        ts = [_req(t, "weight").contiguous() for t in ts]
-        keep.extend(ts)
-        return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
-
     for s, dim in enumerate((vd, qd, ad)):
         if tuple(tucker[s][0].shape) != (h, dim) or tuple(rank[s][0].shape) != (h, h):
             raise ValueError("weight shapes do not match the inputs")
-    twv, tg, tb = arr([t[0] for t in tucker]), arr([t[1] for t in tucker]), arr([t[2] for t in tucker])
-    rwv, rg, rb = arr([t[0] for t in rank]), arr([t[1] for t in rank]), arr([t[2] for t in rank])
+    twv, tg, tb, rwv, rg, rb, keep = _weight_arrays(tucker, rank)
     Tg = T_g.contiguous()
     out = torch.empty((B, V, Q, A, G), device=v.device, dtype=torch.float32)
     mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
     if out.numel() == 0:                                   # empty batch (or a zero-length axis): nothing to launch
         return (out, mask) if want_mask else out
     pr = _prec(prec)
+    prep_ptr = 0
+    if prepared is not None:
+        if prepared[1] != pr:
+            raise ValueError("the prepared block was built for another precision mode")
+        prep_ptr = prepared[0].data_ptr()
     lib = L.lib()
     wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
@@ -281,7 +308,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     with _timed("tcnet_forward"):
         L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                       _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
-                                      ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
+                                      prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
     return (out, mask) if want_mask else out
 
 

@@ -93,6 +93,12 @@ class TCNet(nn.Module):
         for net in (self.v_tucker, self.q_tucker, self.a_tucker):
             l = self._last_linear(net)
             tucker.append((l.weight_v.detach(), l.weight_g.detach(), l.bias.detach()))
+        # the batch-independent part of the fused forward (weight-norm scales, T_eff, the weights' operand planes), rebuilt only when a
+        # parameter, T_g or the precision mode changes: inference holds its weights in GEMM-operand form
+        pkey = (key, tuple((t.data_ptr(), t._version) for tk in tucker for t in tk), (self.T_g.data_ptr(), self.T_g._version), ops.get_precision())
+        if getattr(self, "_prep_key", None) != pkey:
+            self._prep = ops.tcnet_prepare(tucker, self._pack, self.T_g.detach())
+            self._prep_key = pkey
         return tucker, self._pack
 
     def _fusable(self, *inputs):
@@ -103,7 +109,7 @@ class TCNet(nn.Module):
         if self._fusable(v, q, a):
             tucker, rank = self._fused_args()
             res = ops.tcnet_forward(v.float(), q.float(), a.float(), tucker, rank, self.T_g.detach(), relu=(self._act == 'ReLU'),
-                                    want_mask=_want_mask)
+                                    want_mask=_want_mask, prepared=self._prep)
             if _want_mask:
                 return res[0].squeeze(4), res[1]
             return res.squeeze(4)

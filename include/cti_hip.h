@@ -113,15 +113,25 @@ size_t cti_paralind_core_workspace_bytes(int B, int VQ, int A, int G, int K, int
  * ev_core_begin / ev_core_end: NULL, or hipEvent_t handles (cti_event_create) recorded on `stream` immediately before and
  * after the mode-3 GEMM launch -- how bench.py measures the dominant kernel inside the timed region.
  * aux_stream: NULL, or a second hipStream_t of the caller: the v/q-side chain + M build then run on it beside the a-side chain
- * (fork/join by events inside the call; on return all work is ordered behind `stream` as usual). */
+ * (fork/join by events inside the call; on return all work is ordered behind `stream` as usual).
+ * prepared: NULL (weight-norm scales, T_eff and the weights' operand planes are recomputed in this call), or the block written by
+ * cti_tcnet_prepare for the SAME weights, widths and precision: inference then holds its weights in GEMM-operand form and the call
+ * starts with the activations. */
 int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                       const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                       const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                       uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
-                      int G, int act, int prec, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                      int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                       void* ev_core_end, void* aux_stream, void* stream);
 size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                          int G, int prec);
+/* The batch-independent part of cti_tcnet_forward, computed once per parameter update: the six weight-norm scales, T_eff (and its
+ * [r][(j,k,g)][i] copy), and in the bf16 modes the hi/lo operand planes of the six weight matrices.  `prepared`: a device block of
+ * cti_tcnet_prepared_bytes(...) owned by the caller; valid until a weight, T_g or the precision changes. */
+int cti_tcnet_prepare(const float* const* tucker_wv, const float* const* tucker_g, const float* const* rank_wv, const float* const* rank_g,
+                      const float* T_g, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec, void* prepared, size_t prepared_bytes,
+                      void* stream);
+size_t cti_tcnet_prepared_bytes(int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
 
 /* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
 

@@ -314,3 +314,22 @@ def test_gemm_tn_row_contraction_vs_float64(M, N, K, precision):
     b = rs.standard_normal((M, K)).astype(np.float32)
     ref = a.astype(np.float64).T @ b.astype(np.float64)
     check(cti_amd.ops.gemm_tn(T(a), T(b)), ref, what="a^T b %dx%dx%d" % (M, N, K))
+
+
+def test_prepared_weights_follow_parameter_updates():
+    """TCNet keeps its weights as a prepared block (scales, T_eff, operand planes) between eval forwards; an in-place parameter update,
+    a load_state_dict or a precision switch must rebuild it."""
+    fx = gu.load("g3_tcnet_small")
+    m = _tri(fx).TriAtt
+    v, q, a = T(fx.i["v"]), T(fx.i["q"]), T(fx.i["a"])
+    with torch.no_grad():
+        check(m(v, q, a), fx.o["raw"], what="first call")
+        check(m(v, q, a), fx.o["raw"], what="second call (cached block)")
+        lin = [mod for mod in m.v_tucker.main if hasattr(mod, "weight_v")][0]
+        lin.weight_v.mul_(1.25)
+        m.T_g.mul_(0.5)
+        p = {k: x.detach().cpu().numpy() for k, x in m.state_dict().items()}
+        check(m(v, q, a), O.tcnet_forward(fx.i["v"], fx.i["q"], fx.i["a"], p, dtype=np.float64), what="after in-place updates")
+        other = "fp32" if cti_amd.get_precision() != "fp32" else "bf16x3"
+        cti_amd.set_precision(other)
+        check(m(v, q, a), O.tcnet_forward(fx.i["v"], fx.i["q"], fx.i["a"], p, dtype=np.float64), what="after a precision switch")

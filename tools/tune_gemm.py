@@ -71,6 +71,15 @@ def run(rounds=5, prec=1):
     # the auxiliary stream of cti_tcnet_forward: on by default like the product path (CTI_TUNE_AUX=0 disables, CTI_TUNE_AUX_PRIO=-1 = high priority)
     aux_obj = torch.cuda.Stream(priority=int(os.environ.get('CTI_TUNE_AUX_PRIO', '0'))) if os.environ.get('CTI_TUNE_AUX', '1') == '1' else None
     AUX = aux_obj.cuda_stream if aux_obj is not None else None
+    use_prep = os.environ.get('CTI_TUNE_PREPARED', '1') == '1'          # weights held as a prepared block, like TCNet in eval mode
+    preps = {}
+    for name, l in libs.items():
+        if use_prep and hasattr(l, "cti_tcnet_prepare"):
+            nb = l.cti_tcnet_prepared_bytes(c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, prec)
+            blk = torch.empty(nb, device=dev, dtype=torch.uint8)
+            rc = l.cti_tcnet_prepare(args6[0], args6[1], args6[3], args6[4], Tg.data_ptr(), c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, prec, blk.data_ptr(), nb, st)
+            assert rc == 0, l.cti_last_error_string()
+            preps[name] = blk
     for rnd in range(rounds + 1):
         for name, l in libs.items():
             wsb = l.cti_tcnet_forward_workspace_bytes(B, V, Q, A, c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, prec)
@@ -78,7 +87,8 @@ def run(rounds=5, prec=1):
             e = [l.cti_event_create() for _ in range(4)]
             l.cti_event_record(e[0], st)
             rc = l.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), *args6, Tg.data_ptr(), out.data_ptr(), None, B, V, Q, A,
-                                     c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, 1, prec, ws.data_ptr(), wsb, e[1], e[2], AUX, st)
+                                     c["v_dim"], c["q_dim"], c["a_dim"], h, R, G, 1, prec, preps[name].data_ptr() if name in preps else None,
+                                     ws.data_ptr(), wsb, e[1], e[2], AUX, st)
             assert rc == 0, (name, rc, l.cti_last_error_string())
             l.cti_event_record(e[3], st)
             torch.cuda.synchronize()
