@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import ops
 
 
 class FlatAdamaxDP:
@@ -80,6 +81,7 @@ class FlatAdamaxDP:
         L.check(lib.cti_adamax_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.n,
                                     self.partial.data_ptr(), float(self.clip_norm), float(self.lr), self.betas[0], self.betas[1], self.eps,
                                     self.step_count, self.grad_norm.data_ptr(), st), "cti_adamax_step")
+        ops.invalidate_caches()                                  # the kernel wrote the parameters behind autograd's version counters
         return self.grad_norm
 
     def state_dict(self):

@@ -33,7 +33,7 @@ class WNLinear(nn.Module):
     def scale(self):
         """g / ||V||_F on the device, cached until weight_v / weight_g change (optimizer steps bump `_version`, .to() / load_state_dict
         change the storage): in eval mode the norm of a 6M-element weight is computed once, not per forward."""
-        key = (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version)
+        key = (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version, ops._param_epoch[0])
         if getattr(self, "_scale_key", None) != key:
             self._scale_val = ops.wn_scale(self.weight_v.detach(), self.weight_g.detach())
             self._scale_key = key
@@ -118,7 +118,7 @@ class HoistedProjection:
         layers = self._layers()
         if layers is None:
             return None
-        key = tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
+        key = (ops._param_epoch[0],) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
         if key != self._key:
             with torch.no_grad():
                 self._w = torch.cat([l.weight_v.detach() for l in layers], 0).contiguous()

@@ -29,6 +29,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Modules cache what they derive from their parameters (weight-norm scales, packed rank nets, the prepared block of the fused forward,
+# concatenated glimpse projections), keyed by each parameter's storage pointer and autograd version counter.  An update that goes
+# around the version counter -- FlatAdamaxDP's fused kernel writes the flat parameter buffer directly; user code doing
+# `p.data.mul_(...)` -- must call invalidate_caches(), which every cache key also contains.
+_param_epoch = [0]
+
+
+def invalidate_caches():
+    _param_epoch[0] += 1
+
+
 import os as _os
 
 _aux = {}

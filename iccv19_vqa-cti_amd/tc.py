@@ -84,7 +84,7 @@ class TCNet(nn.Module):
         """(tucker, rank) argument lists of ops.tcnet_forward; the packed rank weights are cached until a parameter
         changes (optimizer steps bump `_version`, load_state_dict / .to() change `data_ptr`)."""
         nets = (self.v_net, self.q_net, self.a_net)
-        key = tuple((p.data_ptr(), p._version) for ns in nets for n in ns for p in n.parameters())
+        key = (ops._param_epoch[0],) + tuple((p.data_ptr(), p._version) for ns in nets for n in ns for p in n.parameters())
         if getattr(self, "_pack_key", None) != key:
             with torch.no_grad():
                 self._pack = [tuple(t.detach() for t in self._rank_pack(ns)) for ns in nets]

@@ -138,3 +138,29 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch():
     finally:
         cti_amd.set_precision("bf16x3")
     assert np.allclose(res[0], one, rtol=2e-4, atol=2e-6)                # equal up to fp32 reduction order
+
+
+def test_eval_after_a_fused_optimizer_step_sees_the_new_parameters():
+    """FlatAdamaxDP's kernel writes the parameters directly (no autograd version bump): the modules' derived caches (weight-norm scales,
+    the prepared block of the fused TCNet forward, batched glimpse projections) must not survive the step."""
+    from oracle import cti_oracle as O
+    torch.manual_seed(5)
+    att = cti_amd.TriAttention(24, 16, 16, 32, 1, 4, 2, 1).to(DEV)
+    v, q, a, _ = make_batch(4, 3)
+    v, q, a = v[:, :, :24].contiguous().to(DEV), q[:, :, :16].contiguous().to(DEV), a[:, :, :16].contiguous().to(DEV)
+    att.eval()
+    with torch.no_grad():
+        p0, _ = att(v, q, a)                                       # builds the caches
+    opt = cti_amd.FlatAdamaxDP(att, lr=5e-2, clip_norm=0.0)
+    att.train()
+    opt.zero_grad()
+    out, _ = att(v, q, a)
+    (out * torch.arange(out.numel(), device=DEV).view_as(out).float()).sum().backward()
+    opt.step()
+    att.eval()
+    with torch.no_grad():
+        p1, _ = att(v, q, a)
+    sd = {k: x.detach().cpu().numpy() for k, x in att.state_dict().items()}
+    ref, _ = O.tri_attention(v.cpu().numpy(), q.cpu().numpy(), a.cpu().numpy(), sd, dtype=np.float64)
+    assert O.norm_max_err(p1.cpu().numpy(), ref) < 1e-4
+    assert float((p1 - p0).abs().max()) > 1e-6                     # the step did change the attention
