@@ -345,6 +345,62 @@ extern "C" int cti_gemm_tn(const float* a, int64_t lda, const float* b, int64_t 
     return gemm_nt_planes(g, st);
 }
 
+// ---- resident operand planes: a weight matrix split once, reused by every forward until it changes -----------------------------------
+// Block layout: [hi | lo], each (rows + PLANE_SLACK_ROWS) x Kp bf16, chunk-major.
+extern "C" size_t cti_operand_planes_bytes(int64_t rows, int K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return planes_bytes(rows + PLANE_SLACK_ROWS, K);
+}
+extern "C" int cti_split_operand(const float* x, int64_t ld, int64_t rows, int K, void* planes, size_t planes_bytes_, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(planes);
+    CTI_REQUIRE(rows > 0 && K > 0 && ld >= K, CTI_E_SHAPE, "cti_split_operand: rows=%lld K=%d ld=%lld", (long long)rows, K, (long long)ld);
+    CTI_REQUIRE(planes_bytes_ >= cti_operand_planes_bytes(rows, K), CTI_E_WORKSPACE, "cti_split_operand: block too small");
+    const int64_t ra = rows + PLANE_SLACK_ROWS;
+    unsigned short* hi = static_cast<unsigned short*>(planes);
+    return split_planes(x, ld, rows, K, hi, hi + (size_t)ra * planes_kp(K), ra, as_stream(stream));
+}
+
+// cti_gemm_nt with the B operand given as resident planes (cti_split_operand of the (rowsB_total x K) matrix): only A is split here.
+extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
+    if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t n = al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K));
+    if (rowsA_total < (1ll << 31) && rowsB_total < (1ll << 31)) {
+        const int S = plan_ksplit((int)rowsA_total, (int)rowsB_total, planes_kp(K), 1);
+        if (S > 1) n += al(sizeof(float) * (size_t)S * (size_t)rowsA_total * (size_t)rowsB_total);
+    }
+    return n;
+}
+extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                              float* C, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
+                              const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(A); CTI_REQUIRE_PTR(B_planes); CTI_REQUIRE_PTR(C); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && nb1 > 0 && lda >= K, CTI_E_SHAPE, "cti_gemm_nt_pb: M=%d N=%d K=%d nb=%d", M, N, K, nb1);
+    CTI_REQUIRE((int64_t)(nb1 - 1) * rA1 + M <= rowsA_total && (int64_t)(nb1 - 1) * rB1 + N <= rowsB_total, CTI_E_SHAPE, "cti_gemm_nt_pb: batches run past the operand rows");
+    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_gemm_nt_pb: act=%d", act);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_nt_pb: prec=%d (resident planes exist in the bf16 modes only)", prec);
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_nt_pb_workspace_bytes(rowsA_total, rowsB_total, K, prec), CTI_E_WORKSPACE, "cti_gemm_nt_pb: workspace too small");
+    const int Kp = planes_kp(K);
+    const int64_t ra = rowsA_total + PLANE_SLACK_ROWS, rb = rowsB_total + PLANE_SLACK_ROWS;
+    unsigned short* ah = static_cast<unsigned short*>(workspace);
+    unsigned short* al = ah + (size_t)ra * Kp;
+    const unsigned short* bh = static_cast<const unsigned short*>(B_planes);
+    const unsigned short* bl = bh + (size_t)rb * Kp;
+    int rc = split_planes(A, lda, rowsA_total, K, ah, al, ra, as_stream(stream)); if (rc) return rc;
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb;
+    g.rA1 = rA1; g.rB1 = rB1; g.nb1 = nb1; g.nb2 = 1;
+    g.M = M; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    g.C = C; g.ldc_m = ldc_m; g.ldc_n = 1; g.sC1 = sC1; g.epi = 0; g.gdiv = 1;
+    g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = act == CTI_ACT_RELU;
+    g.scale_bs = scale_bs; g.bias_bs = bias_bs;
+    if (nb1 == 1 && M == rowsA_total && N == rowsB_total) {
+        const int S = plan_ksplit(M, N, Kp, 1);
+        if (S > 1) { g.ksplit = S; g.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255)); }
+    }
+    return gemm_nt_planes(g, as_stream(stream));
+}
+
 extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

@@ -124,7 +124,8 @@ size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec) {
 }
 
 int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
-                    int B, int T, int I, int H, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+                    int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                    void* stream) {
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(w_ih); CTI_REQUIRE_PTR(w_hh); CTI_REQUIRE_PTR(b_ih); CTI_REQUIRE_PTR(b_hh); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && T > 0 && I > 0 && H > 0 && (int64_t)B * T < (1ll << 31), CTI_E_SHAPE, "cti_gru_forward: B=%d T=%d I=%d H=%d", B, T, I, H);
     CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gru_forward: prec=%d", prec);
@@ -168,8 +169,10 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
     unsigned short* hp_[2]; unsigned short* hl_[2];
     for (int i = 0; i < 2; ++i) { hp_[i] = ws.take<unsigned short>(planes_bytes(rh, H)); hl_[i] = hp_[i] + (size_t)rh * KpH; }
     int rc = split_planes(x, I, (int64_t)B * T, I, xh, xl, rx, st); if (rc) return rc;
-    rc = split_planes(w_ih, I, H3, I, wih, wil, rw, st); if (rc) return rc;
-    rc = split_planes(w_hh, H, H3, H, whh, whl, rw, st); if (rc) return rc;
+    if (w_ih_planes) { wih = static_cast<unsigned short*>(const_cast<void*>(w_ih_planes)); wil = wih + (size_t)rw * KpI; }   // resident planes
+    else { rc = split_planes(w_ih, I, H3, I, wih, wil, rw, st); if (rc) return rc; }
+    if (w_hh_planes) { whh = static_cast<unsigned short*>(const_cast<void*>(w_hh_planes)); whl = whh + (size_t)rw * KpH; }
+    else { rc = split_planes(w_hh, H, H3, H, whh, whl, rw, st); if (rc) return rc; }
     if (KpH != H) {                                                       // K tail of the h planes stays zero (the kernel writes [0, H) only)
         for (int i = 0; i < 2; ++i) { hipError_t e = hipMemsetAsync(hp_[i], 0, planes_bytes(rh, H), st); if (e != hipSuccess) return fail((int)e, "cti_gru_forward: memset"); }
     }

@@ -39,10 +39,19 @@ class WNLinear(nn.Module):
             self._scale_key = key
         return self._scale_val
 
+    def planes(self):
+        """weight_v as resident bf16 hi/lo operand planes (None in the exact-fp32 mode), cached like scale(): inference splits a weight once,
+        not once per forward."""
+        key = (self.weight_v.data_ptr(), self.weight_v._version, ops._param_epoch[0], ops.get_precision())
+        if getattr(self, "_planes_key", None) != key:
+            self._planes_val = ops.split_operand(self.weight_v.detach())
+            self._planes_key = key
+        return self._planes_val
+
     def forward(self, x, relu=False):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad or self.weight_g.requires_grad or self.bias.requires_grad):
             return AG.WNLinearFn.apply(x, self.weight_v, self.weight_g, self.bias, relu, 1)
-        return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu)
+        return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu, w_planes=self.planes())
 
 
 class FCNet(nn.Module):
@@ -118,15 +127,16 @@ class HoistedProjection:
         layers = self._layers()
         if layers is None:
             return None
-        key = (ops._param_epoch[0],) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
+        key = (ops._param_epoch[0], ops.get_precision()) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
         if key != self._key:
             with torch.no_grad():
                 self._w = torch.cat([l.weight_v.detach() for l in layers], 0).contiguous()
                 self._b = torch.cat([l.bias.detach() for l in layers], 0).contiguous()
                 self._s = torch.cat([l.scale().view(1) for l in layers], 0).contiguous()
+                self._wp = ops.split_operand(self._w)
             self._key = key
         n, out_dim = len(layers), layers[0].out_features
         x2 = x.reshape(-1, x.shape[-1])
         y = ops.gemm_nt(x2, self._w, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, scale=self._s, scale_div=out_dim, scale_bs=1,
-                        bias=self._b, bias_bs=out_dim, relu=True)
+                        bias=self._b, bias_bs=out_dim, relu=True, B_planes=self._wp)
         return [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]

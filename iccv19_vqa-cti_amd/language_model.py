@@ -84,7 +84,11 @@ class QuestionEmbedding(nn.Module):
         ps = (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ps)):
             return AG.GRUFn.apply(x, *ps)
-        return ops.gru_forward(x, *[p.detach() for p in ps])[0]
+        key = (ps[0].data_ptr(), ps[0]._version, ps[1].data_ptr(), ps[1]._version, ops._param_epoch[0], ops.get_precision())
+        if getattr(self, "_planes_key", None) != key:                       # the two weight matrices as resident operand planes
+            self._planes = (ops.split_operand(ps[0].detach()), ops.split_operand(ps[1].detach()))
+            self._planes_key = key
+        return ops.gru_forward(x, *[p.detach() for p in ps], w_planes=self._planes if self._planes[0] is not None else None)[0]
 
     def forward(self, x):
         # x: [batch, sequence, in_dim] -> the last hidden state [batch, num_hid]

@@ -145,8 +145,8 @@ def wn_scale(weight_v, weight_g):
     return out
 
 
-def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None):
-    """act(scale[n // scale_div] * x @ weight_v.T + bias) through the MFMA GEMM."""
+def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None, w_planes=None):
+    """act(scale[n // scale_div] * x @ weight_v.T + bias) through the MFMA GEMM.  w_planes: split_operand(weight_v) kept by the caller."""
     _req(x, "x"); _req(weight_v, "weight_v")
     out_dim, in_dim = weight_v.shape
     if x.shape[-1] != in_dim:
@@ -159,6 +159,11 @@ def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None):
         return y
     pr = _prec(prec)
     lib = L.lib()
+    if w_planes is not None and pr != L.PREC_F32:
+        y2 = y.view(-1, out_dim)
+        gemm_nt(x2, w, M=rows, N=out_dim, out=y2, c_strides=(out_dim, 1), scale=scale, scale_div=scale_div, bias=bias, relu=relu, prec=prec,
+                B_planes=w_planes)
+        return y
     wsb = lib.cti_wn_linear_workspace_bytes(rows, in_dim, out_dim, pr)
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8) if wsb else None
     with _timed("wn_linear_%dx%dx%d" % (rows, in_dim, out_dim)):
@@ -430,7 +435,7 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
 
 # ---- backward-pass primitives ---------------------------------------------------------------------------------------
 def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None, sC1=0, scale=None, scale_div=1, bias=None, relu=False,
-            prec=None, scale_bs=0, bias_bs=0):
+            prec=None, scale_bs=0, bias_bs=0, B_planes=None):
     """C[z][m,n] = act(scale * sum_k A[z*rA1 + m, k] * B[z*rB1 + n, k] + bias).  A (rowsA, K), B (rowsB, K) 2-D row-major."""
     _req(A, "A"); _req(B, "B")
     A2, lda = _rows2d(A); B2, ldb = _rows2d(B)
@@ -445,12 +450,35 @@ def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None,
         ldc_m, ldc_n = c_strides
     pr = _prec(prec)
     lib = L.lib()
+    if B_planes is not None and pr != L.PREC_F32 and ldc_n == 1:
+        wsb = lib.cti_gemm_nt_pb_workspace_bytes(A2.shape[0], B2.shape[0], K, pr)
+        ws = torch.empty(wsb, device=A.device, dtype=torch.uint8)
+        L.check(lib.cti_gemm_nt_pb(A2.data_ptr(), lda, A2.shape[0], rA1, B_planes.data_ptr(), B2.shape[0], rB1, out.data_ptr(), ldc_m, sC1, nb1, M, N, K,
+                                   _ptr(scale), int(scale_div), int(scale_bs), _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                   ws.data_ptr(), wsb, _stream()), "cti_gemm_nt_pb")
+        return out
     wsb = lib.cti_gemm_nt_workspace_bytes(A2.shape[0], B2.shape[0], K, pr)
     ws = torch.empty(wsb, device=A.device, dtype=torch.uint8) if wsb else None
     L.check(lib.cti_gemm_nt(A2.data_ptr(), lda, A2.shape[0], rA1, 0, B2.data_ptr(), ldb, B2.shape[0], rB1, 0, out.data_ptr(), ldc_m, ldc_n,
                             sC1, 0, nb1, 1, M, N, K, _ptr(scale), int(scale_div), int(scale_bs), _ptr(bias), int(bias_bs),
                             L.ACT_RELU if relu else L.ACT_NONE, pr, _ptr(ws), wsb, _stream()), "cti_gemm_nt")
     return out
+
+
+def split_operand(w, prec=None):
+    """A (rows, K) fp32 matrix -> its resident bf16 hi/lo operand planes (one uint8 block) for gemm_nt(..., B_planes=...): split a weight
+    once, multiply against it many times.  Returns None in the exact-fp32 mode (no planes there)."""
+    _req(w, "w")
+    pr = _prec(prec)
+    if pr == L.PREC_F32:
+        return None
+    w2, ld = _rows2d(w)
+    rows, K = w2.shape
+    lib = L.lib()
+    nb = lib.cti_operand_planes_bytes(rows, K)
+    block = torch.empty(nb, device=w.device, dtype=torch.uint8)
+    L.check(lib.cti_split_operand(w2.data_ptr(), ld, rows, K, block.data_ptr(), nb, _stream()), "cti_split_operand")
+    return block
 
 
 def transpose(src, rows, cols, batch=1, s_src=0, ld_src=None, dst=None, s_dst=0, ld_dst=None):
@@ -691,7 +719,7 @@ def col_sum(x2, alpha=1.0):
     return out
 
 
-def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None):
+def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=None):
     """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H), in ONE library
     call (the time loop lives behind the C ABI).  want_save: also returns save (T,B,5,H) = (r, z, n, W_hn h + b_hn, h_t)."""
     _req(x, "x")
@@ -708,6 +736,8 @@ def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None):
     with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
         L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
                                     b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
+                                    _ptr(w_planes[0]) if w_planes and pr != L.PREC_F32 else 0,
+                                    _ptr(w_planes[1]) if w_planes and pr != L.PREC_F32 else 0,
                                     ws.data_ptr(), wsb, _stream()), "cti_gru_forward")
     return out, save
 

@@ -187,6 +187,16 @@ int cti_gemm_nt(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, i
                 const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
 
+/* Resident operand planes: split a (rows x K) fp32 matrix -- a weight -- into the GEMM's bf16 hi/lo operand layout ONCE (block of
+ * cti_operand_planes_bytes), then run any number of products against it with cti_gemm_nt_pb (= cti_gemm_nt, nb2 = 1, contiguous C rows,
+ * whose B operand is that block; batch b1 uses rows [b1*rB1, +N) of it).  bf16 modes only. */
+size_t cti_operand_planes_bytes(int64_t rows, int K);
+int cti_split_operand(const float* x, int64_t ld, int64_t rows, int K, void* planes, size_t planes_bytes, void* stream);
+int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                   float* C, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
+                   const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
+
 /* C (N x K, contiguous) = a^T b for a (M x N, row stride lda) and b (M x K, row stride ldb): the weight-gradient contraction over the
  * ROW axis (dW = dz^T x; src/fc.py:22-29 under autograd).  Both operands are written straight to transposed bf16 hi/lo planes, the M axis
  * is split over extra workgroups and a reduce kernel sums the partials.  prec = BF16X3 or BF16 (the exact-fp32 mode uses
@@ -280,9 +290,11 @@ int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout,
 /* nn.GRU(in, H, 1, batch_first=True) from a zero state (src/language_model.py:57-61,91-96; gate order r, z, n), every step in one
  * call: x (B,T,I), w_ih (3H,I), w_hh (3H,H), b_ih / b_hh (3H) -> out (B,T,H) = all hidden states.  save: NULL, or (T,B,5,H) =
  * (r, z, n, W_hn h + b_hn, h_t) per step, what cti_gru_backward needs.  The input projection is one GEMM over all steps; a step is
- * one split-K GEMM against pre-split recurrent weights + one gate kernel that also emits h_t as the next GEMM's bf16 planes. */
+ * one split-K GEMM against pre-split recurrent weights + one gate kernel that also emits h_t as the next GEMM's bf16 planes.
+ * w_ih_planes / w_hh_planes: NULL, or resident planes of the two weight matrices (cti_split_operand; bf16 modes). */
 int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
-                    int B, int T, int I, int H, int prec, void* workspace, size_t workspace_bytes, void* stream);
+                    int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                    void* stream);
 size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec);
 /* Back-propagation through time.  dout (B,T,H) contiguous; writes the pre-activation gradients dgi (B,T,3H) (input side: dx = dgi W_ih,
  * dW_ih = dgi^T x, db_ih = column sums) and dgh (T,B,3H) (hidden side, time-major: dW_hh = sum_t dgh_t^T h_{t-1}, db_hh = column
