@@ -642,7 +642,9 @@ extern "C" int cti_tri_pool_bwd(const float* dout, const float* vt, const float*
                        dvt, dqt, dat, V, Q, A, D);
     rc = launch_status("cti_tri_pool_bwd"); if (rc) return rc;
     if (dw) {
-        hipLaunchKernelGGL((pool_dw_kernel<4, 8>), dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
+        // (q, a) accumulator block per lane: A <= 4 (the FFOE model's 3 answer tokens) -> 8 x 4, no FMAs on padded answers and half the sweeps over D
+        if (A <= 4) hipLaunchKernelGGL((pool_dw_kernel<8, 4>), dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
+        else        hipLaunchKernelGGL((pool_dw_kernel<4, 8>), dim3((unsigned)(B * V)), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, 1);
         rc = launch_status("cti_tri_pool_bwd/dw");
     }
     return rc;
