@@ -10,6 +10,8 @@ through a generic broadcast), the sequence sums and the classifier.
 Outside the path (they raise): the counting module (`--use_counter`, src/counting.py) and the SAN baseline; tf-idf
 initialisation of the embeddings (`tfidf_loading`, src/utils.py) is data preparation -- load a checkpoint or call
 `WordEmbedding.init_embedding`."""
+import os as _os
+
 import torch
 import torch.nn as nn
 
@@ -92,7 +94,17 @@ class _TriModel(nn.Module):
         att, logits = t_att(v, q_emb, ans_emb)                              # b x v x q x a x g
         if not hasattr(self, "_v_hoist"):
             object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net]))
-        vp = self._v_hoist.maybe(v)                                         # N1: the glimpses' v projections as one batched GEMM
+        # N1: the glimpses' v projections as one batched GEMM.  `v_replication` = r > 1 (set by the caller; the MC pipeline feeds every image
+        # once per candidate answer, src/MC/train.py:75-79, so rows b*r .. b*r+r-1 of v are identical): the projections run once per image
+        rep = int(getattr(self, "v_replication", 1))
+        if rep > 1 and v.shape[0] % rep == 0:
+            if _os.environ.get("CTI_CHECK_REPLICATION", "0") == "1":
+                assert torch.equal(v.view(v.shape[0] // rep, rep, *v.shape[1:])[:, :1].expand(-1, rep, -1, -1).reshape(v.shape), v), "v_replication does not hold"
+            vp = self._v_hoist.maybe(v[::rep])
+            if vp is not None:
+                vp = [x.repeat_interleave(rep, 0) for x in vp]              # one (B,V,N) copy per glimpse: far cheaper than the projection
+        else:
+            vp = self._v_hoist.maybe(v)
         for g in range(self.glimpse):
             w_g = att[:, :, :, :, g]
             b_emb = (self.t_net[g].forward_with_weights(v, q_emb, ans_emb, w_g) if vp is None
@@ -140,6 +152,8 @@ class TanModel(_TriModel):
         self.q_prj = nn.ModuleList(q_prj)
         self.a_prj = nn.ModuleList(a_prj)
         self.classifier = classifier
+
+    v_replication = 1       # set to the number of candidate answers per image (4 in the reference's Visual7W pipeline) to de-duplicate v
 
     def forward(self, v, b, q, ans):
         return self._forward(self.v_att, v, q, ans)

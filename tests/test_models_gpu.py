@@ -238,3 +238,15 @@ def test_model_train_mode_runs_dropout_and_backward():
     out1.sum().backward()
     assert m.w_emb.emb.weight.grad is not None and float(m.w_emb.emb.weight.grad.abs().sum()) > 0
     assert float(m.q_emb.rnn.weight_hh_l0.grad.abs().sum()) > 0
+
+
+def test_mc_v_replication_gives_identical_logits():
+    """MC feeds each image once per candidate answer: with v_replication = 4 the glimpses' v projections run once per image."""
+    fx, p, m = build("g9_mc_cti", "build_mc_cti")
+    v, b, q, a = T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), T(fx.i["ans"])
+    with torch.no_grad():
+        ref, att_ref = m(v, b, q, a)
+        m.v_replication = 4
+        out, att = m(v, b, q, a)
+    check(out, fx.o["logits"], TOL, "MC TAN logits, v de-duplicated")
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
