@@ -89,8 +89,19 @@ class _TriModel(nn.Module):
     """The forward shared by FFOE CTIModel (src/FFOE/base_model.py:112-136) and MC TanModel (src/MC/base_model.py:128-152)."""
 
     def _forward(self, t_att, v, q, ans):
-        q_emb = self.q_emb.forward_all(self.w_emb(q))                       # [batch, q_len, q_dim]
-        ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+        side = None if torch.is_grad_enabled() else ops.aux_stream_object(v.device)
+        if side is not None:
+            # inference: the answer GRU (a few short, latency-bound steps) runs on the auxiliary stream beside the question GRU
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
+            cur.wait_stream(side)
+            ans_emb.record_stream(cur)
+        else:
+            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
+            ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
         att, logits = t_att(v, q_emb, ans_emb)                              # b x v x q x a x g
         if not hasattr(self, "_v_hoist"):
             object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net]))

@@ -51,10 +51,17 @@ def _aux_stream(device):
     allocated on the current stream and only reused after the call's join event, so the caching allocator stays consistent."""
     if not use_aux_stream:
         return None
+    return aux_stream_object(device).cuda_stream
+
+
+def aux_stream_object(device):
+    """The torch.cuda.Stream behind _aux_stream (one per device), or None when the overlap is disabled."""
+    if not use_aux_stream:
+        return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _aux:
         _aux[key] = torch.cuda.Stream(device=device)
-    return _aux[key].cuda_stream
+    return _aux[key]
 
 
 # ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
