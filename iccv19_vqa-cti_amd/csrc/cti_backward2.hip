@@ -280,6 +280,23 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_staged_kernel(const float* __
             if (vp < (V + 1) / 2) {
                 const int v0 = 2 * vp, v1 = min(V - 1, v0 + 1), i0 = iq * 4;
                 float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                if (G == 2) {
+                    // four consecutive jk and both g per trip: T[i][(jk..jk+3)*2 + g] are 8 consecutive floats (two 16-B reads per i), the dX rows
+                    // of g = 0 / 1 one 16-B read each: 12 reads of 16 B feed 64 FMAs (the generic loop issues 48 reads of 4 B)
+                    for (int jb = slice; jb < HH / 4; jb += 8) {
+                        const int jk = jb * 4;
+                        const float4 x00 = *reinterpret_cast<const float4*>(Xs + (v0 * 2 + 0) * HH + jk), x01 = *reinterpret_cast<const float4*>(Xs + (v0 * 2 + 1) * HH + jk);
+                        const float4 x10 = *reinterpret_cast<const float4*>(Xs + (v1 * 2 + 0) * HH + jk), x11 = *reinterpret_cast<const float4*>(Xs + (v1 * 2 + 1) * HH + jk);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const float* tr = Rg + (i0 + n) * TP + jk * 2;
+                            const float4 ta = *reinterpret_cast<const float4*>(tr), tb = *reinterpret_cast<const float4*>(tr + 4);
+                            // ta = (jk,g0) (jk,g1) (jk+1,g0) (jk+1,g1);  tb = (jk+2,g0) (jk+2,g1) (jk+3,g0) (jk+3,g1)
+                            a0[n] += x00.x * ta.x + x01.x * ta.y + x00.y * ta.z + x01.y * ta.w + x00.z * tb.x + x01.z * tb.y + x00.w * tb.z + x01.w * tb.w;
+                            a1[n] += x10.x * ta.x + x11.x * ta.y + x10.y * ta.z + x11.y * ta.w + x10.z * tb.x + x11.z * tb.y + x10.w * tb.z + x11.w * tb.w;
+                        }
+                    }
+                } else
                 for (int e = slice; e < inner; e += 8) {
                     const int g = e / HH, jk = e - g * HH;
                     const float x0 = Xs[(v0 * G + g) * HH + jk], x1 = Xs[(v1 * G + g) * HH + jk];
@@ -304,11 +321,20 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_staged_kernel(const float* __
             float acc[HR];
 #pragma unroll
             for (int n = 0; n < HR; ++n) acc[n] = 0.f;
-            for (int v = 0; v < V; ++v) {
-                const float x = Xs[(v * G + tg) * HH + tjk];
-                const float* vr = Vs + v * HR + i0;
+            if (ni == 8) {                                                   // hr = 16, G = 2: two 16-B reads of the Vr row per object
+                for (int v = 0; v < V; ++v) {
+                    const float x = Xs[(v * G + tg) * HH + tjk];
+                    const float4 va = *reinterpret_cast<const float4*>(Vs + v * HR + i0), vb4 = *reinterpret_cast<const float4*>(Vs + v * HR + i0 + 4);
+                    acc[0] = fmaf(va.x, x, acc[0]); acc[1] = fmaf(va.y, x, acc[1]); acc[2] = fmaf(va.z, x, acc[2]); acc[3] = fmaf(va.w, x, acc[3]);
+                    acc[4] = fmaf(vb4.x, x, acc[4]); acc[5] = fmaf(vb4.y, x, acc[5]); acc[6] = fmaf(vb4.z, x, acc[6]); acc[7] = fmaf(vb4.w, x, acc[7]);
+                }
+            } else {
+                for (int v = 0; v < V; ++v) {
+                    const float x = Xs[(v * G + tg) * HH + tjk];
+                    const float* vr = Vs + v * HR + i0;
 #pragma unroll
-                for (int n = 0; n < HR; ++n) if (n < ni) acc[n] = fmaf(vr[n], x, acc[n]);
+                    for (int n = 0; n < HR; ++n) if (n < ni) acc[n] = fmaf(vr[n], x, acc[n]);
+                }
             }
             float* o = dTpart + ((int64_t)b * R + r) * HR * inner + (int64_t)i0 * inner + tc;
 #pragma unroll
