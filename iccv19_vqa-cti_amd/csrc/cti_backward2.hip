@@ -217,11 +217,24 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_staged_kernel(const float* __
             float tcol[HR];
 #pragma unroll
             for (int i = 0; i < HR; ++i) tcol[i] = Rg[i * TP + xc];
-            for (int v = xsp; v < V; v += xns) {
-                float x = 0.f;
+            if ((inner & 63) == 0) {
+                // a wave shares its v (inner % 64 == 0): Vr[v][0..HR) comes through the scalar path (s_load -> SGPR operands), no LDS traffic
+                const int vfirst = __builtin_amdgcn_readfirstlane(xsp);
+                const float* vsrc = vb + r * HR;
+                for (int v = vfirst; v < V; v += xns) {
+                    const float* vr = vsrc + (int64_t)v * K;
+                    float x = 0.f;
 #pragma unroll
-                for (int i = 0; i < HR; ++i) x = fmaf(tcol[i], Vs[v * HR + i], x);
-                Xs[v * G * HH + x_off] = x;
+                    for (int i = 0; i < HR; ++i) x = fmaf(tcol[i], vr[i], x);
+                    Xs[v * G * HH + x_off] = x;
+                }
+            } else {
+                for (int v = xsp; v < V; v += xns) {
+                    float x = 0.f;
+#pragma unroll
+                    for (int i = 0; i < HR; ++i) x = fmaf(tcol[i], Vs[v * HR + i], x);
+                    Xs[v * G * HH + x_off] = x;
+                }
             }
         }
         __syncthreads();                                                        // T readers done: the region becomes the dM slice
