@@ -460,6 +460,62 @@ __global__ __launch_bounds__(256) void tri_pool_bwd_kernel(const float* __restri
         for (int a = 0; a < A; ++a) dat[((int64_t)b * A + a) * D + d] = da[a * 256 + t];
     }
 }
+// Small-shape form of the kernel above (A <= 8, Q <= 16: the model configurations): the attention slice is compacted into LDS once
+// ([v][q][AP], one broadcast 16-B read per (v,q)), qt / at columns and the dqt / dat accumulators live in registers -- the generic
+// kernel reads w through dependent scalar loads and keeps its accumulators in LDS (217 us at B = 256; this one ~1/4 of that).
+template <int AP>
+__global__ __launch_bounds__(256) void tri_pool_bwd_small_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                                 const float* __restrict__ at, const float* __restrict__ w, int64_t w_sb, int64_t w_sv,
+                                                                 int64_t w_sq, int64_t w_sa, float* __restrict__ dvt, float* __restrict__ dqt,
+                                                                 float* __restrict__ dat, int V, int Q, int A, int D) {
+    constexpr int QM = 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [V*Q][AP]
+    const int b = blockIdx.y, t = threadIdx.x, d = blockIdx.x * 256 + t;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int i = t; i < V * Q * AP; i += 256) {
+        const int a = i % AP, vq = i / AP, q = vq % Q, v = vq / Q;
+        sm[i] = a < A ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+    }
+    float qr[QM], dq[QM], ar[AP], da[AP];
+#pragma unroll
+    for (int q = 0; q < QM; ++q) { qr[q] = q < Q ? qt[((int64_t)b * Q + q) * D + dd] : 0.f; dq[q] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < AP; ++a) { ar[a] = a < A ? at[((int64_t)b * A + a) * D + dd] : 0.f; da[a] = 0.f; }
+    const float g = dout[(int64_t)b * D + dd];
+    __syncthreads();
+    const float* vb = vt + (int64_t)b * V * D + dd;
+    for (int v = 0; v < V; ++v) {
+        const float gx = g * vb[(int64_t)v * D];
+        const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * Q * AP);
+        float sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < QM; ++q) {
+            if (q < Q) {
+                const float4 w0 = wr[q * (AP / 4)];
+                const float gq = gx * qr[q];
+                float tq = w0.x * ar[0] + w0.y * ar[1] + w0.z * ar[2] + w0.w * ar[3];
+                da[0] = fmaf(gq, w0.x, da[0]); da[1] = fmaf(gq, w0.y, da[1]); da[2] = fmaf(gq, w0.z, da[2]); da[3] = fmaf(gq, w0.w, da[3]);
+                if (AP == 8) {
+                    const float4 w1 = wr[q * 2 + 1];
+                    tq += w1.x * ar[AP - 4] + w1.y * ar[AP - 3] + w1.z * ar[AP - 2] + w1.w * ar[AP - 1];
+                    da[AP - 4] = fmaf(gq, w1.x, da[AP - 4]); da[AP - 3] = fmaf(gq, w1.y, da[AP - 3]);
+                    da[AP - 2] = fmaf(gq, w1.z, da[AP - 2]); da[AP - 1] = fmaf(gq, w1.w, da[AP - 1]);
+                }
+                sv = fmaf(qr[q], tq, sv);
+                dq[q] = fmaf(gx, tq, dq[q]);
+            }
+        }
+        if (live) dvt[((int64_t)b * V + v) * D + d] = g * sv;
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < Q) dqt[((int64_t)b * Q + q) * D + d] = dq[q];
+#pragma unroll
+        for (int a = 0; a < AP; ++a) if (a < A) dat[((int64_t)b * A + a) * D + d] = da[a];
+    }
+}
 // dw[b,v,q,a] = sum_d x[d] * qt[b,q,d] * at[b,a,d], x[d] = dout[b,d/kdiv] * vt[b,v,d]; also serves the bi pool (A = 1, at == NULL)
 // (PQC, PAC) = the per-lane block of (q, a) accumulators: (4, 8) for the tri pool, (16, 1) for the bi pool -- one sweep over D covers
 // every q there, and no FMA is spent on padded answers
@@ -675,10 +731,18 @@ extern "C" int cti_tri_pool_bwd(const float* dout, const float* vt, const float*
     CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w);
     CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt); CTI_REQUIRE_PTR(dat);
     CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && A > 0 && D > 0, CTI_E_SHAPE, "cti_tri_pool_bwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
-    const size_t lds = sizeof(float) * 256 * 2 * (size_t)(Q + A);
-    int rc = set_lds(tri_pool_bwd_kernel, lds, "cti_tri_pool_bwd"); if (rc) return rc;
-    hipLaunchKernelGGL(tri_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, at, w, w_sb, w_sv, w_sq, w_sa,
-                       dvt, dqt, dat, V, Q, A, D);
+    int rc;
+    const int AP = A <= 4 ? 4 : 8;
+    if (A <= 8 && Q <= 16 && sizeof(float) * (size_t)V * Q * AP <= 64 * 1024) {
+        const size_t lds_s = sizeof(float) * (size_t)V * Q * AP;
+        if (AP == 4) hipLaunchKernelGGL(tri_pool_bwd_small_kernel<4>, dim3((D + 255) / 256, B), dim3(256), lds_s, as_stream(stream), dout, vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, dvt, dqt, dat, V, Q, A, D);
+        else         hipLaunchKernelGGL(tri_pool_bwd_small_kernel<8>, dim3((D + 255) / 256, B), dim3(256), lds_s, as_stream(stream), dout, vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, dvt, dqt, dat, V, Q, A, D);
+    } else {
+        const size_t lds = sizeof(float) * 256 * 2 * (size_t)(Q + A);
+        rc = set_lds(tri_pool_bwd_kernel, lds, "cti_tri_pool_bwd"); if (rc) return rc;
+        hipLaunchKernelGGL(tri_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, at, w, w_sb, w_sv, w_sq, w_sa,
+                           dvt, dqt, dat, V, Q, A, D);
+    }
     rc = launch_status("cti_tri_pool_bwd"); if (rc) return rc;
     if (dw) {
         // (q, a) accumulator block per lane: A <= 4 (the FFOE model's 3 answer tokens) -> 8 x 4, no FMAs on padded answers and half the sweeps over D
