@@ -764,6 +764,66 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
 #undef CTI_TPM_COMPUTE
 }
 
+// =====================================================================================================
+// Attention-gradient of the sum-pools on the MFMA (fp32-grade mode):  dw[b,v,(q,a)] = sum_d (dout[b,d] vt[b,v,d]) (qt[b,q,d] at[b,a,d])
+// (bi pool: at == NULL, columns are q).  Per sample a (V x D) . (Q*A x D)^T contraction with the channel axis d contiguous in every
+// operand: fragments straight from global memory, both operands formed on the fly (two element-wise products), no LDS.  The VALU form
+// spends its time in 32 wave reductions per (b, v) workgroup (350 us at B = 256); this one ~1/10 of that.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void pool_dw_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                           const float* __restrict__ at, float* __restrict__ dw, int V, int Q, int A, int D,
+                                                           int MT, int NT, int dper) {
+    const int b = blockIdx.x, ks = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    const int N = Q * A;
+    const int d_lo = ks * dper, d_hi = min(D, d_lo + dper);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tile = wid; tile < MT * NT; tile += 4) {
+        const int mt = tile % MT, nt = tile / MT;
+        const int v = mt * 32 + r, c = nt * 32 + r;
+        const bool vok = v < V, cok = c < N;
+        const int q = cok ? c / A : 0, a = cok ? c - q * A : 0;
+        const float* vp = vt + ((int64_t)b * V + (vok ? v : 0)) * D + kg * 8;
+        const float* gp = dout + (int64_t)b * D + kg * 8;
+        const float* qp = qt + ((int64_t)b * Q + q) * D + kg * 8;
+        const float* ap = at ? at + ((int64_t)b * A + a) * D + kg * 8 : nullptr;
+        lf32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int d0 = d_lo; d0 < d_hi; d0 += 16) {
+            float4 x0 = z4, x1 = z4, p0 = z4, p1 = z4;
+            if (vok) {
+                const float4 a0 = *reinterpret_cast<const float4*>(vp + d0), a1 = *reinterpret_cast<const float4*>(vp + d0 + 4);
+                const float4 g0 = *reinterpret_cast<const float4*>(gp + d0), g1 = *reinterpret_cast<const float4*>(gp + d0 + 4);
+                x0 = make_float4(a0.x * g0.x, a0.y * g0.y, a0.z * g0.z, a0.w * g0.w);
+                x1 = make_float4(a1.x * g1.x, a1.y * g1.y, a1.z * g1.z, a1.w * g1.w);
+            }
+            if (cok) {
+                p0 = *reinterpret_cast<const float4*>(qp + d0); p1 = *reinterpret_cast<const float4*>(qp + d0 + 4);
+                if (ap) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(ap + d0), t1 = *reinterpret_cast<const float4*>(ap + d0 + 4);
+                    p0 = make_float4(p0.x * t0.x, p0.y * t0.y, p0.z * t0.z, p0.w * t0.w);
+                    p1 = make_float4(p1.x * t1.x, p1.y * t1.y, p1.z * t1.z, p1.w * t1.w);
+                }
+            }
+            lbf16x8 xh, xl, ph, pl;
+            split8(x0, x1, xh, xl);
+            split8(p0, p1, ph, pl);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, ph, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, pl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ph, acc, 0, 0, 0);
+        }
+        if (cok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int vv = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                if (vv < V) atomicAdd(dw + ((int64_t)b * V + vv) * N + c, acc[e]);
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -960,4 +1020,18 @@ extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const flo
     else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
 #undef CTI_TM
     return launch_status("cti_tri_pool_mfma_fwd");
+}
+
+extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float* qt, const float* at, float* dw, int B, int V, int Q, int A, int D,
+                                void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(dw);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && A > 0 && D > 0, CTI_E_SHAPE, "cti_pool_dw_mfma: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    if (D % 16 != 0 || !aligned16(dout) || !aligned16(vt) || !aligned16(qt) || (at && !aligned16(at))) return CTI_E_UNSUPPORTED;
+    const int MT = (V + 31) / 32, NT = (Q * A + 31) / 32;
+    const int KS = D >= 512 ? 2 : 1;
+    const int dper = ((D / 16 + KS - 1) / KS) * 16;
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)B * V * Q * A, as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "cti_pool_dw_mfma: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(pool_dw_mfma_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, MT, NT, dper);
+    return launch_status("cti_pool_dw_mfma");
 }

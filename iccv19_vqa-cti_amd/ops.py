@@ -652,8 +652,15 @@ def tri_pool_bwd(dout, vt, qt, at, w, need_dw=True):
     dvt, dqt, dat = torch.empty_like(vt), torch.empty_like(qt), torch.empty_like(at)
     dw = torch.empty((B, V, Q, A), device=vt.device, dtype=torch.float32) if need_dw else None
     sb, sv, sq, sa = w.stride()
-    L.check(L.lib().cti_tri_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, dvt.data_ptr(),
-                                     dqt.data_ptr(), dat.data_ptr(), _ptr(dw), B, V, Q, A, D, _stream()), "cti_tri_pool_bwd")
+    lib = L.lib()
+    dw_done = False
+    if need_dw and get_precision() != "fp32":                 # the attention gradient as an MFMA contraction over the channels
+        rc = lib.cti_pool_dw_mfma(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), at.data_ptr(), dw.data_ptr(), B, V, Q, A, D, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_pool_dw_mfma")
+            dw_done = True
+    L.check(lib.cti_tri_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, dvt.data_ptr(),
+                                 dqt.data_ptr(), dat.data_ptr(), 0 if dw_done else _ptr(dw), B, V, Q, A, D, _stream()), "cti_tri_pool_bwd")
     return dvt, dqt, dat, dw
 
 
@@ -664,8 +671,15 @@ def bi_pool_bwd(dout, vt, qt, w, k, need_dw=True):
     dvt, dqt = torch.empty_like(vt), torch.empty_like(qt)
     dw = torch.empty((B, V, Q), device=vt.device, dtype=torch.float32) if (need_dw and w is not None) else None
     sb, sv, sq = w.stride() if w is not None else (0, 0, 0)
-    L.check(L.lib().cti_bi_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, dvt.data_ptr(), dqt.data_ptr(), _ptr(dw),
-                                    B, V, Q, D, k, _stream()), "cti_bi_pool_bwd")
+    lib = L.lib()
+    dw_done = False
+    if dw is not None and k == 1 and get_precision() != "fp32":
+        rc = lib.cti_pool_dw_mfma(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), 0, dw.data_ptr(), B, V, Q, 1, D, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_pool_dw_mfma")
+            dw_done = True
+    L.check(lib.cti_bi_pool_bwd(dout.data_ptr(), vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, dvt.data_ptr(), dqt.data_ptr(),
+                                0 if dw_done else _ptr(dw), B, V, Q, D, k, _stream()), "cti_bi_pool_bwd")
     return dvt, dqt, dw
 
 

@@ -256,6 +256,11 @@ int cti_masked_softmax_bi_bwd(const float* p, const float* dp, float* dlogits, i
 int cti_tri_pool_bwd(const float* dout, const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
                      int64_t w_sq, int64_t w_sa, float* dvt, float* dqt, float* dat, float* dw, int B, int V, int Q, int A, int D,
                      void* stream);
+/* The attention gradient of either pool on the MFMA (fp32-grade 3-product bf16 mode), k = 1:
+ *   dw[b,v,q,a] = sum_d dout[b,d] vt[b,v,d] qt[b,q,d] at[b,a,d]      (at == NULL, A = 1: the bi pool, dw (B,V,Q)).
+ * Returns CTI_E_UNSUPPORTED without a message when D % 16 != 0 or an operand is not 16-B aligned: pass dw to cti_*_pool_bwd then. */
+int cti_pool_dw_mfma(const float* dout, const float* vt, const float* qt, const float* at, float* dw, int B, int V, int Q, int A, int D,
+                     void* stream);
 /* Backward of cti_bi_pool_fwd: dout (B, D/k); dvt (B,V,D), dqt (B,Q,D), dw (B,V,Q) contiguous or NULL. */
 int cti_bi_pool_bwd(const float* dout, const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
                     float* dvt, float* dqt, float* dw, int B, int V, int Q, int D, int k, void* stream);
