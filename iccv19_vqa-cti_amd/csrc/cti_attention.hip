@@ -824,6 +824,158 @@ __global__ __launch_bounds__(256) void pool_dw_mfma_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================
+// Bilinear-logits backward on the MFMA (fp32-grade mode; G <= 8, V <= 64, Q <= 16, D % 32 == 0).  With U[g] = dlogits[b,g] (V x Q):
+//   dvt[v,d] = hs sum_g h[g,d] (U[g] qt)[v,d]       dh_b[g,d] = hs sum_v vt[v,d] (U[g] qt)[v,d]       (kernel 1: contraction over q)
+//   dqt[q,d] = hs sum_g h[g,d] (U[g]^T vt)[q,d]                                                        (kernel 2: contraction over v)
+// Lane = channel d (N axis): qt / vt / h are read as coalesced rows and turned into B fragments per lane; U (16 KiB per sample) is staged
+// once per workgroup in LDS, zero-padded to the fragment shapes, and provides the A fragments; the per-g products with h[g,d] and the
+// sums over v are in-lane.  The VALU kernel keeps V + Q accumulators per channel in LDS and walks G*V*Q terms per channel: 3.4 ms at
+// B = 256, G = 8, D = 3072.
+// =====================================================================================================
+constexpr int BLG = 8;       // G bound of these kernels
+
+__global__ __launch_bounds__(256) void bi_logits_bwd_vh_kernel(const float* __restrict__ dl, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                               const float* __restrict__ h, const float* __restrict__ h_scale,
+                                                               float* __restrict__ dvt, float* __restrict__ dhpart, int G, int V, int Q, int D,
+                                                               int tiles_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // Us[g][64 v][16 q (+4 pad)]
+    constexpr int UP = 20;
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const float* dlb = dl + (int64_t)b * G * V * Q;
+    for (int i = t; i < G * 64 * 16; i += 256) {
+        const int q = i & 15, v = (i >> 4) & 63, g = i >> 10;
+        sm[(g * 64 + v) * UP + q] = (v < V && q < Q) ? dlb[((int64_t)g * V + v) * Q + q] : 0.f;
+    }
+    __syncthreads();
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const bool two = V > 32;
+    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    for (int ti = 0; ti < tiles_per_wave; ++ti) {
+        const int d0 = (tile0 + ti) * 32;
+        if (d0 >= D) break;
+        const int d = d0 + l31;
+        // B fragment: qt[q = kg*8 .. +8, d]
+        float qv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qv[u] = (kg * 8 + u < Q) ? qt[((int64_t)b * Q + kg * 8 + u) * D + d] : 0.f;
+        lbf16x8 qh, ql;
+        split8(make_float4(qv[0], qv[1], qv[2], qv[3]), make_float4(qv[4], qv[5], qv[6], qv[7]), qh, ql);
+        float v0[16], v1[16];
+        const float* vb = vt + (int64_t)b * V * D + d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;
+            v0[e] = v < V ? vb[(int64_t)v * D] : 0.f;
+            v1[e] = (two && v + 32 < V) ? vb[(int64_t)(v + 32) * D] : 0.f;
+        }
+        lf32x16 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+        for (int g = 0; g < G; ++g) {
+            const float hg = h[(int64_t)g * D + d];
+            const float* u0 = sm + (g * 64 + l31) * UP + kg * 8;
+            lbf16x8 ah, al;
+            split8(*reinterpret_cast<const float4*>(u0), *reinterpret_cast<const float4*>(u0 + 4), ah, al);
+            lf32x16 w0, w1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { w0[e] = 0.f; w1[e] = 0.f; }
+            // four products here (lo*lo too): dh_b feeds the weight-norm gain gradient <G, V> / g, a cancelling sum that amplifies the 2^-16 of
+            // the three-product form past the 1e-4 bar on small layers; the MFMA time of this kernel is negligible either way
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ql, w0, 0, 0, 0);
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh, w0, 0, 0, 0);
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql, w0, 0, 0, 0);
+            w0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh, w0, 0, 0, 0);
+            if (two) {
+                const float* u1 = u0 + 32 * UP;
+                lbf16x8 bh, bl;
+                split8(*reinterpret_cast<const float4*>(u1), *reinterpret_cast<const float4*>(u1 + 4), bh, bl);
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ql, w1, 0, 0, 0);
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, qh, w1, 0, 0, 0);
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ql, w1, 0, 0, 0);
+                w1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, qh, w1, 0, 0, 0);
+            }
+            float sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o0[e] = fmaf(hg, w0[e], o0[e]); o1[e] = fmaf(hg, w1[e], o1[e]);
+                sacc = fmaf(w0[e], v0[e], sacc); sacc = fmaf(w1[e], v1[e], sacc);
+            }
+            sacc += __shfl_xor(sacc, 32, 64);
+            if (kg == 0) dhpart[((int64_t)b * G + g) * D + d] = hs * sacc;
+        }
+        float* ob = dvt + (int64_t)b * V * D + d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (v < V) ob[(int64_t)v * D] = hs * o0[e];
+            if (two && v + 32 < V) ob[(int64_t)(v + 32) * D] = hs * o1[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bi_logits_bwd_q_kernel(const float* __restrict__ dl, const float* __restrict__ vt, const float* __restrict__ h,
+                                                              const float* __restrict__ h_scale, float* __restrict__ dqt, int G, int V, int Q, int D,
+                                                              int tiles_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // Ut[g][32 q][64 v (+4 pad)]
+    constexpr int TPv = 68;
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const float* dlb = dl + (int64_t)b * G * V * Q;
+    for (int i = t; i < G * 32 * 64; i += 256) {
+        const int v = i & 63, q = (i >> 6) & 31, g = i >> 11;
+        sm[(g * 32 + q) * TPv + v] = (v < V && q < Q) ? dlb[((int64_t)g * V + v) * Q + q] : 0.f;
+    }
+    __syncthreads();
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const int KS = (V + 15) / 16;                                      // 16-deep steps over v
+    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    for (int ti = 0; ti < tiles_per_wave; ++ti) {
+        const int d0 = (tile0 + ti) * 32;
+        if (d0 >= D) break;
+        const int d = d0 + l31;
+        const float* vb = vt + (int64_t)b * V * D + d;
+        lbf16x8 vh[4], vl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int v = ks * 16 + kg * 8 + u; x[u] = (ks < KS && v < V) ? vb[(int64_t)v * D] : 0.f; }
+            split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), vh[ks], vl[ks]);
+        }
+        lf32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float hg = h[(int64_t)g * D + d];
+            lf32x16 w;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < KS) {
+                    const float* u0 = sm + (g * 32 + l31) * TPv + ks * 16 + kg * 8;
+                    lbf16x8 ah, al;
+                    split8(*reinterpret_cast<const float4*>(u0), *reinterpret_cast<const float4*>(u0 + 4), ah, al);
+                    w = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vl[ks], w, 0, 0, 0);     // four products, as in the dvt kernel
+                    w = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vh[ks], w, 0, 0, 0);
+                    w = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vl[ks], w, 0, 0, 0);
+                    w = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vh[ks], w, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = fmaf(hg, w[e], o[e]);
+        }
+        float* ob = dqt + (int64_t)b * Q * D + d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (q < Q) ob[(int64_t)q * D] = hs * o[e];
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -1034,4 +1186,21 @@ extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float*
     if (e != hipSuccess) return fail((int)e, "cti_pool_dw_mfma: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(pool_dw_mfma_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, MT, NT, dper);
     return launch_status("cti_pool_dw_mfma");
+}
+
+extern "C" int cti_bi_logits_bwd_mfma(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
+                                      float* dqt, float* dh_partial, int B, int G, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(dlogits); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt); CTI_REQUIRE_PTR(dh_partial);
+    CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_bwd_mfma: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
+    if (G > BLG || V > 64 || Q > 16 || D % 32 != 0) return CTI_E_UNSUPPORTED;       // the caller takes cti_bi_logits_bwd
+    const int tiles = D / 32;
+    const int tpw = tiles >= 64 ? 4 : (tiles >= 16 ? 2 : 1);
+    const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
+    const size_t lds1 = sizeof(float) * (size_t)G * 64 * 20, lds2 = sizeof(float) * (size_t)G * 32 * 68;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bi_logits_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail((int)e, "cti_bi_logits_bwd_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(bi_logits_bwd_vh_kernel, grid, dim3(256), lds1, as_stream(stream), dlogits, vt, qt, h, h_scale, dvt, dh_partial, G, V, Q, D, tpw);
+    int rc = launch_status("cti_bi_logits_bwd_mfma/dvt"); if (rc) return rc;
+    hipLaunchKernelGGL(bi_logits_bwd_q_kernel, grid, dim3(256), lds2, as_stream(stream), dlogits, vt, h, h_scale, dqt, G, V, Q, D, tpw);
+    return launch_status("cti_bi_logits_bwd_mfma/dqt");
 }

@@ -784,3 +784,10 @@ extern "C" int cti_bi_logits_bwd(const float* dlogits, const float* vt, const fl
     hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), dlogits, dh_bias_partial, rows, V * Q);
     return launch_status("cti_bi_logits_bwd/bias");
 }
+
+extern "C" int cti_row_sum(const float* x, float* out, int64_t rows, int cols, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(rows > 0 && cols > 0, CTI_E_SHAPE, "cti_row_sum: rows=%lld cols=%d", (long long)rows, cols);
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, out, rows, cols);
+    return launch_status("cti_row_sum");
+}

@@ -692,7 +692,17 @@ def bi_logits_bwd(dl, vt, qt, h, h_scale):
     dvt, dqt = torch.empty_like(vt), torch.empty_like(qt)
     hp = torch.empty((B, G, D), device=vt.device, dtype=torch.float32)
     bp = torch.empty((B, G), device=vt.device, dtype=torch.float32)
-    L.check(L.lib().cti_bi_logits_bwd(dl.data_ptr(), vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), dvt.data_ptr(), dqt.data_ptr(),
+    lib = L.lib()
+    done = False
+    if get_precision() != "fp32":                              # the three contractions on the MFMA (fp32-grade), the bias gradient as row sums
+        rc = lib.cti_bi_logits_bwd_mfma(dl.data_ptr(), vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), dvt.data_ptr(), dqt.data_ptr(),
+                                        hp.data_ptr(), B, G, V, Q, D, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_bi_logits_bwd_mfma")
+            L.check(lib.cti_row_sum(dl.data_ptr(), bp.data_ptr(), B * G, V * Q, _stream()), "cti_row_sum")
+            done = True
+    if not done:
+        L.check(lib.cti_bi_logits_bwd(dl.data_ptr(), vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), dvt.data_ptr(), dqt.data_ptr(),
                                       hp.data_ptr(), bp.data_ptr(), B, G, V, Q, D, _stream()), "cti_bi_logits_bwd")
     return dvt, dqt, sum_batches(hp, B, G * D).view(G, D), sum_batches(bp, B, G)
 

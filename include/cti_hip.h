@@ -269,6 +269,14 @@ int cti_bi_pool_bwd(const float* dout, const float* vt, const float* qt, const f
 int cti_bi_logits_bwd(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
                       float* dqt, float* dh_partial, float* dh_bias_partial, int B, int G, int V, int Q, int D, void* stream);
 
+/* out[r] = sum_c x[r, c] for a contiguous (rows, cols) matrix, one wave per row (the bias gradient of the bilinear logits). */
+int cti_row_sum(const float* x, float* out, int64_t rows, int cols, void* stream);
+
+/* dvt, dqt and dh_partial of cti_bi_logits_bwd on the MFMA (fp32-grade mode) for G <= 8, V <= 64, Q <= 16, D % 32 == 0; the bias partial
+ * stays with cti_bi_logits_bwd's row sums.  Returns CTI_E_UNSUPPORTED without a message otherwise. */
+int cti_bi_logits_bwd_mfma(const float* dlogits, const float* vt, const float* qt, const float* h, const float* h_scale, float* dvt,
+                           float* dqt, float* dh_partial, int B, int G, int V, int Q, int D, void* stream);
+
 /* ---- data-parallel update -------------------------------------------------------------------------------
  * What follows the single RCCL all-reduce of the flat gradient buffer; replaces Trainer._all_reduce_and_rescale + _opt
  * (src/FFOE/trainer.py:221-269), utils.clip_grad_norm_ (src/utils.py:323-328) and torch.optim.Adamax.step (src/FFOE/train.py:34).
