@@ -1197,8 +1197,14 @@ extern "C" int cti_bi_logits_bwd_mfma(const float* dlogits, const float* vt, con
     const int tpw = tiles >= 64 ? 4 : (tiles >= 16 ? 2 : 1);
     const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
     const size_t lds1 = sizeof(float) * (size_t)G * 64 * 20, lds2 = sizeof(float) * (size_t)G * 32 * 68;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bi_logits_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "cti_bi_logits_bwd_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bi_logits_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "cti_bi_logits_bwd_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
     hipLaunchKernelGGL(bi_logits_bwd_vh_kernel, grid, dim3(256), lds1, as_stream(stream), dlogits, vt, qt, h, h_scale, dvt, dh_partial, G, V, Q, D, tpw);
     int rc = launch_status("cti_bi_logits_bwd_mfma/dvt"); if (rc) return rc;
     hipLaunchKernelGGL(bi_logits_bwd_q_kernel, grid, dim3(256), lds2, as_stream(stream), dlogits, vt, h, h_scale, dqt, G, V, Q, D, tpw);
