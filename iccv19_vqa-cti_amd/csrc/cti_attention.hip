@@ -604,6 +604,17 @@ __global__ __launch_bounds__(64) void bi_logits_kernel(const float* __restrict__
 // al*bh + ah*bl + ah*bh.  One 512-thread workgroup per (sample, half of D): its 8 waves own the (m-tile, n-tile) pairs;
 // the two D halves meet by atomicAdd (two addends: order-independent).  716 us -> ~60 us at B=256, G=8, D=3072.
 // =====================================================================================================
+// zero fill as a KERNEL: a hipMemsetAsync captured into a hipGraph did not re-zero the buffer on the second replay (observed on ROCm 7.0:
+// the accumulating kernels below then added onto stale data), a kernel node does
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+static inline int zero_fill(float* p, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+    return launch_status("zero_fill");
+}
+
 typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
 typedef float lf32x16 __attribute__((ext_vector_type(16)));
 
@@ -1143,8 +1154,7 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;
     const int KS = D >= 1024 ? 2 : 1;
     const int dper = ((D / 16 + KS - 1) / KS) * 16;
-    hipError_t e = hipMemsetAsync(logits, 0, sizeof(float) * (size_t)B * G * V * Q, as_stream(stream));
-    if (e != hipSuccess) return fail((int)e, "cti_bi_logits_mfma_fwd: memset: %s", hipGetErrorString(e));
+    int rcz = zero_fill(logits, (int64_t)B * G * V * Q, as_stream(stream)); if (rcz) return rcz;
     hipLaunchKernelGGL(bi_logits_mfma_kernel, dim3(B, KS), dim3(512), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, MT, NT, dper);
     return launch_status("cti_bi_logits_mfma_fwd");
 }
@@ -1182,8 +1192,7 @@ extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float*
     const int MT = (V + 31) / 32, NT = (Q * A + 31) / 32;
     const int KS = D >= 512 ? 2 : 1;
     const int dper = ((D / 16 + KS - 1) / KS) * 16;
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)B * V * Q * A, as_stream(stream));
-    if (e != hipSuccess) return fail((int)e, "cti_pool_dw_mfma: memset: %s", hipGetErrorString(e));
+    int rcz = zero_fill(dw, (int64_t)B * V * Q * A, as_stream(stream)); if (rcz) return rcz;
     hipLaunchKernelGGL(pool_dw_mfma_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, MT, NT, dper);
     return launch_status("cti_pool_dw_mfma");
 }

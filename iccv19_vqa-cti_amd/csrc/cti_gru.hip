@@ -88,6 +88,17 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// zero fill as a kernel (a hipMemsetAsync captured into a hipGraph was not re-executed reliably on replay; see cti_attention.hip)
+__global__ __launch_bounds__(256) void zero_u16_kernel(unsigned short* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+inline int zero_planes(unsigned short* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / sizeof(unsigned short);
+    hipLaunchKernelGGL(zero_u16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+    return launch_status("zero_planes");
+}
+
 struct Carve {
     char* p; size_t used;
     template <class T> T* take(size_t bytes) { T* r = reinterpret_cast<T*>(p + used); used += al256(bytes); return r; }
@@ -174,7 +185,7 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
     if (w_hh_planes) { whh = static_cast<unsigned short*>(const_cast<void*>(w_hh_planes)); whl = whh + (size_t)rw * KpH; }
     else { rc = split_planes(w_hh, H, H3, H, whh, whl, rw, st); if (rc) return rc; }
     if (KpH != H) {                                                       // K tail of the h planes stays zero (the kernel writes [0, H) only)
-        for (int i = 0; i < 2; ++i) { hipError_t e = hipMemsetAsync(hp_[i], 0, planes_bytes(rh, H), st); if (e != hipSuccess) return fail((int)e, "cti_gru_forward: memset"); }
+        for (int i = 0; i < 2; ++i) { rc = zero_planes(hp_[i], planes_bytes(rh, H), st); if (rc) return rc; }
     }
     {
         PlaneGemmArgs g{};
@@ -228,7 +239,7 @@ int cti_gru_backward(const float* dout, const float* w_hh, const float* save, fl
         wth = ws.take<unsigned short>(planes_bytes(rw, H3)); wtl = wth + (size_t)rw * KpW;
         gh_ = ws.take<unsigned short>(planes_bytes(rg, H3)); gl_ = gh_ + (size_t)rg * KpW;
         rc = split_planes(wt, H3, H, H3, wth, wtl, rw, st); if (rc) return rc;
-        if (KpW != H3) { hipError_t e = hipMemsetAsync(gh_, 0, planes_bytes(rg, H3), st); if (e != hipSuccess) return fail((int)e, "cti_gru_backward: memset"); }
+        if (KpW != H3) { rc = zero_planes(gh_, planes_bytes(rg, H3), st); if (rc) return rc; }
     }
     const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
     for (int t = T - 1; t >= 0; --t) {

@@ -250,3 +250,33 @@ def test_mc_v_replication_gives_identical_logits():
         out, att = m(v, b, q, a)
     check(out, fx.o["logits"], TOL, "MC TAN logits, v de-duplicated")
     assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("name,builder", [("g9_ffoe_cti", "build_cti"), ("g9_ffoe_ban", "build_ban")])
+def test_eval_forward_is_graph_capturable_and_replays_identically(name, builder):
+    """hipGraph capture of a whole eval forward (torch.cuda.CUDAGraph): three replays reproduce the eager logits bit for bit.  (A captured
+    hipMemsetAsync did not: the library zero-fills with kernels.)"""
+    fx, p, m = build(name, builder)
+    if builder == "build_cti":
+        args = (T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]))
+        fwd = lambda: m(*args)
+    else:
+        args = (T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), None)
+        fwd = lambda: m(*args)[0]
+    with torch.no_grad():
+        for _ in range(2):
+            ref = fwd().clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fwd()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=s):
+                out = fwd()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
