@@ -280,3 +280,26 @@ def test_eval_forward_is_graph_capturable_and_replays_identically(name, builder)
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("B,Tn,I,H", [(3, 1, 8, 16), (1, 2, 8, 16), (2, 5, 20, 32), (1, 1, 4, 8), (4, 14, 600, 64)])
+def test_gru_against_torch_gru_on_cpu(B, Tn, I, H):
+    """torch's own nn.GRU on the CPU is an independent reference that exists on the GPU box: forward states and every gradient for edge
+    shapes (one step, one sample, widths that are no multiple of the K padding)."""
+    torch.manual_seed(B * 10 + Tn)
+    g = cti_amd.QuestionEmbedding(I, H, 1, False, 0.0)
+    ref = torch.nn.GRU(I, H, 1, batch_first=True)
+    ref.load_state_dict(g.rnn.state_dict())
+    x = torch.randn(B, Tn, I)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    cot = torch.randn_like(yr)
+    (yr * cot).sum().backward()
+    g = g.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = g.forward_all(xg)
+    (yg * cot.to(DEV)).sum().backward()
+    check(yg, yr.detach().numpy(), TOL, "states")
+    check(xg.grad, xr.grad.numpy(), TOL, "d x")
+    for (n, pg), (_, pr) in zip(g.rnn.named_parameters(), ref.named_parameters()):
+        check(pg.grad, pr.grad.numpy(), TOL, "d " + n)
