@@ -53,11 +53,19 @@ __device__ __forceinline__ uint4 pack8(const unsigned short* h) {
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, int Kp,
                                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                                     int64_t pitch) {
+#ifndef CTI_SPLIT_KFAST
+#define CTI_SPLIT_KFAST 1        // K group on the fast grid axis: workgroups dispatched together read the SAME rows (whole 1.2-KB rows of `a` instead of
+#endif                           // one 128-B piece of every row per pass)
+#if CTI_SPLIT_KFAST
+    const int64_t idx = ((int64_t)blockIdx.y * gridDim.z + blockIdx.z) * 256 + threadIdx.x;
+    const int kg = blockIdx.x;
+#else
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (row, 16-B piece) inside K chunk blockIdx.y
+    const int kg = blockIdx.y;
+#endif
     const int c = (int)(idx & 3);
     const int64_t row = idx >> 2;
     if (row >= rows) return;
-    const int kg = blockIdx.y;
     const int k0 = kg * 32 + c * 8;
     const float* src = x + row * ld + k0;
     float v[8];
@@ -570,8 +578,15 @@ int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short
                  hipStream_t st) {
     const int Kp = planes_kp(K);
     const int64_t n = rows * 4;
+#if CTI_SPLIT_KFAST
+    const int64_t blocks = (n + 255) / 256;
+    const unsigned gz = (unsigned)((blocks + 65534) / 65535);              // row blocks spread over (y, z): y <= 65535
+    const unsigned gy = (unsigned)((blocks + gz - 1) / gz);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)(Kp >> 5), gy, gz), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo, rows_alloc * 16);
+#else
     hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(Kp >> 5)), dim3(256), 0, st, x, ld, rows, K, Kp, hi, lo,
                        rows_alloc * 16);
+#endif
     return launch_status("split_planes");
 }
 
