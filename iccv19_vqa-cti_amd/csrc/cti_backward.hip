@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     }
 }
 
-// multi-workgroup form for large matrices: partial <G,V> and ||V||^2 per 16,384-element chunk, then every workgroup of the
+// multi-workgroup form for large matrices: partial <G,V> and ||V||^2 per 4,096-element chunk, then every workgroup of the
 // apply pass re-reduces its matrix's partials in the same fixed order
-constexpr int64_t WNB_CHUNK = 16384;
+constexpr int64_t WNB_CHUNK = 4096;
 __global__ __launch_bounds__(256) void wn_bwd_partial_kernel(const float* __restrict__ G, const float* __restrict__ V, float* __restrict__ part,
                                                              int64_t elems, int cpm) {
     __shared__ float r0[4], r1[4];

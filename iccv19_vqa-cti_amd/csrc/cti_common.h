@@ -40,7 +40,7 @@ __device__ __forceinline__ float wave_max(float x) {
 
 // ---- weight-norm scales of several layers in two launches (cti_paralind.hip) --------------------------------------
 constexpr int WN_MAX = 8;
-constexpr int64_t WN_CHUNK = 16384;
+constexpr int64_t WN_CHUNK = 4096;
 struct WnBatch {
     int n;
     const float* wv[WN_MAX]; const float* g[WN_MAX]; float* scale[WN_MAX];

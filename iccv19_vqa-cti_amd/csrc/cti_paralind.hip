@@ -38,7 +38,7 @@ __global__ __launch_bounds__(1024) void wn_scale_kernel(const float* __restrict_
 }
 
 // ---- the same for several layers in two launches (used by cti_tcnet_forward) -------------------------------------
-// Launch 1: one 256-thread workgroup per 16,384-element chunk of any matrix -> partial sum of squares (fixed tree).
+// Launch 1: one 256-thread workgroup per 4,096-element chunk of any matrix -> partial sum of squares (fixed tree).
 // Launch 2: one wave per matrix adds its chunk partials in index order -> scale.  Deterministic, and a 1M-element
 // Tucker weight is read by 64 CUs instead of one.
 __global__ __launch_bounds__(256) void wn_partial_kernel(WnBatch d, float* __restrict__ partial) {
@@ -198,7 +198,7 @@ extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float*
     }
     CTI_REQUIRE(workspace_bytes >= cti_wn_scale_workspace_bytes(n_mats, elems), CTI_E_WORKSPACE, "cti_wn_scale: workspace %zu < %zu",
                 workspace_bytes, cti_wn_scale_workspace_bytes(n_mats, elems));
-    WnBatch wb{};                                           // large matrices: 16,384-element chunks over many CUs, then a fixed-order sum
+    WnBatch wb{};                                           // large matrices: 4,096-element chunks over many CUs, then a fixed-order sum
     wb.n = 1; wb.wv[0] = weight_v; wb.g[0] = weight_g; wb.scale[0] = scale; wb.n_mats[0] = n_mats; wb.elems[0] = elems;
     wn_batch_finish(wb);
     return wn_scale_batch(wb, static_cast<float*>(workspace), as_stream(stream));

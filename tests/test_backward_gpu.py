@@ -273,6 +273,8 @@ def test_model_width_backward_agrees_between_arithmetic_modes():
     for k in p32:
         if p32[k].dim() == 0:
             gains_a.append(float(p3[k])); gains_b.append(float(p32[k]))
+        elif k.endswith("h_bias"):
+            continue                     # mathematically zero (the softmax is shift-invariant per (b, g) row): both modes hold rounding noise
         elif float(p32[k].abs().max()) > 1e-6:
             # parameter gradients behind a ReLU: a pre-activation within rounding distance of zero flips its mask between the two modes
             # and changes single terms of the sums, so these are compared in the L2 sense (the smooth quantities above: max norm)
