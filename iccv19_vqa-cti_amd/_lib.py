@@ -46,6 +46,7 @@ SIGNATURES = {
     "cti_bi_pool_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_flat_scale_sumsq": (_int, [_vp, _i64, C.c_float, _vp, _vp]),
+    "cti_flat_gather": (_int, [_vp, _int, _vp, _i64, _vp]),
     "cti_adamax_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _int, _vp, _vp]),
     "cti_optim_workspace_bytes": (_sz, []),
     "cti_embedding_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),

@@ -1,15 +1,19 @@
 """Data-parallel training step for models built on the CTI modules.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  All trainable parameters, their gradients and the
-Adamax state live in FOUR flat fp32 buffers; `param.data` and `param.grad` are views into them, so
-  * backward accumulates straight into the flat gradient buffer (no pack / unpack copies: the reference's
-    _get_flat_grads / _set_flat_grads, src/FFOE/trainer.py:245-263, disappear),
+Adamax state live in FOUR flat fp32 buffers; `param.data` is a view into the first, so
+  * backward leaves each gradient in the tensor autograd produced (zero_grad() sets `.grad = None`, so AccumulateGrad keeps that tensor
+    instead of launching one add per parameter -- 344 of them in the FFOE CTI model) and ONE gather kernel packs them into the flat
+    gradient buffer (the reference's _get_flat_grads torch.cat + _set_flat_grads copies, src/FFOE/trainer.py:245-263); after step()
+    `param.grad` is a view of that buffer (the averaged, unclipped gradient),
   * ONE all-reduce(sum) of that buffer is the only communication of the step,
   * scale by 1/(world*update_freq), global-norm clip and the Adamax update are two HIP kernels with no host sync
     (the reference blocks on grad_norm.item(), src/utils.py:324).
 Semantics restated from the reference: loss is divided by the LOCAL batch (trainer.py:189-190), gradients are summed over ranks
 and divided by world_size * update_freq, clip coefficient max_norm / (norm + 1e-6) applied only when < 1 (utils.py:323-328),
 Adamax with betas (0.9, 0.999), eps 1e-8, no weight decay (torch.optim.Adamax defaults, train.py:34)."""
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -40,11 +44,13 @@ class FlatAdamaxDP:
         self.exp_avg = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.exp_inf = torch.zeros(self.n, device=dev, dtype=torch.float32)
         off = 0
+        self.offsets = []
         for p in self.params:                                   # named_parameters() order, like Trainer._get_flat_grads
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
-            p.grad = self.flat_g[off:off + k].view(p.shape)
+            p.grad = None
+            self.offsets.append(off)
             off += (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         lib = L.lib()
         self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
@@ -60,17 +66,34 @@ class FlatAdamaxDP:
             dist.broadcast(self.flat_p, src=src, group=self.pg)
 
     def zero_grad(self):
-        self.flat_g.zero_()                                     # grads stay views of the flat buffer (set_to_none would detach them)
+        for p in self.params:                                   # no fill kernel: cti_flat_gather zeroes whatever has no gradient
+            p.grad = None
 
-    def check_grads_are_views(self):
-        lo, hi = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.n
-        for p in self.params:
-            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
-                raise RuntimeError("a parameter's .grad left the flat buffer (zero_grad(set_to_none=True) or an optimizer touched it)")
+    def gather_grads(self):
+        """param.grad tensors -> flat_g (one kernel); afterwards every param.grad is a view of its flat_g slot."""
+        keep = []
+        rows = []
+        for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None:
+                rows.append((0, off, p.numel()))
+                continue
+            if g.dtype != torch.float32 or g.device != self.flat_g.device or g.shape != p.shape:
+                raise TypeError("gradient of a %s parameter is %s %s on %s" % (tuple(p.shape), g.dtype, tuple(g.shape), g.device))
+            if not g.is_contiguous():
+                g = g.contiguous()
+            keep.append(g)
+            rows.append((g.data_ptr(), off, p.numel()))
+        table = (ctypes.c_int64 * (3 * len(rows)))(*[x for r in rows for x in r])       # host array: the entries ride in kernel arguments
+        L.check(L.lib().cti_flat_gather(table, len(rows), self.flat_g.data_ptr(), self.n, torch.cuda.current_stream().cuda_stream),
+                "cti_flat_gather")
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+        del keep                                                 # stream-ordered: the caching allocator reuses them only after the gather
 
     def step(self):
         """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm."""
-        self.check_grads_are_views()
+        self.gather_grads()
         if self.world > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
         self.step_count += 1

@@ -282,6 +282,13 @@ int cti_bi_logits_bwd_mfma(const float* dlogits, const float* vt, const float* q
  * (src/FFOE/trainer.py:221-269), utils.clip_grad_norm_ (src/utils.py:323-328) and torch.optim.Adamax.step (src/FFOE/train.py:34).
  * grad *= inv_denom in place, partial[0..1023] = per-workgroup sums of squares (workspace of cti_optim_workspace_bytes()). */
 int cti_flat_scale_sumsq(float* grad, int64_t n, float inv_denom, float* partial, void* stream);
+/* Packs per-parameter gradient tensors into the flat buffer in one launch (replaces Trainer._get_flat_grads' torch.cat,
+ * src/FFOE/trainer.py:245-255).  table: HOST array of n_entries x 3 int64 {source address (0 = no gradient), first float of the
+ * parameter's slot in flat, element count}, sorted by slot start, slots disjoint and starting on multiples of 4 floats;
+ * flat[slot + j] = src[j]; every float outside the sources (alignment padding, parameters without a gradient) is set to 0; an entry
+ * whose source already IS its slot is left untouched.  n: floats in flat, a multiple of 4.  The entries travel in kernel arguments
+ * (160 per launch), so the host array may be reused as soon as the call returns. */
+int cti_flat_gather(const int64_t* table, int n_entries, float* flat, int64_t n, void* stream);
 /* norm = sqrt(sum partial); coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping); g' = coef * grad;
  * exp_avg = b1*exp_avg + (1-b1)*g'; exp_inf = max(b2*exp_inf, |g'| + eps); param -= lr / (1 - b1^step) * exp_avg / exp_inf.
  * grad_norm_out: NULL or one float (the pre-clip norm, for logging without a blocking .item() in the step). */

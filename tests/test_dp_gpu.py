@@ -164,3 +164,63 @@ def test_eval_after_a_fused_optimizer_step_sees_the_new_parameters():
     ref, _ = O.tri_attention(v.cpu().numpy(), q.cpu().numpy(), a.cpu().numpy(), sd, dtype=np.float64)
     assert O.norm_max_err(p1.cpu().numpy(), ref) < 1e-4
     assert float((p1 - p0).abs().max()) > 1e-6                     # the step did change the attention
+
+
+def test_flat_gather_packs_zeroes_and_keeps_in_place_entries():
+    """cti_flat_gather on its own: > 160 entries (several launches), misaligned sources, odd counts, a parameter without a gradient,
+    an entry that already lives in its slot; bit-exact against a host-side pack."""
+    import ctypes
+    L = cti_amd.pkg._lib
+    g = torch.Generator().manual_seed(3)
+    counts = [int(c) for c in torch.randint(1, 700, (400,), generator=g)] + [70000, 1, 4097]
+    offs, off = [], 0
+    for c in counts:
+        offs.append(off)
+        off += (c + 63) // 64 * 64
+    n = off
+    flat = torch.full((n,), 7.0, device=DEV)
+    want = np.zeros(n, np.float32)
+    rows, keep = [], []
+    for i, (c, o) in enumerate(zip(counts, offs)):
+        if i % 11 == 5:                                                  # no gradient: the slot must come out zero
+            rows += [0, o, c]
+        elif i % 13 == 7:                                                # already in place: untouched (keeps the 7.0 fill)
+            rows += [flat.data_ptr() + 4 * o, o, c]
+            want[o:o + c] = 7.0
+        else:
+            base = torch.randn(c + 3, generator=g).to(DEV)
+            src = base[i % 4:i % 4 + c]                                  # 4-, 8-, 12-byte misaligned sources take the scalar path
+            keep.append(base)
+            rows += [src.data_ptr(), o, c]
+            want[o:o + c] = src.cpu().numpy()
+    table = (ctypes.c_int64 * len(rows))(*rows)
+    L.check(L.lib().cti_flat_gather(table, len(counts), flat.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "cti_flat_gather")
+    assert np.array_equal(flat.cpu().numpy(), want)
+    L.check(L.lib().cti_flat_gather(None, 0, flat.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "cti_flat_gather")
+    assert float(flat.abs().max()) == 0.0                               # no entries: the whole buffer is zeroed
+    bad = (ctypes.c_int64 * 6)(0, 0, 100, 0, 64, 10)                    # second slot starts inside the first
+    assert L.lib().cti_flat_gather(bad, 2, flat.data_ptr(), n, torch.cuda.current_stream().cuda_stream) < 0
+
+
+def test_update_freq_accumulates_micro_batches():
+    """update_freq = 2: two backward() calls accumulate in param.grad (AccumulateGrad, in place on the tensors it kept), one step() divides by
+    2 -- the same parameters as one step on the concatenated batch with loss / B_micro (src/FFOE/trainer.py:189-190, :232-236)."""
+    cti_amd.set_precision("fp32")
+    try:
+        res = []
+        for freq in (2, 1):
+            torch.manual_seed(11)
+            m = TinyCTI().to(DEV)
+            opt = cti_amd.FlatAdamaxDP(m, lr=2e-3, clip_norm=0.25, update_freq=freq)
+            v, q, a, y = (t.to(DEV) for t in make_batch(8, 100))
+            opt.zero_grad()
+            if freq == 2:
+                for sl in (slice(0, 4), slice(4, 8)):
+                    loss_fn(m(v[sl], q[sl], a[sl]), y[sl]).backward()
+            else:
+                loss_fn(m(v, q, a), y).backward()
+            opt.step()
+            res.append(opt.flat_p.clone())
+        assert torch.allclose(res[0], res[1], rtol=2e-4, atol=2e-6)
+    finally:
+        cti_amd.set_precision("bf16x3")
