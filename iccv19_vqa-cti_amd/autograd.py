@@ -188,19 +188,33 @@ class RankNetsDropFn(torch.autograd.Function):
     """The R rank nets FCNet([h, hr]) of src/tc.py:29-31 in TRAIN mode.  Each net owns a Dropout on the SHARED input
     (src/fc.py:25-26), i.e. R independent masks: the input is expanded into R masked copies by one Philox kernel and the R
     projections run as ONE batched MFMA GEMM (per-batch weight-norm scale and bias); the backward is three batched GEMMs.
-    Same distribution as the reference's 3 x R separate Dropout + Linear modules, ~40 launches instead of ~2000."""
+    Same distribution as the reference's 3 x R separate Dropout + Linear modules, ~40 launches instead of ~2000.
+    For hr <= 16, h <= 512 (the real widths: 16 and 512) the masked copies are never materialised: the mask is drawn alone and the three
+    contractions apply it to their operand fragments (cti_ranknets.hip)."""
 
     @staticmethod
     def forward(ctx, x, wv, g, b, relu, R, p):
         h = x.shape[-1]
         rows = x.numel() // h
         hr = wv.shape[0] // R
-        Xd, mask = ops.dropout(x.contiguous().view(rows, h), p, copies=R)            # (R, rows, h)
+        x2 = x.contiguous().view(rows, h)
         scale = ops.wn_scale(wv.reshape(R, -1), g.reshape(-1))
-        y = torch.empty((rows, R * hr), device=x.device, dtype=torch.float32)
-        ops.gemm_nt(Xd.view(R * rows, h), wv, nb1=R, rA1=rows, rB1=hr, M=rows, N=hr, out=y, c_strides=(R * hr, 1), sC1=hr,
-                    scale=scale, scale_div=max(hr, 1), scale_bs=1, bias=b, bias_bs=hr, relu=relu)
-        ctx.save_for_backward(Xd, mask, y, wv, g, scale)
+        wvc = wv.contiguous()
+        # fused route: only the (R, rows, h) byte mask exists; the three kernels of cti_ranknets.hip apply it to their operand fragments
+        y = None
+        if hr <= 16 and h % 4 == 0 and h <= 512 and rows > 0:
+            mask = ops.dropout_mask((R, rows, h), p, x.device)
+            y = ops.ranknets_drop_fwd(x2, mask, wvc, scale, b, R, p, relu)
+        if y is not None:
+            ctx.save_for_backward(x2, mask, y, wvc, g, scale)
+            ctx.fused = True
+        else:
+            Xd, mask = ops.dropout(x2, p, copies=R)                                  # (R, rows, h)
+            y = torch.empty((rows, R * hr), device=x.device, dtype=torch.float32)
+            ops.gemm_nt(Xd.view(R * rows, h), wv, nb1=R, rA1=rows, rB1=hr, M=rows, N=hr, out=y, c_strides=(R * hr, 1), sC1=hr,
+                        scale=scale, scale_div=max(hr, 1), scale_bs=1, bias=b, bias_bs=hr, relu=relu)
+            ctx.save_for_backward(Xd, mask, y, wv, g, scale)
+            ctx.fused = False
         ctx.cfg = (relu, R, p, hr, rows, h, x.shape)
         return y.view(x.shape[:-1] + (R * hr,))
 
@@ -209,6 +223,11 @@ class RankNetsDropFn(torch.autograd.Function):
         Xd, mask, y, wv, g, scale = ctx.saved_tensors
         relu, R, p, hr, rows, h, xshape = ctx.cfg
         dzs, db = ops.act_bwd(dy, y, scale, hr, relu)                                # (rows, R*hr), (R*hr,)
+        if ctx.fused:
+            G = ops.ranknets_drop_dw(dzs, Xd, mask, R, p)                            # Xd is the plain (rows, h) input here
+            dV, dg = ops.wn_bwd(G, wv, g, R)
+            dx = ops.ranknets_drop_dx(dzs, wv, mask, R, p).view(xshape) if ctx.needs_input_grad[0] else None
+            return dx, dV.view_as(wv), dg.view_as(g), db, None, None, None
         # dW_r = dzs_r^T @ Xd[r]  (contraction over the rows axis)
         dzsT = ops.transpose(dzs, rows, R * hr).view(R * hr, rows)
         XdT = ops.transpose(Xd, rows, h, R, rows * h)                                # (R, h, rows)

@@ -140,6 +140,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     // fast path: the whole group of 4 is in range and 16-B / 4-B aligned in x, y and mask (period a multiple of 4: the group does not
     // straddle two copies): one 16-B load, one 16-B store, one 4-B mask access, one 64-bit modulo per group instead of per element
     const int64_t s0 = period ? i0 % period : i0;
+    if (!y) {                                                           // mask only (cti_ranknets_drop_* apply it where they form their operands)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) mask[i0 + j] = rr[j] >= thr ? 1 : 0;
+        return;
+    }
     if (vec && i0 + 4 <= n) {
         const float4 xv = *reinterpret_cast<const float4*>(x + s0);
         uchar4 mk;
@@ -207,7 +213,8 @@ using namespace cti;
 
 extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
                            int64_t period, void* stream) {
-    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(mask);
+    CTI_REQUIRE_PTR(mask);
+    if (y || use_mask) { CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); }
     CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f && period >= 0, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
     const int64_t groups = (n + 3) / 4;
     const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0 &&

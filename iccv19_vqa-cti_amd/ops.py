@@ -594,6 +594,47 @@ def dropout(x, p, mask=None, copies=1):
     return y
 
 
+def dropout_mask(shape, p, device):
+    """A fresh keep-mask (uint8, 1 = keep) from the same Philox stream as dropout(); nothing else is written."""
+    mask = torch.empty(tuple(shape), device=device, dtype=torch.uint8)
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
+    _dropout_calls[0] += 1
+    L.check(L.lib().cti_dropout(None, None, mask.data_ptr(), mask.numel(), float(p), seed, 0, 0, 0, _stream()), "cti_dropout (mask only)")
+    return mask
+
+
+def ranknets_drop_fwd(x2, mask, wv, scale, bias, R, p, relu):
+    """Train-mode rank nets without the R masked copies (cti_ranknets_drop_fwd); None when the shape is outside the kernel."""
+    rows, h = x2.shape
+    hr = wv.shape[0] // R
+    y = torch.empty((rows, R * hr), device=x2.device, dtype=torch.float32)
+    rc = L.lib().cti_ranknets_drop_fwd(_req(x2, "x").data_ptr(), mask.data_ptr(), _req(wv, "W").data_ptr(), _req(scale, "scale").data_ptr(),
+                                       _ptr(bias), y.data_ptr(), rows, h, R, hr, float(p), 1 if relu else 0, _stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "cti_ranknets_drop_fwd")
+    return y
+
+
+def ranknets_drop_dw(dzs, x2, mask, R, p):
+    rows, h = x2.shape
+    hr = dzs.shape[1] // R
+    G = torch.empty((R * hr, h), device=x2.device, dtype=torch.float32)
+    L.check(L.lib().cti_ranknets_drop_dw(_req(dzs, "dzs").data_ptr(), x2.data_ptr(), mask.data_ptr(), G.data_ptr(), rows, h, R, hr, float(p), _stream()),
+            "cti_ranknets_drop_dw")
+    return G
+
+
+def ranknets_drop_dx(dzs, wv, mask, R, p):
+    rows = dzs.shape[0]
+    h = wv.shape[1]
+    hr = wv.shape[0] // R
+    dx = torch.empty((rows, h), device=dzs.device, dtype=torch.float32)
+    L.check(L.lib().cti_ranknets_drop_dx(_req(dzs, "dzs").data_ptr(), _req(wv, "W").data_ptr(), mask.data_ptr(), dx.data_ptr(), rows, h, R, hr, float(p),
+                                         _stream()), "cti_ranknets_drop_dx")
+    return dx
+
+
 def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
     """-> dVr, dQr, dTeff (summed over the batch)."""
     R, I, J, K, G = Teff.shape

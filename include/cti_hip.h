@@ -228,9 +228,25 @@ size_t cti_act_bwd_workspace_bytes(int64_t rows, int n);
 /* nn.Dropout (src/fc.py:20-21,25-26; src/bc.py:29).  use_mask = 0: draw keep ~ Bernoulli(1-p) from Philox-4x32-10 keyed by
  * `seed`, counter = offset + element/4; store it in mask[i] (1 byte) and write y = x * keep / (1-p).  use_mask = 1: reuse the
  * stored mask (the backward pass: x = dy).  x == y is allowed.  period > 0: x is read at i % period, i.e. y is n / period
- * independently masked copies of x (the R rank nets of src/tc.py:29-31 each draw their own mask of the shared input). */
+ * independently masked copies of x (the R rank nets of src/tc.py:29-31 each draw their own mask of the shared input).
+ * y == NULL with use_mask = 0: only the mask is drawn (x is not read) -- the input of cti_ranknets_drop_*. */
 int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
                 int64_t period, void* stream);
+
+/* The R rank nets of TCNet in train mode (src/tc.py:29-31, 44-46 with src/fc.py:25-28: every FCNet([h, hr]) drops its OWN mask on the
+ * shared input) without materialising the R masked copies: mask (R, rows, h) bytes from cti_dropout(y = NULL), x (rows, h), W (R*hr, h) the
+ * packed weight_v, scale (R,) from cti_wn_scale, bias (R*hr,) or NULL, p the drop probability.
+ *   fwd: y[m, r*hr+n]  = act(scale[r]/(1-p) * sum_k x[m,k] mask[r,m,k] W[r*hr+n,k] + bias[r*hr+n])            y (rows, R*hr)
+ *   dw : G[r*hr+n, k]  = 1/(1-p) * sum_m dzs[m, r*hr+n] x[m,k] mask[r,m,k]                (input of cti_wn_bwd)  G (R*hr, h)
+ *   dx : dx[m, k]      = 1/(1-p) * sum_r mask[r,m,k] sum_n dzs[m, r*hr+n] W[r*hr+n, k]                          dx (rows, h)
+ * dzs (rows, R*hr) is cti_act_bwd's output.  fp32 MFMA (exact products) in every precision mode.  Shapes outside hr <= 16, h % 4 == 0
+ * (fwd: h <= 512) or unaligned operands return CTI_E_UNSUPPORTED without a message: the caller takes cti_dropout(period) + cti_gemm_nt. */
+int cti_ranknets_drop_fwd(const float* x, const uint8_t* mask, const float* W, const float* scale, const float* bias, float* y, int64_t rows,
+                          int h, int R, int hr, float p, int relu, void* stream);
+int cti_ranknets_drop_dw(const float* dzs, const float* x, const uint8_t* mask, float* G, int64_t rows, int h, int R, int hr, float p,
+                         void* stream);
+int cti_ranknets_drop_dx(const float* dzs, const float* W, const uint8_t* mask, float* dx, int64_t rows, int h, int R, int hr, float p,
+                         void* stream);
 
 /* Gradient through weight_norm(dim=None) (torch `_weight_norm` backward): W = g * V / ||V||_F = s * V.  Given
  * G = dzs^T x (n_mats matrices of `elems` floats, the gradient w.r.t. V through the direct path):
