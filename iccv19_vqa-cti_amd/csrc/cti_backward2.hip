@@ -659,6 +659,75 @@ int set_lds(K kern, size_t bytes, const char* what) {
     return e == hipSuccess ? CTI_OK : fail((int)e, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
 }
 
+
+// =====================================================================================================
+// Backward of mode 3 + rank sum (out[b,v,q,a,g] = sum_k M[b,v,q,g,k] Ar[b,a,k], src/Tensor.py:16-20 with src/tc.py:50):
+//   dM[b,v,q,g,k] = sum_a dout[b,v,q,a,g] Ar[b,a,k]        contraction over A (3 or 6): an element-wise pass that WRITES dM once
+//   dAr[b,a,k]    = sum_{v,q,g} dout[b,v,q,a,g] M[b,v,q,g,k]  A output rows per sample: a streaming reduction that READS M once
+// As GEMMs both need transposed copies of M / dout and plane splits of a (B, V*Q*G, K) tensor (528 MB at B = 256) for a contraction of
+// length 3 resp. an output of 3 rows; here each is one pass at the HBM rate, exact fp32.
+// =====================================================================================================
+constexpr int CB_AMAX = 8;
+
+__global__ __launch_bounds__(256) void core_bwd_dm_kernel(const float* __restrict__ dout, const float* __restrict__ Ar, float* __restrict__ dM,
+                                                          int VQ, int A, int G, int K4, int64_t total4) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;       // float4 index into dM (B, VQ, G, K/4)
+    if (e >= total4) return;
+    const int c = (int)(e % K4);
+    const int64_t row = e / K4;                                       // (b, vq, g)
+    const int g = (int)(row % G);
+    const int64_t bvq = row / G;
+    const int64_t b = bvq / VQ;
+    const float* dp = dout + bvq * A * G + g;
+    const float4* ap = reinterpret_cast<const float4*>(Ar + b * A * (int64_t)K4 * 4) + c;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < A; ++a) {
+        const float d = dp[a * G];
+        const float4 r = ap[(int64_t)a * K4];
+        o.x = fmaf(d, r.x, o.x); o.y = fmaf(d, r.y, o.y); o.z = fmaf(d, r.z, o.z); o.w = fmaf(d, r.w, o.w);
+    }
+    reinterpret_cast<float4*>(dM)[e] = o;
+}
+
+// one workgroup per (sample, 128 columns): 32 column groups (float4) x 8 row phases; the phases meet in LDS in a fixed order
+__global__ __launch_bounds__(256) void core_bwd_dar_kernel(const float* __restrict__ dout, const float* __restrict__ M, float* __restrict__ dAr,
+                                                           int VQ, int A, int G, int K4) {
+    __shared__ float4 red[8][CB_AMAX][32];
+    const int b = blockIdx.y, cg = threadIdx.x & 31, rp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cg;
+    const bool cok = c < K4;
+    const int J = VQ * G;
+    const float* db = dout + (int64_t)b * VQ * A * G;
+    const float4* mb = reinterpret_cast<const float4*>(M) + (int64_t)b * J * K4 + c;
+    float4 acc[CB_AMAX];
+#pragma unroll
+    for (int a = 0; a < CB_AMAX; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = rp; j < J; j += 8) {
+        const int vq = j / G, g = j - vq * G;
+        const float4 m = cok ? mb[(int64_t)j * K4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* dp = db + (int64_t)vq * A * G + g;
+#pragma unroll
+        for (int a = 0; a < CB_AMAX; ++a)
+            if (a < A) {
+                const float d = dp[a * G];
+                acc[a].x = fmaf(d, m.x, acc[a].x); acc[a].y = fmaf(d, m.y, acc[a].y); acc[a].z = fmaf(d, m.z, acc[a].z); acc[a].w = fmaf(d, m.w, acc[a].w);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < CB_AMAX; ++a)
+        if (a < A) red[rp][a][cg] = acc[a];
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * 32; i += 256) {
+        const int a = i >> 5, cc = i & 31;
+        if (blockIdx.x * 32 + cc < K4) {
+            float4 s = red[0][a][cc];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) { const float4 t = red[r][a][cc]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            reinterpret_cast<float4*>(dAr)[((int64_t)b * A + a) * K4 + blockIdx.x * 32 + cc] = s;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -790,4 +859,19 @@ extern "C" int cti_row_sum(const float* x, float* out, int64_t rows, int cols, v
     CTI_REQUIRE(rows > 0 && cols > 0, CTI_E_SHAPE, "cti_row_sum: rows=%lld cols=%d", (long long)rows, cols);
     hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, out, rows, cols);
     return launch_status("cti_row_sum");
+}
+
+extern "C" int cti_paralind_core_bwd(const float* dout, const float* M, const float* Ar, float* dM, float* dAr, int B, int V, int Q, int A, int G,
+                                     int K, void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(M); CTI_REQUIRE_PTR(Ar); CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(dAr);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && G > 0 && K > 0, CTI_E_SHAPE, "cti_paralind_core_bwd: B=%d V=%d Q=%d A=%d G=%d K=%d", B, V, Q, A, G, K);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(Ar) | reinterpret_cast<uintptr_t>(dM) | reinterpret_cast<uintptr_t>(dAr);
+    if (K % 4 != 0 || A > CB_AMAX || B > 65535 || (al & 15)) return CTI_E_UNSUPPORTED;      // the caller takes the transposed-GEMM route
+    const int K4 = K / 4, VQ = V * Q;
+    const int64_t total4 = (int64_t)B * VQ * G * K4;
+    CTI_REQUIRE((total4 + 255) / 256 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd: %lld elements exceed one launch", (long long)total4 * 4);
+    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, total4);
+    int rc = launch_status("cti_paralind_core_bwd/dM"); if (rc) return rc;
+    hipLaunchKernelGGL(core_bwd_dar_kernel, dim3((K4 + 31) / 32, B), dim3(256), 0, as_stream(stream), dout, M, dAr, VQ, A, G, K4);
+    return launch_status("cti_paralind_core_bwd/dAr");
 }

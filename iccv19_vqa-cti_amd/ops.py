@@ -652,11 +652,21 @@ def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
 
 
 def paralind_core_bwd(dout, M, Ar, prec=None):
-    """dout (B,V,Q,A,G), M (B,V,Q,G,K), Ar (B,A,K) -> dM, dAr: two batched NT GEMMs over transposed operands."""
+    """dout (B,V,Q,A,G), M (B,V,Q,G,K), Ar (B,A,K) -> dM, dAr (cti_paralind_core_bwd; shapes outside it: two batched NT GEMMs over
+    transposed operands)."""
     B, V, Q, G, K = M.shape
     A = Ar.shape[1]
     VQG = V * Q * G
     dout, M, Ar = dout.contiguous(), M.contiguous(), Ar.contiguous()
+    if B > 0:
+        # two streaming passes (contraction of length A / A output rows): no transposed copies or plane splits of the (B, V*Q*G, K) tensors
+        dM = torch.empty_like(M)
+        dAr = torch.empty_like(Ar)
+        rc = L.lib().cti_paralind_core_bwd(_req(dout, "dout").data_ptr(), _req(M, "M").data_ptr(), _req(Ar, "Ar").data_ptr(), dM.data_ptr(),
+                                           dAr.data_ptr(), B, V, Q, A, G, K, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_paralind_core_bwd")
+            return dM, dAr
     doutT = transpose(dout, A, G, B * V * Q, A * G)                       # (B*VQ, G, A): rows (vq,g), a contiguous
     ArT = transpose(Ar, A, K, B, A * K)                                   # (B, K, A)
     dM = gemm_nt(doutT.view(B * VQG, A), ArT.view(B * K, A), nb1=B, rA1=VQG, rB1=K, M=VQG, N=K, prec=prec)

@@ -233,6 +233,12 @@ size_t cti_act_bwd_workspace_bytes(int64_t rows, int n);
 int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
                 int64_t period, void* stream);
 
+/* Backward of cti_paralind_core_fwd (mode 3 + rank sum, src/Tensor.py:16-20, src/tc.py:50) as two streaming passes, exact fp32:
+ * dM[b,v,q,g,k] = sum_a dout[b,v,q,a,g] Ar[b,a,k];  dAr[b,a,k] = sum_{v,q,g} dout[b,v,q,a,g] M[b,v,q,g,k].  dout (B,V,Q,A,G), M and dM
+ * (B,V,Q,G,K), Ar and dAr (B,A,K), all contiguous.  K % 4 != 0, A > 8 or operands off 16-B alignment: CTI_E_UNSUPPORTED, no message. */
+int cti_paralind_core_bwd(const float* dout, const float* M, const float* Ar, float* dM, float* dAr, int B, int V, int Q, int A, int G, int K,
+                          void* stream);
+
 /* The R rank nets of TCNet in train mode (src/tc.py:29-31, 44-46 with src/fc.py:25-28: every FCNet([h, hr]) drops its OWN mask on the
  * shared input) without materialising the R masked copies: mask (R, rows, h) bytes from cti_dropout(y = NULL), x (rows, h), W (R*hr, h) the
  * packed weight_v, scale (R,) from cti_wn_scale, bias (R*hr,) or NULL, p the drop probability.

@@ -291,3 +291,16 @@ def test_model_width_backward_agrees_between_arithmetic_modes():
             assert rel < 1e-3, "d %s: relative L2 difference %.3g" % (k, rel)
     ga, gb = np.array(gains_a), np.array(gains_b)
     assert np.linalg.norm(ga - gb) / np.linalg.norm(gb) < 1e-3, "weight-norm gains"
+
+
+@pytest.mark.parametrize("B,V,Q,A,G,K", [(3, 5, 4, 3, 2, 64), (2, 36, 14, 6, 2, 512), (4, 7, 3, 8, 1, 132), (2, 3, 2, 3, 3, 20),
+                                          (2, 4, 3, 9, 2, 32), (2, 4, 3, 3, 2, 30)])
+def test_core_backward_streaming_passes_match_the_einsum(B, V, Q, A, G, K):
+    """cti_paralind_core_bwd (and, for A > 8 or K % 4 != 0, the transposed-GEMM route behind the same op) against float64 einsums."""
+    g = torch.Generator().manual_seed(B * 100 + K)
+    dout = torch.randn(B, V, Q, A, G, generator=g)
+    M = torch.randn(B, V, Q, G, K, generator=g)
+    Ar = torch.randn(B, A, K, generator=g)
+    dM, dAr = cti_amd.pkg.ops.paralind_core_bwd(dout.to(DEV), M.to(DEV), Ar.to(DEV))
+    check(dM, torch.einsum("bvqag,bak->bvqgk", dout.double(), Ar.double()).numpy(), tol=1e-5, what="dM")
+    check(dAr, torch.einsum("bvqag,bvqgk->bak", dout.double(), M.double()).numpy(), tol=1e-5, what="dAr")
