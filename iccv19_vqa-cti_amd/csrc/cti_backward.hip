@@ -36,8 +36,35 @@ __global__ __launch_bounds__(256) void sum_batches_kernel(const float* __restric
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += src[(int64_t)b * n + i];
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {                                   // four loads in flight; still one fixed summation order
+        const float a0 = src[(int64_t)b * n + i], a1 = src[(int64_t)(b + 1) * n + i], a2 = src[(int64_t)(b + 2) * n + i], a3 = src[(int64_t)(b + 3) * n + i];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; b < nb; ++b) s += src[(int64_t)b * n + i];
     dst[i] = alpha * s + (beta != 0.f ? beta * dst[i] : 0.f);
+}
+// many batches, few columns (the per-sample partials of a weight gradient): 64 columns x 4 batch lanes per workgroup, lanes meet in LDS
+__global__ __launch_bounds__(256) void sum_batches_tall_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int64_t n,
+                                                               float alpha, float beta) {
+    __shared__ float sb[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (i < n) {
+        int b = rl;
+        for (; b + 12 < nb; b += 16) {
+            const float a0 = src[(int64_t)b * n + i], a1 = src[(int64_t)(b + 4) * n + i], a2 = src[(int64_t)(b + 8) * n + i], a3 = src[(int64_t)(b + 12) * n + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; b < nb; b += 4) s += src[(int64_t)b * n + i];
+    }
+    sb[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        const float t = (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]);
+        dst[i] = alpha * t + (beta != 0.f ? beta * dst[i] : 0.f);
+    }
 }
 
 // ---- column sums of a tall matrix: partial[g][c] = sum of rows [g*rpg, (g+1)*rpg) of column c; 64 columns x 4 row lanes per workgroup
@@ -84,6 +111,40 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < RL; ++i) t += sb[i][cl];
         part_b[(int64_t)blockIdx.y * n + col] = t;
+    }
+}
+
+// wide matrices (n % 4 == 0, 16-B aligned): a thread owns 4 consecutive columns; 64 column groups x 4 row lanes per workgroup
+__global__ __launch_bounds__(256) void act_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
+                                                         int scale_div, float* __restrict__ dzs, float* __restrict__ part_b, int64_t rows, int n,
+                                                         int relu, int64_t rows_per_chunk) {
+    __shared__ float4 sb[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cl) * 4;
+    const int64_t r_lo = (int64_t)blockIdx.y * rows_per_chunk, r_hi = min(rows, r_lo + rows_per_chunk);
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n) {
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (scale) s = make_float4(scale[col / scale_div], scale[(col + 1) / scale_div], scale[(col + 2) / scale_div], scale[(col + 3) / scale_div]);
+        for (int64_t r = r_lo + rl; r < r_hi; r += 4) {
+            float4 g = *reinterpret_cast<const float4*>(dy + r * n + col);
+            if (relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + r * n + col);
+                if (!(yy.x > 0.f)) g.x = 0.f;
+                if (!(yy.y > 0.f)) g.y = 0.f;
+                if (!(yy.z > 0.f)) g.z = 0.f;
+                if (!(yy.w > 0.f)) g.w = 0.f;
+            }
+            *reinterpret_cast<float4*>(dzs + r * n + col) = make_float4(g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w);
+            ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+        }
+    }
+    sb[rl][cl] = ab;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        const float4 a = sb[0][cl], b = sb[1][cl], c = sb[2][cl], d = sb[3][cl];
+        *reinterpret_cast<float4*>(part_b + (int64_t)blockIdx.y * n + col) =
+            make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
     }
 }
 
@@ -189,20 +250,27 @@ __global__ __launch_bounds__(256) void wn_bwd_partial_kernel(const float* __rest
 }
 __global__ __launch_bounds__(256) void wn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ V, const float* __restrict__ g,
                                                            const float* __restrict__ part, float* __restrict__ dV, float* __restrict__ dg,
-                                                           int64_t elems, int cpm) {
-    __shared__ float cs;
+                                                           int64_t elems, int cpm, int vec) {
+    __shared__ float r0[4], r1[4];
     const int mat = blockIdx.y, ch = blockIdx.x;
-    if (threadIdx.x == 0) {
-        float d = 0.f, n2 = 0.f;
-        for (int c = 0; c < cpm; ++c) { d += part[((int64_t)mat * cpm + c) * 2]; n2 += part[((int64_t)mat * cpm + c) * 2 + 1]; }
-        cs = d / n2;
-        if (ch == 0) dg[mat] = d / g[mat];
-    }
+    float d = 0.f, n2 = 0.f;                                        // every workgroup re-reduces its matrix's partials in the same fixed tree
+    for (int c = threadIdx.x; c < cpm; c += 256) { d += part[((int64_t)mat * cpm + c) * 2]; n2 += part[((int64_t)mat * cpm + c) * 2 + 1]; }
+    d = wave_sum(d); n2 = wave_sum(n2);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = d; r1[threadIdx.x >> 6] = n2; }
     __syncthreads();
-    const float c = cs;
+    d = (r0[0] + r0[1]) + (r0[2] + r0[3]); n2 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    if (ch == 0 && threadIdx.x == 0) dg[mat] = d / g[mat];
+    const float c = d / n2;
     const int64_t lo = (int64_t)ch * WNB_CHUNK, hi = min(elems, lo + WNB_CHUNK);
     const float* w = G + (int64_t)mat * elems; const float* v = V + (int64_t)mat * elems;
     float* o = dV + (int64_t)mat * elems;
+    if (vec) {                                                      // elems % 4 == 0 and 16-B aligned bases: whole float4s only
+        for (int64_t j = lo + 4 * (int64_t)threadIdx.x; j < hi; j += 1024) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + j), vv = *reinterpret_cast<const float4*>(v + j);
+            *reinterpret_cast<float4*>(o + j) = make_float4(fmaf(-c, vv.x, ww.x), fmaf(-c, vv.y, ww.y), fmaf(-c, vv.z, ww.z), fmaf(-c, vv.w, ww.w));
+        }
+        return;
+    }
     for (int64_t j = lo + threadIdx.x; j < hi; j += 256) o[j] = fmaf(-c, v[j], w[j]);
 }
 
@@ -239,7 +307,10 @@ extern "C" int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch
 extern "C" int cti_sum_batches(const float* src, float* dst, int nb, int64_t n, float alpha, float beta, void* stream) {
     CTI_REQUIRE_PTR(src); CTI_REQUIRE_PTR(dst);
     CTI_REQUIRE(nb > 0 && n > 0, CTI_E_SHAPE, "cti_sum_batches: nb=%d n=%lld", nb, (long long)n);
-    hipLaunchKernelGGL(sum_batches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, nb, n, alpha, beta);
+    if (nb >= 32 && n < (1 << 20))
+        hipLaunchKernelGGL(sum_batches_tall_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, as_stream(stream), src, dst, nb, n, alpha, beta);
+    else
+        hipLaunchKernelGGL(sum_batches_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, nb, n, alpha, beta);
     return launch_status("cti_sum_batches");
 }
 
@@ -279,7 +350,10 @@ extern "C" int cti_act_bwd(const float* dy, const float* y, const float* scale, 
     const int64_t rpc = (rows + chunks - 1) / chunks;
     float* pb = static_cast<float*>(workspace);
     const int relu = act == CTI_ACT_RELU ? 1 : 0, sdiv = scale ? scale_div : 1;
-    if (n <= 16)      hipLaunchKernelGGL(act_bwd_kernel<16>, dim3((n + 15) / 16, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
+    const bool v4 = n >= 256 && n % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dzs) |
+                                                 reinterpret_cast<uintptr_t>(pb)) & 15) == 0;
+    if (v4)           hipLaunchKernelGGL(act_bwd_v4_kernel, dim3((n / 4 + 63) / 64, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
+    else if (n <= 16) hipLaunchKernelGGL(act_bwd_kernel<16>, dim3((n + 15) / 16, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
     else if (n <= 32) hipLaunchKernelGGL(act_bwd_kernel<32>, dim3((n + 31) / 32, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
     else              hipLaunchKernelGGL(act_bwd_kernel<64>, dim3((n + 63) / 64, chunks), dim3(256), 0, as_stream(stream), dy, y, scale, sdiv, dzs, pb, rows, n, relu, rpc);
     int rc = launch_status("cti_act_bwd"); if (rc) return rc;
@@ -304,8 +378,9 @@ extern "C" int cti_wn_bwd(const float* G, const float* weight_v, const float* we
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(wn_bwd_partial_kernel, dim3(cpm, n_mats), dim3(256), 0, as_stream(stream), G, weight_v, part, elems, cpm);
     int rc = launch_status("cti_wn_bwd/partial"); if (rc) return rc;
+    const int vec = elems % 4 == 0 && ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(weight_v) | reinterpret_cast<uintptr_t>(dweight_v)) & 15) == 0;
     hipLaunchKernelGGL(wn_bwd_apply_kernel, dim3(cpm, n_mats), dim3(256), 0, as_stream(stream), G, weight_v, weight_g, part, dweight_v, dweight_g,
-                       elems, cpm);
+                       elems, cpm, vec);
     return launch_status("cti_wn_bwd/apply");
 }
 
