@@ -73,6 +73,9 @@ SIGNATURES = {
     "cti_kd_rows_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _int, _int, C.c_float, C.c_float, _vp]),
     "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _i64, _vp]),
     "cti_paralind_core_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_paralind_core_planes_fwd": (_int, [_vp, _vp, _i64, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_paralind_core_planes_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "cti_paralind_core_bwd_planes": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_ranknets_drop_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _int, _vp]),
     "cti_ranknets_drop_dw": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _vp]),
     "cti_ranknets_drop_dx": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _vp]),

@@ -94,6 +94,32 @@ class CoreFn(torch.autograd.Function):
         return ops.paralind_core_bwd(dout, M, Ar)
 
 
+class MBuildCoreFn(torch.autograd.Function):
+    """MBuildFn + CoreFn in the MFMA modes with M kept ONLY as the bf16 hi/lo operand planes of the mode-3 GEMM (what the fused eval forward
+    does): no fp32 M, no split pass over it; the backward rebuilds M = hi + lo for dAr and never needs it for the M-build gradients."""
+
+    @staticmethod
+    def supported(Vr, Ar, Teff):
+        R, I, J, K, G = Teff.shape
+        return (ops.get_precision() in ("bf16x3", "bf16") and I == J == K and (R * K) % 32 == 0 and Ar.shape[1] <= 8 and Vr.shape[0] > 0
+                and Vr.shape[0] <= 65535)
+
+    @staticmethod
+    def forward(ctx, Vr, Qr, Teff, Ar):
+        Mh, Ml = ops.paralind_mbuild_planes(Vr, Qr, Teff)
+        B, V, Q, G = Vr.shape[0], Vr.shape[1], Qr.shape[1], Teff.shape[4]
+        ctx.save_for_backward(Vr, Qr, Teff, Ar, Mh, Ml)
+        ctx.G = G
+        return ops.paralind_core_planes(Mh, Ml, Ar, B, V, Q, G)
+
+    @staticmethod
+    def backward(ctx, dout):
+        Vr, Qr, Teff, Ar, Mh, Ml = ctx.saved_tensors
+        dM, dAr = ops.paralind_core_bwd_planes(dout, Mh, Ml, Ar, ctx.G)
+        dVr, dQr, dTeff = ops.paralind_mbuild_bwd(dM, Vr, Qr, Teff)
+        return dVr, dQr, dTeff, dAr
+
+
 class TriSoftmaxFn(torch.autograd.Function):
     """Masked softmax of TriAttention (src/attention.py:55-58).  The -inf fill happens on logits' DATA, untracked, exactly like the
     reference's `logits.data.masked_fill_`; masked positions have p = 0 and receive a zero gradient."""

@@ -141,3 +141,29 @@ extern "C" int cti_paralind_core_fwd(const float* M, const float* Ar, float* out
         return gemm_nt_planes(c, as_stream(stream));
     }
 }
+
+// mode 3 + rank sum with M already in operand planes (cti_paralind_mbuild_planes_fwd): only Ar is split here
+extern "C" size_t cti_paralind_core_planes_workspace_bytes(int B, int A, int K, int prec) {
+    if (prec == CTI_PREC_F32 || B <= 0 || A <= 0 || K <= 0) return 0;
+    return align256(planes_bytes((int64_t)B * A + PLANE_SLACK_ROWS, K));
+}
+
+extern "C" int cti_paralind_core_planes_fwd(const void* Mh, const void* Ml, int64_t rows_alloc, const float* Ar, float* out, int B, int VQ, int A, int G,
+                                            int K, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(Mh); CTI_REQUIRE_PTR(Ml); CTI_REQUIRE_PTR(Ar); CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && VQ > 0 && A > 0 && G > 0 && K > 0 && K % 32 == 0 && rows_alloc >= (int64_t)B * VQ * G + PLANE_SLACK_ROWS, CTI_E_SHAPE,
+                "cti_paralind_core_planes_fwd: B=%d VQ=%d A=%d G=%d K=%d (a multiple of 32) rows_alloc=%lld", B, VQ, A, G, K, (long long)rows_alloc);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_paralind_core_planes_fwd: precision mode %d", prec);
+    CTI_REQUIRE(workspace_bytes >= cti_paralind_core_planes_workspace_bytes(B, A, K, prec), CTI_E_WORKSPACE, "cti_paralind_core_planes_fwd: workspace too small");
+    const int Kp = planes_kp(K);
+    const int64_t arows = (int64_t)B * A, rb = arows + PLANE_SLACK_ROWS;
+    unsigned short* ah = static_cast<unsigned short*>(workspace);
+    unsigned short* al = ah + (size_t)rb * Kp;
+    int rc = split_planes(Ar, K, arows, K, ah, al, rb, as_stream(stream)); if (rc) return rc;
+    PlaneGemmArgs c{};
+    c.Ah = static_cast<const unsigned short*>(Mh); c.Al = static_cast<const unsigned short*>(Ml); c.Bh = ah; c.Bl = al; c.rows_allocA = rows_alloc; c.rows_allocB = rb;
+    c.rA1 = (int64_t)VQ * G; c.rB1 = A; c.nb1 = B; c.nb2 = 1;
+    c.M = VQ * G; c.N = A; c.Kp = Kp; c.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; c.epi = 3; c.gdiv = G;
+    c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC1 = (int64_t)VQ * A * G;
+    return gemm_nt_planes(c, as_stream(stream));
+}

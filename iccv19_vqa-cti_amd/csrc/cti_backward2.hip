@@ -728,6 +728,48 @@ __global__ __launch_bounds__(256) void core_bwd_dar_kernel(const float* __restri
     }
 }
 
+
+// dAr with M held as bf16 hi/lo operand planes ([k >> 4][row][k & 15], the training forward's M): one workgroup per (16-column chunk, sample),
+// 8 column pairs x 32 row phases; M = hi + lo (16 mantissa bits)
+__global__ __launch_bounds__(256) void core_bwd_dar_planes_kernel(const float* __restrict__ dout, const unsigned short* __restrict__ Mh,
+                                                                  const unsigned short* __restrict__ Ml, int64_t rows_alloc, float* __restrict__ dAr,
+                                                                  int VQ, int A, int G, int K) {
+    __shared__ float red[32][CB_AMAX][16];
+    const int kc = blockIdx.x, b = blockIdx.y;
+    const int kp = threadIdx.x & 7, rp = threadIdx.x >> 3;
+    const int J = VQ * G;
+    const int64_t base = ((int64_t)kc * rows_alloc + (int64_t)b * J) * 16;
+    const uint32_t* ph = reinterpret_cast<const uint32_t*>(Mh + base) + kp;
+    const uint32_t* pl = reinterpret_cast<const uint32_t*>(Ml + base) + kp;
+    const float* db = dout + (int64_t)b * VQ * A * G;
+    float acc[CB_AMAX][2];
+#pragma unroll
+    for (int a = 0; a < CB_AMAX; ++a) { acc[a][0] = 0.f; acc[a][1] = 0.f; }
+    for (int j = rp; j < J; j += 32) {
+        const uint32_t hh = ph[(int64_t)j * 8], ll = pl[(int64_t)j * 8];
+        const float m0 = __uint_as_float(hh << 16) + __uint_as_float(ll << 16);
+        const float m1 = __uint_as_float(hh & 0xffff0000u) + __uint_as_float(ll & 0xffff0000u);
+        const int vq = j / G, g = j - vq * G;
+        const float* dp = db + (int64_t)vq * A * G + g;
+#pragma unroll
+        for (int a = 0; a < CB_AMAX; ++a)
+            if (a < A) { const float d = dp[a * G]; acc[a][0] = fmaf(d, m0, acc[a][0]); acc[a][1] = fmaf(d, m1, acc[a][1]); }
+    }
+#pragma unroll
+    for (int a = 0; a < CB_AMAX; ++a)
+        if (a < A) { red[rp][a][2 * kp] = acc[a][0]; red[rp][a][2 * kp + 1] = acc[a][1]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * 16; i += 256) {
+        const int a = i >> 4, kk = i & 15, k = kc * 16 + kk;
+        if (k < K) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) s += red[r][a][kk];
+            dAr[((int64_t)b * A + a) * K + k] = s;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace cti
 
@@ -874,4 +916,21 @@ extern "C" int cti_paralind_core_bwd(const float* dout, const float* M, const fl
     int rc = launch_status("cti_paralind_core_bwd/dM"); if (rc) return rc;
     hipLaunchKernelGGL(core_bwd_dar_kernel, dim3((K4 + 31) / 32, B), dim3(256), 0, as_stream(stream), dout, M, dAr, VQ, A, G, K4);
     return launch_status("cti_paralind_core_bwd/dAr");
+}
+
+extern "C" int cti_paralind_core_bwd_planes(const float* dout, const void* Mh, const void* Ml, int64_t rows_alloc, const float* Ar, float* dM, float* dAr,
+                                            int B, int V, int Q, int A, int G, int K, void* stream) {
+    CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(Mh); CTI_REQUIRE_PTR(Ml); CTI_REQUIRE_PTR(Ar); CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(dAr);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && A > 0 && A <= CB_AMAX && G > 0 && K > 0 && K % 32 == 0 &&
+                rows_alloc >= (int64_t)B * V * Q * G, CTI_E_SHAPE, "cti_paralind_core_bwd_planes: B=%d V=%d Q=%d A=%d (<= 8) G=%d K=%d (a multiple of 32)", B, V, Q, A, G, K);
+    CTI_REQUIRE(((reinterpret_cast<uintptr_t>(Ar) | reinterpret_cast<uintptr_t>(dM) | reinterpret_cast<uintptr_t>(Mh) | reinterpret_cast<uintptr_t>(Ml)) & 15) == 0,
+                CTI_E_SHAPE, "cti_paralind_core_bwd_planes: operands must be 16-B aligned");
+    const int K4 = K / 4, VQ = V * Q;
+    const int64_t total4 = (int64_t)B * VQ * G * K4;
+    CTI_REQUIRE((total4 + 255) / 256 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd_planes: %lld elements exceed one launch", (long long)total4 * 4);
+    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, total4);
+    int rc = launch_status("cti_paralind_core_bwd_planes/dM"); if (rc) return rc;
+    hipLaunchKernelGGL(core_bwd_dar_planes_kernel, dim3(K / 16, B), dim3(256), 0, as_stream(stream), dout, static_cast<const unsigned short*>(Mh),
+                       static_cast<const unsigned short*>(Ml), rows_alloc, dAr, VQ, A, G, K);
+    return launch_status("cti_paralind_core_bwd_planes/dAr");
 }

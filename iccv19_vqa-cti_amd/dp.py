@@ -52,6 +52,7 @@ class FlatAdamaxDP:
             p.grad = None
             self.offsets.append(off)
             off += (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self._grad_views = [self.flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]   # built once, re-attached every step
         lib = L.lib()
         self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
@@ -87,8 +88,8 @@ class FlatAdamaxDP:
         table = (ctypes.c_int64 * (3 * len(rows)))(*[x for r in rows for x in r])       # host array: the entries ride in kernel arguments
         L.check(L.lib().cti_flat_gather(table, len(rows), self.flat_g.data_ptr(), self.n, torch.cuda.current_stream().cuda_stream),
                 "cti_flat_gather")
-        for p, off in zip(self.params, self.offsets):
-            p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+        for p, gv in zip(self.params, self._grad_views):
+            p.grad = gv
         del keep                                                 # stream-ordered: the caching allocator reuses them only after the gather
 
     def step(self):

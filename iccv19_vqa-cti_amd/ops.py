@@ -231,8 +231,10 @@ def paralind_mbuild_planes(Vr, Qr, Teff, use_mfma=True):
         raise ValueError("R*hr = %d must be a multiple of 32 (the planes' K padding)" % (R * K))
     Vr, Qr, Teff = Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
     rows_alloc = B * V * Q * G + 256
-    Mh = torch.zeros((R * K // 16, rows_alloc, 16), device=Vr.device, dtype=torch.int16)
-    Ml = torch.zeros_like(Mh)
+    Mh = torch.empty((R * K // 16, rows_alloc, 16), device=Vr.device, dtype=torch.int16)
+    Ml = torch.empty_like(Mh)
+    Mh[:, rows_alloc - 256:, :].zero_()                                    # only the tile over-read slack needs defined contents
+    Ml[:, rows_alloc - 256:, :].zero_()
     Tt = transpose(Teff, I, J * K * G, batch=R, s_src=I * J * K * G, ld_src=J * K * G, s_dst=I * J * K * G, ld_dst=I).view(R, J * K * G, I) if use_mfma else None
     L.check(L.lib().cti_paralind_mbuild_planes_fwd(Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), _ptr(Tt), Mh.data_ptr(), Ml.data_ptr(), B, V, Q, R, I, G,
                                                    rows_alloc, _stream()), "cti_paralind_mbuild_planes_fwd")
@@ -257,6 +259,33 @@ def paralind_core(M, Ar, prec=None):
       L.check(lib.cti_paralind_core_fwd(M.data_ptr(), Ar.data_ptr(), out.data_ptr(), B, V * Q, A, G, K, pr, _ptr(ws), wsb, _stream()),
             "cti_paralind_core_fwd")
     return out
+
+
+def paralind_core_planes(Mh, Ml, Ar, B, V, Q, G, prec=None):
+    """Mode 3 + rank sum with M given as operand planes (paralind_mbuild_planes): out (B,V,Q,A,G)."""
+    _req(Ar, "Ar")
+    Ar = Ar.contiguous()
+    A, K = Ar.shape[1], Ar.shape[2]
+    out = torch.empty((B, V, Q, A, G), device=Ar.device, dtype=torch.float32)
+    pr = _prec(prec)
+    lib = L.lib()
+    wsb = lib.cti_paralind_core_planes_workspace_bytes(B, A, K, pr)
+    ws = torch.empty(max(wsb, 16), device=Ar.device, dtype=torch.uint8)
+    L.check(lib.cti_paralind_core_planes_fwd(Mh.data_ptr(), Ml.data_ptr(), Mh.shape[1], Ar.data_ptr(), out.data_ptr(), B, V * Q, A, G, K, pr,
+                                             ws.data_ptr(), wsb, _stream()), "cti_paralind_core_planes_fwd")
+    return out
+
+
+def paralind_core_bwd_planes(dout, Mh, Ml, Ar, G):
+    """dM (B,V,Q,G,K) and dAr (B,A,K) from dout (B,V,Q,A,G) with M held as operand planes."""
+    B, V, Q, A, _ = dout.shape
+    K = Ar.shape[2]
+    dout, Ar = _req(dout, "dout").contiguous(), Ar.contiguous()
+    dM = torch.empty((B, V, Q, G, K), device=dout.device, dtype=torch.float32)
+    dAr = torch.empty_like(Ar)
+    L.check(L.lib().cti_paralind_core_bwd_planes(dout.data_ptr(), Mh.data_ptr(), Ml.data_ptr(), Mh.shape[1], Ar.data_ptr(), dM.data_ptr(), dAr.data_ptr(),
+                                                 B, V, Q, A, G, K, _stream()), "cti_paralind_core_bwd_planes")
+    return dM, dAr
 
 
 def _weight_arrays(tucker, rank):

@@ -124,8 +124,11 @@ class TCNet(nn.Module):
             raise RuntimeError("TCNet.forward: h_out must be 1 (src/Tensor.py:6 cannot view the core otherwise)")
         if _needs_grad(Vr, Qr, Ar, T):
             Teff = AG.TeffFn.apply(T)
-            M = AG.MBuildFn.apply(Vr, Qr, Teff)
-            f_emb = AG.CoreFn.apply(M, Ar)
+            if AG.MBuildCoreFn.supported(Vr, Ar, Teff):
+                f_emb = AG.MBuildCoreFn.apply(Vr, Qr, Teff, Ar)
+            else:
+                M = AG.MBuildFn.apply(Vr, Qr, Teff)
+                f_emb = AG.CoreFn.apply(M, Ar)
         else:
             Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
             M = ops.paralind_mbuild(Vr, Qr, Teff)

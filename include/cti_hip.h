@@ -239,6 +239,16 @@ int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uin
 int cti_paralind_core_bwd(const float* dout, const float* M, const float* Ar, float* dM, float* dAr, int B, int V, int Q, int A, int G, int K,
                           void* stream);
 
+/* The same pair with M held as the bf16 hi/lo operand planes cti_paralind_mbuild_planes_fwd writes (element (row, k) at
+ * [k >> 4][row][k & 15], rows_alloc rows per 16-column chunk) -- the TRAINING forward keeps M only in this form: the mode-3 GEMM reads it
+ * without a split pass, the backward rebuilds M = hi + lo for dAr.  K % 32 == 0; fwd: prec = CTI_PREC_BF16X3 or CTI_PREC_BF16,
+ * workspace of cti_paralind_core_planes_workspace_bytes (the planes of Ar); bwd: A <= 8. */
+int cti_paralind_core_planes_fwd(const void* Mh, const void* Ml, int64_t rows_alloc, const float* Ar, float* out, int B, int VQ, int A, int G, int K,
+                                 int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_paralind_core_planes_workspace_bytes(int B, int A, int K, int prec);
+int cti_paralind_core_bwd_planes(const float* dout, const void* Mh, const void* Ml, int64_t rows_alloc, const float* Ar, float* dM, float* dAr, int B,
+                                 int V, int Q, int A, int G, int K, void* stream);
+
 /* The R rank nets of TCNet in train mode (src/tc.py:29-31, 44-46 with src/fc.py:25-28: every FCNet([h, hr]) drops its OWN mask on the
  * shared input) without materialising the R masked copies: mask (R, rows, h) bytes from cti_dropout(y = NULL), x (rows, h), W (R*hr, h) the
  * packed weight_v, scale (R,) from cti_wn_scale, bias (R*hr,) or NULL, p the drop probability.

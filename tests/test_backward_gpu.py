@@ -304,3 +304,24 @@ def test_core_backward_streaming_passes_match_the_einsum(B, V, Q, A, G, K):
     dM, dAr = cti_amd.pkg.ops.paralind_core_bwd(dout.to(DEV), M.to(DEV), Ar.to(DEV))
     check(dM, torch.einsum("bvqag,bak->bvqgk", dout.double(), Ar.double()).numpy(), tol=1e-5, what="dM")
     check(dAr, torch.einsum("bvqag,bvqgk->bak", dout.double(), M.double()).numpy(), tol=1e-5, what="dAr")
+
+
+@pytest.mark.parametrize("B,V,Q,A,R,hr,G", [(3, 36, 14, 3, 32, 16, 2), (2, 7, 5, 6, 8, 4, 1), (2, 10, 3, 3, 2, 16, 2), (2, 5, 4, 4, 4, 8, 3)])
+def test_training_core_on_planes_matches_the_fp32_M_route(B, V, Q, A, R, hr, G):
+    """MBuildCoreFn (M only as bf16 hi/lo planes; MFMA and VALU plane-writing M builds) against MBuildFn + CoreFn: outputs and all four gradients."""
+    AG = cti_amd.pkg.autograd
+    g = torch.Generator().manual_seed(R * 10 + hr)
+    mk = lambda *s: (torch.randn(*s, generator=g) / 2).to(DEV).requires_grad_(True)
+    Vr, Qr, Ar, Teff = mk(B, V, R * hr), mk(B, Q, R * hr), mk(B, A, R * hr), mk(R, hr, hr, hr, G)
+    if not AG.MBuildCoreFn.supported(Vr, Ar, Teff):
+        pytest.skip("the exact-fp32 mode keeps M in fp32")
+    cot = torch.randn(B, V, Q, A, G, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        out = AG.MBuildCoreFn.apply(Vr, Qr, Teff, Ar) if fused else AG.CoreFn.apply(AG.MBuildFn.apply(Vr, Qr, Teff), Ar)
+        (out * cot).sum().backward()
+        res.append([out.detach().cpu().numpy()] + [t.grad.cpu().numpy() for t in (Vr, Qr, Teff, Ar)])
+        for t in (Vr, Qr, Teff, Ar):
+            t.grad = None
+    for n_, a_, b_ in zip(("out", "dVr", "dQr", "dTeff", "dAr"), res[0], res[1]):
+        check(torch.from_numpy(a_), b_, tol=2e-5, what="core on planes " + n_)
