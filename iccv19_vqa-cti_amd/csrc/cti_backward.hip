@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     // straddle two copies): one 16-B load, one 16-B store, one 4-B mask access, one 64-bit modulo per group instead of per element
     const int64_t s0 = period ? i0 % period : i0;
     if (!y) {                                                           // mask only (cti_ranknets_drop_* apply it where they form their operands)
+        if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(mask) & 3) == 0) {
+            *reinterpret_cast<uchar4*>(mask + i0) = make_uchar4(rr[0] >= thr, rr[1] >= thr, rr[2] >= thr, rr[3] >= thr);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (i0 + j < n) mask[i0 + j] = rr[j] >= thr ? 1 : 0;
@@ -334,7 +338,7 @@ extern "C" int cti_col_sum(const float* src, int64_t rows, int n, float* dst, fl
     return cti_sum_batches(part, dst, groups, n, alpha, beta, stream);
 }
 
-static int act_chunks(int64_t rows) { int c = (int)((rows + 255) / 256); return c < 1 ? 1 : (c > 1024 ? 1024 : c); }
+static int act_chunks(int64_t rows) { int64_t c = (rows + 63) / 64; return (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c)); }   // x column blocks = workgroups
 
 extern "C" size_t cti_act_bwd_workspace_bytes(int64_t rows, int n) {
     if (rows <= 0 || n <= 0) return 0;

@@ -670,23 +670,27 @@ int set_lds(K kern, size_t bytes, const char* what) {
 constexpr int CB_AMAX = 8;
 
 __global__ __launch_bounds__(256) void core_bwd_dm_kernel(const float* __restrict__ dout, const float* __restrict__ Ar, float* __restrict__ dM,
-                                                          int VQ, int A, int G, int K4, int64_t total4) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;       // float4 index into dM (B, VQ, G, K/4)
-    if (e >= total4) return;
-    const int c = (int)(e % K4);
-    const int64_t row = e / K4;                                       // (b, vq, g)
-    const int g = (int)(row % G);
-    const int64_t bvq = row / G;
-    const int64_t b = bvq / VQ;
-    const float* dp = dout + bvq * A * G + g;
-    const float4* ap = reinterpret_cast<const float4*>(Ar + b * A * (int64_t)K4 * 4) + c;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int a = 0; a < A; ++a) {
-        const float d = dp[a * G];
-        const float4 r = ap[(int64_t)a * K4];
-        o.x = fmaf(d, r.x, o.x); o.y = fmaf(d, r.y, o.y); o.z = fmaf(d, r.z, o.z); o.w = fmaf(d, r.w, o.w);
+                                                          int VQ, int A, int G, int K4, int rows_total) {
+    // 8 rows (b, vq, g) per workgroup, 32 lanes per row: the row's A cotangents are loaded once and reused for all its float4 columns
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), c0 = threadIdx.x & 31;
+    if (row >= rows_total) return;
+    const int bvq = row / G, g = row - bvq * G, b = bvq / VQ;
+    const float* dp = dout + (int64_t)bvq * A * G + g;
+    float d[CB_AMAX];
+#pragma unroll
+    for (int a = 0; a < CB_AMAX; ++a) d[a] = a < A ? dp[a * G] : 0.f;
+    const float4* ap = reinterpret_cast<const float4*>(Ar) + (int64_t)b * A * K4;
+    float4* op = reinterpret_cast<float4*>(dM) + (int64_t)row * K4;
+    for (int c = c0; c < K4; c += 32) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < CB_AMAX; ++a)
+            if (a < A) {
+                const float4 r = ap[(int64_t)a * K4 + c];
+                o.x = fmaf(d[a], r.x, o.x); o.y = fmaf(d[a], r.y, o.y); o.z = fmaf(d[a], r.z, o.z); o.w = fmaf(d[a], r.w, o.w);
+            }
+        op[c] = o;
     }
-    reinterpret_cast<float4*>(dM)[e] = o;
 }
 
 // one workgroup per (sample, 128 columns): 32 column groups (float4) x 8 row phases; the phases meet in LDS in a fixed order
@@ -729,42 +733,89 @@ __global__ __launch_bounds__(256) void core_bwd_dar_kernel(const float* __restri
 }
 
 
-// dAr with M held as bf16 hi/lo operand planes ([k >> 4][row][k & 15], the training forward's M): one workgroup per (16-column chunk, sample),
-// 8 column pairs x 32 row phases; M = hi + lo (16 mantissa bits)
+// dAr with M held as bf16 hi/lo operand planes ([k >> 4][row][k & 15], the training forward's M): one workgroup per (16-column chunk, sample);
+// a thread owns 8 columns of one row per step (one 16-B load per plane), 128 row phases; M = hi + lo (16 mantissa bits).  The sample's
+// cotangents sit in LDS; the row phases meet by wave shuffles, the 4 waves in LDS, all in a fixed order.
+__device__ __forceinline__ void unpack_bf16x8(const uint4 h, const uint4 l, float* m) {
+    const uint32_t hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m[2 * i] = __uint_as_float(hh[i] << 16) + __uint_as_float(ll[i] << 16);
+        m[2 * i + 1] = __uint_as_float(hh[i] & 0xffff0000u) + __uint_as_float(ll[i] & 0xffff0000u);
+    }
+}
+template <int AT>
 __global__ __launch_bounds__(256) void core_bwd_dar_planes_kernel(const float* __restrict__ dout, const unsigned short* __restrict__ Mh,
                                                                   const unsigned short* __restrict__ Ml, int64_t rows_alloc, float* __restrict__ dAr,
-                                                                  int VQ, int A, int G, int K) {
-    __shared__ float red[32][CB_AMAX][16];
+                                                                  int VQ, int A, int G, int K, int lds_dout) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [4 waves][2][AT][8] partials, then dout[b] (VQ*A*G floats) when it fits
+    float* red = sm;
+    float* ds = sm + 4 * 2 * AT * 8;
     const int kc = blockIdx.x, b = blockIdx.y;
-    const int kp = threadIdx.x & 7, rp = threadIdx.x >> 3;
+    const int t = threadIdx.x, kp = t & 1, rp = t >> 1, lane = t & 63, wid = t >> 6;
     const int J = VQ * G;
-    const int64_t base = ((int64_t)kc * rows_alloc + (int64_t)b * J) * 16;
-    const uint32_t* ph = reinterpret_cast<const uint32_t*>(Mh + base) + kp;
-    const uint32_t* pl = reinterpret_cast<const uint32_t*>(Ml + base) + kp;
     const float* db = dout + (int64_t)b * VQ * A * G;
-    float acc[CB_AMAX][2];
+    if (lds_dout) {
+        for (int i = t; i < VQ * A * G; i += 256) ds[i] = db[i];
+        __syncthreads();
+    }
+    const float* dsrc = lds_dout ? ds : db;
+    const int64_t base = ((int64_t)kc * rows_alloc + (int64_t)b * J) * 16 + kp * 8;
+    const unsigned short* ph = Mh + base;
+    const unsigned short* pl = Ml + base;
+    float acc[AT][8];
 #pragma unroll
-    for (int a = 0; a < CB_AMAX; ++a) { acc[a][0] = 0.f; acc[a][1] = 0.f; }
-    for (int j = rp; j < J; j += 32) {
-        const uint32_t hh = ph[(int64_t)j * 8], ll = pl[(int64_t)j * 8];
-        const float m0 = __uint_as_float(hh << 16) + __uint_as_float(ll << 16);
-        const float m1 = __uint_as_float(hh & 0xffff0000u) + __uint_as_float(ll & 0xffff0000u);
-        const int vq = j / G, g = j - vq * G;
-        const float* dp = db + (int64_t)vq * A * G + g;
+    for (int a = 0; a < AT; ++a)
 #pragma unroll
-        for (int a = 0; a < CB_AMAX; ++a)
-            if (a < A) { const float d = dp[a * G]; acc[a][0] = fmaf(d, m0, acc[a][0]); acc[a][1] = fmaf(d, m1, acc[a][1]); }
+        for (int e = 0; e < 8; ++e) acc[a][e] = 0.f;
+    for (int j0 = rp; j0 < J; j0 += 512) {                           // 4 rows per trip, their loads in flight together
+        uint4 hv[4], lv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 128 * u;
+            if (j < J) { hv[u] = *reinterpret_cast<const uint4*>(ph + (int64_t)j * 16); lv[u] = *reinterpret_cast<const uint4*>(pl + (int64_t)j * 16); }
+            else { hv[u] = make_uint4(0, 0, 0, 0); lv[u] = hv[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 128 * u;
+            if (j < J) {
+                float m[8];
+                unpack_bf16x8(hv[u], lv[u], m);
+                const int vq = j / G, g = j - vq * G;
+                const float* dp = dsrc + vq * A * G + g;
+#pragma unroll
+                for (int a = 0; a < AT; ++a)
+                    if (a < A) {
+                        const float d = dp[a * G];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[a][e] = fmaf(d, m[e], acc[a][e]);
+                    }
+            }
+        }
     }
 #pragma unroll
-    for (int a = 0; a < CB_AMAX; ++a)
-        if (a < A) { red[rp][a][2 * kp] = acc[a][0]; red[rp][a][2 * kp + 1] = acc[a][1]; }
+    for (int a = 0; a < AT; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[a][e];
+#pragma unroll
+            for (int o = 2; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);     // the 32 row phases of this wave (lane bit 0 is the column half)
+            acc[a][e] = v;
+        }
+    if (lane < 2) {
+#pragma unroll
+        for (int a = 0; a < AT; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[((wid * 2 + lane) * AT + a) * 8 + e] = acc[a][e];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < A * 16; i += 256) {
-        const int a = i >> 4, kk = i & 15, k = kc * 16 + kk;
+    for (int i = t; i < A * 16; i += 256) {
+        const int a = i >> 4, kk = i & 15, k = kc * 16 + kk, half = kk >> 3, e = kk & 7;
         if (k < K) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) s += red[r][a][kk];
+            for (int w = 0; w < 4; ++w) s += red[((w * 2 + half) * AT + a) * 8 + e];
             dAr[((int64_t)b * A + a) * K + k] = s;
         }
     }
@@ -912,7 +963,8 @@ extern "C" int cti_paralind_core_bwd(const float* dout, const float* M, const fl
     const int K4 = K / 4, VQ = V * Q;
     const int64_t total4 = (int64_t)B * VQ * G * K4;
     CTI_REQUIRE((total4 + 255) / 256 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd: %lld elements exceed one launch", (long long)total4 * 4);
-    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, total4);
+    CTI_REQUIRE(total4 / K4 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd: %lld rows exceed one launch", (long long)(total4 / K4));
+    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 / K4 + 7) / 8)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, (int)(total4 / K4));
     int rc = launch_status("cti_paralind_core_bwd/dM"); if (rc) return rc;
     hipLaunchKernelGGL(core_bwd_dar_kernel, dim3((K4 + 31) / 32, B), dim3(256), 0, as_stream(stream), dout, M, dAr, VQ, A, G, K4);
     return launch_status("cti_paralind_core_bwd/dAr");
@@ -928,9 +980,16 @@ extern "C" int cti_paralind_core_bwd_planes(const float* dout, const void* Mh, c
     const int K4 = K / 4, VQ = V * Q;
     const int64_t total4 = (int64_t)B * VQ * G * K4;
     CTI_REQUIRE((total4 + 255) / 256 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd_planes: %lld elements exceed one launch", (long long)total4 * 4);
-    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, total4);
+    CTI_REQUIRE(total4 / K4 <= 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_core_bwd_planes: %lld rows exceed one launch", (long long)(total4 / K4));
+    hipLaunchKernelGGL(core_bwd_dm_kernel, dim3((unsigned)((total4 / K4 + 7) / 8)), dim3(256), 0, as_stream(stream), dout, Ar, dM, VQ, A, G, K4, (int)(total4 / K4));
     int rc = launch_status("cti_paralind_core_bwd_planes/dM"); if (rc) return rc;
-    hipLaunchKernelGGL(core_bwd_dar_planes_kernel, dim3(K / 16, B), dim3(256), 0, as_stream(stream), dout, static_cast<const unsigned short*>(Mh),
-                       static_cast<const unsigned short*>(Ml), rows_alloc, dAr, VQ, A, G, K);
+    const size_t dbytes = sizeof(float) * (size_t)VQ * A * G;
+    const int lds_dout = dbytes <= 48 * 1024;
+    const unsigned short* mh = static_cast<const unsigned short*>(Mh);
+    const unsigned short* ml = static_cast<const unsigned short*>(Ml);
+#define CTI_DAR(ATv) hipLaunchKernelGGL((core_bwd_dar_planes_kernel<ATv>), dim3(K / 16, B), dim3(256), sizeof(float) * 4 * 2 * ATv * 8 + (lds_dout ? dbytes : 0), \
+                                        as_stream(stream), dout, mh, ml, rows_alloc, dAr, VQ, A, G, K, lds_dout)
+    if (A <= 3) CTI_DAR(3); else if (A <= 6) CTI_DAR(6); else CTI_DAR(8);
+#undef CTI_DAR
     return launch_status("cti_paralind_core_bwd_planes/dAr");
 }
