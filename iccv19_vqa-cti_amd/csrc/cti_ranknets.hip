@@ -17,8 +17,11 @@ namespace {
 
 typedef float rf32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float4 ld4(const float* p, bool ok) { return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ uchar4 ldm4(const uint8_t* p, bool ok) { return ok ? *reinterpret_cast<const uchar4*>(p) : make_uchar4(0, 0, 0, 0); }
+// Every load below is UNCONDITIONAL from a clamped (always valid) address; out-of-range lanes are zeroed by a select on the value, or
+// left as garbage where the result is never stored (a predicated load costs an exec-mask region and a wait of its own per instruction).
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uchar4 ldm4(const uint8_t* p) { return *reinterpret_cast<const uchar4*>(p); }
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
 
 // ---- forward: a wave owns 16 rows (its x fragments: NS float4 per lane) and walks its share of the ranks ---------------------------
 template <int NS>
@@ -31,21 +34,25 @@ __global__ __launch_bounds__(256) void rn_fwd_kernel(const float* __restrict__ x
     if (tile0 >= rows) return;
     const int64_t m = tile0 + l15;                                   // the row this lane feeds as the A operand
     const bool mok = m < rows, nok = l15 < hr;
+    const int64_t mc = mok ? m : rows - 1;
     float4 xf[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) xf[s] = ld4(x + m * h + s * 16 + 4 * kq, mok && s * 16 + 4 * kq < h);
+    for (int s = 0; s < NS; ++s) {
+        const bool kok = s * 16 + 4 * kq < h;
+        xf[s] = sel4(mok && kok, ld4(x + mc * h + (kok ? s * 16 + 4 * kq : 0)));       // zero rows / columns past the end: they add nothing below
+    }
     const int r_lo = blockIdx.y * r_per, r_hi = min(R, r_lo + r_per);
     const int ldy = R * hr;
     for (int r = r_lo; r < r_hi; ++r) {
-        const uint8_t* mp = mask + ((int64_t)r * rows + (mok ? m : 0)) * h + 4 * kq;
-        const float* wp = W + ((int64_t)r * hr + (nok ? l15 : 0)) * h + 4 * kq;
+        const uint8_t* mp = mask + ((int64_t)r * rows + mc) * h;
+        const float* wp = W + ((int64_t)r * hr + (nok ? l15 : 0)) * h;
         rf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s * 16 < h) {                                        // uniform
-                const bool kok = s * 16 + 4 * kq < h;
-                const uchar4 mk = ldm4(mp + s * 16, mok && kok);
-                const float4 w = ld4(wp + s * 16, nok && kok);
+                const int ko = s * 16 + 4 * kq < h ? s * 16 + 4 * kq : 0;    // past-the-end columns: x is zero there, any W / mask will do
+                const uchar4 mk = ldm4(mp + ko);
+                const float4 w = ld4(wp + ko);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.x ? xf[s].x : 0.f, w.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.y ? xf[s].y : 0.f, w.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.z ? xf[s].z : 0.f, w.z, acc, 0, 0, 0);
@@ -81,15 +88,18 @@ __global__ __launch_bounds__(1024) void rn_dw_kernel(const float* __restrict__ d
     rf32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = rf32x4{0.f, 0.f, 0.f, 0.f};
+    const int kc = kok ? k : 0;                                      // past-the-end columns are computed on column 0's data and never stored
     const float* zp = dzs + (int64_t)r * hr + (nok ? l15 : 0);
-    const float* xp = x + k;
-    const uint8_t* mp = mask + (int64_t)r * rows * h + k;
+    const float* xp = x + kc;
+    const uint8_t* mp = mask + (int64_t)r * rows * h + kc;
     for (int64_t m0 = m_lo; m0 < m_hi; m0 += 8) {                    // two 4-row steps per trip: their loads are in flight together
         const int64_t ra = m0 + kq, rb = m0 + 4 + kq;
         const bool oa = ra < m_hi, ob = rb < m_hi;
-        const float a0 = (oa && nok) ? zp[ra * ldz] : 0.f, a1 = (ob && nok) ? zp[rb * ldz] : 0.f;
-        const float4 x0 = ld4(xp + ra * h, oa && kok), x1 = ld4(xp + rb * h, ob && kok);
-        const uchar4 k0m = ldm4(mp + ra * h, oa && kok), k1m = ldm4(mp + rb * h, ob && kok);
+        const int64_t rac = oa ? ra : rows - 1, rbc = ob ? rb : rows - 1;
+        const float za = zp[rac * ldz], zb = zp[rbc * ldz];
+        const float a0 = (oa && nok) ? za : 0.f, a1 = (ob && nok) ? zb : 0.f;
+        const float4 x0 = sel4(oa, ld4(xp + rac * h)), x1 = sel4(ob, ld4(xp + rbc * h));
+        const uchar4 k0m = ldm4(mp + rac * h), k1m = ldm4(mp + rbc * h);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, k0m.x ? x0.x : 0.f, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, k0m.y ? x0.y : 0.f, acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, k0m.z ? x0.z : 0.f, acc[2], 0, 0, 0);
@@ -129,32 +139,37 @@ __global__ __launch_bounds__(256) void rn_dx_kernel(const float* __restrict__ dz
     rf32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = rf32x4{0.f, 0.f, 0.f, 0.f};
-    const float* zrow = dzs + (mok ? ma : 0) * ldz + 4 * kq;
+    const float* zrow = dzs + (mok ? ma : rows - 1) * ldz + 4 * kq;
+    const int kc = kok ? k : 0;                                      // past-the-end columns / rows: computed on valid data, never stored
+    int64_t mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mrow[i] = min(tile0 + 4 * kq + i, rows - 1) * h + kc;
+#pragma unroll 2
     for (int r = 0; r < R; ++r) {
         // A element j <-> n = 4*kq + j (the lane's contraction slot kq of MFMA j); B element: W[r*hr + 4*kq + j][k .. k+3]
         float a[4];
         if (z4ok && 4 * kq + 4 <= hr) {
-            const float4 z = ld4(zrow + r * hr, mok);
+            const float4 z = sel4(mok, ld4(zrow + r * hr));
             a[0] = z.x; a[1] = z.y; a[2] = z.z; a[3] = z.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = (mok && 4 * kq + j < hr) ? zrow[r * hr + j] : 0.f;
+            for (int j = 0; j < 4; ++j) { const float z = zrow[r * hr + (4 * kq + j < hr ? j : -4 * kq)]; a[j] = (mok && 4 * kq + j < hr) ? z : 0.f; }
         }
         rf32x4 P[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) P[t] = rf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 w = ld4(W + ((int64_t)r * hr + 4 * kq + j) * h + k, kok && 4 * kq + j < hr);
+            const float4 w = ld4(W + ((int64_t)r * hr + (4 * kq + j < hr ? 4 * kq + j : 0)) * h + kc);     // rows past hr meet a[j] = 0
             P[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w.x, P[0], 0, 0, 0);
             P[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w.y, P[1], 0, 0, 0);
             P[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w.z, P[2], 0, 0, 0);
             P[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w.w, P[3], 0, 0, 0);
         }
-        const uint8_t* mp = mask + ((int64_t)r * rows + tile0 + 4 * kq) * h + k;
+        const uint8_t* mp = mask + (int64_t)r * rows * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                               // P[t][i] = product at (row tile0 + 4*kq + i, column k + t)
-            const uchar4 mk = ldm4(mp + (int64_t)i * h, kok && tile0 + 4 * kq + i < rows);
+            const uchar4 mk = ldm4(mp + mrow[i]);
             acc[0][i] += mk.x ? P[0][i] : 0.f;
             acc[1][i] += mk.y ? P[1][i] : 0.f;
             acc[2][i] += mk.z ? P[2][i] : 0.f;
