@@ -21,9 +21,17 @@ typedef float rf32x4 __attribute__((ext_vector_type(4)));
 // left as garbage where the result is never stored (a predicated load costs an exec-mask region and a wait of its own per instruction).
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ uchar4 ldm4(const uint8_t* p) { return *reinterpret_cast<const uchar4*>(p); }
+__device__ __forceinline__ float4 ld4p(const float* p, bool ok) { return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ uchar4 ldm4p(const uint8_t* p, bool ok) { return ok ? *reinterpret_cast<const uchar4*>(p) : make_uchar4(0, 0, 0, 0); }
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
 
 // ---- forward: a wave owns 16 rows (its x fragments: NS float4 per lane) and walks its share of the ranks ---------------------------
+// 186 us for the visual branch (rows 9216, h 512, R 32), ~6x its MFMA time, and remarkably indifferent to what was tried on it
+// (tools/abl_ranknets.py, each measured): W_r staged through LDS by the workgroup, the mask as 16-B loads in a permuted k order, all
+// loads of a rank batched unconditionally at its top, a 4-deep prefetch ring, two or four accumulator chains -- 183-195 us every time;
+// unconditional loads everywhere let the scheduler hoist 64 loads per rank: 256 VGPRs, one wave per SIMD, 423 us.  Ablations: no MFMAs
+// 153 us, no mask loads 142 us, no W reads 187 us, no x loads 183 us, no stores 185 us, the bare loops 45 us.  The x fragments (128 VGPRs)
+// cap it at 2-3 waves per SIMD; the next design would hold them in LDS or split K over waves.
 template <int NS>
 __global__ __launch_bounds__(256) void rn_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, const float* __restrict__ W,
                                                      const float* __restrict__ scale, const float* __restrict__ bias, float* __restrict__ y,
@@ -34,25 +42,21 @@ __global__ __launch_bounds__(256) void rn_fwd_kernel(const float* __restrict__ x
     if (tile0 >= rows) return;
     const int64_t m = tile0 + l15;                                   // the row this lane feeds as the A operand
     const bool mok = m < rows, nok = l15 < hr;
-    const int64_t mc = mok ? m : rows - 1;
     float4 xf[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const bool kok = s * 16 + 4 * kq < h;
-        xf[s] = sel4(mok && kok, ld4(x + mc * h + (kok ? s * 16 + 4 * kq : 0)));       // zero rows / columns past the end: they add nothing below
-    }
+    for (int s = 0; s < NS; ++s) xf[s] = ld4p(x + m * h + s * 16 + 4 * kq, mok && s * 16 + 4 * kq < h);
     const int r_lo = blockIdx.y * r_per, r_hi = min(R, r_lo + r_per);
     const int ldy = R * hr;
     for (int r = r_lo; r < r_hi; ++r) {
-        const uint8_t* mp = mask + ((int64_t)r * rows + mc) * h;
-        const float* wp = W + ((int64_t)r * hr + (nok ? l15 : 0)) * h;
+        const uint8_t* mp = mask + ((int64_t)r * rows + (mok ? m : 0)) * h + 4 * kq;
+        const float* wp = W + ((int64_t)r * hr + (nok ? l15 : 0)) * h + 4 * kq;
         rf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s * 16 < h) {                                        // uniform
-                const int ko = s * 16 + 4 * kq < h ? s * 16 + 4 * kq : 0;    // past-the-end columns: x is zero there, any W / mask will do
-                const uchar4 mk = ldm4(mp + ko);
-                const float4 w = ld4(wp + ko);
+                const bool kok = s * 16 + 4 * kq < h;
+                const uchar4 mk = ldm4p(mp + s * 16, mok && kok);
+                const float4 w = ld4p(wp + s * 16, nok && kok);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.x ? xf[s].x : 0.f, w.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.y ? xf[s].y : 0.f, w.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mk.z ? xf[s].z : 0.f, w.z, acc, 0, 0, 0);
@@ -124,13 +128,13 @@ __global__ __launch_bounds__(1024) void rn_dw_kernel(const float* __restrict__ d
     }
 }
 
-// ---- input gradient: a wave owns a 16-row x 64-column tile of dx and sums the masked per-rank products -------------------------------
+// ---- input gradient: a workgroup owns a 16-row x 64-column tile of dx; its 4 waves sum the masked products of a quarter of the ranks each ---
 __global__ __launch_bounds__(256) void rn_dx_kernel(const float* __restrict__ dzs, const float* __restrict__ W, const uint8_t* __restrict__ mask,
                                                     float* __restrict__ dx, int64_t rows, int h, int R, int hr, float inv_keep, int z4ok) {
+    __shared__ float red[3][16][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wid) * 16;
-    if (tile0 >= rows) return;
+    const int64_t tile0 = (int64_t)blockIdx.x * 16;                  // one 16-row tile per workgroup; its 4 waves take a quarter of the ranks each
     const int k = blockIdx.y * 64 + 4 * l15;
     const bool kok = k < h;
     const int64_t ma = tile0 + l15;                                  // A operand row
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256) void rn_dx_kernel(const float* __restrict__ dz
     int64_t mrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) mrow[i] = min(tile0 + 4 * kq + i, rows - 1) * h + kc;
-#pragma unroll 2
-    for (int r = 0; r < R; ++r) {
+    const int r_per = (R + 3) / 4, r_lo = wid * r_per, r_hi = min(R, r_lo + r_per);
+    for (int r = r_lo; r < r_hi; ++r) {
         // A element j <-> n = 4*kq + j (the lane's contraction slot kq of MFMA j); B element: W[r*hr + 4*kq + j][k .. k+3]
         float a[4];
         if (z4ok && 4 * kq + 4 <= hr) {
@@ -176,7 +180,18 @@ __global__ __launch_bounds__(256) void rn_dx_kernel(const float* __restrict__ dz
             acc[3][i] += mk.w ? P[3][i] : 0.f;
         }
     }
-    if (kok) {
+    if (wid > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wid - 1][t * 4 + i][lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wid == 0 && kok) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i] = ((acc[t][i] + red[0][t * 4 + i][lane]) + red[1][t * 4 + i][lane]) + red[2][t * 4 + i][lane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t row = tile0 + 4 * kq + i;
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256) void rn_dx_kernel(const float* __restrict__ dz
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool rn_shape_ok(int64_t rows, int h, int R, int hr) {
-    return rows > 0 && h > 0 && R > 0 && hr > 0 && hr <= 16 && h % 4 == 0 && R <= 65535 && (rows + 63) / 64 <= 0x7fffffffLL;
+    return rows > 0 && h > 0 && R > 0 && hr > 0 && hr <= 16 && h % 4 == 0 && R <= 65535 && (rows + 15) / 16 <= 0x7fffffffLL;
 }
 
 }  // namespace
@@ -240,7 +255,7 @@ extern "C" int cti_ranknets_drop_dx(const float* dzs, const float* W, const uint
                 (long long)rows, h, R, hr, p);
     if (!rn_shape_ok(rows, h, R, hr) || !aligned16(W) || !aligned16(dx) || (reinterpret_cast<uintptr_t>(mask) & 3)) return CTI_E_UNSUPPORTED;
     const int z4ok = hr % 4 == 0 && aligned16(dzs);
-    hipLaunchKernelGGL(rn_dx_kernel, dim3((unsigned)((rows + 63) / 64), (h + 63) / 64), dim3(256), 0, as_stream(stream), dzs, W, mask, dx, rows, h, R, hr,
+    hipLaunchKernelGGL(rn_dx_kernel, dim3((unsigned)((rows + 15) / 16), (h + 63) / 64), dim3(256), 0, as_stream(stream), dzs, W, mask, dx, rows, h, R, hr,
                        1.f / (1.f - p), z4ok);
     return launch_status("cti_ranknets_drop_dx");
 }

@@ -202,6 +202,8 @@ def test_train_mode_runs_with_dropout_and_gives_gradients_to_every_parameter():
     (3, 6, 24, (7, 3), False, True),           # hr not a multiple of 4 (scalar dzs path), h < one 64-column block, odd rows
     (2, 4, 132, (1, 67), True, True),          # h not a multiple of 16 / 64: ragged k tails; rows not a multiple of 16
     (5, 12, 260, (2, 9), True, True),          # NS = 32 template with a tail
+    (3, 8, 80, (2, 21), True, True),           # h % 16 == 0 (16-B mask loads, permuted k order) with a partial 64-column group
+    (2, 16, 272, (1, 40), False, True),        # the same in the NS = 32 template
     (2, 32, 64, (3, 5), True, False),          # hr > 16: the general route (masked copies + batched GEMMs)
     (2, 8, 576, (2, 4), True, False),          # h > 512: the general route
 ])
