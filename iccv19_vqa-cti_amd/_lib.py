@@ -13,6 +13,8 @@ SIGNATURES = {
     "cti_last_error_string": (C.c_char_p, []),
     "cti_wn_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _sz, _vp]),
     "cti_wn_scale_workspace_bytes": (_sz, [_int, _i64]),
+    "cti_wn_scale_many": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]),
+    "cti_wn_scale_many_workspace_bytes": (_sz, [_vp, _int]),
     "cti_wn_linear_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_wn_linear_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "cti_zero_row_mask": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),

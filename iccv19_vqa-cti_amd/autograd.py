@@ -11,9 +11,10 @@ class WNLinearFn(torch.autograd.Function):
     (n_mats = 1: one FCNet layer, src/fc.py:22-29; n_mats = R: the packed rank nets of src/tc.py:29-31)."""
 
     @staticmethod
-    def forward(ctx, x, weight_v, weight_g, bias, relu, n_mats):
+    def forward(ctx, x, weight_v, weight_g, bias, relu, n_mats, scale=None):
         out_dim = weight_v.shape[0]
-        scale = ops.wn_scale(weight_v.reshape(n_mats, -1), weight_g.reshape(-1))
+        if scale is None:                                        # a layer's cached / batched scale (WNLinear.scale()) or computed here
+            scale = ops.wn_scale(weight_v.reshape(n_mats, -1), weight_g.reshape(-1))
         y = ops.wn_linear(x, weight_v, scale, out_dim // n_mats, bias, relu)
         ctx.save_for_backward(x, y, weight_v, weight_g, scale)
         ctx.relu, ctx.n_mats = relu, n_mats
@@ -30,7 +31,7 @@ class WNLinearFn(torch.autograd.Function):
             dx = ops.gemm_nt(dzs, Vt).view(x.shape)
         G = ops.gemm_tn(dzs, x.contiguous().view(-1, K))                           # (N, K) = dzs^T x
         dV, dg = ops.wn_bwd(G, V, g, ctx.n_mats)
-        return dx, dV.view_as(V), dg.view_as(g), db, None, None
+        return dx, dV.view_as(V), dg.view_as(g), db, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):

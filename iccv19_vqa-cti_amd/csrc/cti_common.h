@@ -39,7 +39,7 @@ __device__ __forceinline__ float wave_max(float x) {
 }
 
 // ---- weight-norm scales of several layers in two launches (cti_paralind.hip) --------------------------------------
-constexpr int WN_MAX = 8;
+constexpr int WN_MAX = 48;        // layers per launch pair (the struct travels in the kernel arguments: 2.3 KiB)
 constexpr int64_t WN_CHUNK = 4096;
 struct WnBatch {
     int n;

@@ -204,6 +204,35 @@ extern "C" int cti_wn_scale(const float* weight_v, const float* weight_g, float*
     return wn_scale_batch(wb, static_cast<float*>(workspace), as_stream(stream));
 }
 
+// scales of MANY layers of different sizes in two launches per WN_MAX layers (a training step recomputes every layer's scale once: 18 launch
+// pairs of ~14 us in the FFOE CTI model, 29 in BAN)
+extern "C" size_t cti_wn_scale_many_workspace_bytes(const int64_t* elems, int n) {
+    size_t chunks = 0;
+    for (int i = 0; i < n; ++i) chunks += elems && elems[i] > 0 ? (size_t)((elems[i] + WN_CHUNK - 1) / WN_CHUNK) : 0;
+    return sizeof(float) * chunks;
+}
+
+extern "C" int cti_wn_scale_many(const float* const* weight_v, const float* const* weight_g, float* const* scale, const int64_t* elems, int n,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(weight_v); CTI_REQUIRE_PTR(weight_g); CTI_REQUIRE_PTR(scale); CTI_REQUIRE_PTR(elems); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(n > 0, CTI_E_SHAPE, "cti_wn_scale_many: n=%d", n);
+    for (int i = 0; i < n; ++i)
+        CTI_REQUIRE(weight_v[i] && weight_g[i] && scale[i] && elems[i] > 0, CTI_E_SHAPE, "cti_wn_scale_many: entry %d has a NULL pointer or no elements", i);
+    CTI_REQUIRE(workspace_bytes >= cti_wn_scale_many_workspace_bytes(elems, n), CTI_E_WORKSPACE, "cti_wn_scale_many: workspace too small");
+    float* part = static_cast<float*>(workspace);
+    for (int i0 = 0; i0 < n; i0 += WN_MAX) {
+        WnBatch wb{};
+        wb.n = n - i0 < WN_MAX ? n - i0 : WN_MAX;
+        for (int j = 0; j < wb.n; ++j) {
+            wb.wv[j] = weight_v[i0 + j]; wb.g[j] = weight_g[i0 + j]; wb.scale[j] = scale[i0 + j]; wb.n_mats[j] = 1; wb.elems[j] = elems[i0 + j];
+        }
+        wn_batch_finish(wb);
+        int rc = wn_scale_batch(wb, part, as_stream(stream)); if (rc) return rc;
+        part += wn_batch_partials(wb);
+    }
+    return 0;
+}
+
 extern "C" int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(mask);
     CTI_REQUIRE(rows > 0 && dim > 0 && ldv >= dim, CTI_E_SHAPE, "cti_zero_row_mask: rows=%lld dim=%d ldv=%lld",

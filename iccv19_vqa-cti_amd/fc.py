@@ -7,12 +7,16 @@ weight-norm factor g/||V||_F (a scalar, computed on the device by cti_wn_scale),
 in its epilogue; the normalised weight is never materialised (the reference re-materialises it every forward
 through the weight_norm pre-forward hook)."""
 import math
+import weakref
 
 import torch
 import torch.nn as nn
 
 from . import ops
 from . import autograd as AG
+
+
+_scale_users = weakref.WeakSet()       # WNLinear layers that have asked for their scale: refreshed TOGETHER, in one launch pair, when stale
 
 
 class WNLinear(nn.Module):
@@ -33,11 +37,28 @@ class WNLinear(nn.Module):
     def scale(self):
         """g / ||V||_F on the device, cached until weight_v / weight_g change (optimizer steps bump `_version`, .to() / load_state_dict
         change the storage): in eval mode the norm of a 6M-element weight is computed once, not per forward."""
-        key = (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version, ops._param_epoch[0])
+        key = self._scale_key_now()
         if getattr(self, "_scale_key", None) != key:
-            self._scale_val = ops.wn_scale(self.weight_v.detach(), self.weight_g.detach())
-            self._scale_key = key
+            # A training step makes every layer's scale stale at once; the first layer to notice refreshes all the layers that have ever asked
+            # (same device) in ONE batched call instead of one launch pair per layer.  The refresh runs on the CURRENT stream: layers whose
+            # scale is consumed on another stream must be forked from it after this point (the models' aux-stream sections use no WNLinear).
+            _scale_users.add(self)
+            dev = self.weight_v.device
+            stale = [m for m in _scale_users if m.weight_v.device == dev and getattr(m, "_scale_key", None) != m._scale_key_now()]
+            if self not in stale:
+                stale.append(self)
+            if len(stale) == 1:
+                self._scale_val = ops.wn_scale(self.weight_v.detach(), self.weight_g.detach())
+                self._scale_key = key
+            else:
+                vals = ops.wn_scale_many([(m.weight_v.detach(), m.weight_g.detach()) for m in stale])
+                for i, m in enumerate(stale):
+                    m._scale_val = vals[i:i + 1]
+                    m._scale_key = m._scale_key_now()
         return self._scale_val
+
+    def _scale_key_now(self):
+        return (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version, ops._param_epoch[0])
 
     def planes(self):
         """weight_v as resident bf16 hi/lo operand planes (None in the exact-fp32 mode), cached like scale(): inference splits a weight once,
@@ -50,7 +71,7 @@ class WNLinear(nn.Module):
 
     def forward(self, x, relu=False):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad or self.weight_g.requires_grad or self.bias.requires_grad):
-            return AG.WNLinearFn.apply(x, self.weight_v, self.weight_g, self.bias, relu, 1)
+            return AG.WNLinearFn.apply(x, self.weight_v, self.weight_g, self.bias, relu, 1, self.scale())
         return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu, w_planes=self.planes())
 
 

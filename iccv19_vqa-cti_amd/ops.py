@@ -152,6 +152,26 @@ def wn_scale(weight_v, weight_g):
     return out
 
 
+def wn_scale_many(pairs):
+    """[(weight_v, weight_g), ...] (single matrices, scalar g, one device) -> a tensor of len(pairs) scales from ONE pair of launches per 48
+    layers (cti_wn_scale_many)."""
+    import ctypes as C
+    n = len(pairs)
+    vs = [_req(v, "weight_v").contiguous() for v, _ in pairs]
+    gs = [_req(g, "weight_g").contiguous().view(-1) for _, g in pairs]
+    dev = vs[0].device
+    out = torch.empty(n, device=dev, dtype=torch.float32)
+    pv = (C.c_void_p * n)(*[v.data_ptr() for v in vs])
+    pg = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
+    ps = (C.c_void_p * n)(*[out.data_ptr() + 4 * i for i in range(n)])
+    el = (C.c_int64 * n)(*[v.numel() for v in vs])
+    lib = L.lib()
+    wsb = lib.cti_wn_scale_many_workspace_bytes(el, n)
+    ws = torch.empty(max(wsb, 16), device=dev, dtype=torch.uint8)
+    L.check(lib.cti_wn_scale_many(pv, pg, ps, el, n, ws.data_ptr(), wsb, _stream()), "cti_wn_scale_many")
+    return out
+
+
 def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None, w_planes=None):
     """act(scale[n // scale_div] * x @ weight_v.T + bias) through the MFMA GEMM.  w_planes: split_operand(weight_v) kept by the caller."""
     _req(x, "x"); _req(weight_v, "weight_v")

@@ -61,7 +61,13 @@ int cti_event_elapsed_ms(void* begin, void* end, float* ms);
  * src/fc.py:22,27 installs; the scaled weight itself is never materialised (the scale is a GEMM-epilogue factor). */
 int cti_wn_scale(const float* weight_v, const float* weight_g, float* scale, int n_mats, int64_t elems, void* workspace,
                  size_t workspace_bytes, void* stream);
-size_t cti_wn_scale_workspace_bytes(int n_mats, int64_t elems);   /* workspace may be NULL (one workgroup per matrix: slow for >16K elements) */
+size_t cti_wn_scale_workspace_bytes(int n_mats, int64_t elems);
+/* The same for n layers of different sizes (n_mats = 1 each) in two launches per 48 layers: scale[i][0] = weight_g[i][0] / ||weight_v[i]||_F over
+ * elems[i] floats.  The four arrays are HOST arrays of device pointers / sizes (consumed before the call returns); workspace of
+ * cti_wn_scale_many_workspace_bytes(elems, n). */
+int cti_wn_scale_many(const float* const* weight_v, const float* const* weight_g, float* const* scale, const int64_t* elems, int n, void* workspace,
+                      size_t workspace_bytes, void* stream);
+size_t cti_wn_scale_many_workspace_bytes(const int64_t* elems, int n);   /* workspace may be NULL (one workgroup per matrix: slow for >16K elements) */
 
 /* y[r, n] = act( scale[n / scale_div] * sum_k x[r, k] * w[n, k] + bias[n] )          (src/fc.py:33-34, nn.Linear)
  * x: rows x in_dim, row stride ldx;  w: out_dim x in_dim (weight_v), row stride ldw;  y: rows x out_dim, row stride ldy.

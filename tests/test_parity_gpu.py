@@ -333,3 +333,30 @@ def test_prepared_weights_follow_parameter_updates():
         other = "fp32" if cti_amd.get_precision() != "fp32" else "bf16x3"
         cti_amd.set_precision(other)
         check(m(v, q, a), O.tcnet_forward(fx.i["v"], fx.i["q"], fx.i["a"], p, dtype=np.float64), what="after a precision switch")
+
+
+def test_wn_scale_many_matches_per_layer_scales():
+    """cti_wn_scale_many: > 48 layers of different sizes (several launch pairs), against g / ||V||_F in float64; and the WNLinear layers of a
+    model refresh their scales together after a parameter update."""
+    g = torch.Generator().manual_seed(4)
+    sizes = [int(s) for s in torch.randint(1, 30000, (101,), generator=g)] + [1, 4096, 4097, 2097152]
+    pairs = [(torch.randn(s, generator=g).to(DEV), (torch.rand((), generator=g) + 0.5).to(DEV)) for s in sizes]
+    got = cti_amd.ops.wn_scale_many(pairs).cpu().numpy()
+    ref = np.array([float(gg) / float(v.double().norm()) for v, gg in pairs])
+    assert np.max(np.abs(got - ref) / ref) < 1e-5
+    nets = [cti_amd.FCNet([24, 40, 16], "ReLU", 0.0).to(DEV) for _ in range(3)]
+    x = torch.randn(5, 24, device=DEV)
+    with torch.no_grad():
+        y0 = [n(x) for n in nets]
+        for n in nets:
+            for p_ in n.parameters():
+                p_.mul_(1.5)                                  # in place: bumps _version, every cached scale is stale
+        y1 = [n(x) for n in nets]
+        for n, a in zip(nets, y1):
+            lins = [m for m in n.main if hasattr(m, "weight_v")]
+            h = x
+            for l in lins:
+                w = l.weight_v * (l.weight_g / l.weight_v.norm())
+                h = torch.relu(h @ w.t() + l.bias)
+            assert torch.allclose(a, h, rtol=1e-4, atol=1e-5)
+    assert not torch.allclose(y0[0], y1[0])
