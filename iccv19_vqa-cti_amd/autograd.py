@@ -211,6 +211,34 @@ class BiLogitsFn(torch.autograd.Function):
         return dvt, dqt, dh.view(h.shape), dg, (None if ctx.hb_shape is None else dhb.view(ctx.hb_shape))
 
 
+class RankPackFn(torch.autograd.Function):
+    """The R rank nets' parameters packed for the batched kernels: (R*hr, h) weight_v, (R,) weight_g, (R*hr,) bias.  Same values as
+    torch.cat / torch.stack; the backward hands each parameter its slice with three unbind calls instead of autograd's 3R narrow nodes
+    (R = 32, three branches: 288 nodes per step on the host)."""
+
+    @staticmethod
+    def forward(ctx, R, *params):
+        wv = torch.cat(params[:R], 0)
+        g = torch.stack(params[R:2 * R])
+        b = torch.cat(params[2 * R:], 0)
+        ctx.R = R
+        ctx.gshape = params[R].shape
+        return wv, g, b
+
+    @staticmethod
+    def backward(ctx, dwv, dg, db):
+        R = ctx.R
+        out = [None]
+        out += list(dwv.view(R, dwv.shape[0] // R, dwv.shape[1]).unbind(0)) if dwv is not None else [None] * R
+        if dg is None:
+            out += [None] * R
+        else:
+            gs = dg.unbind(0)
+            out += list(gs) if gs[0].shape == ctx.gshape else [t.view(ctx.gshape) for t in gs]
+        out += list(db.view(R, db.shape[0] // R).unbind(0)) if db is not None else [None] * R
+        return tuple(out)
+
+
 class RankNetsDropFn(torch.autograd.Function):
     """The R rank nets FCNet([h, hr]) of src/tc.py:29-31 in TRAIN mode.  Each net owns a Dropout on the SHARED input
     (src/fc.py:25-26), i.e. R independent masks: the input is expanded into R masked copies by one Philox kernel and the R

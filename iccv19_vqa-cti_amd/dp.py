@@ -52,6 +52,9 @@ class FlatAdamaxDP:
             p.grad = None
             self.offsets.append(off)
             off += (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self._table = (ctypes.c_int64 * (3 * len(self.params)))()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            self._table[3 * i + 1], self._table[3 * i + 2] = o, p.numel()
         self._grad_views = [self.flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]   # built once, re-attached every step
         lib = L.lib()
         self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
@@ -71,26 +74,28 @@ class FlatAdamaxDP:
             p.grad = None
 
     def gather_grads(self):
-        """param.grad tensors -> flat_g (one kernel); afterwards every param.grad is a view of its flat_g slot."""
+        """param.grad tensors -> flat_g (one kernel); afterwards every param.grad is a view of its flat_g slot.  The host table (slot starts
+        and counts filled once) is reused: its entries ride in the kernel arguments of this call."""
+        tbl = self._table
         keep = []
-        rows = []
-        for p, off in zip(self.params, self.offsets):
+        f32, dev = torch.float32, self.flat_g.device
+        i = 0
+        for p in self.params:
             g = p.grad
             if g is None:
-                rows.append((0, off, p.numel()))
-                continue
-            if g.dtype != torch.float32 or g.device != self.flat_g.device or g.shape != p.shape:
-                raise TypeError("gradient of a %s parameter is %s %s on %s" % (tuple(p.shape), g.dtype, tuple(g.shape), g.device))
-            if not g.is_contiguous():
-                g = g.contiguous()
-            keep.append(g)
-            rows.append((g.data_ptr(), off, p.numel()))
-        table = (ctypes.c_int64 * (3 * len(rows)))(*[x for r in rows for x in r])       # host array: the entries ride in kernel arguments
-        L.check(L.lib().cti_flat_gather(table, len(rows), self.flat_g.data_ptr(), self.n, torch.cuda.current_stream().cuda_stream),
-                "cti_flat_gather")
-        for p, gv in zip(self.params, self._grad_views):
+                tbl[i] = 0
+            else:
+                if g.dtype is not f32 or g.device != dev or g.shape != p.shape:
+                    raise TypeError("gradient of a %s parameter is %s %s on %s" % (tuple(p.shape), g.dtype, tuple(g.shape), g.device))
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    keep.append(g)
+                tbl[i] = g.data_ptr()
+            i += 3
+        L.check(L.lib().cti_flat_gather(tbl, len(self.params), self.flat_g.data_ptr(), self.n, ops._stream()), "cti_flat_gather")
+        for p, gv in zip(self.params, self._grad_views):         # drops the gathered tensors: stream-ordered, the allocator reuses them after the gather
             p.grad = gv
-        del keep                                                 # stream-ordered: the caching allocator reuses them only after the gather
+        del keep
 
     def step(self):
         """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm."""
@@ -98,7 +103,7 @@ class FlatAdamaxDP:
         if self.world > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
         self.step_count += 1
-        st = torch.cuda.current_stream().cuda_stream
+        st = ops._stream()
         lib = L.lib()
         L.check(lib.cti_flat_scale_sumsq(self.flat_g.data_ptr(), self.n, 1.0 / (self.world * self.update_freq), self.partial.data_ptr(), st),
                 "cti_flat_scale_sumsq")

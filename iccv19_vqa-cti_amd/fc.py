@@ -16,6 +16,7 @@ from . import ops
 from . import autograd as AG
 
 
+_NO_BATCH = __import__("os").environ.get("CTI_NO_BATCHED_SCALES", "0") == "1"      # A/B knob: every layer refreshes its own scale
 _scale_users = weakref.WeakSet()       # WNLinear layers that have asked for their scale: refreshed TOGETHER, in one launch pair, when stale
 
 
@@ -47,7 +48,7 @@ class WNLinear(nn.Module):
             stale = [m for m in _scale_users if m.weight_v.device == dev and getattr(m, "_scale_key", None) != m._scale_key_now()]
             if self not in stale:
                 stale.append(self)
-            if len(stale) == 1:
+            if len(stale) == 1 or _NO_BATCH:
                 self._scale_val = ops.wn_scale(self.weight_v.detach(), self.weight_g.detach())
                 self._scale_key = key
             else:

@@ -55,7 +55,12 @@ class TCNet(nn.Module):
         return net.main[-2] if isinstance(net.main[-1], nn.ReLU) else net.main[-1]
 
     def _rank_pack(self, nets):
-        lins = [self._last_linear(n) for n in nets]
+        cache = self.__dict__.setdefault("_lins_cache", {})               # the module structure is static: resolve the R Linear layers once
+        lins = cache.get(id(nets))
+        if lins is None or len(lins) != len(nets):
+            lins = cache[id(nets)] = [self._last_linear(n) for n in nets]
+        if torch.is_grad_enabled() and any(l.weight_v.requires_grad or l.weight_g.requires_grad or l.bias.requires_grad for l in lins):
+            return AG.RankPackFn.apply(len(lins), *[l.weight_v for l in lins], *[l.weight_g for l in lins], *[l.bias for l in lins])
         wv = torch.cat([l.weight_v for l in lins], 0)                      # (R*hr, h)
         g = torch.stack([l.weight_g for l in lins])                        # (R,)
         b = torch.cat([l.bias for l in lins], 0)                           # (R*hr,)

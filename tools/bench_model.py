@@ -49,7 +49,7 @@ CASES = {
 }
 
 
-def run(name, train, steps, warmup=5, B=256, ntoken=20000):
+def run(name, train, steps, warmup=5, B=256, ntoken=20000, around_timed=None):
     builder, gamma, num_ans, Q, A = CASES[name]
     torch.manual_seed(1204)
     m = getattr(cti_amd, builder)(args_of(gamma), DS(ntoken, 2048, num_ans)).to(DEV)
@@ -89,11 +89,16 @@ def run(name, train, steps, warmup=5, B=256, ntoken=20000):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if around_timed:
+        around_timed[0]()                                     # e.g. a host profiler around exactly the timed loop (tools/cpu_profile_train.py)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_host = time.perf_counter() - t0                         # launch-side time: the GPU may still be running
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    if around_timed:
+        around_timed[1](t_host / steps * 1e3)
     nparam = sum(p.numel() for p in m.parameters())
     print(json.dumps({"case": name, "mode": "train_step" if train else "forward", "B": B, "ms": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1),
                       "params": nparam, "precision": cti_amd.get_precision(), "Q": Q, "A": A, "gamma": gamma}), flush=True)
