@@ -22,6 +22,7 @@
 // ([row][2 x 16 B]) and made bank-conflict-free for ds_read_b128 by permuting the SOURCE chunk
 // (c' = c ^ ((row >> 3) & 1)) and applying the same XOR on the read.
 #include "cti_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef CTI_PIPE
@@ -599,6 +600,23 @@ int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, uns
 
 // K ranges for C = a^T b (contraction over the M rows): about two workgroups per CU, at least 256 of depth each
 int plan_ksplit_tn(int64_t M, int N, int K) {
+    // CTI_TN_PLAN=0: the first planner (128 x 128 tiles in mind).  Default: for outputs of at least 64 tiles of 256 x 256 over a deep
+    // contraction (measured, tools/bench_gemm_tn.py: 9216 rows, 3072 x 2048 out: 829 -> 462 us; at 32 tiles and below the first planner is
+    // 3-10 % ahead), plan for the 256 x 256 tile (twice the operand reuse per LDS byte; gemm_nt_planes picks it once tiles x S >= 256): choose the S that
+    // minimises  rounds(S) * depth(S) + the partials' write + read,  rounds = ceil(tiles * S / 256 workgroups).
+    static const int mode = [] { const char* e = getenv("CTI_TN_PLAN"); return e ? atoi(e) : 1; }();
+    const long long t256 = (long long)((N + 255) / 256) * ((K + 255) / 256);
+    if (mode != 0 && t256 >= 64 && M >= 2048) {
+        const long long smax = M / 512 < 32 ? M / 512 : 32;
+        const double pen = (double)N * K * 2e-5;                  // one partial's write + read, in units of one depth step of a 256 x 256 tile
+        double best_cost = 1e300; int best = 1;
+        for (long long sx = 1; sx <= smax; ++sx) {
+            const long long rounds = (t256 * sx + 255) / 256;
+            const double cost = (double)rounds * ((double)M / sx) + (sx > 1 ? pen * sx : 0.0);
+            if (cost < best_cost) { best_cost = cost; best = (int)sx; }
+        }
+        if (t256 * best >= 256) return best;                      // otherwise the 256-tile would not be chosen anyway: fall through
+    }
     const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
     long long s = 512 / (tiles > 0 ? tiles : 1);
     const long long smax = (M + 255) / 256;
