@@ -656,12 +656,23 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     if (a.Kp % KPAD != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, KPAD);
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const long long nb = (long long)a.nb1 * a.nb2;
-    // tile choice: the largest tile that still gives every CU a workgroup (operand bytes through the L2 -> LDS DMA path, the
-    // measured bottleneck, scale with (BM + BN) / (BM * BN))
+    // tile choice by a makespan model: every geometry runs one workgroup per CU, so a launch takes ceil(tiles / 256) rounds of one tile
+    // time; relative tile times from the measured full-grid rates (128x128 ~0.43, 256x128 ~0.7, 256x256 ~1.0 PFLOP/s issued: operand bytes
+    // through the L2 -> LDS DMA path scale with (BM + BN) / (BM * BN)): 2.33 / 2.86 / 4.0.  The first rule -- "the largest tile that still
+    // gives every CU a workgroup", CTI_GEMM_CFG_MODEL=0 -- took 288 tiles of 256x128 (two rounds, the second 1/8 full) over 144 of
+    // 256x256 (one round): CTI model forward 2.03 -> 1.91 ms, training step 8.1 -> 7.8 ms with the model.
     auto tiles = [&](int bm, int bn) { return nb * ((a.M + bm - 1) / bm) * ((ncols + bn - 1) / bn); };
+    static const int model = [] { const char* e = getenv("CTI_GEMM_CFG_MODEL"); return e ? atoi(e) : 1; }();
     int cfg = 0;
-    if (a.M > 128 && tiles(256, 128) >= 256) cfg = 1;
-    if (a.M > 128 && ncols > 128 && tiles(256, 256) >= 256) cfg = 2;
+    if (model) {
+        auto span = [&](int bm, int bn, double t) { return (double)((tiles(bm, bn) + 255) / 256) * t; };
+        double best = span(128, 128, 2.33);
+        if (a.M > 128 && span(256, 128, 2.86) < best) { best = span(256, 128, 2.86); cfg = 1; }
+        if (a.M > 128 && ncols > 128 && span(256, 256, 4.0) < best) { best = span(256, 256, 4.0); cfg = 2; }
+    } else {
+        if (a.M > 128 && tiles(256, 128) >= 256) cfg = 1;
+        if (a.M > 128 && ncols > 128 && tiles(256, 256) >= 256) cfg = 2;
+    }
 #ifdef CTI_FORCE_CFG
     cfg = CTI_FORCE_CFG;
 #endif
