@@ -685,6 +685,123 @@ __global__ __launch_bounds__(512) void bi_logits_mfma_kernel(const float* __rest
     }
 }
 
+// The same contraction with the LEFT operand staged once per workgroup: V <= 64, G*Q <= 128, D % 32 == 0.  In the kernel above every wave
+// splits its own fragments of vt and of h*qt into bf16 hi + lo -- ~90 VALU instructions per 3 MFMAs, with vt split again by every wave that
+// shares its rows -- and the VALU, not the MFMA or HBM, sets its time (182 us at B = 256, G = 8, D = 3072).  Here a 32-deep slice of vt is split
+// ONCE per workgroup into LDS (double-buffered, one barrier per slice); a wave owns two 16-column tiles of (g, q) -- its h*qt fragments are
+// formed and split once and meet all V/16 row tiles -- on the 16x16x32 MFMA (36 rows pad to 48 instead of 64, 112 columns are 7 tiles exactly).
+typedef float lf32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ h,
+                                                            const float* __restrict__ h_scale, const float* __restrict__ h_bias,
+                                                            float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][2][64][40];      // [buffer][hi | lo][row v][32 k + 8 pad]
+    const int b = blockIdx.x, ks = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int N = G * Q;
+    const int d_lo = ks * dper, d_hi = min(D, d_lo + dper);
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // staging role: thread -> (row, 8 consecutive k) of the vt slice
+    const int sr = t >> 2, skq = t & 3;
+    const bool sok = sr < V;
+    const float* sp = vt + ((int64_t)b * V + (sok ? sr : 0)) * D + skq * 8;
+    // right-operand role: this wave's column tiles wid and wid + 4
+    bool cok[2]; int cg[2], cq[2];
+    const float* hp[2]; const float* qp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (wid + 4 * j) * 16 + l15;
+        cok[j] = (wid + 4 * j) < NT && c < N;
+        cg[j] = cok[j] ? c / Q : 0; cq[j] = cok[j] ? c - cg[j] * Q : 0;
+        hp[j] = h + (int64_t)cg[j] * D + kq * 8;
+        qp[j] = qt + ((int64_t)b * Q + cq[j]) * D + kq * 8;
+    }
+    lf32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[j][m] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        float4 a0 = z4, a1 = z4;
+        if (sok && d_lo < d_hi) { a0 = *reinterpret_cast<const float4*>(sp + d_lo); a1 = *reinterpret_cast<const float4*>(sp + d_lo + 4); }
+        lbf16x8 hi, lo;
+        split8(a0, a1, hi, lo);
+        *reinterpret_cast<lbf16x8*>(&As[0][0][sr][skq * 8]) = hi;
+        *reinterpret_cast<lbf16x8*>(&As[0][1][sr][skq * 8]) = lo;
+    }
+    __syncthreads();
+    float4 rh0[2], rh1[2], rq0[2], rq1[2];                           // raw h / qt fragments of the CURRENT slice (loaded one slice ahead)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rh0[j] = rh1[j] = rq0[j] = rq1[j] = z4;
+        if (cok[j] && d_lo < d_hi) {
+            rh0[j] = *reinterpret_cast<const float4*>(hp[j] + d_lo); rh1[j] = *reinterpret_cast<const float4*>(hp[j] + d_lo + 4);
+            rq0[j] = *reinterpret_cast<const float4*>(qp[j] + d_lo); rq1[j] = *reinterpret_cast<const float4*>(qp[j] + d_lo + 4);
+        }
+    }
+    int buf = 0;
+    for (int d0 = d_lo; d0 < d_hi; d0 += 32, buf ^= 1) {
+        const bool more = d0 + 32 < d_hi;
+        lbf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (wid + 4 * j < NT)                                    // uniform
+                split8(make_float4(rh0[j].x * rq0[j].x, rh0[j].y * rq0[j].y, rh0[j].z * rq0[j].z, rh0[j].w * rq0[j].w),
+                       make_float4(rh1[j].x * rq1[j].x, rh1[j].y * rq1[j].y, rh1[j].z * rq1[j].z, rh1[j].w * rq1[j].w), bh[j], bl[j]);
+        float4 n0 = z4, n1 = z4;
+        if (more) {                                                  // the next slice's loads fly under this slice's MFMAs
+            if (sok) { n0 = *reinterpret_cast<const float4*>(sp + d0 + 32); n1 = *reinterpret_cast<const float4*>(sp + d0 + 36); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (cok[j]) {
+                    rh0[j] = *reinterpret_cast<const float4*>(hp[j] + d0 + 32); rh1[j] = *reinterpret_cast<const float4*>(hp[j] + d0 + 36);
+                    rq0[j] = *reinterpret_cast<const float4*>(qp[j] + d0 + 32); rq1[j] = *reinterpret_cast<const float4*>(qp[j] + d0 + 36);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m < MT) {                                            // uniform
+                const lbf16x8 ah = *reinterpret_cast<const lbf16x8*>(&As[buf][0][m * 16 + l15][kq * 8]);
+                const lbf16x8 al = *reinterpret_cast<const lbf16x8*>(&As[buf][1][m * 16 + l15][kq * 8]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (wid + 4 * j < NT) {
+                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j][m], 0, 0, 0);
+                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j][m], 0, 0, 0);
+                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) {
+            lbf16x8 hi, lo;
+            split8(n0, n1, hi, lo);
+            *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][0][sr][skq * 8]) = hi;
+            *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][1][sr][skq * 8]) = lo;
+        }
+        __syncthreads();                                             // the next slice is complete; everyone is done reading this one
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (cok[j]) {
+            const float hb = (h_bias && ks == 0) ? h_bias[cg[j]] : 0.f;
+            float* o = logits + (((int64_t)b * G + cg[j]) * V) * Q + cq[j];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                        // C/D: column = lane & 15, row = 4 * (lane >> 4) + i
+                    const int v = m * 16 + 4 * kq + i;
+                    if (m < MT && v < V) {
+                        const float val = acc[j][m][i] * hs + hb;
+                        if (atomic) atomicAdd(o + (int64_t)v * Q, val); else o[(int64_t)v * Q] = val;
+                    }
+                }
+        }
+    }
+}
+
 // =====================================================================================================
 // Tri pool on the MFMA (fp32-grade 3-product bf16 mode; A = 3 or 6, Q <= 16, V <= 64, D % 32 == 0).  Per sample:
 //   U[v, d] = sum_{(q,a)} w[v,(q,a)] * P[(q,a), d],  P = qt[q,d] * at[a,d];     out[d] = sum_v vt[v,d] * U[v,d]
@@ -1151,6 +1268,17 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
     CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_mfma_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
     if (D % 16 != 0 || !aligned16(vt) || !aligned16(qt) || !aligned16(h))
         return CTI_E_UNSUPPORTED;                                          // the caller takes cti_bi_logits_fwd (no message: not an error)
+#ifndef CTI_BL_LDS
+#define CTI_BL_LDS 1
+#endif
+    if (CTI_BL_LDS && V <= 64 && G * Q <= 128 && D % 32 == 0) {     // left operand split once per workgroup (see bi_logits_lds_kernel)
+        const int KS = D >= 1024 ? 2 : 1;
+        const int dper = ((D / 32 + KS - 1) / KS) * 32;
+        if (KS > 1) { int rcz = zero_fill(logits, (int64_t)B * G * V * Q, as_stream(stream)); if (rcz) return rcz; }
+        hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
+                           (G * Q + 15) / 16, dper, KS > 1 ? 1 : 0);
+        return launch_status("cti_bi_logits_mfma_fwd");
+    }
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;
     const int KS = D >= 1024 ? 2 : 1;
     const int dper = ((D / 16 + KS - 1) / KS) * 16;
