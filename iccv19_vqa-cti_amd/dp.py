@@ -69,9 +69,17 @@ class FlatAdamaxDP:
         if self.world > 1:
             dist.broadcast(self.flat_p, src=src, group=self.pg)
 
-    def zero_grad(self):
-        for p in self.params:                                   # no fill kernel: cti_flat_gather zeroes whatever has no gradient
-            p.grad = None
+    def zero_grad(self, set_to_none=True):
+        """set_to_none=True (default, like torch.optim): no fill kernel -- autograd then keeps the gradient tensors it produces and
+        cti_flat_gather zeroes whatever has none.  False: zero the flat buffer and leave every .grad a view of it (backward then accumulates
+        in place, one add per parameter)."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat_g.zero_()
+            for p, gv in zip(self.params, self._grad_views):
+                p.grad = gv
 
     def gather_grads(self):
         """param.grad tensors -> flat_g (one kernel); afterwards every param.grad is a view of its flat_g slot.  The host table (slot starts

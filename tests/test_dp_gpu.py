@@ -202,6 +202,27 @@ def test_flat_gather_packs_zeroes_and_keeps_in_place_entries():
     assert L.lib().cti_flat_gather(bad, 2, flat.data_ptr(), n, torch.cuda.current_stream().cuda_stream) < 0
 
 
+def test_zero_grad_keeping_views_gives_the_same_step():
+    """zero_grad(set_to_none=False): gradients accumulate in place into the flat buffer's views; the gather finds them already in their
+    slots.  Same parameters as the default route."""
+    cti_amd.set_precision("fp32")
+    try:
+        res = []
+        for keep in (False, True):
+            torch.manual_seed(11)
+            m = TinyCTI().to(DEV)
+            opt = cti_amd.FlatAdamaxDP(m, lr=2e-3, clip_norm=0.25)
+            for step in range(2):
+                v, q, a, y = (t.to(DEV) for t in make_batch(8, 100 + step))
+                opt.zero_grad(set_to_none=not keep)
+                loss_fn(m(v, q, a), y).backward()
+                opt.step()
+            res.append(opt.flat_p.clone())
+        assert torch.allclose(res[0], res[1], rtol=1e-5, atol=1e-7)
+    finally:
+        cti_amd.set_precision("bf16x3")
+
+
 def test_update_freq_accumulates_micro_batches():
     """update_freq = 2: two backward() calls accumulate in param.grad (AccumulateGrad, in place on the tensors it kept), one step() divides by
     2 -- the same parameters as one step on the concatenated batch with loss / B_micro (src/FFOE/trainer.py:189-190, :232-236)."""
