@@ -901,13 +901,21 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
 __global__ __launch_bounds__(256) void pool_dw_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
                                                            const float* __restrict__ at, float* __restrict__ dw, int V, int Q, int A, int D,
                                                            int MT, int NT, int dper) {
+    __shared__ float red[3][16][64];
     const int b = blockIdx.x, ks = blockIdx.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, kg = lane >> 5;
     const int N = Q * A;
-    const int d_lo = ks * dper, d_hi = min(D, d_lo + dper);
+    const int ntiles = MT * NT;
+    // with one or two tiles per sample (the bi pools: V <= 64, Q <= 16) the spare waves take further slices of this workgroup's channel range
+    // for the SAME tiles and hand their accumulators over through LDS (fixed order), instead of idling
+    const int nsub = ntiles == 1 ? 4 : (ntiles == 2 ? 2 : 1);
+    const int sub = nsub > 1 ? wid / ntiles : 0;
+    const int wg_lo = ks * dper, wg_hi = min(D, wg_lo + dper);
+    const int sper = nsub > 1 ? (((wg_hi - wg_lo) / 16 + nsub - 1) / nsub) * 16 : (wg_hi - wg_lo);
+    const int d_lo = wg_lo + sub * sper, d_hi = min(wg_hi, d_lo + sper);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int tile = wid; tile < MT * NT; tile += 4) {
+    for (int tile = nsub > 1 ? wid % ntiles : wid; tile < ntiles; tile += 4) {
         const int mt = tile % MT, nt = tile / MT;
         const int v = mt * 32 + r, c = nt * 32 + r;
         const bool vok = v < V, cok = c < N;
@@ -942,7 +950,19 @@ __global__ __launch_bounds__(256) void pool_dw_mfma_kernel(const float* __restri
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, pl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ph, acc, 0, 0, 0);
         }
-        if (cok) {
+        if (nsub > 1) {                                              // every wave runs this loop body exactly once in that case
+            if (sub > 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[wid - ntiles][e][lane] = acc[e];
+            }
+            __syncthreads();
+            if (sub == 0) {
+                for (int s2 = 1; s2 < nsub; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] += red[s2 * ntiles + tile - ntiles][e][lane];
+            }
+        }
+        if (cok && sub == 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int vv = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
