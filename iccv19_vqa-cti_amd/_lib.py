@@ -64,6 +64,8 @@ SIGNATURES = {
     "cti_col_sum": (_int, [_vp, _i64, _int, _vp, C.c_float, C.c_float, _vp, _sz, _vp]),
     "cti_col_sum_workspace_bytes": (_sz, [_i64, _int]),
     "cti_gemm_tn": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_gemm_nn": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
+    "cti_gemm_nn_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "cti_gemm_tn_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "cti_swish_fwd": (_int, [_vp, _vp, _i64, _vp]),
     "cti_swish_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),

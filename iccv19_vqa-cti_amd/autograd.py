@@ -27,8 +27,7 @@ class WNLinearFn(torch.autograd.Function):
         dzs, db = ops.act_bwd(dy, y, scale, N // ctx.n_mats, ctx.relu)            # (rows, N), (N,)
         dx = None
         if ctx.needs_input_grad[0]:
-            Vt = ops.transpose(V.contiguous(), N, K).view(K, N)                    # (K, N): contraction axis contiguous
-            dx = ops.gemm_nt(dzs, Vt).view(x.shape)
+            dx = ops.gemm_nn(dzs, V.contiguous()).view(x.shape)                     # no transposed copy of the weight
         G = ops.gemm_tn(dzs, x.contiguous().view(-1, K))                           # (N, K) = dzs^T x
         dV, dg = ops.wn_bwd(G, V, g, ctx.n_mats)
         return dx, dV.view_as(V), dg.view_as(g), db, None, None, None

@@ -446,6 +446,44 @@ extern "C" int cti_split_operand(const float* x, int64_t ld, int64_t rows, int K
     return split_planes(x, ld, rows, K, hi, hi + (size_t)ra * planes_kp(K), ra, as_stream(stream));
 }
 
+// C (rows x K) = a (rows x N) . b (N x K), both row-major: the input gradient dx = dzs . V of a Linear layer.  b goes straight to the planes of
+// b^T through the transposing split (its contraction axis N is the ROW axis of b), so no transposed fp32 copy of the weight is written first.
+extern "C" size_t cti_gemm_nn_workspace_bytes(int64_t rows, int N, int K, int prec) {
+    if (prec == CTI_PREC_F32 || rows <= 0 || N <= 0 || K <= 0) return 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t n = al(planes_bytes(rows + PLANE_SLACK_ROWS, N)) + al(planes_bytes((int64_t)K + PLANE_SLACK_ROWS, N));
+    if (rows < (1ll << 31)) {
+        const int S = plan_ksplit((int)rows, K, planes_kp(N), 1);
+        if (S > 1) n += al(sizeof(float) * (size_t)S * (size_t)rows * (size_t)K);
+    }
+    return n;
+}
+extern "C" int cti_gemm_nn(const float* a, int64_t lda, const float* b, int64_t ldb, float* C, int64_t rows, int N, int K, int prec, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(b); CTI_REQUIRE_PTR(C); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(rows > 0 && rows < (1ll << 31) && N > 0 && K > 0 && lda >= N && ldb >= K, CTI_E_SHAPE, "cti_gemm_nn: rows=%lld N=%d K=%d", (long long)rows, N, K);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_nn: prec=%d (the exact-fp32 mode multiplies a transposed fp32 copy with cti_gemm_nt)", prec);
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_nn_workspace_bytes(rows, N, K, prec), CTI_E_WORKSPACE, "cti_gemm_nn: workspace too small");
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int Np = planes_kp(N);
+    const int64_t ra = rows + PLANE_SLACK_ROWS, rb = (int64_t)K + PLANE_SLACK_ROWS;
+    char* w = static_cast<char*>(workspace);
+    unsigned short* ah = reinterpret_cast<unsigned short*>(w);            unsigned short* al_ = ah + (size_t)ra * Np;
+    w += al(planes_bytes(ra, N));
+    unsigned short* bh = reinterpret_cast<unsigned short*>(w);            unsigned short* bl = bh + (size_t)rb * Np;
+    w += al(planes_bytes(rb, N));
+    hipStream_t st = as_stream(stream);
+    int rc = split_planes(a, lda, rows, N, ah, al_, ra, st); if (rc) return rc;
+    rc = split_planes_t(b, ldb, N, K, Np, bh, bl, rb, st); if (rc) return rc;
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
+    g.M = (int)rows; g.N = K; g.Kp = Np; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0;
+    g.C = C; g.ldc_m = K; g.ldc_n = 1; g.scale_div = 1;
+    const int S = plan_ksplit((int)rows, K, Np, 1);
+    if (S > 1) { g.ksplit = S; g.partial = reinterpret_cast<float*>(w); }
+    return gemm_nt_planes(g, st);
+}
+
 // cti_gemm_nt with the B operand given as resident planes (cti_split_operand of the (rowsB_total x K) matrix): only A is split here.
 extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;

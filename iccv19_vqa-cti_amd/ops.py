@@ -600,6 +600,24 @@ def gemm_tn(a, b, prec=None):
     return sum_batches(part, S, N * K).view(N, K)
 
 
+def gemm_nn(a, b, prec=None):
+    """a (rows, N) @ b (N, K), both contiguous: the input gradient of a Linear layer.  bf16 modes: b goes straight to the planes of b^T
+    (cti_gemm_nn); exact-fp32 mode: transposed fp32 copy + gemm_nt."""
+    _req(a, "a"); _req(b, "b")
+    rows, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == N and a.is_contiguous() and b.is_contiguous()
+    pr = _prec(prec)
+    if pr == L.PREC_F32 or rows == 0:
+        return gemm_nt(a, transpose(b, N, K).view(K, N), prec=prec)
+    out = torch.empty((rows, K), device=a.device, dtype=torch.float32)
+    lib = L.lib()
+    wsb = lib.cti_gemm_nn_workspace_bytes(rows, N, K, pr)
+    ws = torch.empty(wsb, device=a.device, dtype=torch.uint8)
+    L.check(lib.cti_gemm_nn(a.data_ptr(), N, b.data_ptr(), K, out.data_ptr(), rows, N, K, pr, ws.data_ptr(), wsb, _stream()), "cti_gemm_nn")
+    return out
+
+
 def act_bwd(dy, y, scale, scale_div, relu):
     """dzs = scale[col // div] * dy * (y > 0); dbias = column sums of dy * (y > 0)."""
     _req(dy, "dy"); _req(y, "y")

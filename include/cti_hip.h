@@ -210,6 +210,11 @@ size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, 
 int cti_gemm_tn(const float* a, int64_t lda, const float* b, int64_t ldb, float* C, int64_t M, int N, int K, int prec, void* workspace,
                 size_t workspace_bytes, void* stream);
 size_t cti_gemm_tn_workspace_bytes(int64_t M, int N, int K, int prec);
+/* C (rows x K) = a (rows x N) . b (N x K), row-major with leading dimensions lda / ldb, C contiguous: the input gradient dx = dzs . V of a
+ * Linear layer (torch.autograd of src/fc.py:22-29) without a transposed copy of the weight.  bf16 modes only. */
+int cti_gemm_nn(const float* a, int64_t lda, const float* b, int64_t ldb, float* C, int64_t rows, int N, int K, int prec, void* workspace,
+                size_t workspace_bytes, void* stream);
+size_t cti_gemm_nn_workspace_bytes(int64_t rows, int N, int K, int prec);
 
 /* dst[b][c][r] = src[b][r][c] (fp32, `batch` matrices of rows x cols). */
 int cti_transpose_f32(const float* src, int64_t ld_src, int64_t batch_stride_src, float* dst, int64_t ld_dst,

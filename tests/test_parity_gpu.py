@@ -360,3 +360,12 @@ def test_wn_scale_many_matches_per_layer_scales():
                 h = torch.relu(h @ w.t() + l.bias)
             assert torch.allclose(a, h, rtol=1e-4, atol=1e-5)
     assert not torch.allclose(y0[0], y1[0])
+
+
+@pytest.mark.parametrize("rows,N,K", [(37, 16, 24), (1000, 70, 33), (5000, 300, 512), (256, 1024, 3072), (9216, 512, 130)])
+def test_gemm_nn_vs_float64(rows, N, K, precision):
+    """a @ b with b given row-major (the input gradient of a Linear layer): transposing split of b (bf16 modes) or a transposed fp32 copy."""
+    rs = np.random.RandomState(rows + N + K)
+    a = rs.standard_normal((rows, N)).astype(np.float32)
+    b = rs.standard_normal((N, K)).astype(np.float32)
+    check(cti_amd.ops.gemm_nn(T(a), T(b)), a.astype(np.float64) @ b.astype(np.float64), what="a b %dx%dx%d" % (rows, N, K))
