@@ -923,8 +923,7 @@ def gru_backward(dout, x, w_ih, w_hh, save, need_dx=True, prec=None):
     db_ih = col_sum(dgi2)
     dx = None
     if need_dx:
-        w_ih_t = transpose(w_ih.contiguous(), 3 * H, I).view(I, 3 * H)
-        dx = gemm_nt(dgi2, w_ih_t).view(B, T, I)
+        dx = gemm_nn(dgi2, w_ih.contiguous()).view(B, T, I)
     return dx, dW_ih, dW_hh, db_ih, db_hh
 
 
