@@ -327,3 +327,17 @@ def test_training_core_on_planes_matches_the_fp32_M_route(B, V, Q, A, R, hr, G):
             t.grad = None
     for n_, a_, b_ in zip(("out", "dVr", "dQr", "dTeff", "dAr"), res[0], res[1]):
         check(torch.from_numpy(a_), b_, tol=2e-5, what="core on planes " + n_)
+
+
+@pytest.mark.parametrize("n", [16, 4096 + 16 * 3, 100003, 37])
+def test_mask_only_dropout_draws_the_same_stream(n):
+    """cti_dropout(y = NULL) (16 mask bytes per thread, or the 4-byte path for a tail / tiny input) draws exactly the mask the y-writing kernel
+    draws from the same seed."""
+    ops = cti_amd.pkg.ops
+    x = torch.randn(n, device=DEV)
+    ops._dropout_calls[0] = 1234
+    _, m1 = ops.dropout(x, 0.3)
+    ops._dropout_calls[0] = 1234
+    m2 = ops.dropout_mask((n,), 0.3, x.device)
+    assert torch.equal(m1, m2)
+    assert abs(float(m2.float().mean()) - 0.7) < (0.2 if n < 100 else 0.03)
