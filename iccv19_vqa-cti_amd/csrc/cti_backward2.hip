@@ -598,6 +598,50 @@ __global__ __launch_bounds__(256) void bi_pool_bwd_kernel(const float* __restric
     if (live) for (int q = 0; q < Q; ++q) dqt[((int64_t)b * Q + q) * D + d] = dq[q * 256 + t];
 }
 
+// The model's case (k = 1, weights given, Q <= 16): a thread owns two channels and keeps qt[q] and its dqt[q] accumulators in REGISTERS; the
+// attention slice w[b] sits in LDS and is read as broadcasts.  The kernel above holds those per-thread vectors in LDS (three LDS operations and
+// one global load of w per (v, q)): 56 us per call at B = 256, D = 1024 against ~25 us of HBM time.
+__global__ __launch_bounds__(128) void bi_pool_bwd_reg_kernel(const float* __restrict__ dout, const float* __restrict__ vt, const float* __restrict__ qt,
+                                                              const float* __restrict__ w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                                                              float* __restrict__ dvt, float* __restrict__ dqt, int V, int Q, int D) {
+    constexpr int QX = 16;
+    extern __shared__ __attribute__((aligned(16))) float ws[];       // [V][16], columns Q..15 zero
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int d = (blockIdx.x * 128 + t) * 2;
+    const bool live = d < D;
+    const float* wb = w + (int64_t)b * w_sb;
+    for (int i = t; i < V * QX; i += 128) { const int v = i >> 4, q = i & 15; ws[i] = q < Q ? wb[v * w_sv + q * w_sq] : 0.f; }
+    float2 qs[QX], dq[QX];
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+        qs[q] = (live && q < Q) ? *reinterpret_cast<const float2*>(qt + ((int64_t)b * Q + q) * D + d) : make_float2(0.f, 0.f);
+        dq[q] = make_float2(0.f, 0.f);
+    }
+    const float2 g = live ? *reinterpret_cast<const float2*>(dout + (int64_t)b * D + d) : make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int v = 0; v < V; ++v) {
+        const float2 x = live ? *reinterpret_cast<const float2*>(vt + ((int64_t)b * V + v) * D + d) : make_float2(0.f, 0.f);
+        const float gx0 = g.x * x.x, gx1 = g.y * x.y;
+        float s0 = 0.f, s1 = 0.f;
+        const float4* wr = reinterpret_cast<const float4*>(ws + v * QX);
+#pragma unroll
+        for (int q4 = 0; q4 < QX / 4; ++q4) {
+            const float4 ww = wr[q4];
+            const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = q4 * 4 + j;
+                s0 = fmaf(wv[j], qs[q].x, s0); s1 = fmaf(wv[j], qs[q].y, s1);
+                dq[q].x = fmaf(gx0, wv[j], dq[q].x); dq[q].y = fmaf(gx1, wv[j], dq[q].y);
+            }
+        }
+        if (live) *reinterpret_cast<float2*>(dvt + ((int64_t)b * V + v) * D + d) = make_float2(g.x * s0, g.y * s1);
+    }
+#pragma unroll
+    for (int q = 0; q < QX; ++q)
+        if (live && q < Q) *reinterpret_cast<float2*>(dqt + ((int64_t)b * Q + q) * D + d) = dq[q];
+}
+
 // =====================================================================================================================
 // bilinear logits backward (lane = d).  logits[b,g,v,q] = hs * sum_d vt[v,d] h[g,d] qt[q,d] + hb[g]
 //   dvt[v,d] = hs sum_{g,q} dl h[g,d] qt[q,d];  dqt[q,d] = hs sum_{g,v} dl h[g,d] vt[v,d];
@@ -919,10 +963,18 @@ extern "C" int cti_bi_pool_bwd(const float* dout, const float* vt, const float* 
                                float* dvt, float* dqt, float* dw, int B, int V, int Q, int D, int k, void* stream) {
     CTI_REQUIRE_PTR(dout); CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(dvt); CTI_REQUIRE_PTR(dqt);
     CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && D > 0 && k > 0 && D >= k, CTI_E_SHAPE, "cti_bi_pool_bwd: B=%d V=%d Q=%d D=%d k=%d", B, V, Q, D, k);
-    const size_t lds = sizeof(float) * 256 * 2 * (size_t)Q;
-    int rc = set_lds(bi_pool_bwd_kernel, lds, "cti_bi_pool_bwd"); if (rc) return rc;
-    hipLaunchKernelGGL(bi_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, w, w_sb, w_sv, w_sq, dvt, dqt,
-                       V, Q, D, k);
+    int rc;
+    const uintptr_t al8 = reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(dvt) |
+                          reinterpret_cast<uintptr_t>(dqt);
+    if (k == 1 && w && Q <= 16 && D % 2 == 0 && (al8 & 7) == 0 && (size_t)V * 16 * sizeof(float) <= 48 * 1024) {
+        hipLaunchKernelGGL(bi_pool_bwd_reg_kernel, dim3((D / 2 + 127) / 128, B), dim3(128), sizeof(float) * (size_t)V * 16, as_stream(stream), dout, vt, qt, w,
+                           w_sb, w_sv, w_sq, dvt, dqt, V, Q, D);
+    } else {
+        const size_t lds = sizeof(float) * 256 * 2 * (size_t)Q;
+        rc = set_lds(bi_pool_bwd_kernel, lds, "cti_bi_pool_bwd"); if (rc) return rc;
+        hipLaunchKernelGGL(bi_pool_bwd_kernel, dim3((D + 255) / 256, B), dim3(256), lds, as_stream(stream), dout, vt, qt, w, w_sb, w_sv, w_sq, dvt, dqt,
+                           V, Q, D, k);
+    }
     rc = launch_status("cti_bi_pool_bwd"); if (rc) return rc;
     if (dw && w) {
         const int Du = (D / k) * k;                         // channels of a ragged tail take no part
