@@ -20,10 +20,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/pmc$i -o p -- $B > $E/pmc$i.log 2>&1 || echo "pmc pass $i ($grp) failed/timeout"
 done
-timeout 300 python tools/bench_model.py > $E/model_fwd.jsonl 2>$E/model_fwd.err
-timeout 300 python tools/bench_model.py --train > $E/model_train.jsonl 2>$E/model_train.err
-timeout 300 python tools/bench_model.py --precision bf16 > $E/model_fwd_bf16.jsonl 2>/dev/null
-timeout 300 python tools/bench_model.py --precision bf16 --train > $E/model_train_bf16.jsonl 2>/dev/null
+timeout 300 python tools/bench_model.py --steps 50 > $E/model_fwd.jsonl 2>$E/model_fwd.err
+timeout 300 python tools/bench_model.py --train --steps 50 > $E/model_train.jsonl 2>$E/model_train.err
+timeout 300 python tools/bench_model.py --precision bf16 --steps 50 > $E/model_fwd_bf16.jsonl 2>/dev/null
+timeout 300 python tools/bench_model.py --precision bf16 --train --steps 50 > $E/model_train_bf16.jsonl 2>/dev/null
 timeout 300 python tools/bench_pools.py 30 2>/dev/null | grep kernel > $E/hbm_kernels.jsonl
 cat $E/model_fwd.jsonl $E/model_train.jsonl | cut -c1-120
 find $E -name "*.csv" | head -20; du -sh $E
