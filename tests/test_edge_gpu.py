@@ -116,3 +116,54 @@ def test_non_contiguous_inputs():
         p, _ = att(v_t, q_t, T(a))
     p_ref, _ = O.tri_attention(vbig[:, ::2, 12:36], qbig[:, :, 1, :], a, sd(att), dtype=np.float64)
     check(p, p_ref, "p (non-contiguous inputs)")
+
+
+# ---- degenerate shapes of the training-side kernels added with the fused rank nets / streaming mode-3 backward -------------------------
+@pytest.mark.parametrize("R,hr,h,rows", [(1, 1, 4, 1), (2, 16, 512, 1), (3, 5, 8, 17), (1, 16, 64, 129)])
+def test_rank_net_kernels_at_degenerate_sizes(R, hr, h, rows):
+    """cti_ranknets_drop_fwd / _dw / _dx against float64 with the mask applied by hand: one row, one rank, hr = 1, a row count one past a tile."""
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(R * 1000 + rows)
+    x = torch.randn(rows, h, generator=g); W = torch.randn(R * hr, h, generator=g) / 4
+    scale = torch.rand(R, generator=g) + 0.5; bias = torch.randn(R * hr, generator=g)
+    dzs = torch.randn(rows, R * hr, generator=g)
+    p = 0.4
+    mask = ops.dropout_mask((R, rows, h), p, torch.device(DEV))
+    mk = mask.cpu().double() / (1 - p)                                                        # (R, rows, h)
+    Xd = x.double()[None] * mk
+    y = ops.ranknets_drop_fwd(x.to(DEV), mask, W.to(DEV), scale.to(DEV), bias.to(DEV), R, p, True)
+    assert y is not None
+    ref = torch.cat([torch.relu(scale[r].double() * (Xd[r] @ W[r * hr:(r + 1) * hr].double().t()) + bias[r * hr:(r + 1) * hr].double()) for r in range(R)], 1)
+    check(y, ref.numpy(), "rank nets fwd", 2e-5)
+    G = ops.ranknets_drop_dw(dzs.to(DEV), x.to(DEV), mask, R, p)
+    refG = torch.cat([dzs[:, r * hr:(r + 1) * hr].double().t() @ Xd[r] for r in range(R)], 0)
+    check(G, refG.numpy(), "rank nets dW", 2e-5)
+    dx = ops.ranknets_drop_dx(dzs.to(DEV), W.to(DEV), mask, R, p)
+    refx = sum(mk[r] * (dzs[:, r * hr:(r + 1) * hr].double() @ W[r * hr:(r + 1) * hr].double()) for r in range(R))
+    check(dx, refx.numpy(), "rank nets dx", 2e-5)
+
+
+@pytest.mark.parametrize("B,V,Q,A,G,K", [(1, 1, 1, 1, 1, 4), (1, 1, 1, 8, 1, 32), (2, 64, 16, 3, 2, 64)])
+def test_core_backward_at_degenerate_sizes(B, V, Q, A, G, K):
+    g = torch.Generator().manual_seed(B + V + K)
+    dout = torch.randn(B, V, Q, A, G, generator=g); M = torch.randn(B, V, Q, G, K, generator=g); Ar = torch.randn(B, A, K, generator=g)
+    dM, dAr = cti_amd.pkg.ops.paralind_core_bwd(dout.to(DEV), M.to(DEV), Ar.to(DEV))
+    check(dM, torch.einsum("bvqag,bak->bvqgk", dout.double(), Ar.double()).numpy(), "dM", 1e-5)
+    check(dAr, torch.einsum("bvqag,bvqgk->bak", dout.double(), M.double()).numpy(), "dAr", 1e-5)
+
+
+@pytest.mark.parametrize("B,G,V,Q,D", [(1, 1, 1, 1, 32), (2, 8, 64, 16, 64), (3, 2, 17, 5, 96), (2, 3, 36, 14, 1056)])
+def test_bilinear_logits_and_bi_pool_backward_at_tile_limits(B, G, V, Q, D):
+    """The LDS-staged bilinear logits (V <= 64, G*Q <= 128) and the register-resident bi-pool backward (Q <= 16) at their bounds and at 1."""
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(B * 7 + D)
+    vt = torch.randn(B, V, D, generator=g); qt = torch.randn(B, Q, D, generator=g); h = torch.randn(G, D, generator=g) / 8
+    hb = torch.randn(G, generator=g); hs = torch.tensor([0.7])
+    lg = ops.bi_logits(vt.to(DEV), qt.to(DEV), h.to(DEV), hs.to(DEV), hb.to(DEV))
+    ref = 0.7 * torch.einsum("bvd,gd,bqd->bgvq", vt.double(), h.double(), qt.double()) + hb.double()[None, :, None, None]
+    check(lg, ref.numpy(), "bi logits", 2e-5)
+    w = torch.rand(B, V, Q, generator=g); dout = torch.randn(B, D, generator=g)
+    dvt, dqt, dw = ops.bi_pool_bwd(dout.to(DEV), vt.to(DEV), qt.to(DEV), w.to(DEV), 1)
+    check(dvt, (dout.double()[:, None, :] * torch.einsum("bvq,bqd->bvd", w.double(), qt.double())).numpy(), "bi pool dvt", 2e-5)
+    check(dqt, (dout.double()[:, None, :] * torch.einsum("bvq,bvd->bqd", w.double(), vt.double())).numpy(), "bi pool dqt", 2e-5)
+    check(dw, torch.einsum("bd,bvd,bqd->bvq", dout.double(), vt.double(), qt.double()).numpy(), "bi pool dw", 2e-5)
