@@ -46,6 +46,7 @@ CASES = {
     "ffoe_cti": ("build_cti", 2, 3129, 14, 3),
     "ffoe_ban": ("build_ban", 8, 3129, 14, 0),
     "mc_cti": ("build_mc_cti", 2, 2, 12, 6),
+    "mc_ban": ("build_mc_ban", 2, 2, 12, 6),
 }
 
 
@@ -68,6 +69,8 @@ def run(name, train, steps, warmup=5, B=256, ntoken=20000, around_timed=None):
             return m(v, q, a)
         if name == "ffoe_ban":
             return m(v, boxes, q, None)[0]
+        if name == "mc_ban":
+            return m(v, boxes, q, a)[0]
         return m(v, boxes, q, a)[0]
 
     if train:
