@@ -11,6 +11,7 @@
 // contraction order, resp. the output column order, is permuted consistently on both operands, and every global access is a 64-B run per
 // 16 lanes.  HBM traffic per branch: the mask (R*rows*h bytes) once per kernel + x / dzs / W; nothing else.
 #include "cti_common.h"
+#include <cstdlib>
 
 namespace cti {
 namespace {
@@ -219,7 +220,8 @@ extern "C" int cti_ranknets_drop_fwd(const float* x, const uint8_t* mask, const 
     if (!rn_shape_ok(rows, h, R, hr) || h > 512 || !aligned16(x) || !aligned16(W) || (reinterpret_cast<uintptr_t>(mask) & 3)) return CTI_E_UNSUPPORTED;
     const int64_t wgs = (rows + 63) / 64;
     int rs = 1;                                                      // split the ranks until ~2 waves per SIMD are in flight
-    while (rs < R && wgs * 4 * rs < 2048) rs *= 2;
+    static const long long rn_target = [] { const char* e = getenv("CTI_RN_WAVES"); return e ? atoll(e) : 4096LL; }();   // A/B knob; 2048 -> 4096 waves: 192 -> 169 us at rows 9216
+    while (rs < R && wgs * 4 * rs < rn_target) rs *= 2;
     const int r_per = (R + rs - 1) / rs;
     const dim3 grid((unsigned)wgs, (unsigned)((R + r_per - 1) / r_per));
     const float inv_keep = 1.f / (1.f - p);
