@@ -217,20 +217,22 @@ def test_batched_rank_nets_under_dropout_match_a_manual_per_rank_evaluation(R, h
     g = (torch.rand(R, device=DEV) + 0.5).requires_grad_(True)
     b = (torch.randn(R * hr, device=DEV) / 10).requires_grad_(True)
     y = AG.RankNetsDropFn.apply(x, wv, g, b, relu, R, 0.5)
-    cot = torch.randn_like(y)
     # the masks are among the saved tensors (before backward frees them)
     mask = y.grad_fn.saved_tensors[1].clone().view(R, *lead, h)
     assert (y.grad_fn.saved_tensors[0].numel() == x.numel()) == fused        # fused: the plain input is saved, not R masked copies
-    (y * cot).sum().backward()
-    got = [t.grad.clone() for t in (x, wv, g, b)]
-    for t in (x, wv, g, b):
-        t.grad = None
     outs = []
     for r in range(R):
         xr = x * (mask[r].float() / 0.5)
         outs.append(AG.WNLinearFn.apply(xr, wv[r * hr:(r + 1) * hr], g[r], b[r * hr:(r + 1) * hr], relu, 1))
     y2 = torch.cat(outs, -1)
     check(y, y2.detach().cpu().numpy(), tol=2e-5, what="batched rank nets forward")
+    # the two routes round differently (exact fp32 vs split bf16): an output within ~1e-6 of zero can sit on opposite sides of the ReLU, and
+    # the gradients then legitimately differ there -- no cotangent on such elements
+    cot = torch.randn_like(y) * ((y > 0) == (y2 > 0)).float()
+    (y * cot).sum().backward()
+    got = [t.grad.clone() for t in (x, wv, g, b)]
+    for t in (x, wv, g, b):
+        t.grad = None
     (y2 * cot).sum().backward()
     for n_, a_, t in zip(("dx", "dwv", "dg", "db"), got, (x, wv, g, b)):
         check(a_, t.grad.cpu().numpy(), tol=1e-4, what="batched rank nets " + n_)
