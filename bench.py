@@ -7,14 +7,19 @@ inputs resident in HBM before the timed region.  The batch axis shards across GP
 (forward-only replicas, weak scaling: 256 rows per GPU); the only collectives are the timing barrier and the
 max-over-ranks of the elapsed time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|bf16x3] [--batch B] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|bf16x3|f16f6|bf16] [--batch B] [--no-cpu-baseline]
+    python bench.py --config c3|c4            full-model forwards of BASELINE configs[2] / [3] (bf16), their own flop tally and roofline
+    python bench.py --mode train              data-parallel training step (configs[4] shape) of the CTI fusion block
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a `torch.distributed.run` child, spawned before
+anything touches a GPU) and relays rank 0's JSON line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
+is a rank.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +32,13 @@ if ROOT not in sys.path:
 
 # BASELINE.json configs[1]
 C2 = dict(B=256, V=36, Q=14, A=3129, v_dim=2048, q_dim=1024, a_dim=300, h_mm=512, rank=32, glimpse=2)
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: f32 MFMA / dense bf16 MFMA
+# MI355X_MICROARCH.md: f32 MFMA / dense bf16(f16) MFMA.  The fp32-grade split modes are priced against the 16-bit dense peak.
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16f6": 2500.0}
+MFMA_UNITS_PER_PRODUCT = {"fp32": 1.0, "bf16x3": 3.0, "bf16": 1.0, "f16f6": 1.5}   # 16-bit-MFMA-equivalents issued per algorithmic product
+HBM_PEAK_GBS = 8000.0
 SEED = 1204                                                         # the reference's default seed (src/FFOE/main.py:53)
+DTYPE_NAME = {"fp32": "f32", "bf16x3": "f32 (bf16x3 split products, f32 accumulate)", "bf16": "bf16 products, f32 accumulate",
+              "f16f6": "f32 (f16 product + two block-scaled fp6 correction products, f32 accumulate)"}
 
 
 def flops_per_sample(c):
@@ -54,9 +64,11 @@ def synth_inputs(c, B, seed, device):
     return v.to(device), q.to(device), a.to(device)
 
 
-def cpu_baseline(c, state, seed, budget_s=20.0):
-    """The oracle (numpy restatement of the reference's CPU path, oracle/cti_oracle.py) timed on this host's cores on a
-    bounded sample of the same workload: B_cpu samples of the C2 shapes, repeated until ~budget_s of CPU work."""
+def cpu_baseline(c, state, inputs, gpu_out=None, budget_s=20.0):
+    """The oracle (numpy restatement of the reference's CPU path, oracle/cti_oracle.py) timed on this host's cores on a bounded sample of
+    the SAME workload: the first B_cpu samples of rank 0's batch, repeated until ~budget_s of CPU work.  Because they are the samples the
+    GPU just processed, the oracle's output also checks the timed launch (`gpu_out` = the HIP result for those samples): the normalised max
+    error goes into the record and a miss of the north-star tolerance aborts the run instead of printing a number."""
     from oracle import cti_oracle as O
     try:
         from threadpoolctl import threadpool_info
@@ -64,19 +76,25 @@ def cpu_baseline(c, state, seed, budget_s=20.0):
     except Exception:
         cores = os.cpu_count() or 1
     Bc = 4
-    v, q, a = synth_inputs(c, Bc, seed + 17, "cpu")
-    v, q, a = v.numpy(), q.numpy(), a.numpy()
+    v, q, a = (t[:Bc].cpu().numpy() for t in inputs)
     O.tcnet_forward(v[:1], q[:1], a[:1], state)                  # warm-up (BLAS threads, page faults)
     t0 = time.perf_counter()
     n = 0
     while True:
-        O.tcnet_forward(v, q, a, state)
+        ref = O.tcnet_forward(v, q, a, state)
         n += Bc
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 1024:
             break
-    return {"value": n / el, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": "oracle.tcnet_forward (numpy fp32), %d samples of the C2 shapes in batches of %d, %.1f s" % (n, Bc, el)}
+    rec = {"value": n / el, "unit": "samples/s", "cores": int(cores), "kind": "port",
+           "sample": "oracle.tcnet_forward (numpy fp32; BLAS threads = cores, the einsum steps are single-threaded), %d samples of the C2 "
+                     "shapes in batches of %d, %.1f s" % (n, Bc, el)}
+    if gpu_out is not None:
+        err = float(O.norm_max_err(gpu_out, ref))
+        rec["parity_of_timed_launch"] = {"samples": Bc, "norm_max_err_vs_oracle": err, "tol": 1e-4}
+        if not err < 1e-4:
+            raise SystemExit("bench.py: the timed launch is %.3g from the oracle on its first %d samples (tolerance 1e-4) -- no number printed" % (err, Bc))
+    return rec
 
 
 def measure(step, steps, warmup, world, sync, dist=None, device="cpu"):
@@ -117,19 +135,66 @@ def whole_job_rate(world, batch_per_rank, steps, elapsed):
     return world * batch_per_rank * steps / elapsed
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a torch.distributed.run CHILD (this process has not touched a GPU
+    and never will), pass everything through, and finish with rank 0's JSON line as the last line of stdout and the child's return code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last_json = None
+    for line in p.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            last_json = line.rstrip()
+        else:
+            sys.stdout.write(line)
+    rc = p.wait()
+    sys.stdout.flush()
+    if last_json is not None:
+        print(last_json, flush=True)
+    return rc
+
+
+def run_dry(args, world, rank):
+    """--dry-launch: the launch + rendezvous + timing path on CPU (gloo), no GPU and no kernels: every rank joins, sleeps through its
+    "steps", and rank 0 reports how many ranks met at the barrier."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    el = measure(lambda: time.sleep(0.01), args.steps, args.warmup, world, lambda: None, dist if world > 1 else None, "cpu")
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": el / args.steps * 1e3}), flush=True)
+
+
 class CTIFusionBlock(torch.nn.Module):
     """The CTI fusion of CTIModel.forward (reference src/FFOE/base_model.py:128-135) at the VQA-2.0 shapes of BASELINE configs[3]/[4]:
-    TriAttention (h_mm 512, rank 32, glimpse 2), one TCNet(k=2) pooling + q_prj/a_prj residual per glimpse, sum, and a stock-torch
-    2-layer classifier (outside the CTI path).  Used by --mode train only."""
+    TriAttention (h_mm 512, rank 32, glimpse 2), one TCNet(k=2) pooling + q_prj/a_prj residual per glimpse, sum, and the reference's
+    SimpleClassifier (src/classifier.py:19-28) -- all of it on the HIP library.  Used by --mode train only."""
 
     def __init__(self, cti, v_dim=2048, num_hid=1024, h_mm=512, rank=32, gamma=2, n_ans=3129):
         super().__init__()
+        import types
         self.gamma = gamma
         self.t_att = cti.TriAttention(v_dim, num_hid, num_hid, h_mm, 1, rank, gamma, 1, dropout=[.2, .5])
         self.t_net = torch.nn.ModuleList([cti.TCNet(v_dim, num_hid, num_hid, h_mm, 1, rank, 1, dropout=[.2, .5], k=2) for _ in range(gamma)])
         self.q_prj = torch.nn.ModuleList([cti.FCNet([num_hid, num_hid], '', .2) for _ in range(gamma)])
         self.a_prj = torch.nn.ModuleList([cti.FCNet([num_hid, num_hid], '', .2) for _ in range(gamma)])
-        self.classifier = torch.nn.Sequential(torch.nn.Linear(num_hid, 2 * num_hid), torch.nn.ReLU(), torch.nn.Linear(2 * num_hid, n_ans))
+        self.classifier = cti.SimpleClassifier(num_hid, 2 * num_hid, n_ans, types.SimpleNamespace(activation="relu", dropout=0.5))
 
     def forward(self, v, q_emb, ans_emb):
         att, _ = self.t_att(v, q_emb, ans_emb)
@@ -147,8 +212,10 @@ def run_train(args, world, rank, dev, dist):
     cti_amd.set_precision(args.precision)
     torch.manual_seed(SEED)
     model = CTIFusionBlock(cti_amd).to(dev).train()
-    opt = cti_amd.FlatAdamaxDP(model, lr=1e-3, clip_norm=0.25)
+    forced = os.environ.get("CTI_BENCH_FORCE_DIST") == "1"
+    opt = cti_amd.FlatAdamaxDP(model, lr=1e-3, clip_norm=0.25, force_collective=forced)
     opt.broadcast_parameters()
+    crit = cti_amd.BCEWithLogitsSum()
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(SEED + 1 + rank)
     v = torch.randn(B, 36, 2048, generator=g).abs_()
@@ -161,7 +228,7 @@ def run_train(args, world, rank, dev, dist):
 
     def step():
         opt.zero_grad()
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(v, q, a), y, reduction="sum") / B
+        loss = crit(model(v, q, a), y) / B
         loss.backward()
         opt.step()
 
@@ -170,54 +237,127 @@ def run_train(args, world, rank, dev, dist):
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
+        coll = "rccl all-reduce of the flat gradient buffer" if world > 1 else ("rccl all-reduce executed (forced, world 1)" if forced else "none (one rank)")
         print(json.dumps({"metric": "CTI fusion-block data-parallel training samples/sec (256 rows/GPU, VQA-2.0 shapes)",
                           "value": whole_job_rate(world, B, args.steps, el), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32 (bf16x3 split products)" if args.precision == "bf16x3" else args.precision,
-                          "data": "synthetic",
-                          "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + classifier, "
-                                                 "train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
-                                     "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world}}))
+                          "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + SimpleClassifier "
+                                                 "+ BCE, train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
+                                     "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world, "collective": coll}}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="forward", choices=["forward", "train"], help="forward (the BASELINE metric) or train (DP step)")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50, help="timed steps (the default run takes well under a minute on the GPU + ~20 s of CPU baseline)")
-    ap.add_argument("--warmup", type=int, default=10, help="untimed steps: allocator growth, one-time kernel attributes, clock ramp")
-    ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
-    ap.add_argument("--precision", default=os.environ.get("CTI_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
-                    help="bf16x3 (default): 3-term split-bf16 MFMA, fp32-grade (1e-5 vs the float64 oracle); fp32: exact fp32 MFMA")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
+# ---- full-model forwards: BASELINE configs[2] (c3: MC CTI, Visual7W shapes) and configs[3] (c4: FFOE BAN + CTI teacher) ---------------
+def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, rep=1):
+    """SURVEY.md 8(d) formulas summed over the module calls of the model forward (per BATCH, flops = 2 MAC).  `rep`: the MC pipeline feeds
+    every image `rep` times; the reference projects v for every row, so the algorithmic count does too (the de-duplicated kernels do less)."""
+    hr = h // R
+    gru = lambda L, i: 2 * L * 3 * nh * (i + nh)                                   # noqa: E731  (input + recurrent products of a 1-layer GRU)
+    cls = lambda o: 2 * (nh * 2 * nh + 2 * nh * o)                                 # noqa: E731
+    if kind == "cti":
+        tucker = 2 * h * (V * vd + Q * nh + A * nh)
+        rank = 2 * h * h * (V + Q + A)
+        core = 2 * V * R * hr * hr * G * hr + 2 * V * Q * R * hr * G * hr + 2 * V * Q * A * G * h
+        d = 2 * h
+        fww = G * (2 * d * (V * vd + Q * nh + A * nh) + 2 * d * (V * Q * A + V * Q + V))
+        prj = G * 2 * 2 * nh * nh
+        per = tucker + rank + core + fww + prj + gru(Q, 600) + gru(A, 600) + cls(n_ans)
+        return B * per
+    if kind == "ban":
+        d3 = 3 * nh
+        att = 2 * d3 * (V * vd + Q * nh) + 2 * G * V * Q * d3 + G * V * d3
+        bnet = G * (2 * nh * (V * vd + Q * nh) + 2 * nh * (V * Q + V))
+        prj = G * 2 * nh * nh
+        per = att + bnet + prj + gru(Q, 600) + cls(n_ans)
+        return B * per
+    raise ValueError(kind)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    import torch.distributed as dist
-    # CTI_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the N > 1 code path -- init, barrier, max-reduce -- on a 1-GPU box)
-    if world > 1 or os.environ.get("CTI_BENCH_FORCE_DIST") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+def run_model(args, world, rank, dev, dist):
+    """--config c3 | c4: eval forward of the full models at BASELINE configs[2] / [3] in plain-bf16 products (the dtype those configs name)."""
+    import types
+    import cti_amd
+    prec = args.precision if args.precision_given else "bf16"
+    cti_amd.set_precision(prec)
+    B, ntoken = args.batch, 20000
+    torch.manual_seed(SEED)
+
+    def ds(num_ans):
+        return types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=ntoken), v_dim=2048, num_ans_candidates=num_ans)
+
+    def margs(gamma):
+        return types.SimpleNamespace(op="c", num_hid=1024, gamma=gamma, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+
+    g = torch.Generator().manual_seed(SEED + 1 + rank)
+
+    def tokens(L):
+        t = torch.randint(0, ntoken, (B, L), generator=g)
+        n = torch.randint(3, L + 1, (B,), generator=g)
+        t[torch.arange(L)[None, :] >= n[:, None]] = ntoken
+        return t.to(dev)
+
+    if args.config == "c3":
+        # Visual7W: 64 images x 4 candidate answers = 256 rows, every image repeated for its candidates (src/MC/train.py:75-79)
+        rep = 4
+        vi = torch.randn(B // rep, 36, 2048, generator=g).abs()
+        nv = torch.randint(10, 37, (B // rep,), generator=g)
+        vi[torch.arange(36)[None, :] >= nv[:, None]] = 0
+        v = vi.unsqueeze(1).expand(-1, rep, -1, -1).contiguous().view(B, 36, 2048).to(dev)
+        q1 = tokens(12)
+        q = q1.view(B // rep, rep, 12)[:, :1].expand(-1, rep, -1).contiguous().view(B, 12)
+        a = tokens(6)
+        boxes = torch.rand(B, 36, 6, generator=g).to(dev)
+        m = cti_amd.build_mc_cti(margs(2), ds(2)).to(dev).eval()
+        m.v_replication = rep
+        fwd = lambda: m(v, boxes, q, a)[0]                                           # noqa: E731
+        flops = model_flops("cti", B, 36, 12, 6, 2, n_ans=2)
+        workload = "BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B
+        out_shape = (B, 2)
     else:
-        torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        v = torch.randn(B, 36, 2048, generator=g).abs()
+        nv = torch.randint(10, 37, (B,), generator=g)
+        v[torch.arange(36)[None, :] >= nv[:, None]] = 0
+        v = v.to(dev)
+        q, a = tokens(14), tokens(3)
+        boxes = torch.rand(B, 36, 6, generator=g).to(dev)
+        ban = cti_amd.build_ban(margs(8), ds(3129)).to(dev).eval()
+        cti = cti_amd.build_cti(margs(2), ds(3129)).to(dev).eval()
 
-    if args.mode == "train":
-        run_train(args, world, rank, dev, dist)
-        if dist is not None and dist.is_initialized():
-            dist.barrier(); dist.destroy_process_group()
-        return
+        def fwd():
+            return ban(v, boxes, q, None)[0], cti(v, q, a)
+        flops = model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2)
+        workload = ("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
+                    ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes" % B)
+        out_shape = (B, 3129)
+
+    holder = {}
+
+    def step():
+        holder["out"] = fwd()
+
+    with torch.no_grad():
+        el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+    out = holder["out"]
+    out0 = out[0] if isinstance(out, tuple) else out
+    assert tuple(out0.shape) == out_shape and bool(torch.isfinite(out0).all())
+    if dist.is_initialized():
+        dist.barrier(); dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        ach = flops * args.steps / el / 1e12
+        peak = PEAK_TFLOPS[prec]
+        print(json.dumps({
+            "metric": "full-model forward samples/sec (%s)" % args.config, "value": whole_job_rate(world, B, args.steps, el), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[prec], "data": "synthetic",
+            "config": {"workload": workload, "global_batch": world * B, "precision": prec, "parallelism": "replicas x%d" % world,
+                       "gflop_per_batch": round(flops / 1e9, 3)},
+            "roofline": {"bound": "mfma", "kernel": "whole forward (launch sequence; dominant kernels are the projection GEMMs)", "achieved": ach,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "note": "algorithmic flops of SURVEY.md 8(d) summed over the module calls / wall time of the forward"}}), flush=True)
+
+
+def run_forward(args, world, rank, dev, dist):
     import cti_amd
     cti_amd.set_precision(args.precision)
     c = dict(C2, B=args.batch)
@@ -237,7 +377,25 @@ def main():
         el = measure(step, args.steps, 0, world, torch.cuda.synchronize, dist, dev)
         kt = cti_amd.ops.profile_stop()
     out = res_holder["out"]
-    assert out.shape == (c["B"], c["V"], c["Q"], c["A"], c["glimpse"]) and bool(torch.isfinite(out[0, 0, 0, 0]).all())
+    assert out.shape == (c["B"], c["V"], c["Q"], c["A"], c["glimpse"])
+    fp32_exact = None
+    if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_fp32_exact:
+        # the strict-fp32 arithmetic (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) on the driver's clock, a few steps
+        gpu_first = out[:4].cpu().numpy()
+        del out, res_holder["out"]
+        cti_amd.set_precision("fp32")
+        with torch.no_grad():
+            el32 = measure(step, 4, 1, 1, torch.cuda.synchronize, None, dev)
+            o32 = res_holder["out"][:4].cpu().numpy()
+        cti_amd.set_precision(args.precision)
+        fl = flops_per_sample(c)
+        fp32_exact = {"value": c["B"] * 4 / el32, "unit": "samples/s", "ms_per_step": el32 / 4 * 1e3, "steps": 4,
+                      "whole_step_tflops": fl["total"] * c["B"] * 4 / el32 / 1e12, "frac_of_f32_mfma_peak": fl["total"] * c["B"] * 4 / el32 / 1e12 / PEAK_TFLOPS["fp32"],
+                      "norm_max_diff_of_default_mode_vs_exact_fp32_first_4_samples": float(np.max(np.abs(gpu_first - o32)) / np.max(np.abs(o32)))}
+        del res_holder["out"]
+    else:
+        gpu_first = out[:4].cpu().numpy() if rank == 0 else None
+    res = None
     if rank == 0:
         fl = flops_per_sample(c)
         core_ms = float(np.mean(kt.get("paralind_core", kt.get("tcnet_forward"))))
@@ -246,46 +404,108 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         kern = {k: round(float(np.mean(ms)), 3) for k, ms in sorted(kt.items())}
         # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled
-        # as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is); the summary is committed under profiles/.
+        # as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is); the summary is committed under profiles/ and names the kernel
+        # variant it was taken on -- a record for another variant / batch is refused (traffic = null) rather than quoted stale.
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "core_traffic.json")
-        if args.precision == "bf16x3" and c["B"] == C2["B"] and os.path.isfile(tf):
+        variant = core_variant(args.precision)
+        if os.path.isfile(tf):
             tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
-        mfma_per_flop = 3.0 if args.precision == "bf16x3" else 1.0
-        if args.precision == "bf16":
-            res_note = "plain-bf16 mode is NOT the BASELINE metric (configs[1] is fp32): reported for reference only"
+            if tj.get("variant") == variant and tj.get("batch") == c["B"]:
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+            else:
+                traffic_src = "profiles/core_traffic.json is for variant %r at B=%r, this run is %r at B=%d: not quoted" % (tj.get("variant"), tj.get("batch"), variant, c["B"])
+        units = MFMA_UNITS_PER_PRODUCT[args.precision]
         res = {
             "metric": "CTI fused-forward samples/sec at B=256 (V=36x2048)",
             "value": whole_job_rate(world, c["B"], args.steps, el), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3 split products, f32 accumulate)", "bf16": "bf16 products, f32 accumulate"}[args.precision],
-            "data": "synthetic",
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: TCNet.forward fp32, B=%d/GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, "
                                    "h_mm=512, glimpse=2" % c["B"], "global_batch": world * c["B"], "precision": args.precision,
                        "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
                        "gflop_per_sample": round(fl["total"] / 1e9, 4)},
-            "roofline": {"bound": "mfma", "kernel": "paralind_core (mode-3 product + rank sum, batched NT GEMM 504x3129x512 x%d)" % (c["B"] * c["glimpse"]),
+            "roofline": {"bound": "mfma", "kernel": "paralind_core (mode-3 product + rank sum, batched NT GEMM 1008x3129x512 x%d): %s" % (c["B"], variant),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "launch_ms": core_ms, "flops_per_launch": core_flops,
-                         "mfma_issued_tflops": achieved * mfma_per_flop, "mfma_issued_frac": achieved * mfma_per_flop / peak,
+                         "mfma_issued_tflops": achieved * units, "mfma_issued_frac": achieved * units / peak,
                          "algorithmic_bytes_per_launch": c["B"] * 4 * (c["V"] * c["Q"] * c["A"] * c["glimpse"] + c["h_mm"] * (c["V"] * c["Q"] * c["glimpse"] + c["A"])),
                          "traffic_source": traffic_src,
-                         "note": "achieved = algorithmic fp32 flops / launch time; bf16x3 issues 3 bf16 MFMAs per product, so the MFMA pipes "
-                                 "run at mfma_issued_tflops against the 2500 TFLOP/s dense bf16 peak"},
+                         "note": "achieved = algorithmic fp32 flops / launch time; the split modes issue %.1f 16-bit-MFMA-equivalents per product, so the "
+                                 "MFMA pipes run at mfma_issued_tflops against the 2500 TFLOP/s dense 16-bit peak" % units},
             "whole_step_tflops": fl["total"] * c["B"] * args.steps / el / 1e12,
             "kernel_ms": kern,
         }
+        if fp32_exact is not None:
+            res["fp32_exact"] = fp32_exact
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
-            res["cpu_baseline"] = cpu_baseline(c, state, SEED, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(c, state, (v, q, a), gpu_first, args.cpu_budget)
     if dist.is_initialized():                                    # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(res), flush=True)
+
+
+def core_variant(precision):
+    """Name of the mode-3 GEMM instantiation a precision mode selects at the configs[1] shape (what profiles/core_traffic.json must match)."""
+    return {"bf16x3": "gemm_planes_kernel<terms=3, epi=INTERLEAVE2, tile 256x256, 4-slot ring>",
+            "bf16": "gemm_planes_kernel<terms=1, epi=INTERLEAVE2, tile 256x256, 4-slot ring>",
+            "fp32": "gemm_nt_f32_kernel<128x128x32>",
+            "f16f6": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x256>"}[precision]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"], help="forward (the BASELINE metric) or train (DP step)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"], help="c2 = BASELINE configs[1] (the metric); c3 / c4 = full-model forwards of configs[2] / [3]")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (the default run takes well under a minute on the GPU + ~20 s of CPU baseline)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps: allocator growth, one-time kernel attributes, clock ramp")
+    ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16", "f16f6"],
+                    help="bf16x3 (default): 3-term split-bf16 MFMA, fp32-grade (1e-5 vs the float64 oracle); fp32: exact fp32 MFMA")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-exact", action="store_true", help="skip the 4-step exact-fp32 sub-record of the default line")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous + timing path only (gloo on CPU, no GPU work)")
+    args = ap.parse_args()
+    args.precision_given = args.precision is not None
+    if args.precision is None:
+        args.precision = os.environ.get("CTI_PRECISION", "bf16x3")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))         # before anything touches a GPU in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if args.dry_launch:
+        return run_dry(args, world, rank)
+    import torch.distributed as dist
+    # CTI_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the N > 1 code path -- init, barrier, max-reduce -- on a 1-GPU box)
+    if world > 1 or os.environ.get("CTI_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if args.mode == "train":
+        run_train(args, world, rank, dev, dist)
+    elif args.config != "c2":
+        run_model(args, world, rank, dev, dist)
+    else:
+        run_forward(args, world, rank, dev, dist)
+    if dist.is_initialized():
+        dist.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@ _i64, _int, _vp, _sz = C.c_int64, C.c_int, C.c_void_p, C.c_size_t
 SIGNATURES = {
     "cti_abi_version": (_int, []),
     "cti_last_error_string": (C.c_char_p, []),
+    "cti_set_tuning": (_int, [_int, _i64]),
+    "cti_get_tuning": (_i64, [_int]),
     "cti_wn_scale": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _sz, _vp]),
     "cti_wn_scale_workspace_bytes": (_sz, [_int, _i64]),
     "cti_wn_scale_many": (_int, [_vp, _vp, _vp, _vp, _int, _vp, _sz, _vp]),
@@ -99,6 +101,7 @@ SIGNATURES = {
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 E_UNSUPPORTED = -4                                   # CTI_E_UNSUPPORTED: shape / mode outside a specialised kernel
 ACT_NONE, ACT_RELU = 0, 1
+TUNE_GEMM_CFG, TUNE_TRI_CHUNK = 1, 2                # cti_set_tuning keys
 
 _lib = None
 

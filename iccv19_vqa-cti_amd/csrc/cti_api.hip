@@ -1,6 +1,7 @@
 // cti_api.hip -- error reporting and the C-ABI entry points that dispatch to the MFMA GEMMs.
 #include "cti_common.h"
 #include <string.h>
+#include <atomic>
 
 namespace cti {
 
@@ -17,9 +18,34 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+static std::atomic<int> g_gemm_cfg{-1};
+static std::atomic<long long> g_tri_chunk{0};
+int tuning_gemm_cfg() { return g_gemm_cfg.load(std::memory_order_relaxed); }
+int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk.load(std::memory_order_relaxed); }
+
 }  // namespace cti
 
 using namespace cti;
+
+extern "C" int cti_set_tuning(int key, int64_t value) {
+    switch (key) {
+        case CTI_TUNE_GEMM_CFG:
+            CTI_REQUIRE(value >= -1 && value <= 2, CTI_E_SHAPE, "cti_set_tuning: GEMM_CFG must be -1 (auto), 0, 1 or 2, got %lld", (long long)value);
+            g_gemm_cfg.store((int)value); return CTI_OK;
+        case CTI_TUNE_TRI_CHUNK:
+            CTI_REQUIRE(value == 0 || (value >= 4 && value <= (1ll << 30) && value % 4 == 0), CTI_E_SHAPE,
+                        "cti_set_tuning: TRI_CHUNK must be 0 (auto) or a multiple of 4 in [4, 2^30], got %lld", (long long)value);
+            g_tri_chunk.store((long long)value); return CTI_OK;
+        default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
+    }
+}
+extern "C" int64_t cti_get_tuning(int key) {
+    switch (key) {
+        case CTI_TUNE_GEMM_CFG: return tuning_gemm_cfg();
+        case CTI_TUNE_TRI_CHUNK: return tuning_tri_chunk();
+        default: return INT64_MIN;
+    }
+}
 
 extern "C" int cti_abi_version(void) { return CTI_ABI_VERSION; }
 extern "C" const char* cti_last_error_string(void) { return err_buf(); }

@@ -1132,7 +1132,7 @@ using namespace cti;
 // chunking of the Tri softmax: chunks of <= 32768 positions (x G floats), at least one per sample
 static void tri_chunks(int V, int64_t QA, int64_t* chunk_n, int* nchunk) {
     const int64_t N = (int64_t)V * QA;
-    const int64_t c = 32768;
+    const int64_t c = tuning_tri_chunk() > 0 ? tuning_tri_chunk() : 32768;
     *nchunk = (int)((N + c - 1) / c);
     *chunk_n = c;
 }

@@ -902,7 +902,7 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
 }
 
 static void tri_chunks_b(int V, int64_t QA, int64_t* chunk_n, int* nchunk) {
-    const int64_t N = (int64_t)V * QA, c = 32768;
+    const int64_t N = (int64_t)V * QA, c = tuning_tri_chunk() > 0 ? tuning_tri_chunk() : 32768;
     *nchunk = (int)((N + c - 1) / c); *chunk_n = c;
 }
 extern "C" size_t cti_softmax_tri_bwd_workspace_bytes(int B, int V, int64_t QA, int G) {

@@ -13,6 +13,11 @@ namespace cti {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// Tuning overrides (cti_set_tuning): process-wide, meant for tests and benchmarks that must reach every tile geometry / the multi-chunk
+// softmax at small shapes.  -1 / 0 = the library's own choice.  They never change results beyond fp32 summation order.
+int tuning_gemm_cfg();            // -1 auto, 0 = 128x128, 1 = 256x128, 2 = 256x256 tile of the plane GEMM
+int64_t tuning_tri_chunk();       // 0 auto (32768), else positions per chunk of the Tri softmax (forward and backward)
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // after a kernel launch: pick up launch errors without synchronising

@@ -676,6 +676,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
 #ifdef CTI_FORCE_CFG
     cfg = CTI_FORCE_CFG;
 #endif
+    if (tuning_gemm_cfg() >= 0) cfg = tuning_gemm_cfg();                   // cti_set_tuning(CTI_TUNE_GEMM_CFG): tests reach every geometry at small shapes
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
     const int key = (a.terms == 3 ? 4 : 0) + epi;
     switch (key) {

@@ -24,7 +24,9 @@ from . import ops
 class FlatAdamaxDP:
     ALIGN = 64                                                  # floats: 256-B parameter alignment inside the flat buffers
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_norm=0.25, update_freq=1, process_group=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_norm=0.25, update_freq=1, process_group=None, force_collective=False):
+        """force_collective: issue the broadcast / all-reduce even in a one-rank group (exercises RCCL on a 1-GPU box; identity there)."""
+        self.force_collective = bool(force_collective)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -66,8 +68,9 @@ class FlatAdamaxDP:
 
     def broadcast_parameters(self, src=0):
         """Identical initial parameters on every rank: one broadcast of the flat buffer."""
-        if self.world > 1:
+        if self.world > 1 or (self.force_collective and dist.is_initialized()):
             dist.broadcast(self.flat_p, src=src, group=self.pg)
+            ops.invalidate_caches()                              # flat_p was overwritten behind autograd's version counters
 
     def zero_grad(self, set_to_none=True):
         """set_to_none=True (default, like torch.optim): no fill kernel -- autograd then keeps the gradient tensors it produces and
@@ -108,7 +111,7 @@ class FlatAdamaxDP:
     def step(self):
         """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm."""
         self.gather_grads()
-        if self.world > 1:
+        if self.world > 1 or (self.force_collective and dist.is_initialized()):
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
         self.step_count += 1
         st = ops._stream()
@@ -122,7 +125,58 @@ class FlatAdamaxDP:
         return self.grad_norm
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_inf": self.exp_inf, "lr": self.lr}
+        """The `torch.optim.Adamax.state_dict()` format the reference saves as `optimizer_state` (src/utils.py:104) and reloads with
+        `optim.load_state_dict` (src/FFOE/main.py:127, trainer.py:87): per-parameter `state[i] = {step, exp_avg, exp_inf}` in the order of
+        `filter(requires_grad, model.parameters())` (src/FFOE/train.py:34) plus one param group.  Tensors are CLONES (later steps do not
+        mutate a dict the caller holds); parameters that have not been stepped yet have no entry, like torch."""
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                k = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                            "exp_inf": self.exp_inf[o:o + k].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "foreach": None, "maximize": False,
+                 "differentiable": False, "capturable": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_inf.copy_(sd["exp_inf"]); self.lr = sd.get("lr", self.lr)
+        """Accepts what state_dict() returns, i.e. a torch.optim.Adamax state dict over the same parameter list (torch 1.1's integer `step`
+        and torch 2.x's tensor `step` both).  Raises on any layout mismatch (parameter count, shapes, unequal step counts, weight decay)
+        instead of mis-assigning moments."""
+        if "param_groups" not in sd or "state" not in sd:
+            raise ValueError("expected a torch.optim.Adamax state_dict ({'state', 'param_groups'})")
+        if len(sd["param_groups"]) != 1:
+            raise ValueError("FlatAdamaxDP holds one parameter group, the state dict has %d" % len(sd["param_groups"]))
+        grp = sd["param_groups"][0]
+        ids = list(grp["params"])
+        if len(ids) != len(self.params):
+            raise ValueError("the state dict covers %d parameters, the model has %d trainable ones" % (len(ids), len(self.params)))
+        if float(grp.get("weight_decay", 0)) != 0.0:
+            raise ValueError("weight_decay != 0 is not supported (the reference trains with torch.optim.Adamax defaults)")
+        state = sd["state"]
+        steps = set()
+        for i, pid in enumerate(ids):
+            st = state.get(pid, state.get(str(pid)))
+            if st is None:
+                continue
+            for key in ("exp_avg", "exp_inf"):
+                if tuple(st[key].shape) != tuple(self.params[i].shape):
+                    raise ValueError("parameter %d: %s has shape %s, expected %s" % (i, key, tuple(st[key].shape), tuple(self.params[i].shape)))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): the fused kernel keeps one bias-correction step" % sorted(steps))
+        # a parameter torch never stepped (no gradient so far) has no entry: zero moments here, which is what torch starts it from
+        self.exp_avg.zero_(); self.exp_inf.zero_()
+        for i, pid in enumerate(ids):
+            st = state.get(pid, state.get(str(pid)))
+            if st is None:
+                continue
+            o, k = self.offsets[i], self.params[i].numel()
+            self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_inf[o:o + k].copy_(st["exp_inf"].reshape(-1))
+        self.step_count = steps.pop() if steps else 0
+        self.lr = float(grp.get("lr", self.lr))
+        self.betas = tuple(grp.get("betas", self.betas))
+        self.eps = float(grp.get("eps", self.eps))
+        ops.invalidate_caches()

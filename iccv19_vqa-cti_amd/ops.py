@@ -50,6 +50,30 @@ def invalidate_caches():
 
 import os as _os
 
+
+class tuning:
+    """Context manager over cti_set_tuning (tests / benchmarks only): `with ops.tuning(gemm_cfg=2, tri_chunk=64): ...` forces the plane GEMM's
+    tile geometry (0 = 128x128, 1 = 256x128, 2 = 256x256) and / or the Tri softmax's chunk length, so small tensors run the instantiations that
+    BASELINE configs[1] selects.  Restores the previous values on exit."""
+
+    def __init__(self, gemm_cfg=None, tri_chunk=None):
+        self.want = {L.TUNE_GEMM_CFG: gemm_cfg, L.TUNE_TRI_CHUNK: tri_chunk}
+
+    def __enter__(self):
+        lib = L.lib()
+        self.old = {k: lib.cti_get_tuning(k) for k, v in self.want.items() if v is not None}
+        for k, v in self.want.items():
+            if v is not None:
+                L.check(lib.cti_set_tuning(k, int(v)), "cti_set_tuning")
+        return self
+
+    def __exit__(self, *exc):
+        lib = L.lib()
+        for k, v in self.old.items():
+            L.check(lib.cti_set_tuning(k, int(v)), "cti_set_tuning")
+        return False
+
+
 _aux = {}
 use_aux_stream = _os.environ.get("CTI_NO_AUX_STREAM", "0") != "1"
 

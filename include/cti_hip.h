@@ -48,6 +48,15 @@ enum { CTI_ACT_NONE = 0, CTI_ACT_RELU = 1 };
 int cti_abi_version(void);
 const char* cti_last_error_string(void);
 
+/* Tuning overrides -- process-wide, for tests and benchmarks only (they select among kernels that compute the same result up to fp32
+ * summation order; the defaults are what production uses).  CTI_TUNE_GEMM_CFG: tile geometry of the plane GEMM (-1 = the makespan model,
+ * 0 = 128x128, 1 = 256x128, 2 = 256x256).  CTI_TUNE_TRI_CHUNK: positions per chunk of the two-level Tri softmax, forward and backward
+ * (0 = 32768; a multiple of 4 otherwise) -- lets a small tensor run the multi-chunk combine that BASELINE configs[1] needs
+ * (1.58 M positions per sample = 49 chunks).  cti_get_tuning returns INT64_MIN for an unknown key. */
+enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2 };
+int cti_set_tuning(int key, int64_t value);
+int64_t cti_get_tuning(int key);
+
 /* hipEvent_t helpers for hosts without HIP bindings (timing on the launch stream). elapsed_ms synchronises on `end`. */
 void* cti_event_create(void);
 int cti_event_destroy(void* ev);

@@ -247,6 +247,49 @@ def tc_c1():
     save("g3_tcnet_forward_c1", cfg, outputs={"raw": raw, "p": p.contiguous(), "logits": logits.contiguous()})
 
 
+def c2_sample_index(n_total, n_pick, seed):
+    """The fixed sample of flat output positions stored by the configs[1] fixture.  Must stay identical to
+    tests/golden_util.py:c2_sample_index."""
+    return np.sort(np.random.RandomState(seed).choice(n_total, size=n_pick, replace=False)).astype(np.int64)
+
+
+def tc_c2():
+    """BASELINE config 2 widths -- the shape the headline metric is quoted on (V=36x2048, Q=14x1024, A=3129x300, rank 32,
+    h_mm 512, glimpse 2) -- at B=3.  Params and inputs from RandomState (regenerated by tests/golden_util.py:c2_case); a
+    sample's output is 3.15 M floats, so the fixture keeps a fixed 65 536-position sample of `raw` (TCNet.forward) and `p`
+    per batch (positions over the flattened (B,V,Q,A,G) tensor), the per-(b,g) argmax of p, log-sum-exp of the masked
+    logits and max|raw| -- enough to pin values, the mask and the softmax normalisation over 1.58 M positions."""
+    seed = 2204
+    m = TriAttention(2048, 1024, 300, 512, 1, 32, 2, 1).eval()
+    fill_state_from_rs(m, seed)
+    rs = np.random.RandomState(seed + 1)
+    B, V, Q, A, G = 3, 36, 14, 3129, 2
+    v = rs_fill(rs, (B, V, 2048), "abs")
+    q = rs_fill(rs, (B, Q, 1024), "scale:1.0")
+    a = rs_fill(rs, (B, A, 300), "scale:1.0")
+    v[0, 29:] = 0
+    v[1, 11:] = 0
+    with torch.no_grad():
+        raw = m.TriAtt(torch.from_numpy(v), torch.from_numpy(q), torch.from_numpy(a)).contiguous()
+        p, logits = m(torch.from_numpy(v), torch.from_numpy(q), torch.from_numpy(a))
+    raw, p, logits = raw.numpy(), p.contiguous().numpy(), logits.contiguous().numpy()
+    assert raw.shape == (B, V, Q, A, G)
+    idx = c2_sample_index(raw.size, 65536, seed + 2)
+    l2 = logits.reshape(B, -1, G).astype(np.float64)
+    mx = l2.max(1, keepdims=True)
+    lse = (mx + np.log(np.exp(l2 - mx).sum(1, keepdims=True)))[:, 0, :]
+    keys = [[k, list(t.shape)] for k, t in m.state_dict().items()]
+    cfg = dict(v_dim=2048, q_dim=1024, a_dim=300, h_dim=512, h_out=1, rank=32, glimpse=G, k=1, B=B, V=V, Q=Q, A=A,
+               seed=seed, zero_from={"0": 29, "1": 11}, state_keys=keys, n_sample=65536,
+               ref="BASELINE.json configs[1] widths at B=3; src/tc.py:41-52, src/attention.py:49-59")
+    save("g3_tcnet_forward_c2", cfg,
+         outputs={"raw_s": raw.reshape(-1)[idx], "p_s": p.reshape(-1)[idx],
+                  "neginf_s": np.isneginf(logits.reshape(-1)[idx]),
+                  "argmax": p.reshape(B, -1, G).argmax(1).astype(np.int64),
+                  "pmax": p.reshape(B, -1, G).max(1), "lse": lse.astype(np.float64),
+                  "raw_absmax": np.float32(np.abs(raw).max()), "p_sum": p.reshape(B, -1, G).astype(np.float64).sum(1)})
+
+
 # ----------------------------------------------------------------------------------------------
 # G6/G7/G8  BCNet three branches, forward_with_weights, BiAttention (+ grads)
 # ----------------------------------------------------------------------------------------------
@@ -351,6 +394,10 @@ def state_keys_real():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                  # regenerate selected fixtures only: make_golden.py tc_c2 ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     g1()
     g2()
     fc_case()
@@ -361,6 +408,7 @@ if __name__ == "__main__":
     tc_fww_case("g5_tcnet_fww_k2", 64, 48, 32, 64, 4, 2, 2, 3, 5, 4, 3, seed=31)
     tc_fww_case("g5_tcnet_fww_k1", 40, 24, 20, 48, 3, 2, 1, 2, 6, 3, 2, seed=32)
     tc_c1()
+    tc_c2()
     bc_case("g6_bcnet_hnone_k1", 64, 48, 32, None, 1, 3, 5, 4, seed=41)
     bc_case("g6_bcnet_h2_k3", 64, 48, 32, 2, 3, 3, 5, 4, seed=42)
     bc_case("g6_bcnet_h40_k1", 64, 48, 32, 40, 1, 2, 5, 4, seed=43)

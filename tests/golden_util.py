@@ -72,6 +72,27 @@ def c1_case():
     return fx, params, v, q, a
 
 
+def c2_sample_index(n_total, n_pick, seed):
+    """Identical copy of tests/golden/make_golden.py:c2_sample_index."""
+    return np.sort(np.random.RandomState(seed).choice(n_total, size=n_pick, replace=False)).astype(np.int64)
+
+
+def c2_case():
+    """BASELINE configs[1] widths at B=3 (fixture g3_tcnet_forward_c2): (fixture, params, v, q, a, sample index) regenerated exactly as
+    make_golden.py:tc_c2 built them."""
+    fx = load("g3_tcnet_forward_c2")
+    c = fx.cfg
+    params = rs_state([(k, tuple(s)) for k, s in c["state_keys"]], c["seed"])
+    rs = np.random.RandomState(c["seed"] + 1)
+    v = rs_fill(rs, (c["B"], c["V"], c["v_dim"]), "abs")
+    q = rs_fill(rs, (c["B"], c["Q"], c["q_dim"]), "scale:1.0")
+    a = rs_fill(rs, (c["B"], c["A"], c["a_dim"]), "scale:1.0")
+    for b, r in c["zero_from"].items():
+        v[int(b), int(r):] = 0
+    idx = c2_sample_index(c["B"] * c["V"] * c["Q"] * c["A"] * c["glimpse"], c["n_sample"], c["seed"] + 2)
+    return fx, params, v, q, a, idx
+
+
 def c4_bi_case():
     fx = load("g7_biattention_c4")
     c = fx.cfg

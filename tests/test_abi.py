@@ -43,6 +43,15 @@ def test_argument_errors_do_not_launch():
     assert lib.cti_softmax_tri_workspace_bytes(0, 36, 56, 2) == 0
 
 
+def test_tuning_rejects_bad_values_and_defaults_to_auto():
+    lib = L.lib()
+    assert lib.cti_set_tuning(1, 3) == -2 and lib.cti_set_tuning(2, 63) == -2 and lib.cti_set_tuning(99, 0) == -4
+    assert lib.cti_get_tuning(1) == -1 and lib.cti_get_tuning(2) == 0
+    with cti_amd.ops.tuning(gemm_cfg=2, tri_chunk=64):
+        assert lib.cti_get_tuning(1) == 2 and lib.cti_get_tuning(2) == 64
+    assert lib.cti_get_tuning(1) == -1 and lib.cti_get_tuning(2) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     with pytest.raises(cti_amd.CtiError):
         cti_amd.ops.zero_row_mask(torch.zeros(2, 3, 4))

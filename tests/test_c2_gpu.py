@@ -1,0 +1,148 @@
+"""Parity at the shape the headline metric is quoted on -- BASELINE.json configs[1]: TCNet.forward (reference src/tc.py:41-52) +
+TriAttention (src/attention.py:49-59) at V=36x2048, Q=14x1024, A=3129x300, rank 32, h_mm 512, glimpse 2.
+
+ (a) B=3 against the reference's own output (fixture g3_tcnet_forward_c2: 65 536 sampled positions of raw / p, -inf pattern, per-(b,g)
+     argmax, log-sum-exp over the 1.58 M positions of a sample) and against the float64 oracle on every element;
+ (b) B=256 once -- the launch bench.py times: the 256x256 `EPI_INTERLEAVE2` GEMM instantiation, 64-bit offsets of the 3.2 GB output, the
+     49-chunk Tri softmax -- checking samples 0 / 127 / 255 against the float64 oracle;
+ (c) every tile geometry of the plane GEMM and the multi-chunk softmax (forward and backward) forced at small shapes through
+     cti_set_tuning, against the reference fixtures.
+
+Tolerance: 1e-4 normalised max error (north_star); masks, -inf patterns and argmax bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+import golden_util as gu
+from oracle import cti_oracle as O
+from test_oracle_golden import c2_checks
+from test_parity_gpu import T, load_into, check, _tri, TOL
+from test_backward_gpu import check_param_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tri_from(cfg, params):
+    return _tri(type("F", (), {"cfg": cfg, "p": params})())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_c2_widths_small_batch(prec):
+    fx, params, v, q, a, idx = gu.c2_case()
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(prec)
+    try:
+        m = _tri_from(fx.cfg, params)
+        with torch.no_grad():
+            raw = m.TriAtt(T(v), T(q), T(a)).cpu().numpy()
+            p, logits = m(T(v), T(q), T(a))
+        p, logits = p.cpu().numpy(), logits.cpu().numpy()
+    finally:
+        cti_amd.set_precision(old)
+    e_raw, e_p = c2_checks(raw, p, logits, fx, idx, TOL, 1e-2, "HIP C2 [%s] vs reference" % prec)
+    raw64 = O.tcnet_forward(v, q, a, params, "TriAtt.", dtype=np.float64)
+    e64 = check(raw, raw64, what="C2 raw vs float64 oracle (all 9.5 M elements)")
+    assert np.array_equal(np.broadcast_to(O.zero_row_mask(v).astype(bool)[:, :, None, None, None], raw.shape), np.isneginf(logits))
+    print("C2 widths B=3 [%s]: raw vs reference sample %.3g, vs float64 truth %.3g" % (prec, e_raw, e64))
+
+
+def _c2_batch(B, seed):
+    rs = np.random.RandomState(seed)
+    v = gu.rs_fill(rs, (B, 36, 2048), "abs")
+    nv = rs.randint(10, 37, size=B)
+    for b in range(B):
+        v[b, nv[b]:] = 0
+    q = gu.rs_fill(rs, (B, 14, 1024), "scale:1.0")
+    a = gu.rs_fill(rs, (B, 3129, 300), "scale:1.0")
+    return v, q, a
+
+
+def test_c2_full_batch_sampled_against_oracle():
+    """The benchmarked launch itself (B=256, bf16x3): samples 0, 127, 255 against the float64 oracle."""
+    fx, params, *_ = gu.c2_case()
+    B = 256
+    v, q, a = _c2_batch(B, 777)
+    v[127, 36:] = 0                                # no padding at all on sample 127 (rs draws 10..36); sample 255 gets the maximum padding
+    v[255, 10:] = 0
+    m = _tri_from(fx.cfg, params)
+    pick = [0, 127, 255]
+    with torch.no_grad():
+        vd, qd, ad = T(v), T(q), T(a)
+        raw = m.TriAtt(vd, qd, ad)
+        assert raw.shape == (B, 36, 14, 3129, 2) and raw.is_contiguous()
+        raw_s = raw[pick].cpu().numpy()
+        del raw
+        p, logits = m(vd, qd, ad)
+        p_s, l_s = p[pick].cpu().numpy(), logits[pick].cpu().numpy()
+        psum = p.view(B, -1, 2).sum(1).cpu().numpy()
+        del p, logits
+    torch.cuda.empty_cache()
+    raw64 = O.tcnet_forward(v[pick], q[pick], a[pick], params, "TriAtt.", dtype=np.float64)
+    e = check(raw_s, raw64, what="B=256 raw (samples 0/127/255) vs float64 oracle")
+    p64, l64 = O.tri_attention(v[pick], q[pick], a[pick], params, dtype=np.float64)
+    assert np.array_equal(np.isneginf(l_s), np.isneginf(l64))
+    assert np.max(np.abs(psum - 1.0)) < 1e-4                       # every sample's 49-chunk softmax normalises
+    for i in range(3):
+        for g in range(2):
+            ref = p64[i, ..., g].reshape(-1)
+            top = np.argsort(ref)[-2:]
+            if ref[top[1]] - ref[top[0]] > 1e-3:                    # a clear winner in float64: the fp32-grade result must agree
+                assert int(np.argmax(p_s[i, ..., g])) == int(top[1])
+    ok = np.isfinite(l64)
+    assert np.max(np.abs(l_s[ok] - l64[ok])) < TOL * np.max(np.abs(l64[ok]))
+    print("C2 B=256 [bf16x3]: raw err vs float64 truth on samples 0/127/255 = %.3g" % e)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_forced_tile_geometry_and_multichunk_softmax_forward(cfg, prec):
+    """g3 fixtures with the GEMM tile geometry forced and the Tri softmax cut into 16-position chunks (4 and 7 chunks)."""
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(prec)
+    tol = TOL if prec == "bf16x3" else 3e-2
+    try:
+        for name in ("g3_tcnet_small", "g3_tcnet_g3_odd"):
+            fx = gu.load(name)
+            m = _tri(fx)
+            v, q, a = T(fx.i["v"]), T(fx.i["q"]), T(fx.i["a"])
+            with cti_amd.ops.tuning(gemm_cfg=cfg, tri_chunk=16), torch.no_grad():
+                raw = m.TriAtt(v, q, a)
+                p, logits = m(v, q, a)
+            check(raw, fx.o["raw"], tol=tol, what="%s raw cfg=%d" % (name, cfg))
+            assert np.array_equal(np.isneginf(logits.cpu().numpy()), np.isneginf(fx.o["logits"]))
+            if prec == "bf16x3":
+                check(p, fx.o["p"], what="%s p cfg=%d" % (name, cfg))
+    finally:
+        cti_amd.set_precision(old)
+    assert cti_amd.pkg._lib.lib().cti_get_tuning(1) == -1 and cti_amd.pkg._lib.lib().cti_get_tuning(2) == 0
+
+
+def test_c1_with_every_tile_geometry():
+    """BASELINE configs[0] at full size with each geometry forced: the 256x256 tile on 1008 x 4 per-sample outputs, 128x128 on the rest."""
+    fx, params, v, q, a = gu.c1_case()
+    m = _tri_from(fx.cfg, params)
+    for cfg in (0, 1, 2):
+        with cti_amd.ops.tuning(gemm_cfg=cfg, tri_chunk=512), torch.no_grad():
+            raw = m.TriAtt(T(v), T(q), T(a))
+            p, logits = m(T(v), T(q), T(a))
+        check(raw, fx.o["raw"], what="C1 raw, geometry %d" % cfg)
+        pn = p.cpu().numpy()
+        for b in range(4):
+            for g in range(2):
+                assert np.argmax(pn[b, ..., g]) == np.argmax(fx.o["p"][b, ..., g])
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_forced_tile_geometry_and_multichunk_softmax_backward(cfg):
+    fx = gu.load("g8_triattention_grad")
+    m = _tri(fx)
+    v, q, a = (T(fx.i[k]).requires_grad_(True) for k in ("v", "q", "a"))
+    with cti_amd.ops.tuning(gemm_cfg=cfg, tri_chunk=16):
+        p, logits = m(v, q, a)
+        check(p, fx.o["p"], what="p under autograd, geometry %d" % cfg)
+        (p * T(fx.i["cot_p"])).sum().backward()
+    for n_, t_ in (("v", v), ("q", q), ("a", a)):
+        check(t_.grad, fx.g[n_], what="d%s geometry %d" % (n_, cfg))
+    check_param_grads(m, fx)

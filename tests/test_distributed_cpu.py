@@ -59,3 +59,18 @@ def test_flop_model_matches_survey():
     f = bench.flops_per_sample(bench.C2)
     assert f["tucker"] == 1051406336 and f["rank"] == 1666711552 and f["core_final"] == 3229728768
     assert abs(f["total"] / 1e6 - 5983.2) < 0.1           # 5 983.2 MFLOP per sample
+
+
+def test_bare_multi_gpu_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (a torch.distributed.run child spawned before any
+    GPU call), not exit: --dry-launch runs exactly that launch + rendezvous + barrier / max-reduce path on CPU (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    res = json.loads(last)                                   # the JSON line is the LAST line of stdout
+    assert res == dict(res, dry_launch=True, n_gpus=2, ranks_seen=2, steps=3, warmup=1)
+    assert res["ms_per_step"] >= 10.0

@@ -245,3 +245,82 @@ def test_update_freq_accumulates_micro_batches():
         assert torch.allclose(res[0], res[1], rtol=2e-4, atol=2e-6)
     finally:
         cti_amd.set_precision("bf16x3")
+
+
+def _ref_step(m2, opt2, batch):
+    """One step of the reference recipe on stock torch: loss / B, clip by max_norm / (norm + 1e-6) (src/utils.py:323-328), torch.optim.Adamax."""
+    v, q, a, y = batch
+    opt2.zero_grad()
+    loss_fn(m2(v, q, a), y).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in m2.parameters() if p.grad is not None])
+    coef = 0.25 / (flat.norm() + 1e-6)
+    if coef < 1:
+        for p in m2.parameters():
+            if p.grad is not None:
+                p.grad.mul_(coef)
+    opt2.step()
+
+
+def test_optimizer_state_dict_is_the_torch_adamax_format_both_ways():
+    """The reference checkpoints `optimizer.state_dict()` of torch.optim.Adamax (src/utils.py:104) and resumes with load_state_dict
+    (src/FFOE/main.py:127).  FlatAdamaxDP emits and accepts that format: train 2 steps here -> resume in torch.optim.Adamax, and 2 steps in
+    torch -> resume here; the third step agrees either way.  The dict holds clones, and a mismatched layout is refused."""
+    cti_amd.set_precision("fp32")
+    try:
+        torch.manual_seed(11)
+        m1, m2 = TinyCTI().to(DEV), TinyCTI().to(DEV)
+        m2.load_state_dict(m1.state_dict())
+        opt1 = cti_amd.FlatAdamaxDP(m1, lr=2e-3, clip_norm=0.25)
+        opt2 = torch.optim.Adamax(m2.parameters(), lr=2e-3)
+        batches = [tuple(t.to(DEV) for t in make_batch(8, 100 + s)) for s in range(3)]
+        for s in range(2):
+            opt1.zero_grad(); loss_fn(m1(*batches[s][:3]), batches[s][3]).backward(); opt1.step()
+            _ref_step(m2, opt2, batches[s])
+        sd1 = opt1.state_dict()
+        assert set(sd1) == {"state", "param_groups"} and sd1["param_groups"][0]["params"] == list(range(len(opt1.params)))
+        snap = sd1["state"][0]["exp_avg"].clone()
+        # ours -> torch: a fresh torch optimizer resumes from our dict
+        m3 = TinyCTI().to(DEV); m3.load_state_dict(m1.state_dict())
+        opt3 = torch.optim.Adamax(m3.parameters(), lr=2e-3)
+        opt3.load_state_dict(sd1)
+        # torch -> ours: a fresh FlatAdamaxDP resumes from torch's dict
+        m4 = TinyCTI().to(DEV); m4.load_state_dict(m2.state_dict())
+        opt4 = cti_amd.FlatAdamaxDP(m4, lr=1.0, clip_norm=0.25)           # lr comes from the dict
+        opt4.load_state_dict(opt2.state_dict())
+        assert opt4.step_count == 2 and abs(opt4.lr - 2e-3) < 1e-12
+        opt1.zero_grad(); loss_fn(m1(*batches[2][:3]), batches[2][3]).backward(); opt1.step()
+        _ref_step(m2, opt2, batches[2])
+        _ref_step(m3, opt3, batches[2])
+        opt4.zero_grad(); loss_fn(m4(*batches[2][:3]), batches[2][3]).backward(); opt4.step()
+        assert torch.equal(sd1["state"][0]["exp_avg"], snap)             # the saved dict did not move with the third step
+        for (n1, p1), (_, p2), (_, p3), (_, p4) in zip(m1.named_parameters(), m2.named_parameters(), m3.named_parameters(), m4.named_parameters()):
+            assert torch.allclose(p1, p2, rtol=1e-4, atol=2e-6), n1
+            assert torch.allclose(p3, p2, rtol=1e-4, atol=2e-6), n1
+            assert torch.allclose(p4, p2, rtol=1e-4, atol=2e-6), n1
+        bad = opt2.state_dict()
+        bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+        with pytest.raises(ValueError):
+            opt4.load_state_dict(bad)
+        bad = opt1.state_dict()
+        bad["state"][0]["exp_avg"] = bad["state"][0]["exp_avg"].reshape(-1)[:-1]
+        with pytest.raises(ValueError):
+            opt4.load_state_dict(bad)
+    finally:
+        cti_amd.set_precision("bf16x3")
+
+
+def test_rccl_executes_once_through_the_dp_step():
+    """backend "nccl" (= RCCL) with one rank on this 1-GPU box: process-group init, the parameter broadcast, the all-reduce of the flat
+    gradient buffer inside FlatAdamaxDP.step(), the timing barrier and the max-reduce all run through RCCL (CTI_BENCH_FORCE_DIST=1)."""
+    import json
+    import subprocess
+    env = dict(os.environ, CTI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 1000),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "32"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["collective"] == "rccl all-reduce executed (forced, world 1)"

@@ -80,6 +80,39 @@ def test_tcnet_forward_c1_baseline_shapes():
             assert np.argmax(p[b, ..., g]) == np.argmax(fx.o["p"][b, ..., g])
 
 
+def c2_checks(raw, p, logits, fx, idx, tol_raw, tol_p, what="", raw_ref=None):
+    """Shared by the CPU (oracle) and GPU (HIP) tests of the configs[1] fixture: sampled values of `raw` and `p`, the -inf pattern, the
+    per-(b,g) argmax (bit-exact), the softmax normaliser over 1.58 M positions (log-sum-exp) and sum(p) = 1."""
+    c = fx.cfg
+    B, G = c["B"], c["glimpse"]
+    scale = float(fx.o["raw_absmax"])
+    e_raw = float(np.max(np.abs(raw.reshape(-1)[idx].astype(np.float64) - fx.o["raw_s"]))) / scale
+    assert e_raw < tol_raw, "%s raw: normalised max error %.3g >= %.3g" % (what, e_raw, tol_raw)
+    assert np.array_equal(np.isneginf(logits.reshape(-1)[idx]), fx.o["neginf_s"]), what + ": -inf pattern"
+    ps = p.reshape(-1)[idx]
+    e_p = float(np.max(np.abs(ps.astype(np.float64) - fx.o["p_s"]))) / float(np.max(fx.o["pmax"]))
+    assert e_p < tol_p, "%s p: normalised max error %.3g >= %.3g" % (what, e_p, tol_p)
+    assert np.array_equal(ps == 0, fx.o["p_s"] == 0), what + ": masked positions are exactly 0"
+    p3 = p.reshape(B, -1, G)
+    assert np.array_equal(p3.argmax(1), fx.o["argmax"]), what + ": argmax"
+    assert np.max(np.abs(p3.astype(np.float64).sum(1) - 1.0)) < 1e-4, what + ": sum(p)"
+    l2 = logits.reshape(B, -1, G).astype(np.float64)
+    mx = l2.max(1, keepdims=True)
+    lse = (mx + np.log(np.exp(l2 - mx).sum(1, keepdims=True)))[:, 0, :]
+    assert np.max(np.abs(lse - fx.o["lse"])) < tol_raw * scale, what + ": log-sum-exp of the masked logits"
+    return e_raw, e_p
+
+
+def test_tcnet_forward_c2_widths():
+    """BASELINE configs[1] widths (A = 3129) at B = 3 against the reference's own output (65 536 sampled positions + statistics)."""
+    fx, params, v, q, a, idx = gu.c2_case()
+    p, logits = O.tri_attention(v, q, a, params)
+    raw = O.tcnet_forward(v, q, a, params, "TriAtt.")
+    assert raw.shape == (3, 36, 14, 3129, 2)
+    e_raw, e_p = c2_checks(raw, p, logits, fx, idx, 3e-5, 1e-2, "oracle C2")
+    print("oracle vs reference at the configs[1] widths: raw %.3g, p %.3g" % (e_raw, e_p))
+
+
 @pytest.mark.parametrize("name", ["g5_tcnet_fww_k2", "g5_tcnet_fww_k1"])
 def test_tcnet_forward_with_weights(name):
     fx = gu.load(name)
