@@ -1,0 +1,156 @@
+// cti_f16f6.h -- the "f16f6" operand format and its device-side encoders (gfx950).
+//
+// WHY.  An fp32-grade product on the matrix cores needs the operands split into pieces the MFMA can multiply.  The bf16x3 mode
+// (cti_gemm_bf16x3.hip) issues three bf16 MFMAs per product: a*b ~= ah*bh + ah*bl + al*bh.  Only the first term needs 8+ bits on
+// BOTH sides; the two cross terms are corrections of relative size 2^-9 whose own precision requirement is a few bits.  gfx950 runs
+// block-scaled fp6 (e2m3, 4 significant bits, one E8M0 scale per 32 elements) at FOUR times the 16-bit MFMA rate, so
+//
+//     a*b ~= a16*b16  +  fp6(a16)*fp6(b - b16)  +  fp6(a - a16)*fp6(b16)
+//
+// with a16 = f16(a) (11 significant bits; the residual is 2^-12 relative) costs 1 + 2 * 1/4 = 1.5 sixteen-bit-MFMA units per
+// product instead of 3, at about the same accuracy as bf16x3 (residual 2^-12 times a 2^-4 rounding = 2^-16 per cross term;
+// tools/emu_f16f6.py emulates it on the BASELINE configs[1] operands: 2.4e-5 normalised max error on the mode-3 GEMM against
+// 6.7e-6 for bf16x3, tolerance 1e-4).  Measured on MI355X (tools/mb/mb_f16f6.hip, random operands in registers): 1003 algorithmic
+// TFLOP/s against 550 for bf16x3.  Both cross terms of one 32-wide K block ride in ONE v_mfma_scale_f32_32x32x64_f8f6f4:
+// its lanes 0-31 carry (A: fp6 of the hi part, B: fp6 of the lo part), lanes 32-63 carry (A: lo, B: hi), each with its own scale.
+//
+// PLANES of an operand X (rows x K), Kb = ceil(K / 32) blocks, block-major like the bf16 planes (one K block of a GEMM tile is a
+// contiguous run of rows):
+//   H   f16   [Kb][rows_alloc][32]      hi part, saturated to +-65504                        64 B per (row, block)
+//   FH  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of H / 2^eh, element j at bits 6j..6j+5    24 B
+//   FL  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of (x - H) / 2^el                          24 B
+//   S   e8m0  [Kb][rows_allocS][2]      byte 0 = eh + 127, byte 1 = el + 127                  2 B     (3.56 B per element in all)
+// eh / el are the smallest exponents with max|.| / 2^e <= 7.5 (the largest e2m3 value) over the block.  rows_alloc = rows + 256 and
+// rows_allocS = rows + 512 (a GEMM tile may over-read that many rows; their contents only feed discarded outputs, but they must be
+// defined E8M0 scales -- not 0xFF = NaN -- so the allocation is zero-filled once by the producer's caller).
+//
+// DOMAIN.  f16 carries 5 exponent bits: the hi part is exact-to-11-bits for 6.1e-5 <= |x| <= 65504.  Smaller values degrade
+// gracefully (absolute error <= 2^-29, the lo part picks up what the subnormal hi part drops); larger ones saturate in H and leave
+// the excess to the 4-bit lo part.  Tensors whose significant magnitudes leave [2^-12, 65504] should use the bf16x3 mode.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cti {
+
+constexpr int F6_BLK = 32;                       // K elements per scale block
+constexpr int F6_SLACK_ROWS = 256;               // H / FH / FL rows a tile may over-read
+constexpr int F6_SLACK_ROWS_S = 512;             // S rows a tile may over-read (its DMA always moves 1 KiB = 512 rows of scales)
+
+// Rows: a producer maps logical row m of its (flat) matrix to plane row (m / rdiv) * rstride + m % rdiv -- batches of rdiv rows start at
+// multiples of rstride (a multiple of 8), because the GEMM's LDS-DMA reads 16 B per lane from batch_start * 24 B (codes) and
+// batch_start * 2 B (scales): every tile origin must be a multiple of 8 rows.  rdiv = 0: identity (one batch).
+struct F6Planes {
+    _Float16* H; uint8_t* FH; uint8_t* FL; uint8_t* S;
+    int64_t rows_alloc, rows_allocS;           // multiples of 8
+    int Kb;
+    int64_t rdiv, rstride;
+};
+inline int64_t f6_round8(int64_t x) { return (x + 7) & ~(int64_t)7; }
+// plane rows of a matrix of `rows` logical rows in batches of rdiv (0 = unbatched)
+inline int64_t f6_plane_rows(int64_t rows, int64_t rdiv) { return rdiv > 0 ? (rows + rdiv - 1) / rdiv * f6_round8(rdiv) : rows; }
+inline size_t f6_planes_bytes(int64_t rows, int K, int64_t rdiv = 0) {
+    const size_t kb = (size_t)((K + F6_BLK - 1) / F6_BLK);
+    const size_t pr = (size_t)f6_plane_rows(rows, rdiv);
+    const size_t ra = (size_t)f6_round8(pr + F6_SLACK_ROWS), rs = (size_t)f6_round8(pr + F6_SLACK_ROWS_S);
+    return kb * (ra * 64 + 2 * ra * 24 + rs * 2) + 4 * 256;
+}
+// carve the four planes out of one block (256-B aligned pieces); base may be NULL (sizes only)
+inline F6Planes f6_carve(void* base, int64_t rows, int K, int64_t rdiv = 0) {
+    F6Planes p{};
+    p.Kb = (K + F6_BLK - 1) / F6_BLK;
+    const int64_t pr = f6_plane_rows(rows, rdiv);
+    p.rows_alloc = f6_round8(pr + F6_SLACK_ROWS); p.rows_allocS = f6_round8(pr + F6_SLACK_ROWS_S);
+    p.rdiv = rdiv; p.rstride = rdiv > 0 ? f6_round8(rdiv) : 0;
+    char* b = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { char* r = b ? b + off : nullptr; off = (off + n + 255) & ~(size_t)255; return r; };
+    p.H = reinterpret_cast<_Float16*>(take((size_t)p.Kb * p.rows_alloc * 64));
+    p.FH = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_alloc * 24));
+    p.FL = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_alloc * 24));
+    p.S = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_allocS * 2));
+    return p;
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t f6_prow(const F6Planes& p, int64_t m) { return p.rdiv > 0 ? (m / p.rdiv) * p.rstride + m % p.rdiv : m; }
+// ---- device-side encoders -------------------------------------------------------------------------------------------
+// exponent e (as E8M0 byte e + 127, clamped to [1, 254]) of the smallest power of two with m / 2^e <= 7.5;  m >= 0 finite
+__device__ __forceinline__ int f6_scale_byte(float m) {
+    const unsigned u = __builtin_bit_cast(unsigned, m);
+    const int E = (int)((u >> 23) & 0xff);                 // biased exponent of m (0 for zero / subnormal)
+    int byte = E - ((u & 0x7fffffu) > 0x700000u ? 1 : 2);  // m / 2^(E-127) in (1.875, 2) needs one binade more
+    return byte < 1 ? 1 : (byte > 254 ? 254 : byte);
+}
+// 2^-(byte - 127) as a float (byte in [1, 254])
+__device__ __forceinline__ float f6_inv_scale(int byte) { return __builtin_bit_cast(float, (unsigned)(254 - byte) << 23); }
+// e2m3 code (6 bits: sign | 5-bit magnitude index) of y, |y| <= 7.5 expected (saturating); round to nearest even.
+// The grid is monotone in the 5-bit index: 0..16 -> 0..2 in steps of 1/8, 16..24 -> 2..4 in steps of 1/4, 24..31 -> 4..7.5 in steps of 1/2.
+__device__ __forceinline__ unsigned f6_code(float y) {
+    const float ay = fabsf(y);
+    float idx;
+    if (ay < 2.f) idx = rintf(ay * 8.f);
+    else if (ay < 4.f) idx = 16.f + rintf((ay - 2.f) * 4.f);
+    else idx = fminf(24.f + rintf((ay - 4.f) * 2.f), 31.f);
+    return (unsigned)idx | ((__builtin_bit_cast(unsigned, y) >> 26) & 32u);
+}
+__device__ __forceinline__ float f6_sat_f16(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+
+// Encode one (row, block): x[32] fp32 -> h[32] f16, 6 + 6 dwords of fp6 codes, two scale bytes.
+__device__ __forceinline__ void f6_encode_block(const float* x, _Float16* h, unsigned* fh, unsigned* fl, int& sh, int& sl) {
+    float lo[32], hf[32];
+    float mh = 0.f, ml = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        h[j] = static_cast<_Float16>(f6_sat_f16(x[j]));
+        hf[j] = static_cast<float>(h[j]);
+        lo[j] = x[j] - hf[j];
+        mh = fmaxf(mh, fabsf(hf[j]));
+        ml = fmaxf(ml, fabsf(lo[j]));
+    }
+    if (!(ml < 3.0e38f)) ml = 0.f;                        // inf / NaN residual (saturated or NaN input): the hi part carries it
+    if (!(mh < 3.0e38f)) mh = 65504.f;
+    sh = f6_scale_byte(mh); sl = f6_scale_byte(ml);
+    const float ih = f6_inv_scale(sh), il = f6_inv_scale(sl);
+#pragma unroll
+    for (int w = 0; w < 6; ++w) { fh[w] = 0u; fl[w] = 0u; }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const unsigned long long ch = f6_code(hf[j] * ih), cl = f6_code(lo[j] * il);
+        const int bit = 6 * j, w = bit >> 5, s = bit & 31;
+        fh[w] |= (unsigned)(ch << s); fl[w] |= (unsigned)(cl << s);
+        if (s > 26) { fh[w + 1] |= (unsigned)(ch >> (32 - s)); fl[w + 1] |= (unsigned)(cl >> (32 - s)); }
+    }
+}
+#endif
+
+// GEMM on f16f6 planes: C[z][m, n] = epilogue(sum_k A[z][m,k] B[z][n,k]); batches z < nb use rows [z*rA, +M) of A and [z*rB, +N) of B.
+struct F6GemmArgs {
+    F6Planes A, B;
+    int64_t rA, rB;
+    int nb, M, N;                              // K = 32 * A.Kb = 32 * B.Kb
+    int epi;                                   // 0: fp32 C[z*sC + m*ldc_m + n*ldc_n] = act(scale[n / scale_div] * acc + bias[n])
+                                               // 3: rows interleaved by gdiv (the mode-3 product: row m' = m*gdiv + g -> C[(m'/gdiv)*ldc_m + m'%gdiv + n*ldc_n])
+                                               // 4: f16f6 planes out (P), columns N..Np-1 zero
+    float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
+    const float* scale; int scale_div; const float* bias; int relu;
+    F6Planes P; int Np;                        // epi 4 (nb = 1): output planes (logical row m -> f6_prow(P, m)), padded column count (multiple of 32)
+};
+int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);
+int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st);
+// store one encoded (row, block) item
+#if defined(__HIPCC__)
+__device__ __forceinline__ void f6_store_block(const F6Planes& p, int64_t prow, int kb, const _Float16* h, const unsigned* fh, const unsigned* fl, int sh, int sl) {
+    const int64_t o = (int64_t)kb * p.rows_alloc + prow;
+    uint4* hd = reinterpret_cast<uint4*>(p.H + o * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hd[j] = *reinterpret_cast<const uint4*>(h + 8 * j);
+    uint2* fd = reinterpret_cast<uint2*>(p.FH + o * 24);
+    fd[0] = make_uint2(fh[0], fh[1]); fd[1] = make_uint2(fh[2], fh[3]); fd[2] = make_uint2(fh[4], fh[5]);
+    fd = reinterpret_cast<uint2*>(p.FL + o * 24);
+    fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
+    *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
+}
+#endif
+
+}  // namespace cti

@@ -569,6 +569,42 @@ def split_operand(w, prec=None):
     return block
 
 
+def quantize_f16f6(x, batch_rows=0):
+    """(rows, K) fp32 -> the f16f6 operand planes (one uint8 block): f16 hi plane + block-scaled fp6 codes of the hi part and of the residual.
+    batch_rows > 0: every batch of batch_rows rows starts at a multiple of 8 plane rows (for batched products)."""
+    _req(x, "x")
+    x2, ld = _rows2d(x)
+    rows, K = x2.shape
+    lib = L.lib()
+    nb = lib.cti_f16f6_planes_bytes(rows, K, int(batch_rows))
+    block = torch.empty(nb, device=x.device, dtype=torch.uint8)
+    L.check(lib.cti_quantize_f16f6(x2.data_ptr(), ld, rows, K, int(batch_rows), block.data_ptr(), nb, _stream()), "cti_quantize_f16f6")
+    return block
+
+
+def gemm_nt_f16f6(A, B, nb=1, M=None, N=None, gdiv=1, scale=None, scale_div=1, bias=None, relu=False):
+    """C[z] = act(scale * A[z] @ B[z].T + bias) through the f16 + fp6 split product.  A (nb*M, K), B (nb*N, K) fp32; gdiv > 1: the rows of A are
+    (m, g) pairs and C comes out as (nb, M/gdiv, N, gdiv) -- the mode-3 product."""
+    _req(A, "A"); _req(B, "B")
+    A2, _ = _rows2d(A); B2, _ = _rows2d(B)
+    K = A2.shape[1]
+    M = A2.shape[0] // nb if M is None else M
+    N = B2.shape[0] // nb if N is None else N
+    pa = quantize_f16f6(A2, M if nb > 1 else 0)
+    pb = quantize_f16f6(B2, N if nb > 1 else 0)
+    if gdiv > 1:
+        C = torch.empty((nb, M // gdiv, N, gdiv), device=A.device, dtype=torch.float32)
+        ldc_m, ldc_n, sC = N * gdiv, gdiv, M * N
+    else:
+        C = torch.empty((nb, M, N), device=A.device, dtype=torch.float32)
+        ldc_m, ldc_n, sC = N, 1, M * N
+    with _timed("gemm_nt_f16f6"):
+        L.check(L.lib().cti_gemm_nt_f16f6(pa.data_ptr(), A2.shape[0], M if nb > 1 else 0, pb.data_ptr(), B2.shape[0], N if nb > 1 else 0, C.data_ptr(),
+                                          ldc_m, ldc_n, sC, gdiv, nb, M, N, K, _ptr(scale), int(scale_div), _ptr(bias),
+                                          L.ACT_RELU if relu else L.ACT_NONE, _stream()), "cti_gemm_nt_f16f6")
+    return C
+
+
 def transpose(src, rows, cols, batch=1, s_src=0, ld_src=None, dst=None, s_dst=0, ld_dst=None):
     """dst[b][c][r] = src[b][r][c] for `batch` (rows x cols) matrices addressed with explicit strides."""
     ld_src = cols if ld_src is None else ld_src

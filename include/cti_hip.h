@@ -212,6 +212,19 @@ int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1
                    const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
 
+/* The "f16f6" operand format (csrc/cti_f16f6.h): an fp32 matrix as an f16 hi plane plus two block-scaled fp6 (e2m3) planes -- codes of the hi
+ * part and of the residual, one E8M0 scale per 32 elements each -- so that a product costs one f16 MFMA and half a (4x-rate) fp6 MFMA:
+ * a*b ~= a16*b16 + fp6(a16)*fp6(b - b16) + fp6(a - a16)*fp6(b16), fp32 accumulate (fp32-grade: ~2e-5 normalised on the mode-3 product).
+ * cti_quantize_f16f6 encodes `rows` x K fp32 (row stride ld) into a caller-owned block of cti_f16f6_planes_bytes (256-B aligned);
+ * batch_rows > 0 places every batch of batch_rows rows at a multiple of 8 plane rows (what batched products need), 0 = one matrix.
+ * cti_gemm_nt_f16f6: C[z][m,n] = act(scale[n/scale_div] * sum_k A[z][m,k] B[z][n,k] + bias[n]) on two such blocks; gdiv > 1 interleaves the
+ * GEMM rows (row m' = m*gdiv + g -> C[z*sC + m*ldc_m + g + n*ldc_n]), the mode-3 product of src/Tensor.py:16-20 with G = gdiv. */
+size_t cti_f16f6_planes_bytes(int64_t rows, int K, int64_t batch_rows);
+int cti_quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, void* planes, size_t planes_bytes, void* stream);
+int cti_gemm_nt_f16f6(const void* A_planes, int64_t rowsA_total, int64_t batch_rowsA, const void* B_planes, int64_t rowsB_total, int64_t batch_rowsB,
+                      float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC, int gdiv, int nb, int M, int N, int K, const float* scale, int scale_div,
+                      const float* bias, int act, void* stream);
+
 /* C (N x K, contiguous) = a^T b for a (M x N, row stride lda) and b (M x K, row stride ldb): the weight-gradient contraction over the
  * ROW axis (dW = dz^T x; src/fc.py:22-29 under autograd).  Both operands are written straight to transposed bf16 hi/lo planes, the M axis
  * is split over extra workgroups and a reduce kernel sums the partials.  prec = BF16X3 or BF16 (the exact-fp32 mode uses

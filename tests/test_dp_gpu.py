@@ -282,7 +282,8 @@ def test_optimizer_state_dict_is_the_torch_adamax_format_both_ways():
         # ours -> torch: a fresh torch optimizer resumes from our dict
         m3 = TinyCTI().to(DEV); m3.load_state_dict(m1.state_dict())
         opt3 = torch.optim.Adamax(m3.parameters(), lr=2e-3)
-        opt3.load_state_dict(sd1)
+        import copy
+        opt3.load_state_dict(copy.deepcopy(sd1))                            # torch adopts same-device tensors without copying: hand it its own
         # torch -> ours: a fresh FlatAdamaxDP resumes from torch's dict
         m4 = TinyCTI().to(DEV); m4.load_state_dict(m2.state_dict())
         opt4 = cti_amd.FlatAdamaxDP(m4, lr=1.0, clip_norm=0.25)           # lr comes from the dict

@@ -1,0 +1,125 @@
+"""The f16 + block-scaled-fp6 split product (csrc/cti_f16f6.h, cti_gemm_f16f6.hip): encoder bit-exact against a numpy restatement of the
+format, GEMM against float64 on random and adversarial operands.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ops = cti_amd.ops
+
+
+def e2m3_grid():
+    idx = np.arange(32)
+    return np.where(idx < 16, idx / 8.0, np.where(idx < 24, 2 + (idx - 16) / 4.0, 4 + (idx - 24) / 2.0))
+
+
+def np_encode(x):
+    """numpy restatement of f6_encode_block for (rows, K) float32, K % 32 == 0 -> (h16, codes_hi, codes_lo, sh, sl) (codes as uint8 per element)."""
+    rows, K = x.shape
+    h = np.clip(x, -65504, 65504).astype(np.float16)
+    hf = h.astype(np.float32)
+    lo = x - hf
+
+    def enc(v):
+        vb = v.reshape(rows, K // 32, 32)
+        m = np.abs(vb).max(-1)
+        u = m.astype(np.float32).view(np.uint32)
+        E = ((u >> 23) & 0xff).astype(np.int64)
+        byte = np.clip(E - np.where((u & 0x7fffff) > 0x700000, 1, 2), 1, 254)
+        inv = ((254 - byte).astype(np.uint32) << 23).view(np.float32)
+        y = vb * inv[..., None]
+        ay = np.abs(y)
+        idx = np.where(ay < 2, np.rint(ay * 8), np.where(ay < 4, 16 + np.rint((ay - 2) * 4), np.minimum(24 + np.rint((ay - 4) * 2), 31)))
+        code = idx.astype(np.uint8) | (np.signbit(y).astype(np.uint8) << 5)
+        return code.reshape(rows, K), byte.astype(np.uint8)
+    ch, sh = enc(hf)
+    cl, sl = enc(lo)
+    return h, ch, cl, sh, sl
+
+
+def unpack(block, rows, K, batch_rows=0):
+    """The plane block -> (h16 (rows,K), codes_hi, codes_lo (rows,K) uint8, sh, sl (rows,Kb)) following cti_f16f6.h's carve."""
+    Kb = (K + 31) // 32
+    r8 = lambda v: (v + 7) // 8 * 8                                  # noqa: E731
+    pr = rows if not batch_rows else (rows + batch_rows - 1) // batch_rows * r8(batch_rows)
+    ra, rs = r8(pr + 256), r8(pr + 512)
+    b = block.cpu().numpy()
+    off = 0
+
+    def take(n):
+        nonlocal off
+        v = b[off:off + n]
+        off = (off + n + 255) // 256 * 256
+        return v
+    H = take(Kb * ra * 64).view(np.float16).reshape(Kb, ra, 32)
+    FH = take(Kb * ra * 24).reshape(Kb, ra, 24)
+    FL = take(Kb * ra * 24).reshape(Kb, ra, 24)
+    S = take(Kb * rs * 2).reshape(Kb, rs, 2)
+    prow = np.arange(rows) if not batch_rows else (np.arange(rows) // batch_rows) * r8(batch_rows) + np.arange(rows) % batch_rows
+
+    def codes(F):
+        bits = np.unpackbits(F[:, prow, :], axis=-1, bitorder="little").reshape(Kb, rows, 32, 6)
+        return (bits * (1 << np.arange(6))).sum(-1).astype(np.uint8).transpose(1, 0, 2).reshape(rows, Kb * 32)
+    return (H[:, prow, :].transpose(1, 0, 2).reshape(rows, Kb * 32), codes(FH), codes(FL), S[:, prow, 0].T, S[:, prow, 1].T)
+
+
+@pytest.mark.parametrize("rows,K,batch", [(70, 64, 0), (37, 96, 0), (45, 64, 9), (300, 512, 0), (5, 40, 0)])
+def test_encoder_is_bit_exact(rows, K, batch):
+    g = torch.Generator().manual_seed(rows * 1000 + K)
+    x = torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 3)
+    x[0, :5] = torch.tensor([0.0, -0.0, 7e4, -1e-7, 1.0])
+    blk = ops.quantize_f16f6(x.to(DEV), batch)
+    Kp = (K + 31) // 32 * 32
+    xp = np.zeros((rows, Kp), np.float32)
+    xp[:, :K] = x.numpy()
+    h, ch, cl, sh, sl = np_encode(xp)
+    H, CH, CL, SH, SL = unpack(blk, rows, K, batch)
+    assert np.array_equal(H.view(np.uint16), h.view(np.uint16))
+    assert np.array_equal(SH, sh) and np.array_equal(SL, sl)
+    assert np.array_equal(CH, ch) and np.array_equal(CL, cl)
+    # the decoded value is within the format's promise of the input (hi + lo reconstruction, |x| <= 65504)
+    grid = e2m3_grid()
+    dec = lambda c, s: np.where(c & 32, -1.0, 1.0) * grid[c & 31] * np.repeat(2.0 ** (s.astype(np.float64) - 127), 32, axis=1)   # noqa: E731
+    rec = h.astype(np.float64) + dec(cl, sl)
+    # hi + decoded lo reconstructs x to 2^-15 of its BLOCK's largest magnitude (the lo codes carry 4 bits below the f16 residual of the
+    # block maximum); saturated elements (|x| > 65504) excluded
+    bmax = np.repeat(np.abs(xp).reshape(rows, -1, 32).max(-1), 32, axis=1)
+    ok = np.abs(xp) <= 65504
+    assert np.max((np.abs(rec - xp) / np.maximum(bmax, 1e-30))[ok & (bmax <= 65504)]) < 2.0 ** -15
+
+
+def _ref(A, B, nb, M, N, gdiv):
+    A64, B64 = A.double().view(nb, M, -1), B.double().view(nb, N, -1)
+    C = torch.einsum("zmk,znk->zmn", A64, B64)
+    if gdiv > 1:
+        C = C.view(nb, M // gdiv, gdiv, N).permute(0, 1, 3, 2).contiguous()
+    return C.numpy()
+
+
+@pytest.mark.parametrize("nb,M,N,K,gdiv", [(1, 300, 200, 64, 1), (1, 256, 192, 512, 1), (3, 40, 29, 96, 2), (2, 1008, 3129, 512, 2), (1, 7, 5, 32, 1),
+                                           (5, 130, 391, 160, 1), (1, 1000, 600, 1024, 1)])
+def test_gemm_against_float64(nb, M, N, K, gdiv):
+    g = torch.Generator().manual_seed(nb * 7 + M + N + K)
+    A = torch.randn(nb * M, K, generator=g) * 3.0
+    B = torch.relu(torch.randn(nb * N, K, generator=g))            # half zeros, like the rank nets' ReLU outputs
+    C = ops.gemm_nt_f16f6(A.to(DEV), B.to(DEV), nb=nb, M=M, N=N, gdiv=gdiv).cpu().numpy()
+    ref = _ref(A, B, nb, M, N, gdiv)
+    err = np.abs(C - ref).max() / np.abs(ref).max()
+    print("f16f6 GEMM nb=%d %dx%dx%d gdiv=%d: normalised max error %.3g" % (nb, M, N, K, gdiv, err))
+    assert err < 5e-5
+
+
+def test_gemm_epilogue_scale_bias_relu_and_dynamic_range():
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 100, 70, 128
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2)      # rows of very different magnitude
+    B = torch.randn(N, K, generator=g) * torch.exp(torch.randn(1, K, generator=g))          # columns too
+    scale = torch.rand(N // 10, generator=g) + 0.5
+    bias = torch.randn(N, generator=g)
+    C = ops.gemm_nt_f16f6(A.to(DEV), B.to(DEV), scale=scale.to(DEV), scale_div=10, bias=bias.to(DEV), relu=True).cpu().numpy()[0]
+    ref = torch.relu((A.double() @ B.double().T) * scale.double().repeat_interleave(10)[None, :] + bias.double()[None, :]).numpy()
+    rowmax = (A.double() @ B.double().T).abs().max(1, keepdim=True).values.numpy()
+    assert np.max(np.abs(C - ref) / rowmax) < 1e-4                                             # per-row normalisation: every row keeps its accuracy

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""A/B tuner for the f16f6 GEMM (cti_gemm_f16f6.hip): builds one libcti_hip_<name>.so per -D flag set here, then on the GPU loads them all in
+ONE process and times cti_gemm_nt_f16f6 at the BASELINE configs[1] mode-3 shape in interleaved rounds.
+    python tools/tune_f16f6.py build name1:-DFOO=1 name2:"-DFOO=2 -DBAR" ...      (here; the .so files travel with gpurun)
+    python tools/tune_f16f6.py run [rounds] [B]                                   (on the GPU box)
+"""
+import ctypes as C
+import glob
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+VDIR = os.path.join(ROOT, "iccv19_vqa-cti_amd", "lib", "variants")
+
+
+def run(rounds=5, B=256):
+    import torch
+    import cti_amd
+    L, ops = cti_amd.pkg._lib, cti_amd.ops
+    libs = {}
+    for f in sorted(glob.glob(os.path.join(VDIR, "*.so")), key=lambda x: (not os.path.basename(x).startswith("libcti_hip_base"), x)):
+        l = C.CDLL(f)
+        for name in ("cti_gemm_nt_f16f6", "cti_last_error_string"):
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = L.SIGNATURES[name]
+        libs[os.path.basename(f)[len("libcti_hip_"):-3]] = l
+    V, Q, A, G, K = 36, 14, 3129, 2, 512
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(1)
+    M = torch.randn(B * V * Q * G, K, device=dev, generator=g) * 8.0
+    Ar = torch.relu(torch.randn(B * A, K, device=dev, generator=g) * 0.7)
+    pa, pb = ops.quantize_f16f6(M, V * Q * G), ops.quantize_f16f6(Ar, A)
+    out = torch.empty((B, V * Q, A, G), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    times = {k: [] for k in libs}
+    ref = None
+    for rnd in range(rounds + 1):
+        for name, l in libs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                rc = l.cti_gemm_nt_f16f6(pa.data_ptr(), M.shape[0], V * Q * G, pb.data_ptr(), Ar.shape[0], A, out.data_ptr(), A * G, G, V * Q * A * G, G, B,
+                                         V * Q * G, A, K, 0, 1, 0, 0, st)
+                assert rc == 0, (name, l.cti_last_error_string())
+            e1.record(); torch.cuda.synchronize()
+            if rnd:
+                times[name].append(e0.elapsed_time(e1) / 3)
+            elif ref is None:
+                ref = out[:2].clone()
+            else:
+                print("%-12s max diff vs first variant: %.2e" % (name, (out[:2] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)))
+    flops = 2.0 * B * V * Q * G * A * K
+    for name, ts in times.items():
+        print("%-12s median %.3f ms (min %.3f)  %.0f TFLOP/s" % (name, statistics.median(ts), min(ts), flops / statistics.median(ts) / 1e9))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        import tune_gemm
+        tune_gemm.build(sys.argv[2:])
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 256)
