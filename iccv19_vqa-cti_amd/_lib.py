@@ -101,7 +101,7 @@ SIGNATURES = {
     "cti_bi_logits_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
 }
 
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3
 E_UNSUPPORTED = -4                                   # CTI_E_UNSUPPORTED: shape / mode outside a specialised kernel
 ACT_NONE, ACT_RELU = 0, 1
 TUNE_GEMM_CFG, TUNE_TRI_CHUNK = 1, 2                # cti_set_tuning keys

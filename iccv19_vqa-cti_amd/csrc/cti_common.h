@@ -9,6 +9,8 @@
 
 namespace cti {
 
+struct F6Planes;                  // cti_f16f6.h
+
 // thread-local last error text (the only mutable state of the library)
 char* err_buf();
 int fail(int code, const char* fmt, ...);
@@ -98,7 +100,8 @@ struct PlaneGemmArgs {
     int nb1, nb2;
     int M, N, Kp;
     int terms;                                 // 3 = bf16x3 (hi*hi + hi*lo + lo*hi), 1 = plain bf16 (hi planes only)
-    int epi;                                   // 0 fp32 C, 1 hi/lo planes out, 3 fp32 C with G-interleaved rows
+    int epi;                                   // 0 fp32 C, 1 hi/lo planes out, 3 fp32 C with G-interleaved rows, 4 f16f6 planes out (f6out)
+    const F6Planes* f6out;                     // epi 4: output planes (logical row b1*sC1 + m -> f6_prow); Np = padded column count
     float* C; int64_t ldc_m, ldc_n, sC1, sC2;  // fp32 output (epi 0/3); for epi 1 sC1/sC2 are batch strides in plane ROWS
     unsigned short* Ph; unsigned short* Pl; int64_t rows_allocP; int Np;     // planes output (epi 1)
     int gdiv;                                  // epi 3

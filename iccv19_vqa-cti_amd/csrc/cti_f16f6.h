@@ -151,6 +151,53 @@ __device__ __forceinline__ void f6_store_block(const F6Planes& p, int64_t prow, 
     fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
     *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
 }
+
+// Encode and store one (row, block) whose 32 fp32 values sit in LDS (16-B aligned, contiguous) -- the form GEMM epilogues and the encoder
+// kernel use: two streaming passes over the LDS copy instead of 32 + 32 + 32 live registers (pass 1: f16 hi part stored 8 values at a time,
+// block maxima; then the two code streams from the hardware converter).  Same codes, value for value, as f6_encode_block.
+typedef float f6_f32x4 __attribute__((ext_vector_type(4)));       // LDS reads as plain vectors (a HIP float4 struct read drains vmcnt(0))
+typedef float f6_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned f6_u32x6 __attribute__((ext_vector_type(6)));
+// 32 fp32 values -> 32 e2m3 codes (6 dwords) of x / 2^floor(log2 scale) in ONE instruction: v_cvt_scalef32_2xpk16_fp6_f32 takes the even
+// elements in its first source and the odd ones in its second (code 2i <- a[i], code 2i+1 <- b[i]); round-to-nearest-even and saturation
+// at 7.5 agree code for code with f6_code (tools/mb/mb_cvt6.hip).  Inline asm with an EARLY-CLOBBER destination: hipcc's builtin of the
+// same name lets the 6-register destination overlap the sources, and the instruction then reads operands it has already overwritten.
+__device__ __forceinline__ f6_u32x6 f6_hw_codes(const f6_f32x16 even, const f6_f32x16 odd, float scale) {
+    f6_u32x6 r;
+    asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(even), "v"(odd), "v"(scale));
+    return r;
+}
+__device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Planes& p, int64_t prow, int kb) {
+    const int64_t o = (int64_t)kb * p.rows_alloc + prow;
+    uint4* hd = reinterpret_cast<uint4*>(p.H + o * 32);
+    float mh = 0.f, ml = 0.f;
+    f6_f32x16 he, ho, le, lo;                                  // hi / lo parts, even / odd elements
+#pragma unroll
+    for (int q8 = 0; q8 < 4; ++q8) {
+        const f6_f32x4 a = *reinterpret_cast<const f6_f32x4*>(src + q8 * 8), b = *reinterpret_cast<const f6_f32x4*>(src + q8 * 8 + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        _Float16 h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h[u] = static_cast<_Float16>(f6_sat_f16(x[u]));
+            const float hf = static_cast<float>(h[u]), lf = x[u] - hf;
+            mh = fmaxf(mh, fabsf(hf)); ml = fmaxf(ml, fabsf(lf));
+            const int j = q8 * 8 + u;
+            if (j & 1) { ho[j >> 1] = hf; lo[j >> 1] = lf; } else { he[j >> 1] = hf; le[j >> 1] = lf; }
+        }
+        hd[q8] = *reinterpret_cast<const uint4*>(h);
+    }
+    if (!(ml < 3.0e38f)) ml = 0.f;
+    if (!(mh < 3.0e38f)) mh = 65504.f;
+    const int sh = f6_scale_byte(mh), sl = f6_scale_byte(ml);
+    const f6_u32x6 fh = f6_hw_codes(he, ho, __builtin_bit_cast(float, (unsigned)sh << 23));     // 2^(byte - 127)
+    const f6_u32x6 fl = f6_hw_codes(le, lo, __builtin_bit_cast(float, (unsigned)sl << 23));
+    uint2* fd = reinterpret_cast<uint2*>(p.FH + o * 24);
+    fd[0] = make_uint2(fh[0], fh[1]); fd[1] = make_uint2(fh[2], fh[3]); fd[2] = make_uint2(fh[4], fh[5]);
+    fd = reinterpret_cast<uint2*>(p.FL + o * 24);
+    fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
+    *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
+}
 #endif
 
 }  // namespace cti

@@ -22,6 +22,7 @@
 // ([row][2 x 16 B]) and made bank-conflict-free for ds_read_b128 by permuting the SOURCE chunk
 // (c' = c ^ ((row >> 3) & 1)) and applying the same XOR on the read.
 #include "cti_common.h"
+#include "cti_f16f6.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -126,8 +127,11 @@ struct PlaneGemmP {
     unsigned short* Ph; unsigned short* Pl; int64_t pitchP; int Np;
     // EPI_INTERLEAVE: GEMM row m' = m*gdiv + g addresses C[(m'/gdiv)*ldc_m + (m'%gdiv) + n*ldc_n] (gdiv = G, ldc_n = G)
     int gdiv;
+    // EPI_F16F6: the result is written as f16 + block-scaled fp6 planes (cti_f16f6.h) -- the operand format of the f16f6 mode-3 product;
+    // columns N..Np-1 (Np a multiple of 32) zero, logical row m -> plane row f6_prow(F6, m)
+    F6Planes F6;
 };
-enum { EPI_F32 = 0, EPI_PLANES = 1, EPI_INTERLEAVE2 = 2, EPI_INTERLEAVE = 3 };
+enum { EPI_F32 = 0, EPI_PLANES = 1, EPI_INTERLEAVE2 = 2, EPI_INTERLEAVE = 3, EPI_F16F6 = 4 };
 
 __device__ __forceinline__ bf16x8 frag(const char* lds_plane, int row, int chunk) {
     return *reinterpret_cast<const bf16x8*>(lds_plane + row * ROW_BYTES + ((chunk ^ ((row >> 3) & 1)) << 4));
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const bool loader = LW > 0 && wid >= WM * WN;
     const int wm = wid / WN, wn = wid % WN;
-    const int tiles_n = ((EPI == EPI_PLANES ? p.Np : p.N) + BN - 1) / BN;
+    const int tiles_n = (((EPI == EPI_PLANES || EPI == EPI_F16F6) ? p.Np : p.N) + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     // Persistent tile loop: the grid is at most one workgroup per CU (a 128-KiB ring leaves room for one anyway); workgroup w
     // walks tiles w, w + grid, ... -- with the grid a multiple of 8 these keep w's XCD, so tile_coords' L2 chunking holds.
@@ -277,9 +281,11 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * TM * 32 + i * 32 + r;
                 const char* rp = s + row * 64;
-                const float4 x0 = *reinterpret_cast<const float4*>(rp + (((2 * h) ^ ((row >> 2) & 3)) << 4));
-                const float4 x1 = *reinterpret_cast<const float4*>(rp + (((2 * h + 1) ^ ((row >> 2) & 3)) << 4));
-                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                // plain vector type, NOT HIP's float4 struct: a struct-typed LDS read may alias the LDS-DMA stores as far as hipcc can tell, and it
+                // then drains vmcnt(0) -- every DMA in flight -- in front of the read (found with the f16f6 kernel; this is what made this path "neutral")
+                const f6_f32x4 x0 = *reinterpret_cast<const f6_f32x4*>(rp + (((2 * h) ^ ((row >> 2) & 3)) << 4));
+                const f6_f32x4 x1 = *reinterpret_cast<const f6_f32x4*>(rp + (((2 * h + 1) ^ ((row >> 2) & 3)) << 4));
+                const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const __bf16 hv = static_cast<__bf16>(xs[e]);
@@ -342,6 +348,33 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
 
     const int64_t boff = b1 * p.sC1 + b2 * p.sC2;
     do {
+    if (EPI == EPI_F16F6) {
+        // Per 32-column MFMA tile the wave parks its (TM*32) x 32 block in a private LDS patch ([row][36 floats]: conflict-free 16-B row reads),
+        // scale / bias / ReLU applied on the way in; then every lane encodes ONE (row, 32-block) item straight into the f16f6 planes.
+        static_assert(TM * 32 == 64, "one (row, block) item per lane");
+        float* stg = reinterpret_cast<float*>(smem) + wid * (64 * 36);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + (wn * TN + j) * 32, n = nb + (lane & 31);
+            const bool real = n < p.N;
+            const float sc = (real && p.scale) ? p.scale[b1 * p.scale_bs + n / p.scale_div] : 1.f;
+            const float bi = (real && p.bias) ? p.bias[b1 * p.bias_bs + n] : 0.f;
+            if (j) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous tile's reads are done before overwriting
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    float x = acc[i][j][e] * sc + bi;
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    stg[row * 36 + (lane & 31)] = real ? x : 0.f;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave writes and reads its patch: in-order LDS, no barrier
+            const int m = m0 + wm * TM * 32 + lane;
+            if (m < p.M && nb < p.Np) f6_encode_row32_lds(stg + lane * 36, p.F6, f6_prow(p.F6, boff + m), nb >> 5);
+        }
+        break;
+    }
     if (EPI == EPI_PLANES || EPI == EPI_F32) {
         // Staged epilogue, 64 columns of the wave's sub-tile at a time.  The wave parks a (TM*32) x 64 fp32 block in its own
         // slice of the (now idle) LDS ([row][16 slots of 16 B], slot ^= row & 1: conflict-free for the ds_write_b32 column
@@ -535,7 +568,7 @@ int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
 template <int TERMS, int EPI>
 int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_t st) {
     if (p.Af) {                                              // fp32 A operand: built for the fp32-grade mode and the row-major epilogues
-        if constexpr (TERMS == 3 && (EPI == 0 || EPI == 1)) {
+        if constexpr (TERMS == 3 && (EPI == 0 || EPI == 1 || EPI == 4)) {
             switch (cfg) {
                 case 2: return launch_cfg<TERMS, EPI, GeoBig, true>(p, nb, ncols, st);
                 case 1: return launch_cfg<TERMS, EPI, GeoMid, true>(p, nb, ncols, st);
@@ -635,6 +668,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
     p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
+    if (a.f6out) p.F6 = *a.f6out;
     if (a.ksplit > 1) {
         if (a.nb1 != 1 || a.nb2 != 1 || a.epi != 0 || a.Af || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
@@ -654,7 +688,8 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     if (a.Af && ((a.ldaf & 3) || (a.Kreal & 3) || (reinterpret_cast<uintptr_t>(a.Af) & 15)))
         return fail(CTI_E_ALIGN, "gemm_nt_planes: fp32 A operand needs 16-B aligned rows and K %% 4 == 0 (ld=%lld K=%d)", (long long)a.ldaf, a.Kreal);
     if (a.Kp % KPAD != 0) return fail(CTI_E_ALIGN, "gemm_nt_planes: Kp=%d is not a multiple of %d", a.Kp, KPAD);
-    const int ncols = a.epi == 1 ? a.Np : a.N;
+    const int ncols = (a.epi == 1 || a.epi == 4) ? a.Np : a.N;
+    if (a.epi == 4 && (!a.f6out || a.Np % 32 != 0 || a.terms != 3)) return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: f16f6 output needs planes, Np %% 32 == 0 and the 3-term mode");
     const long long nb = (long long)a.nb1 * a.nb2;
     // tile choice by a makespan model: every geometry runs one workgroup per CU, so a launch takes ceil(tiles / 256) rounds of one tile
     // time; relative tile times from the measured full-grid rates (128x128 ~0.43, 256x128 ~0.7, 256x256 ~1.0 PFLOP/s issued: operand bytes
@@ -688,6 +723,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
         case 5: return launch_epi<3, 1>(p, nb, ncols, cfg, st);
         case 6: return launch_epi<3, 2>(p, nb, ncols, cfg, st);
         case 7: return launch_epi<3, 3>(p, nb, ncols, cfg, st);
+        case 8: return launch_epi<3, 4>(p, nb, ncols, cfg, st);
         default: return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: epi=%d terms=%d", a.epi, a.terms);
     }
 }

@@ -22,29 +22,36 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // 8-B LDS loads.  NOT HIP's uint2 / uint8_t: loads through struct or char types make hipcc
                                                               // drain vmcnt(0) -- every LDS-DMA in flight -- in front of them (may-alias with the DMA's LDS store)
 
-// ---- quantiser: fp32 rows -> f16f6 planes; one thread per (row, block), rows fastest --------------------------------
+// ---- encoder: fp32 rows -> f16f6 planes.  A wave stages a 64-row x 32-column tile through a private LDS patch: the global loads are
+// coalesced (8 lanes x 16 B = one row's block, 8 rows per instruction), then every lane encodes one row from LDS (pitch 36 floats:
+// conflict-free 16-B row reads) with the streaming encoder the GEMM epilogues use.
 __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, F6Planes p) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int kb = blockIdx.y;
-    if (row >= rows) return;
-    const float* src = x + row * ld + (int64_t)kb * 32;
-    float v[32];
-    const int k0 = kb * 32;
-    if (k0 + 32 <= K && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    __shared__ __attribute__((aligned(16))) float patch[4][64 * 36];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int kb = blockIdx.y, k0 = kb * 32;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
+    if (row0 >= rows) return;
+    float* st = patch[wid];
+    const int c4 = lane & 7, rsub = lane >> 3;
+    const bool vec = (k0 + 32 <= K) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 t = reinterpret_cast<const float4*>(src)[j];
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 8 + rsub;
+        const int64_t row = row0 + rr;
+        f6_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows) {
+            const float* src = x + row * ld + k0 + c4 * 4;
+            if (vec) v = *reinterpret_cast<const f6_f32x4*>(src);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (k0 + c4 * 4 + u < K) v[u] = src[u];
+            }
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = (k0 + j < K) ? src[j] : 0.f;
+        *reinterpret_cast<f6_f32x4*>(st + rr * 36 + c4 * 4) = v;
     }
-    _Float16 h[32];
-    unsigned fh[6], fl[6];
-    int sh, sl;
-    f6_encode_block(v, h, fh, fl, sh, sl);
-    f6_store_block(p, f6_prow(p, row), kb, h, fh, fl, sh, sl);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // same wave writes and reads its patch: in-order LDS, no barrier
+    const int64_t row = row0 + lane;
+    if (row < rows) f6_encode_row32_lds(st + lane * 36, p, f6_prow(p, row), kb);
 }
 
 // ---- GEMM --------------------------------------------------------------------------------------------------------------
@@ -208,6 +215,9 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #endif
     auto sync_only = [&](int b) {
         const int rem = nkb - 1 - b;                                // blocks issued after block b so far: min(NST - 2, rem)
+#if CTI_F6_ABL & 32
+        if (b < NST - 1 && vtile != (int)blockIdx.x) { __builtin_amdgcn_s_barrier(); return; }     // ablation (UNSAFE): no vmcnt wait on the hoisted blocks
+#endif
         if (rem >= NST - 2) { if (extra) wait_vm<(NST - 2) * (CNT_LO + 1)>(); else wait_vm<(NST - 2) * CNT_LO>(); }
         else if (NST >= 4 && rem == 1) { if (extra) wait_vm<CNT_LO + 1>(); else wait_vm<CNT_LO>(); }
         else wait_vm<0>();
@@ -315,8 +325,18 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
                     }
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    if (col + 1 < p.N) { f32x4 v4; v4[0] = odd ? t0 : r0; v4[1] = odd ? t1 : r1; v4[2] = odd ? r2 : t0; v4[3] = odd ? r3 : t1; *reinterpret_cast<f32x4*>(dst) = v4; }
-                    else               { f32x2 v2; v2[0] = odd ? t0 : r0; v2[1] = odd ? t1 : r1; *reinterpret_cast<f32x2*>(dst) = v2; }
+#ifndef CTI_F6_STORE_SC1
+#define CTI_F6_STORE_SC1 0       // 1: write-through stores that do NOT keep the line in the XCD's L2 (the 3.2 GB output stream would otherwise
+#endif                           // evict the operand tiles the LDS-DMA re-reads from L2)
+                    if (col + 1 < p.N) {
+                        f32x4 v4; v4[0] = odd ? t0 : r0; v4[1] = odd ? t1 : r1; v4[2] = odd ? r2 : t0; v4[3] = odd ? r3 : t1;
+                        if (CTI_F6_STORE_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v4) : "memory");
+                        else *reinterpret_cast<f32x4*>(dst) = v4;
+                    } else {
+                        f32x2 v2; v2[0] = odd ? t0 : r0; v2[1] = odd ? t1 : r1;
+                        if (CTI_F6_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v2) : "memory");
+                        else *reinterpret_cast<f32x2*>(dst) = v2;
+                    }
                 }
         }
     } else if (EPI == F6_EPI_PLANES) {
@@ -341,18 +361,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             static_assert(TM * 32 == 64, "one (row, block) item per lane");
-            float v[32];
-#pragma unroll
-            for (int q4 = 0; q4 < 8; ++q4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(stg + lane * 36 + q4 * 4);
-                v[4 * q4] = t4.x; v[4 * q4 + 1] = t4.y; v[4 * q4 + 2] = t4.z; v[4 * q4 + 3] = t4.w;
-            }
             const int m = cm0 + wm * TM * 32 + lane;
-            if (m < p.M && nb < p.Np) {
-                _Float16 hh[32]; unsigned fh[6], fl[6]; int sh, sl;
-                f6_encode_block(v, hh, fh, fl, sh, sl);
-                f6_store_block(p.P, f6_prow(p.P, m), nb >> 5, hh, fh, fl, sh, sl);
-            }
+            if (m < p.M && nb < p.Np) f6_encode_row32_lds(stg + lane * 36, p.P, f6_prow(p.P, m), nb >> 5);
         }
     } else {
 #pragma unroll

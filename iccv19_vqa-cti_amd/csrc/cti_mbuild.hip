@@ -289,9 +289,11 @@ __device__ __forceinline__ uint4 mb_pack8(const unsigned short* h) {
 constexpr int MB_SP = 36;                       // pitch of the wave-private output patch [q][32 rho + 4 pad]
 constexpr int MB_XP = 20;                       // X row pitch in floats (16 j + 4 pad: 80-B rows, 16-B aligned, conflict-free)
 
+// F32OUT: the rows are written as fp32 (row stride pitchM floats) instead of bf16 hi/lo planes -- the f16f6 mode encodes them in one pass
+template <bool F32OUT>
 __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                            const float* __restrict__ Tt, unsigned short* __restrict__ Mh,
-                                                           unsigned short* __restrict__ Ml, int V, int Q, int R, int64_t pitchM) {
+                                                           unsigned short* __restrict__ Ml, float* __restrict__ Mf, int V, int Q, int R, int64_t pitchM) {
     constexpr int HR = 16, G = 2, INNER = HR * HR * G;          // 512 columns c = (j*16 + k)*2 + g
     extern __shared__ __attribute__((aligned(16))) float X2[];  // [V][G][HR(k)][MB_XP], then 16 output patches [16][MB_SP]
     float* stage = X2 + (size_t)V * G * HR * MB_XP;
@@ -375,11 +377,16 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
             if (sq < Q && !((CTI_MM_SKIP & 1) && m[0] != 12345.f)) {
                 const float4 y0 = *reinterpret_cast<const float4*>(stg + sq * MB_SP + sp * 8);
                 const float4 y1 = *reinterpret_cast<const float4*>(stg + sq * MB_SP + sp * 8 + 4);
+                const int64_t row = rows_b + ((int64_t)v * Q + sq) * G;                       // row of g = 0; g = 1 is the next row
+                if (F32OUT) {                                   // lane sp holds rho = 8 sp .. 8 sp + 7 = (g = sp >> 1, k = 8 (sp & 1) ..): 32 B of row (v, q, g)
+                    float* dst = Mf + (row + (sp >> 1)) * pitchM + r * HR + (sp & 1) * 8;
+                    *reinterpret_cast<float4*>(dst) = y0; *reinterpret_cast<float4*>(dst + 4) = y1;
+                    continue;
+                }
                 const float ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
                 unsigned short hb[8], lb[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { hb[u] = bf16_bits(ys[u]); lb[u] = bf16_bits(ys[u] - bf16_to_f32(hb[u])); }
-                const int64_t row = rows_b + ((int64_t)v * Q + sq) * G;                       // row of g = 0; g = 1 is the next row
                 const int64_t o = (int64_t)r * pitchM + row * 16 + sp * 8;
                 *reinterpret_cast<uint4*>(Mh + o) = mb_pack8(hb);
                 *reinterpret_cast<uint4*>(Ml + o) = mb_pack8(lb);
@@ -392,25 +399,27 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
 }  // namespace
 
 // Tt: the core pre-transposed to [r][c][i] (cti_transpose_f32 of T_eff[r] (i x c) for every r).  CTI_E_UNSUPPORTED = take mbuild_fast.
-int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, int B, int V, int Q, int R,
+int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st) {
 #ifdef CTI_NO_MBUILD_MFMA
     return CTI_E_UNSUPPORTED;
 #endif
-    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || !Mh || !Ml) return CTI_E_UNSUPPORTED;
+    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || !((Mh && Ml) || Mf)) return CTI_E_UNSUPPORTED;
+    if (Mf && ((reinterpret_cast<uintptr_t>(Mf) & 15) || (pitchM & 3))) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
     const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + 16 * 16 * MB_SP);
     if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
-    auto kern = mbuild_mfma_kernel;
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (attr_dev != dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mbuild_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mbuild_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail((int)e, "mbuild_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, V, Q, R, pitchM);
+    if (Mf) hipLaunchKernelGGL(mbuild_mfma_kernel<true>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
+    else    hipLaunchKernelGGL(mbuild_mfma_kernel<false>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
     return launch_status("mbuild_mfma");
 }
 

@@ -253,7 +253,7 @@ extern "C" int cti_teff_scramble(const float* src, float* dst, int R, int I, int
 }
 
 namespace cti {
-int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, int B, int V, int Q, int R,
+int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
 }
 
@@ -263,7 +263,7 @@ extern "C" int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, 
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && hr > 0 && G > 0 && rows_alloc >= (int64_t)B * V * Q * G, CTI_E_SHAPE,
                 "cti_paralind_mbuild_planes_fwd: B=%d V=%d Q=%d R=%d hr=%d G=%d rows_alloc=%lld", B, V, Q, R, hr, G, (long long)rows_alloc);
     int rc = CTI_E_UNSUPPORTED;
-    if (Teff_t) rc = mbuild_mfma(Vr, Qr, Teff_t, Mh, Ml, B, V, Q, R, hr, G, rows_alloc * 16, as_stream(stream));
+    if (Teff_t) rc = mbuild_mfma(Vr, Qr, Teff_t, Mh, Ml, nullptr, B, V, Q, R, hr, G, rows_alloc * 16, as_stream(stream));
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(Vr, Qr, Teff, nullptr, Mh, Ml, B, V, Q, R, hr, G, rows_alloc * 16, as_stream(stream));
     if (rc == CTI_E_UNSUPPORTED) return fail(CTI_E_UNSUPPORTED, "cti_paralind_mbuild_planes_fwd: h/rank=%d G=%d V=%d Q=%d is outside the plane-writing M-build kernels", hr, G, V, Q);
     return rc;

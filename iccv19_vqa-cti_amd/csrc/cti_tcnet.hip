@@ -5,9 +5,10 @@
 //   scales (weight-norm) -> [split inputs + weights] -> 3 Tucker GEMMs -> 3 packed rank GEMMs -> T_eff scramble
 //   -> M build (modes 1+2) -> mode-3 GEMM + rank sum, written as out[b,v,q,a,g]
 #include "cti_common.h"
+#include "cti_f16f6.h"
 
 namespace cti {
-int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, int B, int V, int Q, int R,
+int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
@@ -48,6 +49,9 @@ struct Plan {
     // planes mode
     Planes xin[3], wt[3], wr[3], tp[3], Arp, Mp;
     float* Vr; float* Qr;
+    // f16f6 mode: the mode-3 product runs on f16 + fp6 planes (cti_f16f6.h) written by the rank GEMM's epilogue (A^) and an encoding pass (M);
+    // every other GEMM stays on bf16x3
+    F6Planes f_Arp, f_Mp; float* Mf32;
     size_t bytes;
 };
 
@@ -83,14 +87,22 @@ Plan carve(const Dims& d, int prec, void* ws) {
         }
         p.M32 = static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
     } else {
+        const bool f6 = prec == CTI_PREC_F16F6;
         for (int s = 0; s < 3; ++s) {
             p.xin[s] = take_planes(w, rows[s], in[s]);
             p.tp[s] = take_planes(w, rows[s], d.h);
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
         p.Qr = static_cast<float*>(w.take(sizeof(float) * rows[1] * d.h));
-        p.Arp = take_planes(w, rows[2], d.h);
-        p.Mp = take_planes(w, mrows, d.h);
+        if (!f6) {
+            p.Arp = take_planes(w, rows[2], d.h);
+            p.Mp = take_planes(w, mrows, d.h);
+        } else {
+            const int64_t mpb = (int64_t)d.V * d.Q * d.G;
+            p.f_Arp = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, d.A)), rows[2], d.h, d.A);
+            p.Mf32 = static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
+            p.f_Mp = f6_carve(w.take(f6_planes_bytes(mrows, d.h, mpb)), mrows, d.h, mpb);
+        }
     }
     p.bytes = (w.off + 255) & ~(size_t)255;
     return p;
@@ -121,11 +133,12 @@ int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tuck
     if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
         rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * d.G, (int64_t)hr * hr * hr * d.G, p.Tt, hr, (int64_t)hr * hr * hr * d.G, hr, hr * hr * d.G, d.R, stream);
         if (rc) return rc;
-        if (weight_planes)
+        if (weight_planes) {
             for (int s = 0; s < 3; ++s) {
                 rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
                 rc = split_planes(rank_wv[s], d.h, d.h, d.h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
             }
+        }
     }
     return CTI_OK;
 }
@@ -147,7 +160,8 @@ extern "C" int cti_tcnet_prepare(const float* const* tucker_wv, const float* con
     CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(T_g); CTI_REQUIRE_PTR(prepared);
     Dims d{1, 1, 1, 1, v_dim, q_dim, a_dim, h, R, G};
     int rc = check_dims(d); if (rc) return rc;
-    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_tcnet_prepare: prec=%d", prec);
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || prec == CTI_PREC_F16F6, CTI_E_UNSUPPORTED, "cti_tcnet_prepare: prec=%d", prec);
+    CTI_REQUIRE(prec != CTI_PREC_F16F6 || h % 32 == 0, CTI_E_UNSUPPORTED, "cti_tcnet_prepare: the f16f6 mode needs h %% 32 == 0 (h=%d)", h);
     CTI_REQUIRE(prepared_bytes >= cti_tcnet_prepared_bytes(v_dim, q_dim, a_dim, h, R, G, prec), CTI_E_WORKSPACE, "cti_tcnet_prepare: block too small");
     for (int s = 0; s < 3; ++s)
         CTI_REQUIRE(tucker_wv[s] && tucker_g[s] && rank_wv[s] && rank_g[s], CTI_E_NULL, "cti_tcnet_prepare: weight pointer %d is NULL", s);
@@ -176,7 +190,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
     Dims d{B, V, Q, A, v_dim, q_dim, a_dim, h, R, G};
     int rc = check_dims(d); if (rc) return rc;
     CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_tcnet_forward: act=%d", act);
-    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_tcnet_forward: prec=%d", prec);
+    CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || prec == CTI_PREC_F16F6, CTI_E_UNSUPPORTED, "cti_tcnet_forward: prec=%d", prec);
+    CTI_REQUIRE(prec != CTI_PREC_F16F6 || h % 32 == 0, CTI_E_UNSUPPORTED, "cti_tcnet_forward: the f16f6 mode needs h %% 32 == 0 (h=%d)", h);
     for (int s = 0; s < 3; ++s)
         CTI_REQUIRE(tucker_wv[s] && tucker_g[s] && tucker_b[s] && rank_wv[s] && rank_g[s] && rank_b[s], CTI_E_NULL, "cti_tcnet_forward: weight pointer %d is NULL", s);
     Plan p = carve(d, prec, workspace);
@@ -212,7 +227,8 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         return rc;
     }
 
-    const int terms = prec == CTI_PREC_BF16X3 ? 3 : 1;
+    const bool f6 = prec == CTI_PREC_F16F6;
+    const int terms = prec == CTI_PREC_BF16 ? 1 : 3;
     // Two independent chains feed the mode-3 GEMM: chain A (the a side: split, Tucker, rank nets -- 2.8 ms at config 2, opens with the
     // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
     // an auxiliary stream from the caller chain B runs beside chain A's split pass: fork/join with two events, no host sync.
@@ -230,11 +246,13 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         return code;
     };
 #ifndef CTI_AF32
-#define CTI_AF32 0       // option: fp32 A operand split at fragment-read time instead of the split pass (measured neutral on MI355X)
+#define CTI_AF32 1       // fp32 A operand of the Tucker GEMMs split at fragment-read time instead of a split pass: -2.6 % on the whole step once the
+#endif                   // LDS reads of that path stopped draining vmcnt(0) (plain vector type instead of HIP's float4 struct); 0 = the split pass
+#if 0
 #endif
     const int Kh = planes_kp(h);
     auto side = [&](int s, hipStream_t ss) -> int {
-        const bool af32 = CTI_AF32 && prec == CTI_PREC_BF16X3 && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
+        const bool af32 = CTI_AF32 && (prec == CTI_PREC_BF16X3 || f6) && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
         int r_;
         if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
         if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
@@ -255,13 +273,23 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         r.M = (int)rows[s]; r.N = h; r.Kp = Kh; r.terms = terms;
         r.scale = p.scale_r[s]; r.scale_div = hr; r.bias = rank_b[s]; r.relu = relu;
         if (s < 2) { r.epi = 0; r.C = s == 0 ? p.Vr : p.Qr; r.ldc_m = h; r.ldc_n = 1; }
+        else if (f6) { r.epi = 4; r.f6out = &p.f_Arp; r.Np = h; }            // A^ straight into the f16 + fp6 planes of the mode-3 product
         else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.rows_allocP = p.Arp.rows_alloc; r.Np = Kh; }
         return gemm_nt_planes(r, ss);
     };
     // chain B on the auxiliary stream (or first, on the main stream)
     rc = side(0, sb); if (rc) return finish(rc);
     rc = side(1, sb); if (rc) return finish(rc);
-    rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
+    if (f6) {
+        // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
+        // start at multiples of 8 rows
+        rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, nullptr, nullptr, p.Mf32, B, V, Q, R, hr, G, h, sb);
+        if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, p.Mf32, nullptr, nullptr, B, V, Q, R, hr, G, h, sb);
+        if (rc == CTI_E_UNSUPPORTED) rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, p.Mf32, B, V, Q, R, hr, hr, hr, G, sb);
+        if (rc) return finish(rc);
+        rc = quantize_f16f6(p.Mf32, h, (int64_t)B * mrows_per_b, h, p.f_Mp, sb);
+    } else {
+    rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, nullptr, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) {
         // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h)
@@ -269,11 +297,21 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, sb); if (rc) return finish(rc);
         rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, sb);
     }
+    }
     if (rc) return finish(rc);
     if (aux_stream) (void)hipEventRecord(ev_join, sb);
     // chain A on the main stream
     rc = side(2, st); if (rc) return finish(rc);
     if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
+    if (f6) {
+        F6GemmArgs c{};                                      // mode 3 + rank sum on the f16 + fp6 planes
+        c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
+        c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
+        if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
+        rc = gemm_nt_f16f6(c, st);
+        if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
+        return finish(rc);
+    }
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;
     c.rows_allocA = p.Mp.rows_alloc; c.rows_allocB = p.Arp.rows_alloc; c.rA1 = mrows_per_b; c.rB1 = A; c.nb1 = B; c.nb2 = 1;

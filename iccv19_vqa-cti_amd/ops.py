@@ -5,12 +5,13 @@ import torch
 
 from . import _lib as L
 
-_PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
+_PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16, "f16f6": L.PREC_F16F6}
 _default_prec = "bf16x3"     # fp32-grade (1e-5 vs float64 truth at the BASELINE shapes) at 3/16 of the exact-fp32 MFMA cost
 
 
 def set_precision(name):
-    """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade) or 'bf16'."""
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade), 'f16f6' (fused TCNet.forward on f16 + block-scaled fp6 products,
+    fp32-grade; everything else as bf16x3) or 'bf16'."""
     global _default_prec
     if name not in _PREC:
         raise ValueError("precision must be one of %s" % sorted(_PREC))
@@ -21,8 +22,11 @@ def get_precision():
     return _default_prec
 
 
-def _prec(p):
-    return _PREC[p or _default_prec]
+def _prec(p, fused=False):
+    """Precision code of a launch.  'f16f6' exists for the fused TCNet.forward (cti_tcnet_forward / cti_tcnet_prepare) only: every other op runs its
+    bf16x3 form in that mode (same fp32-grade accuracy class)."""
+    c = _PREC[p or _default_prec]
+    return L.PREC_BF16X3 if (c == L.PREC_F16F6 and not fused) else c
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -360,7 +364,9 @@ def tcnet_prepare(tucker, rank, T_g, prec=None):
     R = rank[0][1].numel()
     G = T_g.shape[5]
     vd, qd, ad = (tucker[s][0].shape[1] for s in range(3))
-    pr = _prec(prec)
+    pr = _prec(prec, fused=True)
+    if pr == L.PREC_F16F6 and h % 32:
+        pr = L.PREC_BF16X3                                       # the f16f6 planes need h % 32 == 0
     lib = L.lib()
     nb = lib.cti_tcnet_prepared_bytes(vd, qd, ad, h, R, G, pr)
     block = torch.empty(nb, device=T_g.device, dtype=torch.uint8)
@@ -396,7 +402,9 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
     if out.numel() == 0:                                   # empty batch (or a zero-length axis): nothing to launch
         return (out, mask) if want_mask else out
-    pr = _prec(prec)
+    pr = _prec(prec, fused=True)
+    if pr == L.PREC_F16F6 and h % 32:
+        pr = L.PREC_BF16X3
     prep_ptr = 0
     if prepared is not None:
         if prepared[1] != pr:

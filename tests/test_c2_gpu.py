@@ -28,7 +28,7 @@ def _tri_from(cfg, params):
     return _tri(type("F", (), {"cfg": cfg, "p": params})())
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "f16f6"])
 def test_c2_widths_small_batch(prec):
     fx, params, v, q, a, idx = gu.c2_case()
     old = cti_amd.get_precision()
@@ -59,12 +59,22 @@ def _c2_batch(B, seed):
     return v, q, a
 
 
-def test_c2_full_batch_sampled_against_oracle():
-    """The benchmarked launch itself (B=256, bf16x3): samples 0, 127, 255 against the float64 oracle."""
+@pytest.mark.parametrize("prec", ["bf16x3", "f16f6"])
+def test_c2_full_batch_sampled_against_oracle(prec):
+    """The benchmarked launch itself (B=256): samples 0, 127, 255 against the float64 oracle."""
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(prec)
+    try:
+        _c2_full_batch(prec)
+    finally:
+        cti_amd.set_precision(old)
+
+
+def _c2_full_batch(prec):
     fx, params, *_ = gu.c2_case()
     B = 256
     v, q, a = _c2_batch(B, 777)
-    v[127, 36:] = 0                                # no padding at all on sample 127 (rs draws 10..36); sample 255 gets the maximum padding
+    v[127] = gu.rs_fill(np.random.RandomState(5), (36, 2048), "abs")      # no padding at all on sample 127; sample 255 gets the maximum padding
     v[255, 10:] = 0
     m = _tri_from(fx.cfg, params)
     pick = [0, 127, 255]
@@ -92,7 +102,7 @@ def test_c2_full_batch_sampled_against_oracle():
                 assert int(np.argmax(p_s[i, ..., g])) == int(top[1])
     ok = np.isfinite(l64)
     assert np.max(np.abs(l_s[ok] - l64[ok])) < TOL * np.max(np.abs(l64[ok]))
-    print("C2 B=256 [bf16x3]: raw err vs float64 truth on samples 0/127/255 = %.3g" % e)
+    print("C2 B=256 [%s]: raw err vs float64 truth on samples 0/127/255 = %.3g" % (prec, e))
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
