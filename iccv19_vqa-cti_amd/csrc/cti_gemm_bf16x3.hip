@@ -319,8 +319,16 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             }
 #endif
     };
-    int pos = 0;
-    for (int g = 0; g < ngr; ++g) {
+#ifndef CTI_X3_STAGGER
+#define CTI_X3_STAGGER 0
+#endif
+    // STAGGER (one slot per barrier, no loader waves; OFF here): waves w and w + NW/2 share a SIMD and run the same program; the upper half
+    // reads slice g BEFORE barrier g + 1 and issues its MFMAs AFTER it, so that one SIMD partner computes while the other reads.  It pays in
+    // cti_gemm_f16f6.hip (1.30 -> 1.14 ms on that kernel's MFMA + LDS part: 18 MFMAs behind 24 LDS reads per step); here (24 MFMAs behind 12
+    // reads of 16-deep slices) the whole forward measured 5.48 ms with it against 5.31 ms without, same box, interleaved rounds.
+    constexpr bool STAG = (CTI_X3_STAGGER != 0) && LW == 0 && SPB == 1 && !PIPE;
+    const bool lag = STAG && __builtin_amdgcn_readfirstlane(wid) >= (WM * WN) / 2;
+    auto sync_g = [&](int g) {
         if (issuer) {
             const int rem = ngr - 1 - g;                                 // groups issued after group g so far: min(NG-2, rem)
             if (!EXACT) wait_vmcnt<0>();
@@ -330,6 +338,27 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+    };
+    if (lag) {
+        int pos = 0;
+        sync_g(0);
+        if (issuer && NG - 1 < ngr && !(CTI_ABL & 1)) issue_group(NG - 1, NG - 1);
+        for (int g = 0; g < ngr; ++g) {
+            load_frags(smem + pos * SLOT);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pos = pos == NG - 1 ? 0 : pos + 1;
+            if (g + 1 < ngr) {
+                sync_g(g + 1);
+                if (issuer && g + NG < ngr && !(CTI_ABL & 1)) issue_group(pos == 0 ? NG - 1 : pos - 1, g + NG);
+            } else {
+                __syncthreads();                  // pairs with the lead waves' closing barrier
+            }
+            mfma_frags();
+        }
+    } else {
+    int pos = 0;
+    for (int g = 0; g < ngr; ++g) {
+        sync_g(g);
         if (issuer && g + NG - 1 < ngr && !(CTI_ABL & 1)) issue_group(pos == 0 ? NG - 1 : pos - 1, g + NG - 1);
         if (!loader) {
             if (PIPE) {
@@ -344,6 +373,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
         pos = pos == NG - 1 ? 0 : pos + 1;
     }
     __syncthreads();                              // every wave is done reading the ring before the epilogue reuses it
+    }
     if (!loader) {
 
     const int64_t boff = b1 * p.sC1 + b2 * p.sC2;

@@ -156,3 +156,39 @@ def test_forced_tile_geometry_and_multichunk_softmax_backward(cfg):
     for n_, t_ in (("v", v), ("q", q), ("a", a)):
         check(t_.grad, fx.g[n_], what="d%s geometry %d" % (n_, cfg))
     check_param_grads(m, fx)
+
+
+def test_f16f6_mode_on_the_small_fixtures_and_config_1():
+    """precision='f16f6' (mode-3 product on f16 + block-scaled fp6 planes) against the reference fixtures: reduced dims (h = 64: the fused
+    path with the MFMA M build; h = 48 is not a multiple of 32 and takes the bf16x3 kernels), an all-zero sample, BASELINE configs[0]."""
+    old = cti_amd.get_precision()
+    cti_amd.set_precision("f16f6")
+    try:
+        for name in ("g3_tcnet_small", "g3_tcnet_g3_odd", "g3_tcnet_allzero_sample"):
+            fx = gu.load(name)
+            m = _tri(fx)
+            v, q, a = T(fx.i["v"]), T(fx.i["q"]), T(fx.i["a"])
+            with torch.no_grad():
+                raw = m.TriAtt(v, q, a)
+                p, logits = m(v, q, a)
+            check(raw, fx.o["raw"], what=name + " raw [f16f6]")
+            assert np.array_equal(np.isneginf(logits.cpu().numpy()), np.isneginf(fx.o["logits"]))
+            ok = ~np.isnan(fx.o["p"])
+            assert np.max(np.abs(p.cpu().numpy()[ok] - fx.o["p"][ok])) < TOL * float(np.max(fx.o["p"][ok]))
+        fx, params, v, q, a = gu.c1_case()
+        m = _tri_from(fx.cfg, params)
+        with torch.no_grad():
+            raw = m.TriAtt(T(v), T(q), T(a))
+            p, _ = m(T(v), T(q), T(a))
+        e = check(raw, fx.o["raw"], what="C1 raw [f16f6]")
+        e64 = check(raw, O.tcnet_forward(v, q, a, params, "TriAtt.", dtype=np.float64), what="C1 raw vs float64 [f16f6]")
+        print("C1 [f16f6]: err vs reference %.3g, vs float64 truth %.3g" % (e, e64))
+        pn = p.cpu().numpy()
+        for b in range(4):
+            for g in range(2):
+                assert np.argmax(pn[b, ..., g]) == np.argmax(fx.o["p"][b, ..., g])
+        # values far outside f16's range degrade gracefully (no NaN / inf): the hi part saturates, the fp6 lo part carries the rest at 4 bits
+        big = cti_amd.ops.gemm_nt_f16f6(torch.full((40, 64), 3.0e5, device=DEV), torch.ones(24, 64, device=DEV))
+        assert bool(torch.isfinite(big).all()) and float((big / (3.0e5 * 64) - 1).abs().max()) < 0.1
+    finally:
+        cti_amd.set_precision(old)
