@@ -80,6 +80,9 @@ SIGNATURES = {
     "cti_bce_logits_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _i64, C.c_float, _vp]),
     "cti_kd_rows_fwd": (_int, [_vp, _vp, _vp, _int, _int, C.c_float, _vp]),
     "cti_kd_rows_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _int, _int, C.c_float, C.c_float, _vp]),
+    "cti_dropout_g": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _i64, _vp, _vp]),
+    "cti_adamax_step_g": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "cti_counter_add": (_int, [_vp, _i64, _vp]),
     "cti_dropout": (_int, [_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _int, _i64, _vp]),
     "cti_paralind_core_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_core_planes_fwd": (_int, [_vp, _vp, _i64, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),

@@ -186,7 +186,8 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p); mask byte stored for the backward.  backward: same kernel with x = dy, use_mask = 1.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
                                                       int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask,
-                                                      int64_t period, int vec) {
+                                                      int64_t period, int vec, const unsigned long long* __restrict__ rng_dev) {
+    if (rng_dev) seed += rng_dev[0] * 0x9E3779B97F4A7C15ull;            // device-resident step counter: a replayed hipGraph draws fresh masks
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 4 elements
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // mask only, 16 bytes per thread (four Philox calls, the SAME counters as dropout_kernel: counter = element / 4) and one 16-B store: the 4-B
 // stores of the general kernel wrote the 151 MB mask of the visual rank nets at 1.9 TB/s
 __global__ __launch_bounds__(256) void dropout_mask16_kernel(uint8_t* __restrict__ mask, int64_t n16, float p, unsigned long long seed,
-                                                             unsigned long long offset) {
+                                                             unsigned long long offset, const unsigned long long* __restrict__ rng_dev) {
+    if (rng_dev) seed += rng_dev[0] * 0x9E3779B97F4A7C15ull;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 16 elements
     if (t >= n16) return;
     const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);
@@ -300,15 +302,30 @@ __global__ __launch_bounds__(256) void wn_bwd_apply_kernel(const float* __restri
 
 using namespace cti;
 
+__global__ void counter_add_kernel(long long* ctr, long long inc) { if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += inc; }
+
+extern "C" int cti_counter_add(int64_t* counter, int64_t inc, void* stream) {
+    CTI_REQUIRE_PTR(counter);
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<long long*>(counter), (long long)inc);
+    return launch_status("cti_counter_add");
+}
+
+extern "C" int cti_dropout_g(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
+                             int64_t period, const uint64_t* rng_dev, void* stream);
 extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
                            int64_t period, void* stream) {
+    return cti_dropout_g(x, y, mask, n, p, seed, offset, use_mask, period, nullptr, stream);
+}
+
+extern "C" int cti_dropout_g(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask,
+                             int64_t period, const uint64_t* rng_dev, void* stream) {
     CTI_REQUIRE_PTR(mask);
     if (y || use_mask) { CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); }
     CTI_REQUIRE(n > 0 && p >= 0.f && p < 1.f && period >= 0, CTI_E_SHAPE, "cti_dropout: n=%lld p=%f", (long long)n, p);
     if (!y && !use_mask && n >= 16 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {          // mask only: 16-B stores for the bulk, the tail below
         const int64_t n16 = n / 16;
         hipLaunchKernelGGL(dropout_mask16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, as_stream(stream), mask, n16, p,
-                           (unsigned long long)seed, (unsigned long long)offset);
+                           (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const unsigned long long*>(rng_dev));
         int rc = launch_status("cti_dropout/mask16"); if (rc) return rc;
         if (n16 * 16 == n) return 0;
         mask += n16 * 16; offset += (uint64_t)n16 * 4; n -= n16 * 16;
@@ -317,7 +334,7 @@ extern "C" int cti_dropout(const float* x, float* y, uint8_t* mask, int64_t n, f
     const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 3) == 0 &&
                     (period & 3) == 0;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, mask, n, p,
-                       (unsigned long long)seed, (unsigned long long)offset, use_mask, period, vec);
+                       (unsigned long long)seed, (unsigned long long)offset, use_mask, period, vec, reinterpret_cast<const unsigned long long*>(rng_dev));
     return launch_status("cti_dropout");
 }
 

@@ -73,9 +73,12 @@ __global__ __launch_bounds__(256) void flat_gather_kernel(const GatherBatch tb, 
 
 __global__ __launch_bounds__(256) void adamax_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ u,
                                                      int64_t n, const float* __restrict__ partial, int nparts, float max_norm, float lr_t,
-                                                     float b1, float b2, float eps, float* __restrict__ norm_out) {
+                                                     float b1, float b2, float eps, float* __restrict__ norm_out,
+                                                     const float* __restrict__ lr_dev, const long long* __restrict__ step_dev) {
     __shared__ float red[4];
     __shared__ float coef_s;
+    // graph-safe form: learning rate and the count of completed steps live in device memory (a captured hipGraph replays with fresh values)
+    if (step_dev) lr_t = lr_dev[0] / (1.f - powf(b1, (float)(step_dev[0] + 1)));
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];      // every workgroup re-reduces the same partials in the same order
     s = wave_sum(s);
@@ -151,6 +154,17 @@ extern "C" int cti_adamax_step(float* param, const float* grad, float* exp_avg, 
     const float lr_t = lr / (1.f - powf(beta1, (float)step));
     const int64_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_inf, n,
-                       partial, OPT_BLOCKS, max_norm, lr_t, beta1, beta2, eps, grad_norm_out);
+                       partial, OPT_BLOCKS, max_norm, lr_t, beta1, beta2, eps, grad_norm_out, nullptr, nullptr);
     return launch_status("cti_adamax_step");
+}
+
+extern "C" int cti_adamax_step_g(float* param, const float* grad, float* exp_avg, float* exp_inf, int64_t n, const float* partial, float max_norm,
+                                 const float* lr_dev, float beta1, float beta2, float eps, const int64_t* steps_done_dev, float* grad_norm_out, void* stream) {
+    CTI_REQUIRE_PTR(param); CTI_REQUIRE_PTR(grad); CTI_REQUIRE_PTR(exp_avg); CTI_REQUIRE_PTR(exp_inf); CTI_REQUIRE_PTR(partial);
+    CTI_REQUIRE_PTR(lr_dev); CTI_REQUIRE_PTR(steps_done_dev);
+    CTI_REQUIRE(n > 0, CTI_E_SHAPE, "cti_adamax_step_g: n=%lld", (long long)n);
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(adamax_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_inf, n,
+                       partial, OPT_BLOCKS, max_norm, 0.f, beta1, beta2, eps, grad_norm_out, lr_dev, reinterpret_cast<const long long*>(steps_done_dev));
+    return launch_status("cti_adamax_step_g");
 }

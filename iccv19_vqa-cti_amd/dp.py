@@ -61,10 +61,26 @@ class FlatAdamaxDP:
         lib = L.lib()
         self.partial = torch.empty(lib.cti_optim_workspace_bytes() // 4, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
-        self.lr, self.betas, self.eps, self.clip_norm, self.update_freq = lr, betas, eps, clip_norm, update_freq
+        # what changes from step to step lives in device memory (learning rate, completed-step count, the dropout streams' step counter), so a
+        # whole training step -- forward, backward, this step() -- captured in a hipGraph replays correctly (tools/graph_train.py)
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        ops._rng_tensor(dev)
+        self._lr = float(lr)
+        self.betas, self.eps, self.clip_norm, self.update_freq = betas, eps, clip_norm, update_freq
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.step_count = 0
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        """Learning-rate schedules assign here between steps (src/FFOE/train.py:75-83): the device copy follows (not while capturing)."""
+        self._lr = float(value)
+        self.lr_dev.fill_(self._lr)
 
     def broadcast_parameters(self, src=0):
         """Identical initial parameters on every rank: one broadcast of the flat buffer."""
@@ -113,16 +129,23 @@ class FlatAdamaxDP:
         self.gather_grads()
         if self.world > 1 or (self.force_collective and dist.is_initialized()):
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
-        self.step_count += 1
+        self.step_count += 1                                     # host mirror (eager); the kernels read the device counter
         st = ops._stream()
         lib = L.lib()
         L.check(lib.cti_flat_scale_sumsq(self.flat_g.data_ptr(), self.n, 1.0 / (self.world * self.update_freq), self.partial.data_ptr(), st),
                 "cti_flat_scale_sumsq")
-        L.check(lib.cti_adamax_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.n,
-                                    self.partial.data_ptr(), float(self.clip_norm), float(self.lr), self.betas[0], self.betas[1], self.eps,
-                                    self.step_count, self.grad_norm.data_ptr(), st), "cti_adamax_step")
+        L.check(lib.cti_adamax_step_g(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_inf.data_ptr(), self.n,
+                                      self.partial.data_ptr(), float(self.clip_norm), self.lr_dev.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                      self.step_dev.data_ptr(), self.grad_norm.data_ptr(), st), "cti_adamax_step_g")
+        L.check(lib.cti_counter_add(self.step_dev.data_ptr(), 1, st), "cti_counter_add")
+        ops.rng_advance(self.flat_p.device)                      # the next step's dropout masks differ, also when this step is a graph replay
         ops.invalidate_caches()                                  # the kernel wrote the parameters behind autograd's version counters
         return self.grad_norm
+
+    def steps_done(self):
+        """Completed steps as the device counts them (= step_count in eager use; graph replays advance only the device counter).  Synchronises."""
+        self.step_count = int(self.step_dev.item())
+        return self.step_count
 
     def state_dict(self):
         """The `torch.optim.Adamax.state_dict()` format the reference saves as `optimizer_state` (src/utils.py:104) and reloads with
@@ -130,6 +153,7 @@ class FlatAdamaxDP:
         `filter(requires_grad, model.parameters())` (src/FFOE/train.py:34) plus one param group.  Tensors are CLONES (later steps do not
         mutate a dict the caller holds); parameters that have not been stepped yet have no entry, like torch."""
         state = {}
+        self.steps_done()
         if self.step_count > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 k = p.numel()
@@ -176,6 +200,7 @@ class FlatAdamaxDP:
             self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.exp_inf[o:o + k].copy_(st["exp_inf"].reshape(-1))
         self.step_count = steps.pop() if steps else 0
+        self.step_dev.fill_(self.step_count)
         self.lr = float(grp.get("lr", self.lr))
         self.betas = tuple(grp.get("betas", self.betas))
         self.eps = float(grp.get("eps", self.eps))

@@ -714,23 +714,71 @@ def wn_bwd(G, weight_v, weight_g, n_mats):
     return dV, dg
 
 
+# ---- dropout streams -------------------------------------------------------------------------------------------------------
+# Philox key of a call = f(torch.initial_seed(), host call counter) advanced on the DEVICE by a per-device step counter that
+# FlatAdamaxDP.step() bumps (cti_counter_add): a training step captured in a hipGraph replays with the same kernel arguments and still
+# draws fresh masks.  Re-seeding (torch.manual_seed) resets both counters, so a seed reproduces its masks regardless of what ran before;
+# dropout_rng_state() / set_dropout_rng_state() carry them through a checkpoint.
 _dropout_calls = [0]
+_dropout_seed_seen = [None]
+_rng_dev = {}
+
+
+def _rng_tensor(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _rng_dev.get(key)
+    if t is None:
+        t = _rng_dev[key] = torch.zeros(1, device=device, dtype=torch.int64)
+    return t
+
+
+def _dropout_seed(device):
+    seed0 = torch.initial_seed()
+    if _dropout_seed_seen[0] != seed0:                       # torch.manual_seed(...) since the last call: restart the streams
+        _dropout_seed_seen[0] = seed0
+        _dropout_calls[0] = 0
+        if not torch.cuda.is_current_stream_capturing():
+            for t in _rng_dev.values():
+                t.zero_()
+    seed = (seed0 * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
+    _dropout_calls[0] += 1
+    return seed, _rng_tensor(device).data_ptr()
+
+
+def rng_advance(device=None, inc=1):
+    """Bump the device-side step counter of the dropout streams (stream-ordered; FlatAdamaxDP.step() calls it once per step)."""
+    t = _rng_tensor(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    L.check(L.lib().cti_counter_add(t.data_ptr(), int(inc), _stream()), "cti_counter_add")
+
+
+def dropout_rng_state():
+    """(seed seen, host call counter, {device index: device step counter}) -- synchronises."""
+    return {"seed": _dropout_seed_seen[0], "calls": _dropout_calls[0], "steps": {k: int(t.item()) for k, t in _rng_dev.items()}}
+
+
+def set_dropout_rng_state(st):
+    _dropout_seed_seen[0], _dropout_calls[0] = st["seed"], int(st["calls"])
+    for k, v in st.get("steps", {}).items():
+        _rng_tensor(torch.device("cuda", int(k))).fill_(int(v))
+
+
+def reset_dropout_rng():
+    """Test hook: restart the dropout streams as if torch.manual_seed had just been called."""
+    _dropout_seed_seen[0] = None
 
 
 def dropout(x, p, mask=None, copies=1):
-    """Forward (mask=None): returns (y, mask) with a fresh Philox stream keyed by torch's seed + a call counter; copies = R > 1
-    returns R independently masked copies of x stacked on a new leading axis.  Backward: pass the stored mask, returns
-    dy * mask / (1-p) (same shape as dy)."""
+    """Forward (mask=None): returns (y, mask) with a fresh Philox stream (see above); copies = R > 1 returns R independently masked copies of x
+    stacked on a new leading axis.  Backward: pass the stored mask, returns dy * mask / (1-p) (same shape as dy)."""
     _req(x, "x")
     x = x.contiguous()
     if mask is None:
         shape = ((copies,) + tuple(x.shape)) if copies > 1 else tuple(x.shape)
         y = torch.empty(shape, device=x.device, dtype=torch.float32)
         mask = torch.empty(shape, device=x.device, dtype=torch.uint8)
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
-        _dropout_calls[0] += 1
-        L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), y.numel(), float(p), seed, 0, 0,
-                                    x.numel() if copies > 1 else 0, _stream()), "cti_dropout")
+        seed, rng = _dropout_seed(x.device)
+        L.check(L.lib().cti_dropout_g(x.data_ptr(), y.data_ptr(), mask.data_ptr(), y.numel(), float(p), seed, 0, 0,
+                                      x.numel() if copies > 1 else 0, rng, _stream()), "cti_dropout")
         return y, mask
     y = torch.empty_like(x)
     L.check(L.lib().cti_dropout(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), 0, 0, 1, 0, _stream()), "cti_dropout")
@@ -740,9 +788,8 @@ def dropout(x, p, mask=None, copies=1):
 def dropout_mask(shape, p, device):
     """A fresh keep-mask (uint8, 1 = keep) from the same Philox stream as dropout(); nothing else is written."""
     mask = torch.empty(tuple(shape), device=device, dtype=torch.uint8)
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
-    _dropout_calls[0] += 1
-    L.check(L.lib().cti_dropout(None, None, mask.data_ptr(), mask.numel(), float(p), seed, 0, 0, 0, _stream()), "cti_dropout (mask only)")
+    seed, rng = _dropout_seed(mask.device)
+    L.check(L.lib().cti_dropout_g(None, None, mask.data_ptr(), mask.numel(), float(p), seed, 0, 0, 0, rng, _stream()), "cti_dropout (mask only)")
     return mask
 
 

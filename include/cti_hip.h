@@ -391,6 +391,16 @@ int cti_gru_backward(const float* dout, const float* w_hh, const float* save, fl
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec);
 
+/* hipGraph-safe forms (a captured training step replays with the same kernel arguments): whatever changes from step to step lives in DEVICE
+ * memory.  cti_dropout_g = cti_dropout whose Philox key is advanced by rng_dev[0] (NULL = cti_dropout); cti_adamax_step_g = cti_adamax_step with
+ * the learning rate and the number of COMPLETED steps read from device memory (bias correction 1 - beta1^(steps_done + 1));
+ * cti_counter_add bumps such a counter in stream order (after the kernels that read it). */
+int cti_dropout_g(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, int use_mask, int64_t period,
+                  const uint64_t* rng_dev, void* stream);
+int cti_adamax_step_g(float* param, const float* grad, float* exp_avg, float* exp_inf, int64_t n, const float* partial, float max_norm,
+                      const float* lr_dev, float beta1, float beta2, float eps, const int64_t* steps_done_dev, float* grad_norm_out, void* stream);
+int cti_counter_add(int64_t* counter, int64_t inc, void* stream);
+
 /* Swish (src/activation.py:17-22), the classifier's alternative activation (src/classifier.py:14). */
 int cti_swish_fwd(const float* x, float* y, int64_t n, void* stream);
 int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

@@ -337,6 +337,7 @@ def test_mask_only_dropout_draws_the_same_stream(n):
     draws from the same seed."""
     ops = cti_amd.pkg.ops
     x = torch.randn(n, device=DEV)
+    ops.dropout_mask((16,), 0.5, x.device)              # settle the stream on the current torch seed (a new seed restarts the call counter)
     ops._dropout_calls[0] = 1234
     _, m1 = ops.dropout(x, 0.3)
     ops._dropout_calls[0] = 1234

@@ -325,3 +325,67 @@ def test_rccl_executes_once_through_the_dp_step():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["collective"] == "rccl all-reduce executed (forced, world 1)"
+
+
+def test_training_step_captured_in_a_hipgraph_replays_like_eager_steps():
+    """forward + loss + backward + FlatAdamaxDP.step() captured ONCE (GraphedTrainStep) and replayed on new batches == the same steps run
+    eagerly: Adamax' bias-correction step and the learning rate are read from device memory, so replays 1, 2, 3 are steps 3, 4, 5 of the run
+    (two eager warm-up steps precede the capture, which itself executes nothing); a learning-rate change between replays takes effect without re-capturing."""
+    cti_amd.set_precision("fp32")
+    try:
+        batches = [tuple(t.to(DEV) for t in make_batch(8, 100 + s)) for s in range(6)]
+        torch.manual_seed(11)
+        m1 = TinyCTI().to(DEV)
+        opt1 = cti_amd.FlatAdamaxDP(m1, lr=2e-3, clip_norm=0.25)
+        for k, s in enumerate((0, 0, 1, 2, 3)):           # the graphed run: 2 eager warm-up steps on batch 0 (capturing executes nothing), replays on 1, 2, 3
+            if k == 3:
+                opt1.lr = 1e-3
+            opt1.zero_grad(); loss_fn(m1(*batches[s][:3]), batches[s][3]).backward(); opt1.step()
+        torch.manual_seed(11)
+        m2 = TinyCTI().to(DEV)
+        opt2 = cti_amd.FlatAdamaxDP(m2, lr=2e-3, clip_norm=0.25)
+        gs = cti_amd.GraphedTrainStep(m2, opt2, loss_fn, batches[0][:3], batches[0][3], warmup=2)
+        losses = []
+        for k, s in enumerate((1, 2, 3)):
+            if k == 1:
+                opt2.lr = 1e-3
+            losses.append(float(gs(batches[s][:3], batches[s][3])))
+        assert opt2.steps_done() == 5 and opt1.steps_done() == 5
+        assert len(set(losses)) == 3
+        assert torch.allclose(opt1.flat_p, opt2.flat_p, rtol=1e-5, atol=1e-7)
+    finally:
+        cti_amd.set_precision("bf16x3")
+
+
+def test_graph_replays_draw_fresh_dropout_masks_and_reseeding_restarts_the_streams():
+    ops = cti_amd.ops
+    x = torch.ones(4096, device=DEV)
+    ops.rng_advance(x.device, 0)                         # make sure the device counter exists before the capture
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.dropout(x, 0.5)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            y, mask = ops.dropout(x, 0.5)
+            ops.rng_advance(x.device)
+    torch.cuda.current_stream().wait_stream(s)
+    seen = []
+    for _ in range(3):
+        g.replay(); torch.cuda.synchronize()
+        seen.append(mask.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert abs(float(seen[2].float().mean()) - 0.5) < 0.05
+    # a seed reproduces its masks whatever ran before (the call counter and the device counter restart with it)
+    torch.manual_seed(4242)
+    a1 = ops.dropout_mask((1000,), 0.3, x.device); a2 = ops.dropout_mask((1000,), 0.3, x.device)
+    ops.rng_advance(x.device, 5)
+    torch.manual_seed(777); ops.dropout_mask((10,), 0.3, x.device)
+    torch.manual_seed(4242)
+    b1 = ops.dropout_mask((1000,), 0.3, x.device); b2 = ops.dropout_mask((1000,), 0.3, x.device)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and not torch.equal(a1, a2)
+    st = ops.dropout_rng_state()
+    c1 = ops.dropout_mask((1000,), 0.3, x.device)
+    ops.set_dropout_rng_state(st)
+    assert torch.equal(c1, ops.dropout_mask((1000,), 0.3, x.device))
