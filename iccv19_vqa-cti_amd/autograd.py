@@ -101,7 +101,7 @@ class MBuildCoreFn(torch.autograd.Function):
     @staticmethod
     def supported(Vr, Ar, Teff):
         R, I, J, K, G = Teff.shape
-        return (ops.get_precision() in ("bf16x3", "bf16") and I == J == K and (R * K) % 32 == 0 and Ar.shape[1] <= 8 and Vr.shape[0] > 0
+        return (ops.get_precision() in ("bf16x3", "bf16", "f16f6") and I == J == K and (R * K) % 32 == 0 and Ar.shape[1] <= 8 and Vr.shape[0] > 0
                 and Vr.shape[0] <= 65535)
 
     @staticmethod

@@ -901,6 +901,89 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
     return launch_status("cti_paralind_mbuild_bwd");
 }
 
+// ---- M-build backward for ANY cubic core size (the reference takes any --rank / --h_mm, src/FFOE/main.py:61-64): plain fp32 VALU kernels,
+// one thread per output element, through the same intermediates as the forward (X = mode-1 product):
+//   X[b,v,r,j,k,g]  = sum_i T[r,i,j,k,g] Vr[b,v,r,i]          dX[b,v,r,j,k,g] = sum_q dM[b,v,q,g,r,k] Qr[b,q,r,j]
+//   dQr[b,q,r,j]    = sum_{v,k,g} dM[b,v,q,g,r,k] X[b,v,r,j,k,g]
+//   dVr[b,v,r,i]    = sum_{j,k,g} dX[b,v,r,j,k,g] T[r,i,j,k,g]   dT_partial[b][r,i,j,k,g] = sum_v Vr[b,v,r,i] dX[b,v,r,j,k,g]
+// Exact fp32, slow (no tiling): the fallback behind the staged kernels built for h/rank in {4, 8, 16}.
+namespace cti { namespace {
+struct MbgP { const float* dM; const float* Vr; const float* Qr; const float* T; float* X; float* dX; float* dVr; float* dQr; float* dTp; int B, V, Q, R, H, G; };
+__global__ __launch_bounds__(256) void mbg_x_dx_kernel(MbgP p) {               // thread = (b, v, r, j, k, g)
+    const int64_t n = (int64_t)p.B * p.V * p.R * p.H * p.H * p.G, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int64_t u = t;
+    const int g = u % p.G; u /= p.G; const int k = u % p.H; u /= p.H; const int j = u % p.H; u /= p.H; const int r = u % p.R; u /= p.R;
+    const int v = u % p.V; const int b = u / p.V;
+    const int K = p.R * p.H;
+    float x = 0.f, dx = 0.f;
+    const float* vr = p.Vr + ((int64_t)b * p.V + v) * K + r * p.H;
+    for (int i = 0; i < p.H; ++i) x = fmaf(p.T[((((int64_t)r * p.H + i) * p.H + j) * p.H + k) * p.G + g], vr[i], x);
+    for (int q = 0; q < p.Q; ++q)
+        dx = fmaf(p.dM[((((int64_t)b * p.V + v) * p.Q + q) * p.G + g) * K + r * p.H + k], p.Qr[((int64_t)b * p.Q + q) * K + r * p.H + j], dx);
+    p.X[t] = x; p.dX[t] = dx;
+}
+__global__ __launch_bounds__(256) void mbg_dq_kernel(MbgP p) {                 // thread = (b, q, r, j)
+    const int64_t n = (int64_t)p.B * p.Q * p.R * p.H, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int64_t u = t;
+    const int j = u % p.H; u /= p.H; const int r = u % p.R; u /= p.R; const int q = u % p.Q; const int b = u / p.Q;
+    const int K = p.R * p.H;
+    float s = 0.f;
+    for (int v = 0; v < p.V; ++v)
+        for (int k = 0; k < p.H; ++k)
+            for (int g = 0; g < p.G; ++g)
+                s = fmaf(p.dM[((((int64_t)b * p.V + v) * p.Q + q) * p.G + g) * K + r * p.H + k],
+                         p.X[(((((int64_t)b * p.V + v) * p.R + r) * p.H + j) * p.H + k) * p.G + g], s);
+    p.dQr[((int64_t)b * p.Q + q) * K + r * p.H + j] = s;
+}
+__global__ __launch_bounds__(256) void mbg_dv_kernel(MbgP p) {                 // thread = (b, v, r, i)
+    const int64_t n = (int64_t)p.B * p.V * p.R * p.H, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int64_t u = t;
+    const int i = u % p.H; u /= p.H; const int r = u % p.R; u /= p.R; const int v = u % p.V; const int b = u / p.V;
+    const int inner = p.H * p.H * p.G;
+    const float* dx = p.dX + (((int64_t)b * p.V + v) * p.R + r) * inner;
+    const float* tt = p.T + ((int64_t)r * p.H + i) * inner;
+    float s = 0.f;
+    for (int c = 0; c < inner; ++c) s = fmaf(dx[c], tt[c], s);
+    p.dVr[((int64_t)b * p.V + v) * (p.R * p.H) + r * p.H + i] = s;
+}
+__global__ __launch_bounds__(256) void mbg_dt_kernel(MbgP p) {                 // thread = (b, r, i, c = (j,k,g))
+    const int inner = p.H * p.H * p.G;
+    const int64_t n = (int64_t)p.B * p.R * p.H * inner, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int64_t u = t;
+    const int c = u % inner; u /= inner; const int i = u % p.H; u /= p.H; const int r = u % p.R; const int b = u / p.R;
+    float s = 0.f;
+    for (int v = 0; v < p.V; ++v)
+        s = fmaf(p.Vr[((int64_t)b * p.V + v) * (p.R * p.H) + r * p.H + i], p.dX[(((int64_t)b * p.V + v) * p.R + r) * inner + c], s);
+    p.dTp[t] = s;
+}
+} }
+extern "C" size_t cti_paralind_mbuild_bwd_generic_workspace_bytes(int B, int V, int R, int hr, int G) {
+    if (B <= 0 || V <= 0 || R <= 0 || hr <= 0 || G <= 0) return 0;
+    return 2 * sizeof(float) * (size_t)B * V * R * hr * hr * G;
+}
+extern "C" int cti_paralind_mbuild_bwd_generic(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
+                                               float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(dVr); CTI_REQUIRE_PTR(dQr); CTI_REQUIRE_PTR(dTeff_partial);
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && hr > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd_generic: B=%d V=%d Q=%d R=%d hr=%d G=%d", B, V, Q, R, hr, G);
+    CTI_REQUIRE(workspace_bytes >= cti_paralind_mbuild_bwd_generic_workspace_bytes(B, V, R, hr, G), CTI_E_WORKSPACE, "cti_paralind_mbuild_bwd_generic: workspace too small");
+    const int64_t nx = (int64_t)B * V * R * hr * hr * G;
+    CTI_REQUIRE((nx + 255) / 256 < 0x7fffffffLL && ((int64_t)B * R * hr * hr * hr * G + 255) / 256 < 0x7fffffffLL, CTI_E_SHAPE, "cti_paralind_mbuild_bwd_generic: too large");
+    MbgP p{dM, Vr, Qr, Teff, static_cast<float*>(workspace), static_cast<float*>(workspace) + nx, dVr, dQr, dTeff_partial, B, V, Q, R, hr, G};
+    hipStream_t st = as_stream(stream);
+    auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL(mbg_x_dx_kernel, blocks(nx), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(mbg_dq_kernel, blocks((int64_t)B * Q * R * hr), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(mbg_dv_kernel, blocks((int64_t)B * V * R * hr), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(mbg_dt_kernel, blocks((int64_t)B * R * hr * hr * hr * G), dim3(256), 0, st, p);
+    return launch_status("cti_paralind_mbuild_bwd_generic");
+}
+
 static void tri_chunks_b(int V, int64_t QA, int64_t* chunk_n, int* nchunk) {
     const int64_t N = (int64_t)V * QA, c = tuning_tri_chunk() > 0 ? tuning_tri_chunk() : 32768;
     *nchunk = (int)((N + c - 1) / c); *chunk_n = c;

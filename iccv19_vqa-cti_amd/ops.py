@@ -835,8 +835,15 @@ def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
     dM, Vr, Qr, Teff = dM.contiguous(), Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
     dVr, dQr = torch.empty_like(Vr), torch.empty_like(Qr)
     part = torch.empty((B,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
-    L.check(L.lib().cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
-                                            part.data_ptr(), B, V, Q, R, I, G, _stream()), "cti_paralind_mbuild_bwd")
+    lib = L.lib()
+    rc = lib.cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
+                                     part.data_ptr(), B, V, Q, R, I, G, _stream())
+    if rc == L.E_UNSUPPORTED:                                  # h/rank outside {4, 8, 16} (or beyond the staged kernels' budgets): the generic VALU form
+        wsb = lib.cti_paralind_mbuild_bwd_generic_workspace_bytes(B, V, R, I, G)
+        ws = torch.empty(wsb, device=Vr.device, dtype=torch.uint8)
+        rc = lib.cti_paralind_mbuild_bwd_generic(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
+                                                 part.data_ptr(), B, V, Q, R, I, G, ws.data_ptr(), wsb, _stream())
+    L.check(rc, "cti_paralind_mbuild_bwd")
     dT = sum_batches(part, B, Teff.numel()).view(Teff.shape)
     return dVr, dQr, dT
 

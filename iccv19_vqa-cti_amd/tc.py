@@ -72,7 +72,9 @@ class TCNet(nn.Module):
 
     def _rank_proj(self, x, nets):
         if self._act not in ('ReLU', ''):
-            raise NotImplementedError("packed rank nets support act in {'ReLU', ''}")
+            # any other nn activation (the reference builds it by name, src/fc.py:24): the R rank nets run one by one through FCNet (GEMM on
+            # the HIP library, the activation as its own module on the GEMM output) -- the packed single-GEMM forms below fuse only ReLU / none
+            return torch.cat([n(x) for n in nets], dim=-1)
         relu = self._act == 'ReLU'
         wv, g, b = self._rank_pack(nets)
         if self.training and self._drop_p(nets[0]) > 0:

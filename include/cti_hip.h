@@ -391,6 +391,12 @@ int cti_gru_backward(const float* dout, const float* w_hh, const float* save, fl
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec);
 
+/* M-build backward for any cubic core size h/rank (plain fp32 VALU kernels through the forward's intermediates; cti_paralind_mbuild_bwd is the
+ * fast form for h/rank in {4, 8, 16} and returns CTI_E_UNSUPPORTED otherwise).  Same outputs: dVr, dQr, per-sample dT_eff partials (B, R,hr,hr,hr,G). */
+int cti_paralind_mbuild_bwd_generic(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr, float* dTeff_partial,
+                                    int B, int V, int Q, int R, int hr, int G, void* workspace, size_t workspace_bytes, void* stream);
+size_t cti_paralind_mbuild_bwd_generic_workspace_bytes(int B, int V, int R, int hr, int G);
+
 /* hipGraph-safe forms (a captured training step replays with the same kernel arguments): whatever changes from step to step lives in DEVICE
  * memory.  cti_dropout_g = cti_dropout whose Philox key is advanced by rng_dev[0] (NULL = cti_dropout); cti_adamax_step_g = cti_adamax_step with
  * the learning rate and the number of COMPLETED steps read from device memory (bias correction 1 - beta1^(steps_done + 1));

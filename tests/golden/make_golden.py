@@ -178,6 +178,28 @@ def tc_case(name, v_dim, q_dim, a_dim, h, R, G, k, B, V, Q, A, seed, zr):
          grads=grads)
 
 
+def tc_act_case(name, act, seed):
+    """TCNet with an activation other than ReLU (reference src/fc.py:24 takes any nn activation by name): forward + gradients."""
+    v_dim, q_dim, a_dim, h, R, G, B, V, Q, A = 24, 20, 12, 32, 4, 2, 2, 4, 3, 3
+    torch.manual_seed(seed)
+    m = TCNet(v_dim, q_dim, a_dim, h, 1, R, G, act=act).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    v = torch.randn(B, V, v_dim, generator=g).abs()
+    q = torch.tanh(torch.randn(B, Q, q_dim, generator=g))
+    a = torch.tanh(torch.randn(B, A, a_dim, generator=g))
+    v1, q1, a1 = (t.clone().requires_grad_(True) for t in (v, q, a))
+    raw = m(v1, q1, a1)
+    cot = torch.randn(raw.shape, generator=g)
+    (raw * cot).sum().backward()
+    grads = {"v": v1.grad, "q": q1.grad, "a": a1.grad}
+    for n_, p_ in m.named_parameters():
+        if p_.grad is not None:
+            grads["p/" + n_] = p_.grad.clone()
+    cfg = dict(v_dim=v_dim, q_dim=q_dim, a_dim=a_dim, h_dim=h, h_out=1, rank=R, glimpse=G, k=1, act=act, B=B, V=V, Q=Q, A=A,
+               ref="src/tc.py:10-52 with act=%r (src/fc.py:24)" % act)
+    save(name, cfg, params=sd(m), inputs={"v": v, "q": q, "a": a, "cot_raw": cot}, outputs={"raw": raw.detach().contiguous()}, grads=grads)
+
+
 def tc_att_grad_case(name, seed):
     """Gradient THROUGH the masked softmax (TriAttention p), no zero-only samples."""
     v_dim, q_dim, a_dim, h, R, G, k, B, V, Q, A = 24, 20, 12, 32, 4, 2, 1, 2, 4, 3, 2
@@ -395,8 +417,9 @@ def state_keys_real():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:                                  # regenerate selected fixtures only: make_golden.py tc_c2 ...
-        for fn in sys.argv[1:]:
-            globals()[fn]()
+        for fn in sys.argv[1:]:                            # "tc_c2" or "tc_act_case:g3_tcnet_act_tanh:Tanh:25" (':'-separated arguments, ints parsed)
+            name, *fargs = fn.split(":")
+            globals()[name](*[int(x) if x.lstrip("-").isdigit() else x for x in fargs])
         sys.exit(0)
     g1()
     g2()
@@ -407,6 +430,7 @@ if __name__ == "__main__":
     tc_att_grad_case("g8_triattention_grad", seed=24)
     tc_fww_case("g5_tcnet_fww_k2", 64, 48, 32, 64, 4, 2, 2, 3, 5, 4, 3, seed=31)
     tc_fww_case("g5_tcnet_fww_k1", 40, 24, 20, 48, 3, 2, 1, 2, 6, 3, 2, seed=32)
+    tc_act_case("g3_tcnet_act_tanh", "Tanh", seed=25)
     tc_c1()
     tc_c2()
     bc_case("g6_bcnet_hnone_k1", 64, 48, 32, None, 1, 3, 5, 4, seed=41)

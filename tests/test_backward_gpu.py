@@ -344,3 +344,20 @@ def test_mask_only_dropout_draws_the_same_stream(n):
     m2 = ops.dropout_mask((n,), 0.3, x.device)
     assert torch.equal(m1, m2)
     assert abs(float(m2.float().mean()) - 0.7) < (0.2 if n < 100 else 0.03)
+
+
+def test_tcnet_with_another_activation_forward_and_backward():
+    """The reference builds every FCNet activation by name (src/fc.py:24: getattr(nn, act)); TCNet(act='Tanh') takes the per-rank-net route
+    (no packed single-GEMM form) and must still match the reference's output and gradients (fixture g3_tcnet_act_tanh)."""
+    fx = gu.load("g3_tcnet_act_tanh")
+    c = fx.cfg
+    m = load_into(cti_amd.TCNet(c["v_dim"], c["q_dim"], c["a_dim"], c["h_dim"], 1, c["rank"], c["glimpse"], act=c["act"]), fx.p)
+    v, q, a = T(fx.i["v"], True), T(fx.i["q"], True), T(fx.i["a"], True)
+    with torch.no_grad():
+        check(m(v.detach(), q.detach(), a.detach()), fx.o["raw"], what="TCNet(act=Tanh) eval forward")
+    raw = m(v, q, a)
+    check(raw, fx.o["raw"], what="TCNet(act=Tanh) forward under autograd")
+    (raw * T(fx.i["cot_raw"])).sum().backward()
+    for n_, t_ in (("v", v), ("q", q), ("a", a)):
+        check(t_.grad, fx.g[n_], what="TCNet(act=Tanh) d%s" % n_)
+    check_param_grads(m, fx)

@@ -167,3 +167,24 @@ def test_bilinear_logits_and_bi_pool_backward_at_tile_limits(B, G, V, Q, D):
     check(dvt, (dout.double()[:, None, :] * torch.einsum("bvq,bqd->bvd", w.double(), qt.double())).numpy(), "bi pool dvt", 2e-5)
     check(dqt, (dout.double()[:, None, :] * torch.einsum("bvq,bvd->bqd", w.double(), vt.double())).numpy(), "bi pool dqt", 2e-5)
     check(dw, torch.einsum("bd,bvd,bqd->bvq", dout.double(), vt.double(), qt.double()).numpy(), "bi pool dw", 2e-5)
+
+
+@pytest.mark.parametrize("hr,R,G", [(3, 5, 2), (12, 2, 3), (32, 2, 1)])
+def test_mbuild_backward_for_any_core_size(hr, R, G):
+    """h/rank outside {4, 8, 16} (the reference takes any --rank / --h_mm, src/FFOE/main.py:61-64): the generic VALU backward against float64
+    autograd of the closed form M[b,v,q,g,r,k] = sum_ij T[r,i,j,k,g] Vr[b,v,r,i] Qr[b,q,r,j]."""
+    ops = cti_amd.ops
+    g = torch.Generator().manual_seed(hr * 100 + R)
+    B, V, Q = 3, 5, 4
+    Vr = torch.randn(B, V, R * hr, generator=g); Qr = torch.randn(B, Q, R * hr, generator=g)
+    T_ = torch.randn(R, hr, hr, hr, G, generator=g); dM = torch.randn(B, V, Q, G, R * hr, generator=g)
+    dVr, dQr, dT = ops.paralind_mbuild_bwd(dM.to(DEV), Vr.to(DEV), Qr.to(DEV), T_.to(DEV))
+    v64, q64, t64 = (x.double().requires_grad_(True) for x in (Vr, Qr, T_))
+    M = torch.einsum("rijkg,bvri,bqrj->bvqgrk", t64, v64.view(B, V, R, hr), q64.view(B, Q, R, hr)).reshape(B, V, Q, G, R * hr)
+    (M * dM.double()).sum().backward()
+    for got, ref, n_ in ((dVr, v64.grad, "dVr"), (dQr, q64.grad, "dQr"), (dT, t64.grad, "dT")):
+        e = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e < 1e-5, (n_, e)
+    # and the forward of the same shapes (generic kernel) for completeness
+    Mf = ops.paralind_mbuild(Vr.to(DEV), Qr.to(DEV), T_.to(DEV))
+    assert float((Mf.cpu().double() - M.detach()).abs().max() / M.abs().max()) < 1e-5
