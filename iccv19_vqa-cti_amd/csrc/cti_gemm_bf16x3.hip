@@ -141,14 +141,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // Tile geometry: WM x WN consumer waves, each TM x TN MFMA tiles of 32 x 32; LW loader waves; NST ring slots (16-deep
 // K slices), SPB slots consumed per barrier.
-template <int WM_, int WN_, int TM_, int TN_, int LW_, int NST_, int SPB_>
+template <int WM_, int WN_, int TM_, int TN_, int LW_, int NST_, int SPB_, int PL_ = 2>
 struct Geo {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, LW = LW_, NST = NST_, SPB = SPB_;
+    static constexpr int PL = PL_;                                     // planes per operand held in a slot: 2 (hi + lo) or 1 (plain bf16: hi only)
     static_assert(NST_ % SPB_ == 0 && NST_ > SPB_, "ring = whole groups of SPB slots, at least one group in flight");
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NCONS = WM * WN * 64, NTHR = NCONS + LW * 64;
     static constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
-    static constexpr int STAGE = 2 * (A_PLANE + B_PLANE);              // [A_hi | A_lo | B_hi | B_lo]
+    static constexpr int STAGE = PL * (A_PLANE + B_PLANE);             // [A_hi | A_lo | B_hi | B_lo]  (PL = 1: [A_hi | B_hi])
     static constexpr int LDS = NST * STAGE;
 };
 
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     constexpr int NG = NST / SPB;                                       // ring length in barrier groups
     constexpr int NW = LW > 0 ? LW : WM * WN;                           // waves that issue the DMA
     constexpr int NPLANE = TERMS == 3 ? 2 : 1;
+    static_assert(G::PL >= NPLANE, "a hi-only slot cannot feed the 3-term products");
     constexpr int PAT = NPLANE * BM / 32, PBT = NPLANE * BN / 32;       // pieces per slot of the A / B operand (hi [+ lo])
     constexpr bool EXACT = (PAT % NW == 0) && (PBT % NW == 0);          // every issuing wave issues the same count
     constexpr int PA = (PAT + NW - 1) / NW, PB = (PBT + NW - 1) / NW;
@@ -243,12 +245,12 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             if (EXACT) {
                 if (AF32) dma_pieces_f32<PA>(Af, ldaf, (int)kc * 16, Kreal, rows_valid, s, iw, NW, lane);   // pieces of 16 rows x 64 B
                 else      dma_pieces<BM, PA, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw, NW, lane);
-                dma_pieces<BN, PB, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + 2 * A_PLANE, iw, NW, lane);
+                dma_pieces<BN, PB, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + G::PL * A_PLANE, iw, NW, lane);
             } else {                                                     // uneven split (plain-bf16 mode only): waves beyond the piece count idle
 #pragma unroll
                 for (int u = 0; u < PA; ++u) if (iw + u * NW < PAT) dma_pieces<BM, 1, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw + u * NW, NW, lane);
 #pragma unroll
-                for (int u = 0; u < PB; ++u) if (iw + u * NW < PBT) dma_pieces<BN, 1, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + 2 * A_PLANE, iw + u * NW, NW, lane);
+                for (int u = 0; u < PB; ++u) if (iw + u * NW < PBT) dma_pieces<BN, 1, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + G::PL * A_PLANE, iw + u * NW, NW, lane);
             }
         }
     };
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     auto load_frags = [&](const char* s) {
         const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
         const char* sAl = s + A_PLANE + (wm * TM * 32) * ROW_BYTES;
-        const char* sBh = s + 2 * A_PLANE + (wn * TN * 32) * ROW_BYTES;
-        const char* sBl = s + 2 * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
+        const char* sBh = s + G::PL * A_PLANE + (wn * TN * 32) * ROW_BYTES;
+        const char* sBl = s + G::PL * A_PLANE + B_PLANE + (wn * TN * 32) * ROW_BYTES;
         if (AF32) {
             // the slot's A region holds fp32 [row][16]: read this lane's 8 floats (two swizzled 16-B chunks) and split them
             // here -- ~24 VALU per fragment pair, issued in the slots the MFMAs leave free
@@ -565,6 +567,16 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 #define CTI_BIG_SPB 1
 #endif
 using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
+// plain-bf16 products (one MFMA per product): slots hold the hi planes only (16 KiB per 16-deep slice of the 256 x 256 tile).  Measured at the
+// configs[1] mode-3 shape (tools/tune_gemm.py run 5 2): 4 slots / 1 per barrier 1.52 ms, 6 / 2 1.54 ms, deeper rings slower -- the kernel is
+// not ring-latency-bound; its DMA (0.5 ms), MFMA (0.7 ms) and store (0.4 ms) phases add up instead of overlapping, as in the 3-term form.
+#ifndef CTI_BIG1_NST
+#define CTI_BIG1_NST 4
+#endif
+#ifndef CTI_BIG1_SPB
+#define CTI_BIG1_SPB 1
+#endif
+using GeoBig1 = Geo<4, 2, 2, 4, CTI_LW, CTI_BIG1_NST, CTI_BIG1_SPB, 1>;
 using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;
 using GeoSmall = Geo<2, 2, 2, 2, (CTI_LW > 2 ? 2 : CTI_LW), 6, 2>;
 
@@ -609,7 +621,7 @@ int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_
         }
     }
     switch (cfg) {
-        case 2: return launch_cfg<TERMS, EPI, GeoBig>(p, nb, ncols, st);
+        case 2: if constexpr (TERMS == 1) return launch_cfg<TERMS, EPI, GeoBig1>(p, nb, ncols, st); else return launch_cfg<TERMS, EPI, GeoBig>(p, nb, ncols, st);
         case 1: return launch_cfg<TERMS, EPI, GeoMid>(p, nb, ncols, st);
         default: return launch_cfg<TERMS, EPI, GeoSmall>(p, nb, ncols, st);
     }

@@ -113,4 +113,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
     else:
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
