@@ -1,29 +1,33 @@
 #!/bin/bash
 # Round evidence on the GPU box: tests, bench lines, rocprofv3 kernel stats and the separate PMC passes of the same bench command.
-# Usage (through gpurun): bash tools/collect_evidence.sh   -> everything under gpurun_out/evidence/
+# Usage (through gpurun): bash tools/collect_evidence.sh [all|quick]  -> everything under gpurun_out/evidence/
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; rm -rf $E; mkdir -p $E
-if [ "${1:-all}" != "pmc" ]; then
 python -m pytest tests -m gpu -q > $E/pytest_gpu.log 2>&1; tail -2 $E/pytest_gpu.log
-python bench.py > $E/bench_bf16x3.log 2>&1; tail -1 $E/bench_bf16x3.log | cut -c1-200
+python bench.py > $E/bench_f16f6.log 2>&1; tail -1 $E/bench_f16f6.log | cut -c1-200
+python bench.py --precision bf16x3 --no-cpu-baseline > $E/bench_bf16x3.log 2>&1
 python bench.py --precision fp32 --no-cpu-baseline > $E/bench_fp32.log 2>&1
-python bench.py --precision bf16 --no-cpu-baseline > $E/bench_bf16.log 2>&1
+python bench.py --precision bf16 --no-cpu-baseline --no-fp32-exact > $E/bench_bf16.log 2>&1
 python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.log | cut -c1-200
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/rocprof_stats.log 2>&1
-fi
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+python bench.py --config c3 > $E/bench_c3.log 2>&1; python bench.py --config c4 > $E/bench_c4.log 2>&1
+CTI_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-fp32-exact --steps 10 > $E/bench_rccl_world1.log 2>&1; tail -1 $E/bench_rccl_world1.log | cut -c1-120
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-exact > $E/rocprof_stats.log 2>&1
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-exact"
 # one small counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md counter budget); a group the
 # hardware cannot collect makes rocprofv3 abort and then hang, so every pass is bounded by `timeout`
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/pmc$i -o p -- $B > $E/pmc$i.log 2>&1 || echo "pmc pass $i ($grp) failed/timeout"
 done
+if [ "${1:-all}" != "quick" ]; then
 timeout 300 python tools/bench_model.py --steps 50 > $E/model_fwd.jsonl 2>$E/model_fwd.err
 timeout 300 python tools/bench_model.py --train --steps 50 > $E/model_train.jsonl 2>$E/model_train.err
 timeout 300 python tools/bench_model.py --precision bf16 --steps 50 > $E/model_fwd_bf16.jsonl 2>/dev/null
-timeout 300 python tools/bench_model.py --precision bf16 --train --steps 50 > $E/model_train_bf16.jsonl 2>/dev/null
+timeout 300 python tools/graph_train.py ffoe_cti 30 > $E/graph_train.jsonl 2>/dev/null; timeout 300 python tools/graph_train.py ffoe_ban 30 >> $E/graph_train.jsonl 2>/dev/null
 timeout 300 python tools/bench_pools.py 30 2>/dev/null | grep kernel > $E/hbm_kernels.jsonl
-cat $E/model_fwd.jsonl $E/model_train.jsonl | cut -c1-120
+timeout 300 python tools/bench_f16f6.py 256 20 > $E/mode3_f16f6_vs_bf16x3.json 2>/dev/null
+timeout 120 ./tools/mb/mb_f16f6 > $E/mb_f16f6.txt 2>&1
+fi
 find $E -name "*.csv" | head -20; du -sh $E

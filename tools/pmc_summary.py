@@ -16,7 +16,7 @@ from collections import defaultdict
 
 def short(n):
     n = re.sub(r"^void ", "", n).replace("cti::(anonymous namespace)::", "").replace("cti::", "")
-    n = re.sub(r"Geo<([^>]*)>", lambda m: "G<" + m.group(1).replace(" ", "") + ">", n)
+    n = re.sub(r"GeoF?<([^>]*)>", lambda m: "G<" + m.group(1).replace(" ", "") + ">", n)
     return re.sub(r"\(.*", "", n)
 
 
@@ -35,7 +35,7 @@ def main():
             dur[short(row["Name"])] = float(row["AverageNs"]) / 1e3
     res = {}
     for k, cs in acc.items():
-        if not k.startswith(("gemm_planes", "mbuild", "split_kernel")):
+        if not k.startswith(("gemm_planes", "gemm_f16f6", "mbuild", "split_kernel", "quantize_f16f6")):
             continue
         e = {c: v[0] / v[1] for c, v in cs.items()}
         e["calls_seen"] = max(v[1] for v in cs.values())
