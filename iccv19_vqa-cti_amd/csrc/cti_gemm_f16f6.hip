@@ -122,6 +122,12 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     int z = 0, m0 = 0, n0 = 0;
     int64_t rowA = 0, rowB = 0;
     F6Piece pa[HA_R], pb[HB_R + 1], pl[LIN_R];
+#ifndef CTI_F6_PREFETCH
+#define CTI_F6_PREFETCH 0        // > 0: every wave touches (one dword per 128-B line, 64 lines) part of the K block issued PREFETCH blocks later.
+#endif                           // MEASURED AND REJECTED (2.0 -> 2.3 ms at distances 2, 3, 5): the extra requests cost more than the earlier misses save
+    constexpr int NPF = CTI_F6_PREFETCH > 0 ? 1 : 0;               // prefetch loads per wave and slot (they count in vmcnt like the DMA pieces)
+    const char* pf_src = nullptr; int64_t pf_kstride = 0;
+    int pf_sink = 0;                                                // destination register of every prefetch load: stays reserved to the end
     auto setup_tile = [&](int vt) {
         int tm, tn;
         tile_coords(vt, p.total_tiles, tiles_m, tiles_n, z, tm, tn);
@@ -150,6 +156,21 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
             else                                    { g -= G::PBF; base = p.BS + rowB * 2; ks = p.pBS * 2; lds = G::OFF_BS; }
             pl[u].src = base + g * 1024; pl[u].kstride = ks; pl[u].lds = lds + g * 1024;
         }
+        if (NPF) {
+            // L2 prefetch experiment (off).  The ring holds two K blocks in flight (104 KiB); the idea was that a touch of the lines a LATER
+            // block will DMA moves their miss out of the DMA -- more bytes in flight without LDS to land them in.  It made the kernel slower.  wave: 0,1 B_H halves (96 lines), 2 B_FH, 3 B_FL, 4,5 A_H halves, 6 A_FH, 7 A_FL
+            const int64_t lo = (int64_t)lane * 128;
+            switch (wid) {
+                case 0: pf_src = p.BH + rowB * 64 + lo; pf_kstride = p.pB * 64; break;
+                case 1: pf_src = p.BH + rowB * 64 + (lane < 32 ? 8192 + lo : lo); pf_kstride = p.pB * 64; break;
+                case 2: pf_src = p.BFH + rowB * 24 + (lane < 36 ? lo : 0); pf_kstride = p.pB * 24; break;
+                case 3: pf_src = p.BFL + rowB * 24 + (lane < 36 ? lo : 0); pf_kstride = p.pB * 24; break;
+                case 4: pf_src = p.AH + rowA * 64 + lo; pf_kstride = p.pA * 64; break;
+                case 5: pf_src = p.AH + rowA * 64 + 8192 + lo; pf_kstride = p.pA * 64; break;
+                case 6: pf_src = p.AFH + rowA * 24 + (lane < 48 ? lo : 0); pf_kstride = p.pA * 24; break;
+                default: pf_src = p.AFL + rowA * 24 + (lane < 48 ? lo : 0); pf_kstride = p.pA * 24; break;
+            }
+        }
     };
     auto issue_slot = [&](int pos, int64_t kb) {
         char* slot = smem + pos * SLOT;
@@ -160,6 +181,11 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
         if (HB_REM && extra) dma16(pb[HB_R].src + kb * pb[HB_R].kstride + hoff, slot + pb[HB_R].lds);
 #pragma unroll
         for (int u = 0; u < LIN_R; ++u) dma16(pl[u].src + kb * pl[u].kstride + loff, slot + pl[u].lds);
+        if (NPF) {                                                  // exactly one load per slot, whatever kb (the counted waits rely on it)
+            const int64_t kp = kb + CTI_F6_PREFETCH < p.Kb ? kb + CTI_F6_PREFETCH : p.Kb - 1;
+            const char* a = pf_src + kp * pf_kstride;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(a) : "memory");
+        }
     };
     const int nkb = p.Kb;
     auto prologue = [&]() {
@@ -218,8 +244,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #if CTI_F6_ABL & 32
         if (b < NST - 1 && vtile != (int)blockIdx.x) { __builtin_amdgcn_s_barrier(); return; }     // ablation (UNSAFE): no vmcnt wait on the hoisted blocks
 #endif
-        if (rem >= NST - 2) { if (extra) wait_vm<(NST - 2) * (CNT_LO + 1)>(); else wait_vm<(NST - 2) * CNT_LO>(); }
-        else if (NST >= 4 && rem == 1) { if (extra) wait_vm<CNT_LO + 1>(); else wait_vm<CNT_LO>(); }
+        if (rem >= NST - 2) { if (extra) wait_vm<(NST - 2) * (CNT_LO + 1 + NPF)>(); else wait_vm<(NST - 2) * (CNT_LO + NPF)>(); }
+        else if (NST >= 4 && rem == 1) { if (extra) wait_vm<CNT_LO + 1 + NPF>(); else wait_vm<CNT_LO + NPF>(); }
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
     };
@@ -391,6 +417,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     }
     vtile = next;
     }                                             // persistent tile loop
+    if (NPF) asm volatile("s_waitcnt vmcnt(0)\n; prefetch sink %0" ::"v"(pf_sink) : "memory");
 }
 
 using GeoF6 = GeoF<4, 2, 2, 3, 3>;                // 256 x 192, 3 slots of 52 KiB
