@@ -15,7 +15,15 @@ int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, 
 }
 using namespace cti;
 
+#ifndef CTI_AF32
+#define CTI_AF32 1       // fp32 A operand of the Tucker GEMMs split at fragment-read time instead of a split pass: -2.6 % on the whole step once the
+#endif                   // LDS reads of that path stopped draining vmcnt(0) (plain vector type instead of HIP's float4 struct); 0 = the split pass
+
 namespace {
+
+// the Tucker GEMM of side s reads its fp32 input directly (no input planes in the workspace): decided by sizes only, so that
+// cti_tcnet_forward_workspace_bytes and the call agree; the call then REQUIRES a 16-B aligned input pointer
+inline bool af32_side(int prec, int in_dim) { return CTI_AF32 && (prec == CTI_PREC_BF16X3 || prec == CTI_PREC_F16F6) && in_dim % 4 == 0; }
 
 struct Bump {
     char* base; size_t off, cap;
@@ -89,7 +97,8 @@ Plan carve(const Dims& d, int prec, void* ws) {
     } else {
         const bool f6 = prec == CTI_PREC_F16F6;
         for (int s = 0; s < 3; ++s) {
-            p.xin[s] = take_planes(w, rows[s], in[s]);
+            if (!af32_side(prec, in[s])) p.xin[s] = take_planes(w, rows[s], in[s]);
+            else { p.xin[s] = Planes{}; p.xin[s].Kp = planes_kp(in[s]); p.xin[s].rows_alloc = rows[s] + PLANE_SLACK_ROWS; }
             p.tp[s] = take_planes(w, rows[s], d.h);
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
@@ -245,14 +254,10 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         if (ev_join) (void)hipEventDestroy(ev_join);
         return code;
     };
-#ifndef CTI_AF32
-#define CTI_AF32 1       // fp32 A operand of the Tucker GEMMs split at fragment-read time instead of a split pass: -2.6 % on the whole step once the
-#endif                   // LDS reads of that path stopped draining vmcnt(0) (plain vector type instead of HIP's float4 struct); 0 = the split pass
-#if 0
-#endif
     const int Kh = planes_kp(h);
     auto side = [&](int s, hipStream_t ss) -> int {
-        const bool af32 = CTI_AF32 && (prec == CTI_PREC_BF16X3 || f6) && (in[s] % 4 == 0) && ((reinterpret_cast<uintptr_t>(x[s]) & 15) == 0);
+        const bool af32 = af32_side(prec, in[s]);
+        if (af32 && (reinterpret_cast<uintptr_t>(x[s]) & 15)) return fail(CTI_E_ALIGN, "cti_tcnet_forward: input %d must be 16-B aligned (its rows are DMA'd as fp32)", s);
         int r_;
         if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
         if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
