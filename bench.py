@@ -467,7 +467,7 @@ def core_variant(precision):
     return {"bf16x3": "gemm_planes_kernel<terms=3, epi=INTERLEAVE2, tile 256x256, 4-slot ring>",
             "bf16": "gemm_planes_kernel<terms=1, epi=INTERLEAVE2, tile 256x256, 4-slot ring>",
             "fp32": "gemm_nt_f32_kernel<128x128x32>",
-            "f16f6": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x256>"}[precision]
+            "f16f6": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x192>"}[precision]
 
 
 def main():
