@@ -215,18 +215,21 @@ def test_ffoe_cti_train_step_matches_reference():
     got_n = np.array([float(named[n].grad.norm()) for n in c["used"]])
     got_p = np.array([float((named[n].grad.double().cpu() * torch.from_numpy(proj[n]).double()).sum()) for n in c["used"]])
     ref_n, ref_p = fx.o["gnorm"], fx.o["gproj"]
-    assert np.max(np.abs(got_n - ref_n) / (ref_n + 1e-3 * ref_n.max())) < 2e-3, "per-parameter gradient norms"
-    assert np.max(np.abs(got_p - ref_p)) / np.max(np.abs(ref_p)) < 2e-3, "per-parameter gradient projections"
+    e_n = np.max(np.abs(got_n - ref_n) / (ref_n + 1e-3 * ref_n.max()))
+    e_p = np.max(np.abs(got_p - ref_p)) / np.max(np.abs(ref_p))
+    print("g10 train step: worst per-parameter gradient-norm deviation %.3g, projection deviation %.3g" % (e_n, e_p))
+    assert e_n < 1e-4, "per-parameter gradient norms"                       # the north-star tolerance (measured: 1e-6 in fp32, 1.8e-5 in bf16x3)
+    assert e_p < 1e-4, "per-parameter gradient projections"
     unused = [n for n, prm in m.named_parameters() if prm.requires_grad and n not in c["used"]]
     for n in unused:                                                         # rank nets / T_g of the t_nets never see a gradient
         assert named[n].grad is None, n
     opt.step()
     for n in unused:                                                         # ... and their slots of the flat buffer are zeroed by the gather
         assert float(named[n].grad.abs().max()) == 0.0, n
-    assert abs(float(opt.grad_norm) - float(fx.o["grad_norm"])) < 1e-3 * float(fx.o["grad_norm"])
+    assert abs(float(opt.grad_norm) - float(fx.o["grad_norm"])) < 1e-4 * float(fx.o["grad_norm"])
     with torch.no_grad():
         loss2 = cti_amd.BCEWithLogitsSum()(m(v, q, a), tgt) / c["B"]
-    assert abs(float(loss2) - float(fx.o["loss_after"])) < 2e-3 * float(fx.o["loss_after"])
+    assert abs(float(loss2) - float(fx.o["loss_after"])) < 2e-4 * float(fx.o["loss_after"])
 
 
 def test_model_train_mode_runs_dropout_and_backward():
@@ -305,3 +308,34 @@ def test_gru_against_torch_gru_on_cpu(B, Tn, I, H):
     check(xg.grad, xr.grad.numpy(), TOL, "d x")
     for (n, pg), (_, pr) in zip(g.rnn.named_parameters(), ref.named_parameters()):
         check(pg.grad, pr.grad.numpy(), TOL, "d " + n)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16", 2e-2), ("f16f6", 1e-4)])
+def test_full_models_in_the_other_arithmetic_modes(mode, tol, precision):
+    """BASELINE configs[2] / [3] name bf16: the three full models (FFOE CTI, FFOE BAN gamma 8, MC CTI) in precision='bf16' (one bf16 MFMA per
+    product) against the reference's own outputs (g9 fixtures) within that mode's tolerance, attention arg-max exact; and in 'f16f6' (the bench's
+    headline mode) within the fp32 tolerance."""
+    if precision != "bf16x3":
+        pytest.skip("mode set explicitly below; run once")
+    cti_amd.set_precision(mode)
+    fx, p, m = build("g9_ffoe_cti", "build_cti")
+    with torch.no_grad():
+        out = m(T(fx.i["v"]), T(fx.i["q"]), T(fx.i["ans"]))
+    check(out, fx.o["logits"], tol, "FFOE CTI logits [%s]" % mode)
+    fx, p, m = build("g9_ffoe_ban", "build_ban")
+    with torch.no_grad():
+        out, att = m(T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), None)
+    check(out, fx.o["logits"], tol, "FFOE BAN logits [%s]" % mode)
+    check(att, fx.o["att"], tol, "FFOE BAN att [%s]" % mode)
+    a, r = att.cpu().numpy(), fx.o["att"]
+    assert np.array_equal(a.reshape(a.shape[0], a.shape[1], -1).argmax(2), r.reshape(r.shape[0], r.shape[1], -1).argmax(2))
+    assert np.array_equal(a == 0, r == 0)                                   # masked positions exactly zero
+    fx, p, m = build("g9_mc_cti", "build_mc_cti")
+    with torch.no_grad():
+        out, att = m(T(fx.i["v"]), T(fx.i["b"]), T(fx.i["q"]), T(fx.i["ans"]))
+    check(out, fx.o["logits"], tol, "MC CTI logits [%s]" % mode)
+    check(att, fx.o["att"], tol, "MC CTI att [%s]" % mode)
+    a, r = att.cpu().numpy(), fx.o["att"]
+    B_, G_ = a.shape[0], a.shape[-1]
+    assert np.array_equal(a.reshape(B_, -1, G_).argmax(1), r.reshape(B_, -1, G_).argmax(1))
+    assert np.array_equal(a == 0, r == 0)
