@@ -86,6 +86,113 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
     }
 }
 
+// ---- fused forward step (bf16 modes): gh = h_{t-1} W_hh^T and the gates in ONE kernel, no split-K partials -------------------------------
+// Tile: 64 batch rows x 16 hidden units x the 3 gates, the whole K = H: 4 waves, wave w owns rows 16w..16w+15 and the three 16 x 16 gate tiles
+// of the workgroup's 16 units (v_mfma_f32_16x16x32_bf16), so r, z, n of a unit meet in one lane and the gate arithmetic is the epilogue.
+// Operands: the chunk-major hi/lo planes of h_{t-1} (written by the previous step's epilogue) and of W_hh (split once), staged through a 4-slot
+// LDS ring of 32-deep K steps by LDS-DMA with counted vmcnt (16 pieces of 1 KiB per slot: 4 per wave).  B = 256, H = 1024: 256 workgroups,
+// each streams 448 KiB through LDS -- the floor of a step is that 115 MB of L2 -> LDS traffic (~9 us); the unfused form took a split-K GEMM
+// (~19 us) + a partial-summing gate kernel (~5 us).
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GF_NST = 4, GF_SLOT = 16384;                         // slot: A [plane][chunk][64 rows][32 B] = 8 KiB, B likewise (48 of 64 rows used)
+template <int N> __device__ __forceinline__ void gf_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
+                                                             const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl, int64_t pitchW,
+                                                             int nsteps, const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ b_hh,
+                                                             const float* __restrict__ hprev, float* __restrict__ out, int64_t ld_out,
+                                                             float* __restrict__ h_tm, float* __restrict__ save, unsigned short* __restrict__ ph,
+                                                             unsigned short* __restrict__ pl, int64_t pitchP, int B, int H) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u0 = blockIdx.x * 16, row0 = blockIdx.y * 64;
+    constexpr int NPL = TERMS == 3 ? 2 : 1;
+    // this wave's 4 DMA pieces per slot (2 with one plane): piece q of 16 = (operand, plane, chunk, half); a piece = 32 rows x 32 B of one plane-chunk.
+    // A rows are contiguous in the plane; B rows are the three gates' 16-row groups: half 0 = gates r, z, half 1 = gate n (+ gate r again: unused)
+    const unsigned short* src[4]; int ldso[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = wid * 4 + u, opnd = q >> 3, plane = (q >> 2) & 1, chunk = (q >> 1) & 1, half = q & 1;
+        const int r32 = lane >> 1, c16 = lane & 1;                 // lane -> (row of the piece, 16-B half of the 32-B chunk row)
+        const unsigned short* base; int64_t row;
+        if (opnd == 0) { base = plane ? Hl : Hh; row = row0 + half * 32 + r32; base += (int64_t)chunk * pitchH; }
+        else {
+            const int gate = half == 0 ? (r32 >> 4) : (r32 < 16 ? 2 : 0);
+            base = plane ? Wl : Wh; row = (int64_t)gate * H + u0 + (r32 & 15); base += (int64_t)chunk * pitchW;
+        }
+        src[u] = base + row * 16 + c16 * 8;
+        ldso[u] = opnd * 8192 + plane * 4096 + chunk * 2048 + half * 1024;
+    }
+    const int64_t kstepH = 2 * pitchH, kstepW = 2 * pitchW;       // elements per 32-deep K step
+    auto issue = [&](int pos, int ks) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wid * 4 + u;
+            if (NPL == 1 && ((q >> 2) & 1)) continue;              // plain bf16: the lo planes are not staged
+            const unsigned short* s_ = src[u] + (int64_t)ks * ((q >> 3) ? kstepW : kstepH);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
+                                             (__attribute__((address_space(3))) void*)(gsm + pos * GF_SLOT + ldso[u]), 16, 0, 0);
+        }
+    };
+    constexpr int PER = 4;                                         // DMA instructions per wave and slot (plain bf16: waves 0 and 2 issue 4, waves 1 and 3 -- the lo planes -- none)
+    g_f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < GF_NST - 1; ++i) if (i < nsteps) issue(i, i);
+    // fragment addresses: lane l -> row (l & 15), k = 8 (l >> 4) .. + 7 of the 32-deep step = chunk (l >> 5), 16-B half (l >> 4) & 1
+    const int fa = (lane >> 5) * 2048 + (wid * 16 + (lane & 15)) * 32 + ((lane >> 4) & 1) * 16;
+    const int fb = 8192 + (lane >> 5) * 2048 + (lane & 15) * 32 + ((lane >> 4) & 1) * 16;
+    int pos = 0;
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const int rem = nsteps - 1 - ks;
+        if (rem >= GF_NST - 2) gf_wait<(GF_NST - 2) * PER>(); else if (rem == 1) gf_wait<PER>(); else gf_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        if (ks + GF_NST - 1 < nsteps) issue(pos == 0 ? GF_NST - 1 : pos - 1, ks + GF_NST - 1);
+        const char* s = gsm + pos * GF_SLOT;
+        const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(s + fa);
+        g_bf16x8 al = ah;
+        if (TERMS == 3) al = *reinterpret_cast<const g_bf16x8*>(s + fa + 4096);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int go = g < 2 ? g * 512 : 1024;                 // gates r, z: rows 0-15, 16-31 of half 0; gate n: rows 0-15 of half 1
+            const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(s + fb + go);
+            if (TERMS == 3) {
+                const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(s + fb + go + 4096);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[g], 0, 0, 0);
+            }
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[g], 0, 0, 0);
+        }
+        pos = pos == GF_NST - 1 ? 0 : pos + 1;
+    }
+    // epilogue: C/D map of the 16x16 MFMA: column = lane & 15 (unit), row = 4 (lane >> 4) + reg
+    const int j = u0 + (lane & 15);
+    if (j >= H) return;
+    const float bb0 = b_hh[j], bb1 = b_hh[H + j], bb2 = b_hh[2 * H + j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = row0 + wid * 16 + (lane >> 4) * 4 + e;
+        if (b >= B) continue;
+        const float g0 = acc[0][e] + bb0, g1 = acc[1][e] + bb1, g2 = acc[2][e] + bb2;
+        const float* gib = gi + (int64_t)b * ld_gi;
+        const int64_t idx = (int64_t)b * H + j;
+        const float hp = hprev ? hprev[idx] : 0.f;
+        const float r = sigm(gib[j] + g0), z = sigm(gib[H + j] + g1);
+        const float n = tanhf(gib[2 * H + j] + r * g2);
+        const float h = (1.f - z) * n + z * hp;
+        out[(int64_t)b * ld_out + j] = h;
+        if (h_tm) h_tm[idx] = h;
+        if (save) {
+            float* sv = save + (int64_t)b * 5 * H;
+            sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = g2; sv[4 * H + j] = h;
+        }
+        if (ph) store_planes(ph, pl, pitchP, b, j, h);
+    }
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // zero fill as a kernel (a hipMemsetAsync captured into a hipGraph was not re-executed reliably on replay; see cti_attention.hip)
@@ -193,8 +300,33 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         g.M = B * T; g.N = H3; g.Kp = KpI; g.terms = terms; g.epi = 0; g.C = gi; g.ldc_m = H3; g.ldc_n = 1; g.scale_div = 1; g.bias = b_ih;
         rc = gemm_nt_planes(g, st); if (rc) return rc;
     }
+#ifndef CTI_GRU_FUSED
+#define CTI_GRU_FUSED 1
+#endif
+    const bool fused = CTI_GRU_FUSED && KpH % 32 == 0 && (H + 15) / 16 <= 65535 && (B + 63) / 64 <= 65535;
+    if (fused) {
+        static thread_local int attr_dev = -1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (attr_dev != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            if (e != hipSuccess) return fail((int)e, "cti_gru_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_dev = dev;
+        }
+    }
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prev = cur ^ 1;
+        if (fused && t) {
+            const dim3 grid((H + 15) / 16, (B + 63) / 64);
+#define CTI_GF(TR) hipLaunchKernelGGL(gru_step_fused_kernel<TR>, grid, dim3(256), GF_NST * GF_SLOT, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, \
+                                      gi + (size_t)t * H3, (int64_t)T * H3, b_hh, h_tm + (size_t)(t - 1) * B * H, out + (size_t)t * H, (int64_t)T * H,                     \
+                                      h_tm + (size_t)t * B * H, save ? save + (size_t)t * B * 5 * H : nullptr, hp_[cur], hl_[cur], rh * 16, B, H)
+            if (terms == 3) CTI_GF(3); else CTI_GF(1);
+#undef CTI_GF
+            rc = launch_status("cti_gru_forward/fused step"); if (rc) return rc;
+            continue;
+        }
         if (t) { rc = step_gemm(hp_[prev], hl_[prev], rh, whh, whl, rw, B, H3, KpH, S, terms, part, st); if (rc) return rc; }
         hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(nblk), dim3(256), 0, st, gi + (size_t)t * H3, (int64_t)T * H3, part, t ? S : 0, b_hh,
                            t ? h_tm + (size_t)(t - 1) * B * H : nullptr, out + (size_t)t * H, (int64_t)T * H, h_tm + (size_t)t * B * H,
