@@ -475,8 +475,8 @@ def main():
     ap.add_argument("--mode", default="forward", choices=["forward", "train"], help="forward (the BASELINE metric) or train (DP step)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"], help="c2 = BASELINE configs[1] (the metric); c3 / c4 = full-model forwards of configs[2] / [3]")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50, help="timed steps (the default run takes well under a minute on the GPU + ~20 s of CPU baseline)")
-    ap.add_argument("--warmup", type=int, default=10, help="untimed steps: allocator growth, one-time kernel attributes, clock ramp")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (about 1 s of GPU time at the default workload: long enough for the clocks to settle; + ~20 s of CPU baseline)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps: allocator growth, one-time kernel attributes, clock ramp")
     ap.add_argument("--batch", type=int, default=C2["B"], help="rows per GPU (default 256 = BASELINE configs[1])")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16x3", "bf16", "f16f6"],
                     help="f16f6 (default of the headline line): mode-3 product as f16 hi x hi + one block-scaled fp6 MFMA for both cross terms, every "

@@ -84,8 +84,12 @@ struct GeoF {
     static_assert(LDS <= 160 * 1024, "ring exceeds the CU's LDS");
 };
 
+#ifndef CTI_F6_NT_B
+#define CTI_F6_NT_B 0            // 1: the B operand's pieces (streamed once per XCD) are loaded non-temporally so that they do not displace the A tiles in L2
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 #ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue stores
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #pragma unroll
         for (int u = 0; u < HA_R; ++u) dma16(pa[u].src + kb * pa[u].kstride + hoff, slot + pa[u].lds);
 #pragma unroll
-        for (int u = 0; u < HB_R; ++u) dma16(pb[u].src + kb * pb[u].kstride + hoff, slot + pb[u].lds);
-        if (HB_REM && extra) dma16(pb[HB_R].src + kb * pb[HB_R].kstride + hoff, slot + pb[HB_R].lds);
+        for (int u = 0; u < HB_R; ++u) dma16<CTI_F6_NT_B ? 2 : 0>(pb[u].src + kb * pb[u].kstride + hoff, slot + pb[u].lds);
+        if (HB_REM && extra) dma16<CTI_F6_NT_B ? 2 : 0>(pb[HB_R].src + kb * pb[HB_R].kstride + hoff, slot + pb[HB_R].lds);
 #pragma unroll
         for (int u = 0; u < LIN_R; ++u) dma16(pl[u].src + kb * pl[u].kstride + loff, slot + pl[u].lds);
         if (NPF) {                                                  // exactly one load per slot, whatever kb (the counted waits rely on it)
