@@ -13,16 +13,19 @@
 // 6.7e-6 for bf16x3, tolerance 1e-4).  Measured on MI355X (tools/mb/mb_f16f6.hip, random operands in registers): 1003 algorithmic
 // TFLOP/s against 550 for bf16x3.  Both cross terms of one 32-wide K block ride in ONE v_mfma_scale_f32_32x32x64_f8f6f4:
 // its lanes 0-31 carry (A: fp6 of the hi part, B: fp6 of the lo part), lanes 32-63 carry (A: lo, B: hi), each with its own scale.
+// The fp6 codes of the HI part never touch memory: the GEMM derives them from the f16 fragment it has just read (one
+// v_cvt_scalef32_pk32_fp6_f16 per fragment, the SIMD-half partner's 16 codes fetched with v_permlane32_swap).
 //
 // PLANES of an operand X (rows x K), Kb = ceil(K / 32) blocks, block-major like the bf16 planes (one K block of a GEMM tile is a
 // contiguous run of rows):
 //   H   f16   [Kb][rows_alloc][32]      hi part, saturated to +-65504                        64 B per (row, block)
-//   FH  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of H / 2^eh, element j at bits 6j..6j+5    24 B
-//   FL  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of (x - H) / 2^el                          24 B
-//   S   e8m0  [Kb][rows_allocS][2]      byte 0 = eh + 127, byte 1 = el + 127                  2 B     (3.56 B per element in all)
-// eh / el are the smallest exponents with max|.| / 2^e <= 7.5 (the largest e2m3 value) over the block.  rows_alloc = rows + 256 and
-// rows_allocS = rows + 512 (a GEMM tile may over-read that many rows; their contents only feed discarded outputs, but they must be
-// defined E8M0 scales -- not 0xFF = NaN -- so the allocation is zero-filled once by the producer's caller).
+//   FL  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of (x - H) / 2^el, position p at bits 6p   24 B
+//   S   e8m0  [Kb][rows_allocS][2]      byte 0 = eh + 127, byte 1 = el + 127                  2 B     (2.81 B per element in all)
+// eh / el are the smallest exponents with max|.| / 2^e <= 7.5 (the largest e2m3 value) over the block (eh: of the hi part, which the GEMM
+// needs to derive its codes).  FL holds the block in the ORDER THE GEMM'S LANES MEET IT, position p <-> element k = F6_PI(p): a lane of the
+// f16 MFMA holds k = 8h .. 8h+7 and 16+8h .. 16+8h+7 of a row (h = its SIMD half), so the derived hi codes of lane half 0 come as
+// [0-7, 16-23 | 8-15, 24-31]; the lo codes they multiply must come in the same order.  rows_alloc = rows + 256 and rows_allocS = rows + 512
+// (a GEMM tile may over-read that many rows; their contents only feed discarded outputs).
 //
 // DOMAIN.  f16 carries 5 exponent bits: the hi part is exact-to-11-bits for 6.1e-5 <= |x| <= 65504.  Smaller values degrade
 // gracefully (absolute error <= 2^-29, the lo part picks up what the subnormal hi part drops); larger ones saturate in H and leave
@@ -40,8 +43,9 @@ constexpr int F6_SLACK_ROWS_S = 512;             // S rows a tile may over-read 
 // Rows: a producer maps logical row m of its (flat) matrix to plane row (m / rdiv) * rstride + m % rdiv -- batches of rdiv rows start at
 // multiples of rstride (a multiple of 8), because the GEMM's LDS-DMA reads 16 B per lane from batch_start * 24 B (codes) and
 // batch_start * 2 B (scales): every tile origin must be a multiple of 8 rows.  rdiv = 0: identity (one batch).
+constexpr int f6_pi(int p) { return (p >= 8 && p < 16) ? p + 8 : ((p >= 16 && p < 24) ? p - 8 : p); }   // position -> element (an involution)
 struct F6Planes {
-    _Float16* H; uint8_t* FH; uint8_t* FL; uint8_t* S;
+    _Float16* H; uint8_t* FL; uint8_t* S;
     int64_t rows_alloc, rows_allocS;           // multiples of 8
     int Kb;
     int64_t rdiv, rstride;
@@ -53,7 +57,7 @@ inline size_t f6_planes_bytes(int64_t rows, int K, int64_t rdiv = 0) {
     const size_t kb = (size_t)((K + F6_BLK - 1) / F6_BLK);
     const size_t pr = (size_t)f6_plane_rows(rows, rdiv);
     const size_t ra = (size_t)f6_round8(pr + F6_SLACK_ROWS), rs = (size_t)f6_round8(pr + F6_SLACK_ROWS_S);
-    return kb * (ra * 64 + 2 * ra * 24 + rs * 2) + 4 * 256;
+    return kb * (ra * 64 + ra * 24 + rs * 2) + 3 * 256;
 }
 // carve the four planes out of one block (256-B aligned pieces); base may be NULL (sizes only)
 inline F6Planes f6_carve(void* base, int64_t rows, int K, int64_t rdiv = 0) {
@@ -66,7 +70,6 @@ inline F6Planes f6_carve(void* base, int64_t rows, int K, int64_t rdiv = 0) {
     size_t off = 0;
     auto take = [&](size_t n) { char* r = b ? b + off : nullptr; off = (off + n + 255) & ~(size_t)255; return r; };
     p.H = reinterpret_cast<_Float16*>(take((size_t)p.Kb * p.rows_alloc * 64));
-    p.FH = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_alloc * 24));
     p.FL = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_alloc * 24));
     p.S = reinterpret_cast<uint8_t*>(take((size_t)p.Kb * p.rows_allocS * 2));
     return p;
@@ -96,32 +99,6 @@ __device__ __forceinline__ unsigned f6_code(float y) {
 }
 __device__ __forceinline__ float f6_sat_f16(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
 
-// Encode one (row, block): x[32] fp32 -> h[32] f16, 6 + 6 dwords of fp6 codes, two scale bytes.
-__device__ __forceinline__ void f6_encode_block(const float* x, _Float16* h, unsigned* fh, unsigned* fl, int& sh, int& sl) {
-    float lo[32], hf[32];
-    float mh = 0.f, ml = 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        h[j] = static_cast<_Float16>(f6_sat_f16(x[j]));
-        hf[j] = static_cast<float>(h[j]);
-        lo[j] = x[j] - hf[j];
-        mh = fmaxf(mh, fabsf(hf[j]));
-        ml = fmaxf(ml, fabsf(lo[j]));
-    }
-    if (!(ml < 3.0e38f)) ml = 0.f;                        // inf / NaN residual (saturated or NaN input): the hi part carries it
-    if (!(mh < 3.0e38f)) mh = 65504.f;
-    sh = f6_scale_byte(mh); sl = f6_scale_byte(ml);
-    const float ih = f6_inv_scale(sh), il = f6_inv_scale(sl);
-#pragma unroll
-    for (int w = 0; w < 6; ++w) { fh[w] = 0u; fl[w] = 0u; }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned long long ch = f6_code(hf[j] * ih), cl = f6_code(lo[j] * il);
-        const int bit = 6 * j, w = bit >> 5, s = bit & 31;
-        fh[w] |= (unsigned)(ch << s); fl[w] |= (unsigned)(cl << s);
-        if (s > 26) { fh[w + 1] |= (unsigned)(ch >> (32 - s)); fl[w + 1] |= (unsigned)(cl >> (32 - s)); }
-    }
-}
 #endif
 
 // GEMM on f16f6 planes: C[z][m, n] = epilogue(sum_k A[z][m,k] B[z][n,k]); batches z < nb use rows [z*rA, +M) of A and [z*rB, +N) of B.
@@ -131,30 +108,15 @@ struct F6GemmArgs {
     int nb, M, N;                              // K = 32 * A.Kb = 32 * B.Kb
     int epi;                                   // 0: fp32 C[z*sC + m*ldc_m + n*ldc_n] = act(scale[n / scale_div] * acc + bias[n])
                                                // 3: rows interleaved by gdiv (the mode-3 product: row m' = m*gdiv + g -> C[(m'/gdiv)*ldc_m + m'%gdiv + n*ldc_n])
-                                               // 4: f16f6 planes out (P), columns N..Np-1 zero
     float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
     const float* scale; int scale_div; const float* bias; int relu;
-    F6Planes P; int Np;                        // epi 4 (nb = 1): output planes (logical row m -> f6_prow(P, m)), padded column count (multiple of 32)
 };
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);
 int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st);
-// store one encoded (row, block) item
 #if defined(__HIPCC__)
-__device__ __forceinline__ void f6_store_block(const F6Planes& p, int64_t prow, int kb, const _Float16* h, const unsigned* fh, const unsigned* fl, int sh, int sl) {
-    const int64_t o = (int64_t)kb * p.rows_alloc + prow;
-    uint4* hd = reinterpret_cast<uint4*>(p.H + o * 32);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) hd[j] = *reinterpret_cast<const uint4*>(h + 8 * j);
-    uint2* fd = reinterpret_cast<uint2*>(p.FH + o * 24);
-    fd[0] = make_uint2(fh[0], fh[1]); fd[1] = make_uint2(fh[2], fh[3]); fd[2] = make_uint2(fh[4], fh[5]);
-    fd = reinterpret_cast<uint2*>(p.FL + o * 24);
-    fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
-    *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
-}
-
 // Encode and store one (row, block) whose 32 fp32 values sit in LDS (16-B aligned, contiguous) -- the form GEMM epilogues and the encoder
 // kernel use: two streaming passes over the LDS copy instead of 32 + 32 + 32 live registers (pass 1: f16 hi part stored 8 values at a time,
-// block maxima; then the two code streams from the hardware converter).  Same codes, value for value, as f6_encode_block.
+// block maxima; then the lo codes from the hardware converter, in the f6_pi order).  Same codes, value for value, as f6_code.
 typedef float f6_f32x4 __attribute__((ext_vector_type(4)));       // LDS reads as plain vectors (a HIP float4 struct read drains vmcnt(0))
 typedef float f6_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned f6_u32x6 __attribute__((ext_vector_type(6)));
@@ -171,7 +133,7 @@ __device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Pl
     const int64_t o = (int64_t)kb * p.rows_alloc + prow;
     uint4* hd = reinterpret_cast<uint4*>(p.H + o * 32);
     float mh = 0.f, ml = 0.f;
-    f6_f32x16 he, ho, le, lo;                                  // hi / lo parts, even / odd elements
+    float lf[32];                                              // residuals, element order
 #pragma unroll
     for (int q8 = 0; q8 < 4; ++q8) {
         const f6_f32x4 a = *reinterpret_cast<const f6_f32x4*>(src + q8 * 8), b = *reinterpret_cast<const f6_f32x4*>(src + q8 * 8 + 4);
@@ -180,21 +142,20 @@ __device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Pl
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             h[u] = static_cast<_Float16>(f6_sat_f16(x[u]));
-            const float hf = static_cast<float>(h[u]), lf = x[u] - hf;
-            mh = fmaxf(mh, fabsf(hf)); ml = fmaxf(ml, fabsf(lf));
-            const int j = q8 * 8 + u;
-            if (j & 1) { ho[j >> 1] = hf; lo[j >> 1] = lf; } else { he[j >> 1] = hf; le[j >> 1] = lf; }
+            const float hf = static_cast<float>(h[u]);
+            lf[q8 * 8 + u] = x[u] - hf;
+            mh = fmaxf(mh, fabsf(hf)); ml = fmaxf(ml, fabsf(lf[q8 * 8 + u]));
         }
         hd[q8] = *reinterpret_cast<const uint4*>(h);
     }
     if (!(ml < 3.0e38f)) ml = 0.f;
     if (!(mh < 3.0e38f)) mh = 65504.f;
     const int sh = f6_scale_byte(mh), sl = f6_scale_byte(ml);
-    const f6_u32x6 fh = f6_hw_codes(he, ho, __builtin_bit_cast(float, (unsigned)sh << 23));     // 2^(byte - 127)
-    const f6_u32x6 fl = f6_hw_codes(le, lo, __builtin_bit_cast(float, (unsigned)sl << 23));
-    uint2* fd = reinterpret_cast<uint2*>(p.FH + o * 24);
-    fd[0] = make_uint2(fh[0], fh[1]); fd[1] = make_uint2(fh[2], fh[3]); fd[2] = make_uint2(fh[4], fh[5]);
-    fd = reinterpret_cast<uint2*>(p.FL + o * 24);
+    f6_f32x16 le, lo;                                          // the converter's two sources: positions 2i and 2i + 1, element f6_pi(position)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { le[i] = lf[f6_pi(2 * i)]; lo[i] = lf[f6_pi(2 * i + 1)]; }
+    const f6_u32x6 fl = f6_hw_codes(le, lo, __builtin_bit_cast(float, (unsigned)sl << 23));     // 2^(byte - 127)
+    uint2* fd = reinterpret_cast<uint2*>(p.FL + o * 24);
     fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
     *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
 }

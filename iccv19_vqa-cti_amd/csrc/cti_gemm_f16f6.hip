@@ -2,14 +2,19 @@
 //
 // Per 32-wide K block and 32x32 output tile: two v_mfma_f32_32x32x16_f16 (hi x hi) and ONE v_mfma_scale_f32_32x32x64_f8f6f4
 // whose lane halves carry the two cross terms (lanes 0-31: fp6(A_hi) x fp6(B_lo), lanes 32-63: fp6(A_lo) x fp6(B_hi)), all into
-// the same fp32 accumulator: 96 MFMA cycles per block and tile against 192 for the three-bf16-product form.
+// the same fp32 accumulator: 96 MFMA cycles per block and tile against 192 for the three-bf16-product form.  The fp6 codes of the
+// hi parts are not stored: a lane converts the 16 f16 values it has just read (v_cvt_scalef32_pk32_fp6_f16) and trades halves with
+// its SIMD-half partner (v_permlane32_swap).
 //
-// KERNEL.  256 x 192 tile, 8 waves (4 x 2, each 64 x 96 = 2 x 3 MFMA tiles, 96 accumulator registers), a 3-slot LDS ring of
-// 32-deep K blocks (52 KiB per slot: f16 rows of 64 B, fp6 rows of 24 B for the hi and the lo codes, scale bytes), filled by
-// LDS-DMA with counted vmcnt and one raw s_barrier per block (two blocks in flight behind the MFMAs), persistent XCD-aware tile
-// walk -- the ring protocol of cti_gemm_bf16x3.hip.  LDS images: the f16 rows are XOR-swizzled at the SOURCE (16-B chunk c of row
-// r lands at chunk c ^ ((r >> 2) & 3)): conflict-free ds_read_b128 fragments; the fp6 rows are linear (24-B pitch: three
-// conflict-free ds_read_b64 per lane).
+// KERNEL.  256 x 192 tile, 8 waves (4 x 2, each 64 x 96 = 2 x 3 MFMA tiles, 96 accumulator registers), a 4-slot LDS ring of 32-deep
+// K blocks (40 KiB per slot = exactly 40 LDS-DMA pieces of 1 KiB, five per wave: f16 rows of 64 B, lo-code rows of 24 B, scale
+// bytes), counted vmcnt and one raw s_barrier per block, persistent XCD-aware tile walk.  A workgroup's tiles are ONE stream of K
+// blocks: the ring is refilled across tile boundaries and the epilogue's stores overlap with loads in flight.  LDS images: the f16
+// rows are XOR-swizzled at the SOURCE (16-B chunk c of row r lands at chunk c ^ ((r >> 2) & 3)): conflict-free ds_read_b128
+// fragments; the fp6 rows are linear (24-B pitch, each lane half reads 12 B: conflict-free).
+// What bounds it (round-2 measurements): a wave issues at most one instruction per four cycles and needs ~250 of them per
+// K block beside its 18 MFMAs; with two waves per SIMD the matrix pipe is busy ~45 % of the time.  Removing any one of DMA, MFMAs,
+// conversions or stores takes 10-18 % off; no single phase dominates.
 #include "cti_common.h"
 #include "cti_f16f6.h"
 
@@ -56,343 +61,105 @@ __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __rest
 
 // ---- GEMM --------------------------------------------------------------------------------------------------------------
 struct F6P {
-    const char* AH; const char* AFH; const char* AFL; const char* AS;
-    const char* BH; const char* BFH; const char* BFL; const char* BS;
+    const char* AH; const char* AFL; const char* AS;
+    const char* BH; const char* BFL; const char* BS;
     int64_t pA, pAS, pB, pBS;                  // rows_alloc / rows_allocS of the two operands
     int64_t rA, rB;
     int M, N, Kb, total_tiles;
     float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
     const float* scale; int scale_div; const float* bias; int relu;
-    F6Planes P; int Np;
-    int desync_ticks;                          // 100 MHz ticks over which the workgroups' first tiles are spread (see the kernel)
 };
-enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_PLANES = 4 };
+enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM_, int WN_, int TM_, int TN_, int NST_>
-struct GeoF {
-    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NST = NST_;
+// 256 x 192 tile, 8 waves.  One ring slot = one 32-deep K block of both operands:
+//   A_H 256 rows x 64 B | B_H 192 x 64 B | A_FL 256 x 24 B | B_FL 192 x 24 B | A_S 256 x 2 B | B_S 192 x 2 B (+ 640 B the last piece over-writes)
+// = exactly 40 pieces of 1 KiB (one LDS-DMA wave-instruction each), five per wave; four slots fill the CU's 160 KiB.
+template <int WM_, int WN_, int TM_, int TN_>
+struct GeoF6T {
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NST = 4;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64, NW = WM * WN;
-    // pieces (1 KiB LDS-DMA wave-instructions) per slot: H rows of 64 B, FH / FL rows of 24 B (rounded up), one piece of scales
-    static constexpr int PAH = BM / 16, PAF = (BM * 24 + 1023) / 1024, PBH = BN / 16, PBF = (BN * 24 + 1023) / 1024;
-    static constexpr int OFF_AH = 0, OFF_AFH = OFF_AH + PAH * 1024, OFF_AFL = OFF_AFH + PAF * 1024, OFF_AS = OFF_AFL + PAF * 1024;
-    static constexpr int OFF_BH = OFF_AS + 1024, OFF_BFH = OFF_BH + PBH * 1024, OFF_BFL = OFF_BFH + PBF * 1024, OFF_BS = OFF_BFL + PBF * 1024;
+    static constexpr int PAH = BM / 16, PBH = BN / 16, PAF = BM * 24 / 1024, PBF = BN * 24 / 1024;      // whole pieces; B_FL leaves a 512-B tail
+    static constexpr int OFF_AH = 0, OFF_BH = OFF_AH + BM * 64, OFF_AFL = OFF_BH + BN * 64, OFF_BFL = OFF_AFL + BM * 24;
+    static constexpr int OFF_AS = OFF_BFL + BN * 24, OFF_BS = OFF_AS + BM * 2;
     static constexpr int SLOT = OFF_BS + 1024;
-    static constexpr int NP = SLOT / 1024;                          // pieces per slot
+    static constexpr int NPIECE = PAH + PBH + PAF + PBF + 2;
+    static constexpr int CNT = NPIECE / NW;                        // pieces per wave and slot
     static constexpr int LDS = NST * SLOT;
+    static_assert(BM * 24 % 1024 == 0 && BN * 24 % 1024 == 512 && BM * 2 == 512, "the B_FL tail and the A scales share one piece");
+    static_assert(OFF_AS == OFF_BFL + PBF * 1024 + 512, "the shared piece is contiguous in LDS");
+    static_assert(NPIECE % NW == 0, "every wave issues the same number of pieces");
     static_assert(LDS <= 160 * 1024, "ring exceeds the CU's LDS");
 };
+using GeoF6 = GeoF6T<4, 2, 2, 3>;                    // 8 waves of 64 x 96, two per SIMD
 
-#ifndef CTI_F6_NT_B
-#define CTI_F6_NT_B 0            // 1: the B operand's pieces (streamed once per XCD) are loaded non-temporally so that they do not displace the A tiles in L2
-#endif
-template <int AUX = 0>
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-#ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue stores
+#ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fp6 conversion, 8 no epilogue stores, 64 no lane swaps
 #define CTI_F6_ABL 0
 #endif
 
-// One LDS-DMA piece of this wave: 64 lanes x 16 B from (uniform 64-bit base + per-lane 32-bit offset) into 1 KiB of LDS at a uniform address.
-struct F6Piece { const char* src; int64_t kstride; int lds; };
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 
+// e2m3 codes of the 16 f16 values a lane holds of its row's K block (k-steps 0 and 1 of the f16 MFMA), scaled by 2^(sbyte - 127): three
+// dwords.  The instruction converts 32 values; its upper 16 inputs (and the three dwords they produce) are don't-cares.
+__device__ __forceinline__ u32x6 f6_codes_of_f16(f16x8 k0, f16x8 k1, int sbyte) {
+    const f16x32 in = __builtin_shufflevector(__builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                              __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                              0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    u32x6 out;
+#if CTI_F6_ABL & 4
+    out[0] = __builtin_bit_cast(unsigned, __builtin_shufflevector(k0, k0, 0, 1)); out[1] = __builtin_bit_cast(unsigned, __builtin_shufflevector(k1, k1, 0, 1)); out[2] = sbyte; return out;
+#endif
+    asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(out) : "v"(in), "v"(__builtin_bit_cast(float, (unsigned)(sbyte & 0xff) << 23)));
+    return out;
+}
+
+// ---- epilogue of the tile at (z, m0, n0): the wave's TM x TN accumulator tiles -> C
 template <int EPI, class G>
-__global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
-    constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NST = G::NST, BM = G::BM, BN = G::BN, NW = G::NW, SLOT = G::SLOT;
-    // DMA schedule of a slot.  The pieces are dealt so that every wave's share is the same straight-line code: H pieces (16 rows x 64 B,
-    // XOR-swizzled source chunks) PAH / NW rounds of A and PBH / NW rounds of B (+ a partial round for the waves below HB_REM), then the
-    // 24 "linear" pieces (A_FH, A_FL, B_FH, B_FL copies and the two scale pieces) NLIN / NW rounds.  Waves below HB_REM issue one piece more.
-    constexpr int NLIN = 2 * G::PAF + 2 * G::PBF + 2;
-    static_assert(G::PAH % NW == 0 && NLIN % NW == 0, "the A_H and the linear pieces must split evenly over the waves");
-    constexpr int HA_R = G::PAH / NW, HB_R = G::PBH / NW, HB_REM = G::PBH % NW, LIN_R = NLIN / NW;
-    constexpr int CNT_LO = HA_R + HB_R + LIN_R;                     // pieces per slot of a wave >= HB_REM (the others: one more)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);        // scalar: every piece address below is SGPR base + VGPR lane offset
-    const int wm = wid / WN, wn = wid % WN;
+__device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], const F6P& p, int z, int cm0, int cn0, int wm, int wn, int lane) {
+    constexpr int TM = G::TM, TN = G::TN;
     const int r = lane & 31, h = lane >> 5;
-    const int tiles_n = ((EPI == F6_EPI_PLANES ? p.Np : p.N) + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const bool extra = wid < HB_REM;
-    // per-lane source offsets: H piece = rows (lane >> 2) of the piece, chunk (lane & 3) ^ ((row >> 2) & 3) -- a piece starts at a multiple of 16 rows
-    const unsigned hoff = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
-    const unsigned loff = (unsigned)lane * 16u;
-
-    // Persistent tile walk.  The NEXT tile's first NST - 1 slots are issued BEFORE the current tile's epilogue stores (non-staged
-    // epilogues): the ring is idle by then, and the DMA latency hides behind the store issue (the stores are issue-bound, ~10 us per tile).
-    int z = 0, m0 = 0, n0 = 0;
-    int64_t rowA = 0, rowB = 0;
-    F6Piece pa[HA_R], pb[HB_R + 1], pl[LIN_R];
-#ifndef CTI_F6_PREFETCH
-#define CTI_F6_PREFETCH 0        // > 0: every wave touches (one dword per 128-B line, 64 lines) part of the K block issued PREFETCH blocks later.
-#endif                           // MEASURED AND REJECTED (2.0 -> 2.3 ms at distances 2, 3, 5): the extra requests cost more than the earlier misses save
-    constexpr int NPF = CTI_F6_PREFETCH > 0 ? 1 : 0;               // prefetch loads per wave and slot (they count in vmcnt like the DMA pieces)
-    const char* pf_src = nullptr; int64_t pf_kstride = 0;
-    int pf_sink = 0;                                                // destination register of every prefetch load: stays reserved to the end
-    auto setup_tile = [&](int vt) {
-        int tm, tn;
-        tile_coords(vt, p.total_tiles, tiles_m, tiles_n, z, tm, tn);
-        m0 = tm * BM; n0 = tn * BN;
-        rowA = (int64_t)z * p.rA + m0; rowB = (int64_t)z * p.rB + n0;
-        // this wave's pieces (uniform): source base at K block 0, byte stride per K block, LDS offset inside the slot
-#pragma unroll
-        for (int u = 0; u < HA_R; ++u) {
-            const int q = wid + u * NW;
-            pa[u].src = p.AH + (rowA + q * 16) * 64; pa[u].kstride = p.pA * 64; pa[u].lds = G::OFF_AH + q * 1024;
-        }
-#pragma unroll
-        for (int u = 0; u < HB_R + 1; ++u) {
-            const int q = wid + u * NW;                                 // u == HB_R: only the waves below HB_REM
-            pb[u].src = p.BH + (rowB + q * 16) * 64; pb[u].kstride = p.pB * 64; pb[u].lds = G::OFF_BH + q * 1024;
-        }
-#pragma unroll
-        for (int u = 0; u < LIN_R; ++u) {
-            int g = wid + u * NW;                                       // index among the linear pieces: [A_FH | A_FL | A_S | B_FH | B_FL | B_S]
-            const char* base; int64_t ks; int lds;
-            if (g < G::PAF)                         { base = p.AFH + rowA * 24; ks = p.pA * 24; lds = G::OFF_AFH; }
-            else if ((g -= G::PAF) < G::PAF)        { base = p.AFL + rowA * 24; ks = p.pA * 24; lds = G::OFF_AFL; }
-            else if ((g -= G::PAF) < 1)             { base = p.AS + rowA * 2;   ks = p.pAS * 2; lds = G::OFF_AS; }
-            else if ((g -= 1) < G::PBF)             { base = p.BFH + rowB * 24; ks = p.pB * 24; lds = G::OFF_BFH; }
-            else if ((g -= G::PBF) < G::PBF)        { base = p.BFL + rowB * 24; ks = p.pB * 24; lds = G::OFF_BFL; }
-            else                                    { g -= G::PBF; base = p.BS + rowB * 2; ks = p.pBS * 2; lds = G::OFF_BS; }
-            pl[u].src = base + g * 1024; pl[u].kstride = ks; pl[u].lds = lds + g * 1024;
-        }
-        if (NPF) {
-            // L2 prefetch experiment (off).  The ring holds two K blocks in flight (104 KiB); the idea was that a touch of the lines a LATER
-            // block will DMA moves their miss out of the DMA -- more bytes in flight without LDS to land them in.  It made the kernel slower.  wave: 0,1 B_H halves (96 lines), 2 B_FH, 3 B_FL, 4,5 A_H halves, 6 A_FH, 7 A_FL
-            const int64_t lo = (int64_t)lane * 128;
-            switch (wid) {
-                case 0: pf_src = p.BH + rowB * 64 + lo; pf_kstride = p.pB * 64; break;
-                case 1: pf_src = p.BH + rowB * 64 + (lane < 32 ? 8192 + lo : lo); pf_kstride = p.pB * 64; break;
-                case 2: pf_src = p.BFH + rowB * 24 + (lane < 36 ? lo : 0); pf_kstride = p.pB * 24; break;
-                case 3: pf_src = p.BFL + rowB * 24 + (lane < 36 ? lo : 0); pf_kstride = p.pB * 24; break;
-                case 4: pf_src = p.AH + rowA * 64 + lo; pf_kstride = p.pA * 64; break;
-                case 5: pf_src = p.AH + rowA * 64 + 8192 + lo; pf_kstride = p.pA * 64; break;
-                case 6: pf_src = p.AFH + rowA * 24 + (lane < 48 ? lo : 0); pf_kstride = p.pA * 24; break;
-                default: pf_src = p.AFL + rowA * 24 + (lane < 48 ? lo : 0); pf_kstride = p.pA * 24; break;
-            }
-        }
-    };
-    auto issue_slot = [&](int pos, int64_t kb) {
-        char* slot = smem + pos * SLOT;
-#pragma unroll
-        for (int u = 0; u < HA_R; ++u) dma16(pa[u].src + kb * pa[u].kstride + hoff, slot + pa[u].lds);
-#pragma unroll
-        for (int u = 0; u < HB_R; ++u) dma16<CTI_F6_NT_B ? 2 : 0>(pb[u].src + kb * pb[u].kstride + hoff, slot + pb[u].lds);
-        if (HB_REM && extra) dma16<CTI_F6_NT_B ? 2 : 0>(pb[HB_R].src + kb * pb[HB_R].kstride + hoff, slot + pb[HB_R].lds);
-#pragma unroll
-        for (int u = 0; u < LIN_R; ++u) dma16(pl[u].src + kb * pl[u].kstride + loff, slot + pl[u].lds);
-        if (NPF) {                                                  // exactly one load per slot, whatever kb (the counted waits rely on it)
-            const int64_t kp = kb + CTI_F6_PREFETCH < p.Kb ? kb + CTI_F6_PREFETCH : p.Kb - 1;
-            const char* a = pf_src + kp * pf_kstride;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(a) : "memory");
-        }
-    };
-    const int nkb = p.Kb;
-    auto prologue = [&]() {
-#pragma unroll
-        for (int i = 0; i < NST - 1; ++i) if (i < nkb) issue_slot(i, i);
-    };
-    constexpr bool HOIST = EPI != F6_EPI_PLANES;                    // the planes epilogue stages through the ring's LDS
-
-    int vtile = blockIdx.x;
-    if (vtile >= p.total_tiles) return;
-    // De-synchronise the CUs.  Every workgroup walks tiles of equal cost, so all 256 would reach their epilogues together: 50 MB of stores
-    // per round hit HBM at once (write-bound, ~12 us) and nothing is stored in between.  Spreading the START over one tile time keeps the
-    // phases apart for the whole launch: the stores become a steady stream beside the other CUs' main loops.
-    if (p.desync_ticks > 0) {
-        const unsigned target = (((unsigned)blockIdx.x * 157u) & 255u) * (unsigned)p.desync_ticks >> 8;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < target) __builtin_amdgcn_s_sleep(16);
-    }
-    setup_tile(vtile);
-    prologue();
-    for (;;) {
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // per-lane fragment addresses inside a slot
-    int aH[TM], aF[TM], aS[TM], bH[TN], bF[TN], bS[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + r;
-        aH[i] = G::OFF_AH + row * 64; aF[i] = (h ? G::OFF_AFL : G::OFF_AFH) + row * 24; aS[i] = G::OFF_AS + row * 2 + h;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 32 + r;
-        bH[j] = G::OFF_BH + row * 64; bF[j] = (h ? G::OFF_BFH : G::OFF_BFL) + row * 24; bS[j] = G::OFF_BS + row * 2 + (1 - h);
-    }
-    const int sw = (r >> 2) & 3;                                    // (row >> 2) & 3: rows of a tile start at multiples of 32
-    const int c0 = ((0 + h) ^ sw) << 4, c1 = ((2 + h) ^ sw) << 4;   // swizzled chunk offsets of k-steps 0 and 1
-
-    // K loop.  "sync(b)": this wave's pieces of block b have landed (counted vmcnt), raw barrier (every wave's have, and block b - 1 is
-    // free), refill: block b + NST - 1 is issued into the freed slot.
-    // STAGGER: waves w and w + NW/2 share a SIMD and run the same program; released by the same barrier they would both read their
-    // fragments first (LDS latency exposed, matrix pipe idle) and then both queue MFMAs.  The upper half therefore reads block b BEFORE
-    // sync(b + 1) and issues its MFMAs AFTER it: one SIMD partner computes while the other reads.  Its reads are complete (lgkmcnt(0))
-    // before the barrier, so the slot may be recycled behind it; fragments never live across a loop back-edge.
-#ifndef CTI_F6_STAGGER
-#define CTI_F6_STAGGER 1
-#endif
-    auto sync_only = [&](int b) {
-        const int rem = nkb - 1 - b;                                // blocks issued after block b so far: min(NST - 2, rem)
-#if CTI_F6_ABL & 32
-        if (b < NST - 1 && vtile != (int)blockIdx.x) { __builtin_amdgcn_s_barrier(); return; }     // ablation (UNSAFE): no vmcnt wait on the hoisted blocks
-#endif
-        if (rem >= NST - 2) { if (extra) wait_vm<(NST - 2) * (CNT_LO + 1 + NPF)>(); else wait_vm<(NST - 2) * (CNT_LO + NPF)>(); }
-        else if (NST >= 4 && rem == 1) { if (extra) wait_vm<CNT_LO + 1 + NPF>(); else wait_vm<CNT_LO + NPF>(); }
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-    };
-    auto refill = [&](int b, int pos) {                             // pos = ring position of block b, whose barrier has been passed
-        if (b + NST - 1 < nkb && !(CTI_F6_ABL & 1)) issue_slot(pos == 0 ? NST - 1 : pos - 1, b + NST - 1);
-    };
-#ifndef CTI_F6_LAG_DMA_LATE
-#define CTI_F6_LAG_DMA_LATE 1    // the lagging waves issue their share of the refill BEHIND their MFMAs: right after a barrier the lead waves
-#endif                           // issue DMA (no matrix work yet) while the lagging ones feed the matrix pipe, then the roles swap
-#define CTI_F6_READ_FRAGS(s)                                                                                                          \
-    f16x8 a16[TM][2], b16[TN][2]; i32x8 a6[TM], b6[TN]; int sa[TM], sb[TN];                                                            \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                                  \
-        a16[i][0] = *reinterpret_cast<const f16x8*>((s) + aH[i] + c0);                                                                \
-        a16[i][1] = *reinterpret_cast<const f16x8*>((s) + aH[i] + c1);                                                                \
-        const u32x2 f0 = *reinterpret_cast<const u32x2*>((s) + aF[i]), f1 = *reinterpret_cast<const u32x2*>((s) + aF[i] + 8), f2 = *reinterpret_cast<const u32x2*>((s) + aF[i] + 16); \
-        a6[i][0] = f0.x; a6[i][1] = f0.y; a6[i][2] = f1.x; a6[i][3] = f1.y; a6[i][4] = f2.x; a6[i][5] = f2.y; a6[i][6] = 0; a6[i][7] = 0; \
-        sa[i] = *reinterpret_cast<const int*>((s) + (aS[i] & ~3)) >> ((aS[i] & 3) * 8);   /* the MFMA takes byte 0 of the scale register */ \
-    }                                                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                                  \
-        b16[j][0] = *reinterpret_cast<const f16x8*>((s) + bH[j] + c0);                                                                \
-        b16[j][1] = *reinterpret_cast<const f16x8*>((s) + bH[j] + c1);                                                                \
-        const u32x2 f0 = *reinterpret_cast<const u32x2*>((s) + bF[j]), f1 = *reinterpret_cast<const u32x2*>((s) + bF[j] + 8), f2 = *reinterpret_cast<const u32x2*>((s) + bF[j] + 16); \
-        b6[j][0] = f0.x; b6[j][1] = f0.y; b6[j][2] = f1.x; b6[j][3] = f1.y; b6[j][4] = f2.x; b6[j][5] = f2.y; b6[j][6] = 0; b6[j][7] = 0; \
-        sb[j] = *reinterpret_cast<const int*>((s) + (bS[j] & ~3)) >> ((bS[j] & 3) * 8);                                               \
-    }
-#define CTI_F6_MFMAS()                                                                                                                \
-    if (!(CTI_F6_ABL & 2) || p.Kb < 0) {         /* ablation: never true, the fragments stay live, the MFMAs do not issue */          \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                                \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6[i], b6[j], acc[i][j], 2, 2, 0, sa[i], 0, sb[j]);       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][0], b16[j][0], acc[i][j], 0, 0, 0);                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][1], b16[j][1], acc[i][j], 0, 0, 0);                         \
-            }                                                                                                                         \
-    }
-    const bool lag = CTI_F6_STAGGER && wid >= NW / 2;
-    if (!lag) {
-        int pos = 0;
-        for (int kb = 0; kb < nkb; ++kb) {
-            sync_only(kb); refill(kb, pos);
-            const char* s = smem + pos * SLOT;
-            CTI_F6_READ_FRAGS(s)
-            CTI_F6_MFMAS()
-            pos = pos == NST - 1 ? 0 : pos + 1;
-        }
-        __syncthreads();                          // every wave is done reading the ring before the epilogue / the next tile's DMA reuses it
-    } else {
-        int pos = 0;
-        sync_only(0); refill(0, 0);
-        for (int kb = 0; kb < nkb; ++kb) {
-            const char* s = smem + pos * SLOT;
-            CTI_F6_READ_FRAGS(s)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads complete before the barrier that lets the slot be recycled
-            pos = pos == NST - 1 ? 0 : pos + 1;
-            if (kb + 1 < nkb) { sync_only(kb + 1); if (!CTI_F6_LAG_DMA_LATE) refill(kb + 1, pos); }
-            else __syncthreads();                 // pairs with the lead waves' closing barrier
-            CTI_F6_MFMAS()
-            if (CTI_F6_LAG_DMA_LATE && kb + 1 < nkb) { __builtin_amdgcn_sched_barrier(0); refill(kb + 1, pos); }
-        }
-    }
-#undef CTI_F6_READ_FRAGS
-#undef CTI_F6_MFMAS
-
     float* C = p.C + (int64_t)z * p.sC;
-    const int cm0 = m0, cn0 = n0;                 // the finished tile's origin (setup_tile moves on to the next one)
-    const int next = vtile + (int)gridDim.x;
-    const bool have_next = next < p.total_tiles;
-    if (HOIST && have_next) { setup_tile(next); prologue(); }
     if (EPI == F6_EPI_INTERLEAVE2) {
         // GEMM rows (2m, 2m+1) are the two glimpses of one (v,q) row: registers e, e+1 (e even) of a lane are the adjacent floats
         // out[b, vq, a, 0:2] of column a = n.  Neighbouring lanes (columns n, n+1) trade halves through a DPP quad swap so that the even lane
         // stores out[vq, n:n+2, 0:2] and the odd lane out[vq+1, n-1:n+1, 0:2]: ONE 16-B store per four registers instead of two 8-B ones --
         // the epilogue is store-ISSUE bound (cdna_hip_programming.md T21), so this halves it.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         const bool odd = lane & 1;
         auto swap1 = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); };
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = cn0 + (wn * TN + j) * 32 + r - (odd ? 1 : 0);      // even column: this lane's 16 B start here
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                // One accumulator tile at a time through an explicit VGPR copy: used directly, the allocator moves ALL accumulators out of
+                // the AGPRs in front of the epilogue and spills the next block's operands to make room.
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 tv = acc[i][j];
+                asm volatile("" : "+v"(tv));
 #pragma unroll
                 for (int e = 0; e < 16; e += 4) {
-                    const float r0 = acc[i][j][e], r1 = acc[i][j][e + 1], r2 = acc[i][j][e + 2], r3 = acc[i][j][e + 3];
+                    const float r0 = tv[e], r1 = tv[e + 1], r2 = tv[e + 2], r3 = tv[e + 3];
                     const float t0 = swap1(odd ? r0 : r2), t1 = swap1(odd ? r1 : r3);
                     const int m = cm0 + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * h + (odd ? 2 : 0);      // even GEMM row = (vq, g = 0)
                     if (m >= p.M || col >= p.N || ((CTI_F6_ABL & 8) && r0 != 12345.f)) continue;
                     float* dst = C + (int64_t)(m >> 1) * p.ldc_m + (int64_t)col * 2;
-#if CTI_F6_ABL & 16
-                    dst = p.C + ((((int64_t)(m >> 1) * p.ldc_m + (int64_t)col * 2) & 0x3ffff) + (blockIdx.x & 7) * 0x40000);   // ablation: every store lands in an L2-resident 8 MiB
-#endif
-#ifndef CTI_F6_WIDE_STORES
-#define CTI_F6_WIDE_STORES 1
-#endif
-                    if (!CTI_F6_WIDE_STORES) {
-                        typedef float f32x2n __attribute__((ext_vector_type(2)));
-                        // un-widened form (8-B stores): even lane row m, odd lane row m too -- use the lane's own registers
-                        const int mo = cm0 + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * h, no = cn0 + (wn * TN + j) * 32 + r;
-                        if (no < p.N) {
-                            f32x2n w0; w0[0] = r0; w0[1] = r1; f32x2n w1; w1[0] = r2; w1[1] = r3;
-                            if (mo < p.M) *reinterpret_cast<f32x2n*>(C + (int64_t)(mo >> 1) * p.ldc_m + (int64_t)no * 2) = w0;
-                            if (mo + 2 < p.M) *reinterpret_cast<f32x2n*>(C + (int64_t)((mo >> 1) + 1) * p.ldc_m + (int64_t)no * 2) = w1;
-                        }
-                        continue;
-                    }
-                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef CTI_F6_STORE_SC1
-#define CTI_F6_STORE_SC1 0       // 1: write-through stores that do NOT keep the line in the XCD's L2 (the 3.2 GB output stream would otherwise
-#endif                           // evict the operand tiles the LDS-DMA re-reads from L2)
                     if (col + 1 < p.N) {
                         f32x4 v4; v4[0] = odd ? t0 : r0; v4[1] = odd ? t1 : r1; v4[2] = odd ? r2 : t0; v4[3] = odd ? r3 : t1;
-                        if (CTI_F6_STORE_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v4) : "memory");
-                        else *reinterpret_cast<f32x4*>(dst) = v4;
+                        *reinterpret_cast<f32x4*>(dst) = v4;
                     } else {
                         f32x2 v2; v2[0] = odd ? t0 : r0; v2[1] = odd ? t1 : r1;
-                        if (CTI_F6_STORE_SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v2) : "memory");
-                        else *reinterpret_cast<f32x2*>(dst) = v2;
+                        *reinterpret_cast<f32x2*>(dst) = v2;
                     }
                 }
-        }
-    } else if (EPI == F6_EPI_PLANES) {
-        // Per 32-column tile j the wave parks its 64 x 32 block in a private LDS patch ([row][36 floats]: conflict-free b128 row reads), then
-        // every lane encodes ONE (row, block) item; bias / scale / ReLU applied on the way in.  Same wave writes and reads: in-order LDS.
-        float* stg = reinterpret_cast<float*>(smem) + wid * (TM * 32 * 36);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = cn0 + (wn * TN + j) * 32, n = nb + r;
-            const bool real = n < p.N;
-            const float sc = (real && p.scale) ? p.scale[n / p.scale_div] : 1.f;
-            const float bi = (real && p.bias) ? p.bias[n] : 0.f;
-            if (j) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous tile's reads are done before overwriting
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    float x = acc[i][j][e] * sc + bi;
-                    if (p.relu) x = fmaxf(x, 0.f);
-                    stg[row * 36 + r] = real ? x : 0.f;
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            static_assert(TM * 32 == 64, "one (row, block) item per lane");
-            const int m = cm0 + wm * TM * 32 + lane;
-            if (m < p.M && nb < p.Np) f6_encode_row32_lds(stg + lane * 36, p.P, f6_prow(p.P, m), nb >> 5);
+            }
         }
     } else {
 #pragma unroll
@@ -406,7 +173,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = cm0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m < p.M) {
+                    if (m < p.M && !((CTI_F6_ABL & 8) && sc != 12345.f)) {
                         float x = acc[i][j][e] * sc + bi;
                         if (p.relu) x = fmaxf(x, 0.f);
                         C[(int64_t)(m / p.gdiv) * p.ldc_m + (m % p.gdiv) + (int64_t)n * p.ldc_n] = x;
@@ -414,17 +181,210 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
                 }
         }
     }
-    if (!have_next) break;
-    if (!HOIST) {
-        __syncthreads();                          // (planes epilogue) the LDS patches are free again before the next tile's DMA
-        setup_tile(next); prologue();
-    }
-    vtile = next;
-    }                                             // persistent tile loop
-    if (NPF) asm volatile("s_waitcnt vmcnt(0)\n; prefetch sink %0" ::"v"(pf_sink) : "memory");
 }
 
-using GeoF6 = GeoF<4, 2, 2, 3, 3>;                // 256 x 192, 3 slots of 52 KiB
+template <int EPI, class G>
+__global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
+    constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NST = G::NST, BM = G::BM, BN = G::BN, NW = G::NW, SLOT = G::SLOT, CNT = G::CNT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);        // scalar: every piece address below is SGPR base + VGPR lane offset
+    const int wm = wid / WN, wn = wid % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    if ((int)blockIdx.x >= p.total_tiles) return;
+    // The workgroup's tiles (blockIdx.x, + gridDim.x, ...) are ONE stream of K blocks through the ring: the DMA of the next tile's first
+    // blocks is issued during the current tile's last ones, so that the ring never drains at a tile boundary and the epilogue's stores
+    // overlap with loads already in flight.
+    const int nkb = p.Kb;
+    const int nblk = ((p.total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1) * nkb;
+    // ---- DMA side.  Piece g = wid + 8 u (u = 0 .. 4) of the slot's list [A_H x16 | B_H x12 | A_FL x6 | B_FL x4 | B_FL tail + A_S | B_S]; the
+    // last but one (wave 6, u = 4) takes its lower 32 lanes from the B_FL tail and its upper 32 from the A scales.  Every piece has a per-lane
+    // 64-bit source pointer (H pieces: rows (lane >> 2) of the piece, 16-B chunk (lane & 3) ^ ((row >> 2) & 3); the others 16 B per lane) that
+    // walks the K blocks of the tile being issued: one VALU add per piece and block, no scalar address arithmetic in the loop.
+    const char* vp[CNT]; int64_t kstride[CNT]; int ldsoff[CNT];
+    const bool shared_piece_wave = (G::NPIECE - 2) % NW == wid;
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        int g = wid + u * NW;
+        if (g < G::PAH)                   { kstride[u] = p.pA * 64; ldsoff[u] = G::OFF_AH + g * 1024; }
+        else if ((g -= G::PAH) < G::PBH)  { kstride[u] = p.pB * 64; ldsoff[u] = G::OFF_BH + g * 1024; }
+        else if ((g -= G::PBH) < G::PAF)  { kstride[u] = p.pA * 24; ldsoff[u] = G::OFF_AFL + g * 1024; }
+        else if ((g -= G::PAF) <= G::PBF) { kstride[u] = p.pB * 24; ldsoff[u] = G::OFF_BFL + g * 1024; }   // g == PBF: the tail
+        else                              { kstride[u] = p.pBS * 2; ldsoff[u] = G::OFF_BS; }
+    }
+    const int64_t vks_last = (shared_piece_wave && h) ? p.pAS * 2 : kstride[CNT - 1];       // per lane: the shared piece's halves walk different planes
+    int iss_tile = blockIdx.x, iss_kb = 0, issued = 0;
+    auto issue_tile_setup = [&]() {
+        int zz, tm, tn;
+        tile_coords(iss_tile, p.total_tiles, tiles_m, tiles_n, zz, tm, tn);
+        const int64_t ra = (int64_t)zz * p.rA + tm * BM, rb = (int64_t)zz * p.rB + tn * BN;
+        int w = wid;
+        asm volatile("" : "+s"(w));                                 // (keeps the descriptor arithmetic below out of the K loop's live registers)
+        const unsigned hoff = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4)), loff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            int g = w + u * NW;
+            if (g < G::PAH)                   vp[u] = p.AH + (ra + g * 16) * 64 + hoff;
+            else if ((g -= G::PAH) < G::PBH)  vp[u] = p.BH + (rb + g * 16) * 64 + hoff;
+            else if ((g -= G::PBH) < G::PAF)  vp[u] = p.AFL + ra * 24 + g * 1024 + loff;
+            else if ((g -= G::PAF) <= G::PBF) vp[u] = p.BFL + rb * 24 + g * 1024 + loff;
+            else                              vp[u] = p.BS + rb * 2 + loff;
+        }
+        if (shared_piece_wave && h) vp[CNT - 1] = p.AS + ra * 2 - 512 + loff;       // upper 32 lanes: the A scales, 16 B per lane from lane 32 on
+    };
+    auto issue_next = [&](int pos) {                                // the stream's next K block into ring slot `pos`
+        if (issued >= nblk || (CTI_F6_ABL & 1)) return;
+        char* slot = smem + pos * SLOT;
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            dma16(vp[u], slot + ldsoff[u]);
+            vp[u] += u == CNT - 1 ? vks_last : kstride[u];
+        }
+        ++issued;
+        if (++iss_kb == nkb) {
+            iss_kb = 0; iss_tile += (int)gridDim.x;
+            if (iss_tile < p.total_tiles) issue_tile_setup();
+        }
+    };
+    // vmcnt part of "block b has landed": the pieces this wave issued for the blocks after b may still be in flight -- min(NST - 2, blocks
+    // left) of them at every point this is called from.  vmcnt retires in issue order (stores included), so epilogue stores issued after
+    // those pieces only ever make the wait conservative.
+    auto wait_block = [&](int b) {
+        const int rem = nblk - 1 - b;
+        if (rem >= NST - 2) wait_vm<(NST - 2) * CNT>();
+        else if (NST >= 4 && rem == 1) wait_vm<CNT>();
+        else wait_vm<0>();
+    };
+
+#if CTI_F6_ABL & 128                                                 // clock probe: shader cycles / 100 MHz ticks of this workgroup -> C[2 bx], C[2 bx + 1]
+    const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    issue_tile_setup();
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) issue_next(i);
+
+    // ---- compute side
+    int vtile = blockIdx.x, z = 0, m0 = 0, n0 = 0;
+    auto compute_tile_setup = [&]() {
+        int tm, tn;
+        tile_coords(vtile, p.total_tiles, tiles_m, tiles_n, z, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+    };
+    compute_tile_setup();
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+
+    // per-lane fragment addresses inside a slot; tile i / j of the wave adds a compile-time constant (32 rows) that folds into the ds_read
+    // offset.  fp6 rows: the lower lane half reads dwords 0-2 of its row's 24 B, the upper half dwords 3-5 (the permlane swaps below put them
+    // where the MFMA wants them).  Scales: the dword that holds the row's (hi, lo) byte pair, and the shifts that bring the wanted byte down.
+    const int sw = (r >> 2) & 3;                                    // (row >> 2) & 3: rows of a tile start at multiples of 32
+    const int c0 = ((0 + h) ^ sw) << 4, c1 = ((2 + h) ^ sw) << 4;   // swizzled chunk offsets of k-steps 0 and 1
+    const int rowA = wm * TM * 32 + r, rowB = wn * TN * 32 + r;
+    const int aH0 = G::OFF_AH + rowA * 64 + c0, aH1 = G::OFF_AH + rowA * 64 + c1, bH0 = G::OFF_BH + rowB * 64 + c0, bH1 = G::OFF_BH + rowB * 64 + c1;
+    const int aF = G::OFF_AFL + rowA * 24 + 12 * h, bF = G::OFF_BFL + rowB * 24 + 12 * h;
+    const int aS = G::OFF_AS + ((rowA * 2) & ~3), bS = G::OFF_BS + ((rowB * 2) & ~3);
+    const int shS = (r & 1) * 16;                                   // the row's (hi, lo) scale bytes inside that dword (tile rows are even offsets apart)
+    const int shA = shS + h * 8, shB = shS + (1 - h) * 8;           // the byte the MFMA takes: A lower lanes hi / upper lo, B the other way round
+
+    auto epilogue = [&]() { f6_epilogue<EPI, G>(acc, p, z, m0, n0, wm, wn, lane); };
+
+    // ---- the stream.  Per block b: [vmcnt: my pieces of b have landed] raw barrier (everyone's have, and block b - 1 is free) -> the
+    // stream's next block is issued into the freed slot -> fragments -> MFMAs; after a tile's last block its epilogue.
+    // TILE BOUNDARY: the vmcnt wait that the first barrier after an epilogue needs is taken BEFORE the stores (the block in question was
+    // issued two K blocks earlier), so that no wave waits for its stores to retire before the next tile's first MFMAs.
+    // (Measured and dropped with the continuous stream in place, each within +-1 %: a half-block stagger of the two waves of a SIMD,
+    // spreading the workgroups' start times over one tile, issuing the refill behind the MFMAs.)
+    // Fragments of one K block.  A lane (row r of a 32-row tile, SIMD half h) reads its 2 x 8 f16 values (k = 8h .. 8h+7 and 16+8h .. 16+8h+7),
+    // converts them to fp6 under the row's hi scale, and trades with its partner lane: v_permlane32_swap(X, Y) exchanges X's upper lanes
+    // with Y's lower lanes.  A operand: X = own codes, Y = the lane's half of the lo codes from LDS; after the swap the lower lanes hold
+    // [own | partner's] = the hi codes of the whole block in the f6_pi order, the upper lanes the six lo dwords.  B operand: X = lo codes
+    // from LDS, Y = own; afterwards the lower lanes hold the lo dwords, the upper ones [partner's | own] hi codes.
+#if CTI_F6_ABL & 64
+#define CTI_F6_SWAP(x, y) u32x2{(unsigned)(x), (unsigned)(y)}
+#else
+#define CTI_F6_SWAP(x, y) __builtin_amdgcn_permlane32_swap((unsigned)(x), (unsigned)(y), false, false)
+#endif
+#define CTI_F6_READ_FRAGS(s)                                                                                                          \
+    f16x8 a16[TM][2], b16[TN][2]; i32x8 a6[TM], b6[TN]; int sa[TM], sb[TN]; int fa[TM][3], fb[TN][3], spa[TM], spb[TN];               \
+    {                                                                                                                                 \
+        const char *s_a0 = (s) + aH0, *s_a1 = (s) + aH1, *s_b0 = (s) + bH0, *s_b1 = (s) + bH1, *s_af = (s) + aF, *s_bf = (s) + bF, *s_as = (s) + aS, *s_bs = (s) + bS; \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {         /* every LDS read of the block first: one latency, not five */        \
+            a16[i][0] = *reinterpret_cast<const f16x8*>(s_a0 + i * 2048);                                                             \
+            a16[i][1] = *reinterpret_cast<const f16x8*>(s_a1 + i * 2048);                                                             \
+            _Pragma("unroll") for (int d = 0; d < 3; ++d) fa[i][d] = *reinterpret_cast<const int*>(s_af + i * 768 + 4 * d);           \
+            spa[i] = *reinterpret_cast<const int*>(s_as + i * 64);                                                                    \
+        }                                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                              \
+            b16[j][0] = *reinterpret_cast<const f16x8*>(s_b0 + j * 2048);                                                             \
+            b16[j][1] = *reinterpret_cast<const f16x8*>(s_b1 + j * 2048);                                                             \
+            _Pragma("unroll") for (int d = 0; d < 3; ++d) fb[j][d] = *reinterpret_cast<const int*>(s_bf + j * 768 + 4 * d);           \
+            spb[j] = *reinterpret_cast<const int*>(s_bs + j * 64);                                                                    \
+        }                                                                                                                             \
+    }                                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                           /* (the scheduler would otherwise pair each read with its conversion) */ \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                                  \
+        const u32x6 own = f6_codes_of_f16(a16[i][0], a16[i][1], spa[i] >> shS);                                                       \
+        const auto w0 = CTI_F6_SWAP(own[0], fa[i][0]);                                                                                \
+        const auto w1 = CTI_F6_SWAP(own[1], fa[i][1]);                                                                                \
+        const auto w2 = CTI_F6_SWAP(own[2], fa[i][2]);                                                                                \
+        a6[i][0] = w0[0]; a6[i][1] = w1[0]; a6[i][2] = w2[0]; a6[i][3] = w0[1]; a6[i][4] = w1[1]; a6[i][5] = w2[1]; a6[i][6] = 0; a6[i][7] = 0; \
+        sa[i] = spa[i] >> shA;                                      /* the MFMA takes byte 0: lower lanes multiply hi codes, upper lanes lo codes */ \
+    }                                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                                  \
+        const u32x6 own = f6_codes_of_f16(b16[j][0], b16[j][1], spb[j] >> shS);                                                       \
+        const auto w0 = CTI_F6_SWAP(fb[j][0], own[0]);                                                                                \
+        const auto w1 = CTI_F6_SWAP(fb[j][1], own[1]);                                                                                \
+        const auto w2 = CTI_F6_SWAP(fb[j][2], own[2]);                                                                                \
+        b6[j][0] = w0[0]; b6[j][1] = w1[0]; b6[j][2] = w2[0]; b6[j][3] = w0[1]; b6[j][4] = w1[1]; b6[j][5] = w2[1]; b6[j][6] = 0; b6[j][7] = 0; \
+        sb[j] = spb[j] >> shB;                                                                                                        \
+    }
+#define CTI_F6_MFMAS()                                                                                                                \
+    if (!(CTI_F6_ABL & 2) || p.Kb < 0) {         /* ablation: never true, the fragments stay live, the MFMAs do not issue */          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                                \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a6[i], b6[j], acc[i][j], 2, 2, 0, sa[i], 0, sb[j]);       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][0], b16[j][0], acc[i][j], 0, 0, 0);                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][1], b16[j][1], acc[i][j], 0, 0, 0);                         \
+            }                                                                                                                         \
+    }
+    int kb = 0, pos = 0;
+    bool waited = false;                                            // the vmcnt wait of the next barrier has been taken already
+    for (int b = 0;;) {
+        if (!waited) wait_block(b);
+        waited = false;
+        __builtin_amdgcn_s_barrier();
+        issue_next(pos == 0 ? NST - 1 : pos - 1);
+        const char* s = smem + pos * SLOT;
+        CTI_F6_READ_FRAGS(s)
+        CTI_F6_MFMAS()
+        pos = pos == NST - 1 ? 0 : pos + 1;
+        ++b;
+        if (++kb == nkb) {
+            if (b < nblk) { wait_block(b); waited = true; }
+            epilogue();
+            if (b >= nblk) break;
+            kb = 0; vtile += (int)gridDim.x; compute_tile_setup(); zero_acc();
+        }
+    }
+#undef CTI_F6_READ_FRAGS
+#undef CTI_F6_SWAP
+#undef CTI_F6_MFMAS
+#if CTI_F6_ABL & 128
+    if (t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.C[2 * blockIdx.x] = (float)(__builtin_readcyclecounter() - probe_c0); p.C[2 * blockIdx.x + 1] = (float)(__builtin_amdgcn_s_memrealtime() - probe_r0);
+    }
+#endif
+}
 
 template <int EPI>
 int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
@@ -446,11 +406,6 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
     if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
     long long grid = n_cu;
     if (grid > total) grid = total;
-#ifndef CTI_F6_DESYNC
-#define CTI_F6_DESYNC 100        // percent of one estimated tile time
-#endif
-    // one tile ~ 2 * BM * BN * K flops at ~2 TFLOP/s per CU (the measured full-chip rate of this kernel / 256)
-    p.desync_ticks = total >= 2 * grid ? (int)(2.0 * G::BM * G::BN * p.Kb * 32 / 2.0e12 * 1.0e8 * CTI_F6_DESYNC / 100.0) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NTHR), G::LDS, st, p);
     return launch_status("gemm_nt_f16f6");
 }
@@ -471,22 +426,17 @@ int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st) {
     if ((a.A.rows_alloc | a.A.rows_allocS | a.B.rows_alloc | a.B.rows_allocS) & 7) return fail(CTI_E_ALIGN, "gemm_nt_f16f6: plane row counts must be multiples of 8");
     if (a.nb > 1 && ((a.rA | a.rB) & 7)) return fail(CTI_E_ALIGN, "gemm_nt_f16f6: batch strides rA=%lld rB=%lld must be multiples of 8 rows", (long long)a.rA, (long long)a.rB);
     F6P p{};
-    p.AH = reinterpret_cast<const char*>(a.A.H); p.AFH = reinterpret_cast<const char*>(a.A.FH); p.AFL = reinterpret_cast<const char*>(a.A.FL); p.AS = reinterpret_cast<const char*>(a.A.S);
-    p.BH = reinterpret_cast<const char*>(a.B.H); p.BFH = reinterpret_cast<const char*>(a.B.FH); p.BFL = reinterpret_cast<const char*>(a.B.FL); p.BS = reinterpret_cast<const char*>(a.B.S);
+    p.AH = reinterpret_cast<const char*>(a.A.H); p.AFL = reinterpret_cast<const char*>(a.A.FL); p.AS = reinterpret_cast<const char*>(a.A.S);
+    p.BH = reinterpret_cast<const char*>(a.B.H); p.BFL = reinterpret_cast<const char*>(a.B.FL); p.BS = reinterpret_cast<const char*>(a.B.S);
     p.pA = a.A.rows_alloc; p.pAS = a.A.rows_allocS; p.pB = a.B.rows_alloc; p.pBS = a.B.rows_allocS;
     p.rA = a.rA; p.rB = a.rB; p.M = a.M; p.N = a.N; p.Kb = a.A.Kb;
     p.C = a.C; p.ldc_m = a.ldc_m; p.ldc_n = a.ldc_n; p.sC = a.sC; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.scale = a.scale; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.bias = a.bias; p.relu = a.relu;
-    p.P = a.P; p.Np = a.Np;
     switch (a.epi) {
         case 0: p.gdiv = 1; return launch_f6<F6_EPI_F32>(p, a.nb, a.N, st);
         case 3:
             if (p.gdiv == 2 && a.ldc_n == 2) return launch_f6<F6_EPI_INTERLEAVE2>(p, a.nb, a.N, st);
             return launch_f6<F6_EPI_INTERLEAVE>(p, a.nb, a.N, st);
-        case 4:
-            if (a.nb != 1) return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: planes output needs nb = 1");
-            if (a.Np % 32 != 0 || a.Np < a.N) return fail(CTI_E_SHAPE, "gemm_nt_f16f6: Np=%d (N=%d) must be a multiple of 32", a.Np, a.N);
-            return launch_f6<F6_EPI_PLANES>(p, a.nb, a.Np, st);
         default: return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: epi=%d", a.epi);
     }
 }

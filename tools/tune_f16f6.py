@@ -2,7 +2,7 @@
 """A/B tuner for the f16f6 GEMM (cti_gemm_f16f6.hip): builds one libcti_hip_<name>.so per -D flag set here, then on the GPU loads them all in
 ONE process and times cti_gemm_nt_f16f6 at the BASELINE configs[1] mode-3 shape in interleaved rounds.
     python tools/tune_f16f6.py build name1:-DFOO=1 name2:"-DFOO=2 -DBAR" ...      (here; the .so files travel with gpurun)
-    python tools/tune_f16f6.py run [rounds] [B]                                   (on the GPU box)
+    python tools/tune_f16f6.py run [rounds] [B] [K,K,..]                                (on the GPU box)
 """
 import ctypes as C
 import glob
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 VDIR = os.path.join(ROOT, "iccv19_vqa-cti_amd", "lib", "variants")
 
 
-def run(rounds=5, B=256):
+def run(rounds=5, B=256, K=512):
     import torch
     import cti_amd
     L, ops = cti_amd.pkg._lib, cti_amd.ops
@@ -27,7 +27,7 @@ def run(rounds=5, B=256):
             fn = getattr(l, name)
             fn.restype, fn.argtypes = L.SIGNATURES[name]
         libs[os.path.basename(f)[len("libcti_hip_"):-3]] = l
-    V, Q, A, G, K = 36, 14, 3129, 2, 512
+    V, Q, A, G = 36, 14, 3129, 2
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(1)
     M = torch.randn(B * V * Q * G, K, device=dev, generator=g) * 8.0
@@ -46,6 +46,10 @@ def run(rounds=5, B=256):
                                          V * Q * G, A, K, 0, 1, 0, 0, st)
                 assert rc == 0, (name, l.cti_last_error_string())
             e1.record(); torch.cuda.synchronize()
+            if name.startswith("clk") and rnd == rounds:               # -DCTI_F6_ABL=128 variants: per-workgroup (shader cycles, 100 MHz ticks)
+                pr = out.view(-1)[:512].view(256, 2).double()
+                print("K=%d %-12s shader clock %.0f MHz (min %.0f max %.0f), workgroup time %.3f ms" % (
+                    K, name, (pr[:, 0] / pr[:, 1] * 100).mean().item(), (pr[:, 0] / pr[:, 1] * 100).min().item(), (pr[:, 0] / pr[:, 1] * 100).max().item(), pr[:, 1].mean().item() / 1e5))
             if rnd:
                 times[name].append(e0.elapsed_time(e1) / 3)
             elif ref is None:
@@ -54,7 +58,7 @@ def run(rounds=5, B=256):
                 print("%-12s max diff vs first variant: %.2e" % (name, (out[:2] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)))
     flops = 2.0 * B * V * Q * G * A * K
     for name, ts in times.items():
-        print("%-12s median %.3f ms (min %.3f)  %.0f TFLOP/s" % (name, statistics.median(ts), min(ts), flops / statistics.median(ts) / 1e9))
+        print("K=%d %-12s median %.3f ms (min %.3f)  %.0f TFLOP/s" % (K, name, statistics.median(ts), min(ts), flops / statistics.median(ts) / 1e9))
 
 
 if __name__ == "__main__":
@@ -62,4 +66,5 @@ if __name__ == "__main__":
         import tune_gemm
         tune_gemm.build(sys.argv[2:])
     else:
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 256)
+        for K in ([int(k) for k in sys.argv[4].split(",")] if len(sys.argv) > 4 else [512]):
+            run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 256, K)
