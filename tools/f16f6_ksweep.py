@@ -37,3 +37,14 @@ for K in (32, 64, 128, 256, 512, 1024):
     ms = e0.elapsed_time(e1) / 10
     print("K=%4d  %.3f ms   per tile and CU %.2f us   (%d K blocks)" % (K, ms, ms * 1e3 / (tiles / 256), K // 32))
     del pa, pb
+
+# the output stream alone, for scale: torch's fill of the same 3.2 GB buffer
+for _ in range(2):
+    out.zero_()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    out.zero_()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("fill of the %.2f GB output: %.3f ms = %.2f TB/s" % (out.numel() * 4 / 1e9, ms, out.numel() * 4 / ms / 1e9))
