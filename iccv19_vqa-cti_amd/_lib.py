@@ -30,6 +30,9 @@ SIGNATURES = {
     "cti_event_record": (_int, [_vp, _vp]),
     "cti_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "cti_tcnet_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "cti_tcnet_forward_sm": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "cti_tcnet_softmax_partials_bytes": (_sz, [_int] * 7),
+    "cti_masked_softmax_tri_from_partials_fwd": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_tcnet_prepare": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _sz, _vp]),
     "cti_tcnet_prepared_bytes": (_sz, [_int] * 7),
     "cti_tcnet_forward_workspace_bytes": (_sz, [_int] * 11),

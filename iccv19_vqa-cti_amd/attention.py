@@ -43,13 +43,15 @@ class TriAttention(nn.Module):
         self.TriAtt = TCNet(v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, dropout=dropout, k=k)
 
     def forward(self, v, q, a):
-        logits, mask = self.TriAtt(v, q, a, _want_mask=True)
+        logits, mask, partials = self.TriAtt(v, q, a, _want_mask=True, _want_sm_partials=True)
         if logits.dim() != 5:
             # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises
             raise RuntimeError("TriAttention needs glimpse >= 2 (the reference fails the same way: a 5-D mask is "
                                "expanded to the 4-D logits at src/attention.py:55)")
         if _needs_grad(logits):
             p = AG.TriSoftmaxFn.apply(logits, mask)
+        elif partials is not None:                         # the mode-3 GEMM already reduced its outputs: the softmax reads the logits once
+            p = ops.masked_softmax_tri_from_partials_(logits, mask, partials)
         else:
             p = ops.masked_softmax_tri_(logits, mask)
         return p, logits

@@ -166,6 +166,77 @@ __global__ __launch_bounds__(256) void tri_normalise_v4_kernel(const float* __re
     }
 }
 
+// G = 2 normalise pass that also applies the mask (the partial pass ran in the GEMM's epilogue and left the logits untouched): masked
+// rows get -inf in `logits` (the reference's in-place masked_fill_) and exp(-inf - m) = 0 in p.  Two positions per thread and 16-B access,
+// the owning object v = n / QA tracked incrementally as in tri_partial_g2_kernel.
+__global__ __launch_bounds__(SM_THREADS) void tri_normalise_mask_g2_kernel(float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                                          const float* __restrict__ stats, float* __restrict__ p,
+                                                                          int V, int64_t QA, int64_t chunk_n) {
+    const int b = blockIdx.y, c = blockIdx.x, t = threadIdx.x;
+    const int64_t N = (int64_t)V * QA;
+    const int64_t n_lo = (int64_t)c * chunk_n, n_hi = min(N, n_lo + chunk_n);
+    float* x = logits + (int64_t)b * N * 2;
+    float* y = p + (int64_t)b * N * 2;
+    const uint8_t* mk = mask + (int64_t)b * V;
+    const float* st = stats + (int64_t)b * 4;
+    constexpr float L2E = 1.4426950408889634f;
+    // exp(x - m) / S = exp2(x * log2(e) - m * log2(e)) * (1 / S): one FMA and one v_exp_f32 per element
+    const float m0 = st[0] * L2E, i0 = 1.f / st[1], m1 = st[2] * L2E, i1 = 1.f / st[3];
+    auto pr = [&](float4 v4) {
+        return make_float4(__builtin_amdgcn_exp2f(fmaf(v4.x, L2E, -m0)) * i0, __builtin_amdgcn_exp2f(fmaf(v4.y, L2E, -m1)) * i1,
+                           __builtin_amdgcn_exp2f(fmaf(v4.z, L2E, -m0)) * i0, __builtin_amdgcn_exp2f(fmaf(v4.w, L2E, -m1)) * i1);
+    };
+    // two 16-B loads in flight per thread: positions (n, n+1) and (n + 512, n + 513)
+    int64_t n = n_lo + 2 * t;
+    int64_t va = n < n_hi ? n / QA : 0, ba = (va + 1) * QA;                        // object of the first pair and the first position of the next object
+    int64_t vb = n + 2 * SM_THREADS < n_hi ? (n + 2 * SM_THREADS) / QA : 0, bb = (vb + 1) * QA;
+    for (; n + 2 * SM_THREADS + 1 < n_hi; n += 4 * SM_THREADS) {
+        const int64_t n2 = n + 2 * SM_THREADS;
+        while (n >= ba) { ++va; ba += QA; }
+        while (n2 >= bb) { ++vb; bb += QA; }
+#ifndef CTI_SM_NT
+#define CTI_SM_NT 0        // 1: non-temporal loads and stores (measured: no difference, 351 vs 347 us at B = 64)
+#endif
+#if CTI_SM_NT
+        typedef float nf4 __attribute__((ext_vector_type(4)));
+        const nf4 un = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(x + n * 2)), wn = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(x + n2 * 2));
+        float4 u = make_float4(un[0], un[1], un[2], un[3]), w = make_float4(wn[0], wn[1], wn[2], wn[3]);
+#else
+        float4 u = *reinterpret_cast<const float4*>(x + n * 2), w = *reinterpret_cast<const float4*>(x + n2 * 2);
+#endif
+        const bool ua = mk[va] != 0, ub = (n + 1 >= ba) ? (mk[va + 1] != 0) : ua;
+        const bool wa = mk[vb] != 0, wb = (n2 + 1 >= bb) ? (mk[vb + 1] != 0) : wa;
+        if (ua) { u.x = neg_inf(); u.y = neg_inf(); }
+        if (ub) { u.z = neg_inf(); u.w = neg_inf(); }
+        if (wa) { w.x = neg_inf(); w.y = neg_inf(); }
+        if (wb) { w.z = neg_inf(); w.w = neg_inf(); }
+        if (ua || ub) *reinterpret_cast<float4*>(x + n * 2) = u;
+        if (wa || wb) *reinterpret_cast<float4*>(x + n2 * 2) = w;
+#if CTI_SM_NT
+        { const float4 a = pr(u), b2 = pr(w); nf4 an = {a.x, a.y, a.z, a.w}, bn = {b2.x, b2.y, b2.z, b2.w};
+          __builtin_nontemporal_store(an, reinterpret_cast<nf4*>(y + n * 2)); __builtin_nontemporal_store(bn, reinterpret_cast<nf4*>(y + n2 * 2)); }
+#else
+        *reinterpret_cast<float4*>(y + n * 2) = pr(u);
+        *reinterpret_cast<float4*>(y + n2 * 2) = pr(w);
+#endif
+    }
+    for (; n < n_hi; n += 2 * SM_THREADS) {                                        // the chunk's tail: one pair (or one position) per trip
+        while (n >= ba) { ++va; ba += QA; }
+        if (n + 1 < n_hi) {
+            float4 u = *reinterpret_cast<const float4*>(x + n * 2);
+            const bool ua = mk[va] != 0, ub = (n + 1 >= ba) ? (mk[va + 1] != 0) : ua;
+            if (ua) { u.x = neg_inf(); u.y = neg_inf(); }
+            if (ub) { u.z = neg_inf(); u.w = neg_inf(); }
+            if (ua || ub) *reinterpret_cast<float4*>(x + n * 2) = u;
+            *reinterpret_cast<float4*>(y + n * 2) = pr(u);
+        } else {
+            float2 v2 = *reinterpret_cast<const float2*>(x + n * 2);
+            if (mk[va] != 0) { v2.x = neg_inf(); v2.y = neg_inf(); *reinterpret_cast<float2*>(x + n * 2) = v2; }
+            *reinterpret_cast<float2*>(y + n * 2) = make_float2(__builtin_amdgcn_exp2f(fmaf(v2.x, L2E, -m0)) * i0, __builtin_amdgcn_exp2f(fmaf(v2.y, L2E, -m1)) * i1);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void tri_combine_kernel(const float* __restrict__ part, float* __restrict__ stats /* [B][G][2] */,
                                                          int G, int nchunk) {
     const int b = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
@@ -1178,6 +1249,28 @@ extern "C" int cti_masked_softmax_tri_fwd(float* logits, const uint8_t* mask, fl
         hipLaunchKernelGGL(tri_normalise_kernel, dim3(gx, B), dim3(256), 0, st, logits, stats, p, NG, G);
     }
     return launch_status("cti_masked_softmax_tri_fwd/normalise");
+}
+
+extern "C" int cti_masked_softmax_tri_from_partials_fwd(float* logits, const uint8_t* mask, const float* partials, size_t partials_bytes, float* p,
+                                                        int B, int V, int64_t QA, int G, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(logits); CTI_REQUIRE_PTR(mask); CTI_REQUIRE_PTR(partials); CTI_REQUIRE_PTR(p); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && V > 0 && QA > 0 && B <= 65535, CTI_E_SHAPE, "cti_masked_softmax_tri_from_partials_fwd: B=%d V=%d QA=%lld", B, V, (long long)QA);
+    CTI_REQUIRE(G == 2, CTI_E_UNSUPPORTED, "cti_masked_softmax_tri_from_partials_fwd: G=%d (the fused partial pass exists for glimpse 2)", G);
+    const size_t per = sizeof(float) * (size_t)B * G * 2;
+    CTI_REQUIRE(partials_bytes >= per && partials_bytes % per == 0, CTI_E_SHAPE, "cti_masked_softmax_tri_from_partials_fwd: %zu bytes of partials are not a whole number of (B, G) pairs", partials_bytes);
+    CTI_REQUIRE(workspace_bytes >= per, CTI_E_WORKSPACE, "cti_masked_softmax_tri_from_partials_fwd: workspace %zu < %zu", workspace_bytes, per);
+    CTI_REQUIRE(((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(p)) & 15) == 0 && (((int64_t)V * QA) & 1) == 0, CTI_E_ALIGN,
+                "cti_masked_softmax_tri_from_partials_fwd: logits / p must be 16-B aligned and V*QA even");
+    const int nchunk = (int)(partials_bytes / per);
+    float* stats = static_cast<float*>(workspace);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(tri_combine_kernel, dim3(B, G), dim3(64), 0, st, partials, stats, G, nchunk);
+    int rc = launch_status("cti_masked_softmax_tri_from_partials_fwd/combine"); if (rc) return rc;
+    const int64_t N = (int64_t)V * QA;
+    int64_t cn = 16384;                                              // positions per workgroup (even): 32 trips of 512
+    const int64_t nc = (N + cn - 1) / cn;
+    hipLaunchKernelGGL(tri_normalise_mask_g2_kernel, dim3((unsigned)nc, B), dim3(SM_THREADS), 0, st, logits, mask, stats, p, V, QA, cn);
+    return launch_status("cti_masked_softmax_tri_from_partials_fwd/normalise");
 }
 
 extern "C" int cti_masked_softmax_bi_fwd(float* logits, const uint8_t* mask, float* p, int B, int G, int V, int Q, void* stream) {

@@ -110,7 +110,13 @@ struct F6GemmArgs {
                                                // 3: rows interleaved by gdiv (the mode-3 product: row m' = m*gdiv + g -> C[(m'/gdiv)*ldc_m + m'%gdiv + n*ldc_n])
     float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
     const float* scale; int scale_div; const float* bias; int relu;
+    // epi 3 with gdiv = 2 only, optional: softmax partials of the product (the Tri softmax of attention.py:55-58 runs over all of a
+    // batch's outputs per g = m % 2).  Every wave of every tile writes (max, sum exp(x - max)) per g over its VALID outputs whose row is
+    // not masked -- row m belongs to object m / sm_rows_per_obj, masked iff sm_mask[z * sm_objs + object] != 0 -- to
+    // sm_part[((z * f6_sm_chunks(M, N) + chunk) * 2 + g) * 2 + {0, 1}]: the layout of the softmax's own partial pass.
+    float* sm_part; const uint8_t* sm_mask; int sm_rows_per_obj, sm_objs;
 };
+int f6_sm_chunks(int M, int N);                // partial (max, sum) pairs per batch and g that gemm_nt_f16f6 writes for an M x N product
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);
 int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st);
 #if defined(__HIPCC__)

@@ -68,8 +68,9 @@ struct F6P {
     int M, N, Kb, total_tiles;
     float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
     const float* scale; int scale_div; const float* bias; int relu;
+    float* sm_part; const uint8_t* sm_mask; int sm_rows_per_obj, sm_objs; unsigned sm_magic;      // row / rows_per_obj = umulhi(row, magic) (rows < 2^24)
 };
-enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3 };
+enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_INTERLEAVE2_SM = 5 };   // _SM: + softmax partials
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -121,11 +122,61 @@ __device__ __forceinline__ u32x6 f6_codes_of_f16(f16x8 k0, f16x8 k1, int sbyte) 
 
 // ---- epilogue of the tile at (z, m0, n0): the wave's TM x TN accumulator tiles -> C
 template <int EPI, class G>
-__device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], const F6P& p, int z, int cm0, int cn0, int wm, int wn, int lane) {
+__device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], const F6P& p, int z, int cm0, int cn0, int wm, int wn, int lane, int tile_in_batch, int tiles_per_batch) {
     constexpr int TM = G::TM, TN = G::TN;
     const int r = lane & 31, h = lane >> 5;
     float* C = p.C + (int64_t)z * p.sC;
-    if (EPI == F6_EPI_INTERLEAVE2) {
+    if (EPI == F6_EPI_INTERLEAVE2 || EPI == F6_EPI_INTERLEAVE2_SM) {
+        if (EPI == F6_EPI_INTERLEAVE2_SM) {
+            // Softmax partials of this wave's 64 x 96 outputs, BEFORE the stores (whose predicates are the epilogue's scalar-register peak: the
+            // partials' own scalars are dead by then).  Register e of a tile is row
+            // 8 (e >> 2) + 4 h + (e & 3) of its 32, so g = e & 1.  Sweep 1 replaces what must not count (rows beyond M or of a masked object,
+            // columns beyond N) by -inf and takes the maxima; sweep 2 is one FMA and one v_exp_f32 per element: exp2(x log2e - max log2e).
+            constexpr float L2E = 1.4426950408889634f;
+            const float ninf = -__builtin_huge_valf();
+            float mx[2] = {ninf, ninf}, sum[2] = {0.f, 0.f};
+            f32x16 x[TM][TN];
+            bool cok[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) cok[j] = cn0 + (wn * TN + j) * 32 + r < p.N;
+            // one (v,q) row -- a pair of registers per tile -- at a time, its predicate kept in a VGPR (sixteen live lane masks cost the K loop
+            // its scalar registers: 118 spill moves per block, measured)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int m = cm0 + (wm * TM + i) * 32 + 8 * eg + 4 * h + 2 * pr;
+                        const unsigned mc = (unsigned)min(m, p.M - 1);         // (the load is unconditional: sixteen divergent branches hold sixteen saved exec masks)
+                        const uint8_t mb = p.sm_mask[(int64_t)z * p.sm_objs + (p.sm_magic ? __umulhi(mc, p.sm_magic) : mc)];
+                        int okv = (int)(m < p.M) & (int)(mb == 0);
+                        asm volatile("" : "+v"(okv));               // held as a VGPR value, compared where it is used
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int g = 0; g < 2; ++g) {
+                                const int e = eg * 4 + pr * 2 + g;
+                                const float v = (okv != 0 && cok[j]) ? acc[i][j][e] : ninf;
+                                x[i][j][e] = v;
+                                mx[g] = fmaxf(mx[g], v);
+                            }
+                    }
+            const float sh[2] = {mx[0] == ninf ? 0.f : mx[0] * L2E, mx[1] == ninf ? 0.f : mx[1] * L2E};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum[e & 1] += __builtin_amdgcn_exp2f(fmaf(x[i][j][e], L2E, -sh[e & 1]));
+            float* o = p.sm_part + (((int64_t)z * tiles_per_batch + tile_in_batch) * G::NW + wm * G::WN + wn) * 4;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float wmx = wave_max(mx[g]);
+                const float ws = wave_sum(mx[g] == ninf ? 0.f : sum[g] * __builtin_amdgcn_exp2f((mx[g] - wmx) * L2E));
+                if (lane == 0) { o[g * 2] = wmx; o[g * 2 + 1] = ws; }
+            }
+        }
         // GEMM rows (2m, 2m+1) are the two glimpses of one (v,q) row: registers e, e+1 (e even) of a lane are the adjacent floats
         // out[b, vq, a, 0:2] of column a = n.  Neighbouring lanes (columns n, n+1) trade halves through a DPP quad swap so that the even lane
         // stores out[vq, n:n+2, 0:2] and the odd lane out[vq+1, n-1:n+1, 0:2]: ONE 16-B store per four registers instead of two 8-B ones --
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     const int shS = (r & 1) * 16;                                   // the row's (hi, lo) scale bytes inside that dword (tile rows are even offsets apart)
     const int shA = shS + h * 8, shB = shS + (1 - h) * 8;           // the byte the MFMA takes: A lower lanes hi / upper lo, B the other way round
 
-    auto epilogue = [&]() { f6_epilogue<EPI, G>(acc, p, z, m0, n0, wm, wn, lane); };
+    auto epilogue = [&]() { f6_epilogue<EPI, G>(acc, p, z, m0, n0, wm, wn, lane, (m0 / BM) * tiles_n + n0 / BN, tiles_m * tiles_n); };
 
     // ---- the stream.  Per block b: [vmcnt: my pieces of b have landed] raw barrier (everyone's have, and block b - 1 is free) -> the
     // stream's next block is issued into the freed slot -> fragments -> MFMAs; after a tile's last block its epilogue.
@@ -420,6 +471,8 @@ int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Plan
     return launch_status("quantize_f16f6");
 }
 
+int f6_sm_chunks(int M, int N) { return ((M + GeoF6::BM - 1) / GeoF6::BM) * ((N + GeoF6::BN - 1) / GeoF6::BN) * GeoF6::NW; }
+
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st) {
     if (a.A.Kb != a.B.Kb || a.A.Kb <= 0) return fail(CTI_E_SHAPE, "gemm_nt_f16f6: K blocks %d vs %d", a.A.Kb, a.B.Kb);
     if (a.M <= 0 || a.N <= 0 || a.nb <= 0) return fail(CTI_E_SHAPE, "gemm_nt_f16f6: M=%d N=%d nb=%d", a.M, a.N, a.nb);
@@ -432,10 +485,14 @@ int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st) {
     p.rA = a.rA; p.rB = a.rB; p.M = a.M; p.N = a.N; p.Kb = a.A.Kb;
     p.C = a.C; p.ldc_m = a.ldc_m; p.ldc_n = a.ldc_n; p.sC = a.sC; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.scale = a.scale; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.bias = a.bias; p.relu = a.relu;
+    p.sm_part = a.sm_part; p.sm_mask = a.sm_mask; p.sm_rows_per_obj = a.sm_rows_per_obj > 0 ? a.sm_rows_per_obj : 1; p.sm_objs = a.sm_objs;
+    p.sm_magic = p.sm_rows_per_obj > 1 ? (unsigned)(((1ull << 32) + p.sm_rows_per_obj - 1) / p.sm_rows_per_obj) : 0u;
     switch (a.epi) {
         case 0: p.gdiv = 1; return launch_f6<F6_EPI_F32>(p, a.nb, a.N, st);
         case 3:
-            if (p.gdiv == 2 && a.ldc_n == 2) return launch_f6<F6_EPI_INTERLEAVE2>(p, a.nb, a.N, st);
+            if (a.sm_part && (a.M >= (1 << 24) || a.sm_rows_per_obj >= 256)) return fail(CTI_E_SHAPE, "gemm_nt_f16f6: softmax partials need M < 2^24 and rows per object < 256");
+            if (a.sm_part && !(p.gdiv == 2 && a.ldc_n == 2 && a.sm_mask)) return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: softmax partials need gdiv = 2, ldc_n = 2 and a mask");
+            if (p.gdiv == 2 && a.ldc_n == 2) return a.sm_part ? launch_f6<F6_EPI_INTERLEAVE2_SM>(p, a.nb, a.N, st) : launch_f6<F6_EPI_INTERLEAVE2>(p, a.nb, a.N, st);
             return launch_f6<F6_EPI_INTERLEAVE>(p, a.nb, a.N, st);
         default: return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: epi=%d", a.epi);
     }

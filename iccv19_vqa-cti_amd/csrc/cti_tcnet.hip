@@ -187,12 +187,50 @@ extern "C" size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, 
     return carve(d, prec, nullptr).bytes;
 }
 
+static bool sm_partials_supported(int h, int G, int prec) { return prec == CTI_PREC_F16F6 && G == 2 && h % 32 == 0; }
+
+extern "C" size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec) {
+    if (B <= 0 || V <= 0 || Q <= 0 || A <= 0 || !sm_partials_supported(h, G, prec)) return 0;
+    return sizeof(float) * (size_t)B * f6_sm_chunks(V * Q * G, A) * G * 2;
+}
+
+static int tcnet_forward_impl(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                              const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                              const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                              uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                              int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part);
+
 extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                                  const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                                  uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                  int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                                  void* ev_core_end, void* aux_stream, void* stream) {
+    return tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, out, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
+                              G, act, prec, prepared, workspace, workspace_bytes, ev_core_begin, ev_core_end, aux_stream, stream, nullptr);
+}
+
+extern "C" int cti_tcnet_forward_sm(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                                    const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                                    const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                                    uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                    int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                    void* ev_core_end, void* aux_stream, void* stream, float* sm_partials, size_t sm_partials_bytes) {
+    CTI_REQUIRE_PTR(sm_partials); CTI_REQUIRE_PTR(zero_mask);
+    const size_t need = cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, prec);
+    CTI_REQUIRE(need != 0, CTI_E_UNSUPPORTED, "cti_tcnet_forward_sm: no softmax partials for prec=%d G=%d h=%d (cti_tcnet_softmax_partials_bytes is 0)", prec, G, h);
+    CTI_REQUIRE(sm_partials_bytes >= need, CTI_E_WORKSPACE, "cti_tcnet_forward_sm: partials block %zu < %zu", sm_partials_bytes, need);
+    return tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, out, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
+                              G, act, prec, prepared, workspace, workspace_bytes, ev_core_begin, ev_core_end, aux_stream, stream, sm_partials);
+}
+
+static int tcnet_forward_impl(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                              const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                              const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                              uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                              int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -312,6 +350,7 @@ extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a,
         F6GemmArgs c{};                                      // mode 3 + rank sum on the f16 + fp6 planes
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
         c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
+        if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }     // the Tri softmax's partial pass, from the accumulators
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);

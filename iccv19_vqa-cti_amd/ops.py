@@ -376,10 +376,12 @@ def tcnet_prepare(tucker, rank, T_g, prec=None):
     return block, pr
 
 
-def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None):
+def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False):
     """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
     the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  prepared: the (block, precision) pair of tcnet_prepare for
-    these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)]."""
+    these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)] [, partials]: with want_sm_partials (needs want_mask) the third
+    value is the Tri softmax's partial pass left by the mode-3 GEMM (masked_softmax_tri_from_partials_), or None where the library has no
+    fused form for this precision / glimpse."""
     for t, n in ((v, "v"), (q, "q"), (a, "a"), (T_g, "T_g")):
         _req(t, n)
     v, q, a = v.contiguous(), q.contiguous(), a.contiguous()
@@ -400,8 +402,10 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     Tg = T_g.contiguous()
     out = torch.empty((B, V, Q, A, G), device=v.device, dtype=torch.float32)
     mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
+    if want_sm_partials and not want_mask:
+        raise ValueError("want_sm_partials needs want_mask")
     if out.numel() == 0:                                   # empty batch (or a zero-length axis): nothing to launch
-        return (out, mask) if want_mask else out
+        return ((out, mask, None) if want_sm_partials else (out, mask)) if want_mask else out
     pr = _prec(prec, fused=True)
     if pr == L.PREC_F16F6 and h % 32:
         pr = L.PREC_BF16X3
@@ -417,11 +421,38 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     if _prof is not None:                       # hipEvents around the mode-3 GEMM, recorded by the library on the launch stream
         ev0, ev1 = lib.cti_event_create(), lib.cti_event_create()
         _prof.setdefault("paralind_core", []).append(_LibEventPair(ev0, ev1))
+    part = None
+    if want_sm_partials:
+        pb = lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, pr)
+        if pb and out.data_ptr() % 16 == 0 and (V * Q * A) % 2 == 0:
+            part = torch.empty(pb, device=v.device, dtype=torch.uint8)
     with _timed("tcnet_forward"):
-        L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
-                                      _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
-                                      prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
+        if part is not None:
+            L.check(lib.cti_tcnet_forward_sm(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+                                             _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                             prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream(), part.data_ptr(), pb),
+                    "cti_tcnet_forward_sm")
+        else:
+            L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+                                          _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                          prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
+    if want_sm_partials:
+        return out, mask, part
     return (out, mask) if want_mask else out
+
+
+def masked_softmax_tri_from_partials_(logits, mask, partials):
+    """masked_softmax_tri_ when tcnet_forward(want_sm_partials=True) already ran the partial pass: one read of the logits instead of two."""
+    _req(logits, "logits"); _req(mask, "mask", torch.uint8)
+    assert logits.is_contiguous() and mask.is_contiguous()
+    B, V, Q, A, G = logits.shape
+    p = torch.empty_like(logits)
+    ws = torch.empty(B * G * 2, device=logits.device, dtype=torch.float32)
+    with _timed("masked_softmax_tri"):
+        L.check(L.lib().cti_masked_softmax_tri_from_partials_fwd(logits.data_ptr(), mask.data_ptr(), partials.data_ptr(), partials.numel(), p.data_ptr(),
+                                                                 B, V, Q * A, G, ws.data_ptr(), ws.numel() * 4, _stream()),
+                "cti_masked_softmax_tri_from_partials_fwd")
+    return p
 
 
 def masked_softmax_tri_(logits, mask):

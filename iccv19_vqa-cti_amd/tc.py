@@ -112,11 +112,15 @@ class TCNet(nn.Module):
         return (self._act in ('ReLU', '') and not self.training and not _needs_grad(*inputs, *self.parameters())
                 and all(len([m for m in n.main if hasattr(m, "weight_v")]) == 1 for n in (self.v_tucker, self.q_tucker, self.a_tucker)))
 
-    def forward(self, v, q, a, _want_mask=False):
+    def forward(self, v, q, a, _want_mask=False, _want_sm_partials=False):
+        """_want_mask / _want_sm_partials (TriAttention's private arguments): also return zero_row_mask(v) and, third, the softmax partials
+        the fused forward can leave behind (None when this call did not produce them)."""
         if self._fusable(v, q, a):
             tucker, rank = self._fused_args()
             res = ops.tcnet_forward(v.float(), q.float(), a.float(), tucker, rank, self.T_g.detach(), relu=(self._act == 'ReLU'),
-                                    want_mask=_want_mask, prepared=self._prep)
+                                    want_mask=_want_mask, prepared=self._prep, want_sm_partials=_want_sm_partials)
+            if _want_sm_partials:
+                return res[0].squeeze(4), res[1], res[2]
             if _want_mask:
                 return res[0].squeeze(4), res[1]
             return res.squeeze(4)
@@ -140,6 +144,8 @@ class TCNet(nn.Module):
             Teff = ops.teff_scramble(T.detach()[0, :, :, :, :, :, 0])
             M = ops.paralind_mbuild(Vr, Qr, Teff)
             f_emb = ops.paralind_core(M, Ar)                   # (B,V,Q,A,G)
+        if _want_sm_partials:
+            return f_emb.squeeze(4), ops.zero_row_mask(v), None
         if _want_mask:
             return f_emb.squeeze(4), ops.zero_row_mask(v)
         return f_emb.squeeze(4)

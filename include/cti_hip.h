@@ -143,6 +143,19 @@ int cti_tcnet_forward(const float* v, const float* q, const float* a, const floa
                       void* ev_core_end, void* aux_stream, void* stream);
 size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                          int G, int prec);
+/* cti_tcnet_forward that also leaves the PARTIAL PASS of TriAttention's softmax (src/attention.py:55-58) behind: every wave of the mode-3
+ * GEMM reduces its own accumulators to (max, sum exp(x - max)) per glimpse over the outputs whose v row is not all-zero (zero_mask,
+ * required here), so that the softmax reads the (B,V,Q,A,G) logits ONCE (cti_masked_softmax_tri_from_partials_fwd) instead of twice.
+ * `out` itself is written unmasked, exactly as by cti_tcnet_forward.  sm_partials: a device block of cti_tcnet_softmax_partials_bytes(...)
+ * bytes, laid out [B][chunk][G][2]; that function returns 0 where the fused pass does not exist (today: outside prec = CTI_PREC_F16F6,
+ * G = 2, h % 32 == 0) -- callers then use cti_tcnet_forward + cti_masked_softmax_tri_fwd. */
+int cti_tcnet_forward_sm(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                         const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                         const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
+                         uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                         int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                         void* ev_core_end, void* aux_stream, void* stream, float* sm_partials, size_t sm_partials_bytes);
+size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec);
 /* The batch-independent part of cti_tcnet_forward, computed once per parameter update: the six weight-norm scales, T_eff (and its
  * [r][(j,k,g)][i] copy), and in the bf16 modes the hi/lo operand planes of the six weight matrices.  `prepared`: a device block of
  * cti_tcnet_prepared_bytes(...) owned by the caller; valid until a weight, T_g or the precision changes. */
@@ -158,6 +171,10 @@ size_t cti_tcnet_prepared_bytes(int v_dim, int q_dim, int a_dim, int h, int R, i
  * An all-masked sample yields NaN like the reference.  workspace: cti_softmax_tri_workspace_bytes(). */
 int cti_masked_softmax_tri_fwd(float* logits, const uint8_t* mask, float* p, int B, int V, int64_t QA, int G,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* The same result from the partials cti_tcnet_forward_sm left (partials_bytes = what cti_tcnet_softmax_partials_bytes returned): combine,
+ * then ONE pass over the logits that fills -inf on masked rows and writes p.  G = 2; logits / p 16-B aligned.  workspace: B*G*2 floats. */
+int cti_masked_softmax_tri_from_partials_fwd(float* logits, const uint8_t* mask, const float* partials, size_t partials_bytes, float* p,
+                                             int B, int V, int64_t QA, int G, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_softmax_tri_workspace_bytes(int B, int V, int64_t QA, int G);
 
 /* Bi: logits (B, G, V, Q) contiguous; mask (B,V) or NULL (v_mask=False); p[b,g,:] = softmax over (v,q). */

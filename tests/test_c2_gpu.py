@@ -192,3 +192,40 @@ def test_f16f6_mode_on_the_small_fixtures_and_config_1():
         assert bool(torch.isfinite(big).all()) and float((big / (3.0e5 * 64) - 1).abs().max()) < 0.1
     finally:
         cti_amd.set_precision(old)
+
+
+def test_softmax_partials_from_the_gemm_epilogue_match_the_two_pass_softmax():
+    """precision='f16f6', glimpse 2: TriAttention's partial pass (per-wave max / sum of exponentials) comes out of the mode-3 GEMM's
+    accumulators (cti_tcnet_forward_sm) and the softmax reads the logits once.  Same p and the same in-place -inf fill as the stand-alone
+    masked softmax on the same logits: C2 widths with padded objects (10-36 real rows), an all-zero sample (NaN like the reference), and
+    the reduced fixtures (A = 5 < one tile)."""
+    old = cti_amd.get_precision()
+    cti_amd.set_precision("f16f6")
+    try:
+        fx, params, v, q, a, idx = gu.c2_case()
+        v = v.copy()
+        v[1] = 0                                                   # an all-masked sample
+        cases = [(_tri_from(fx.cfg, params), v, q, a)]
+        for name in ("g3_tcnet_small", "g3_tcnet_allzero_sample"):
+            f2 = gu.load(name)
+            cases.append((_tri(f2), f2.i["v"], f2.i["q"], f2.i["a"]))
+        used = 0
+        for m, v_, q_, a_ in cases:
+            with torch.no_grad():
+                raw, mask, part = m.TriAtt(T(v_), T(q_), T(a_), _want_mask=True, _want_sm_partials=True)
+                if part is None:
+                    continue
+                used += 1
+                ref_logits = raw.clone()
+                p_ref = cti_amd.ops.masked_softmax_tri_(ref_logits, mask)
+                p = cti_amd.ops.masked_softmax_tri_from_partials_(raw, mask, part)
+            pn, pr = p.cpu().numpy(), p_ref.cpu().numpy()
+            assert np.array_equal(np.isnan(pn), np.isnan(pr))
+            ok = ~np.isnan(pr)
+            assert np.max(np.abs(pn[ok] - pr[ok])) <= 1e-5 * np.max(pr[ok])
+            assert np.array_equal(raw.cpu().numpy(), ref_logits.cpu().numpy(), equal_nan=True)      # the same -inf fill, the same finite logits
+            s = pn.reshape(pn.shape[0], -1, 2).sum(1)
+            assert np.all(np.isnan(s) | (np.abs(s - 1) < 1e-4))
+        assert used >= 2
+    finally:
+        cti_amd.set_precision(old)

@@ -73,6 +73,26 @@ def main(reps=20):
         t_all = timeit(run, reps)
         t_copy = timeit(lambda: buf.copy_(lg), reps)
         report("masked_softmax_tri %s" % tag, t_all - t_copy, 2 * f * lg.numel(), B=Bc, A=A, note="copy time subtracted; bytes = read logits + write p")
+    # C2 again with the partial pass taken from the mode-3 GEMM's accumulators (cti_tcnet_forward_sm, precision f16f6): what the softmax
+    # costs is the GEMM's extra time plus combine + the one normalise pass
+    old = cti_amd.get_precision()
+    cti_amd.set_precision("f16f6")
+    try:
+        Bc, Q, A = 64, 14, 3129
+        tc = cti_amd.TCNet(2048, 1024, 300, 512, 1, 32, 2).to(DEV).eval()
+        vv, qq, aa = v[:Bc].contiguous(), torch.randn(Bc, Q, 1024, device=DEV), torch.randn(Bc, A, 300, device=DEV)
+        with torch.no_grad():
+            t_plain = timeit(lambda: tc(vv, qq, aa, _want_mask=True), reps)
+            t_sm = timeit(lambda: tc(vv, qq, aa, _want_mask=True, _want_sm_partials=True), reps)
+            lg, m, part = tc(vv, qq, aa, _want_mask=True, _want_sm_partials=True)
+            assert part is not None
+            src = lg.clone()
+            t_pass = timeit(lambda: (lg.copy_(src), ops.masked_softmax_tri_from_partials_(lg, m, part)), reps) - timeit(lambda: lg.copy_(src), reps)
+        report("masked_softmax_tri C2, partial pass in the mode-3 epilogue", (t_sm - t_plain) + t_pass, 2 * f * lg.numel(), B=Bc, A=A,
+               gemm_extra_us=round(t_sm - t_plain, 1), combine_normalise_us=round(t_pass, 1), tcnet_forward_us=round(t_plain, 1),
+               note="bytes = read logits + write p; time = (forward with partials - forward) + combine + normalise")
+    finally:
+        cti_amd.set_precision(old)
 
 
 if __name__ == "__main__":
