@@ -128,19 +128,18 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
     float* C = p.C + (int64_t)z * p.sC;
     if (EPI == F6_EPI_INTERLEAVE2 || EPI == F6_EPI_INTERLEAVE2_SM) {
         if (EPI == F6_EPI_INTERLEAVE2_SM) {
-            // Softmax partials of this wave's 64 x 96 outputs, BEFORE the stores (whose predicates are the epilogue's scalar-register peak: the
-            // partials' own scalars are dead by then).  Register e of a tile is row
-            // 8 (e >> 2) + 4 h + (e & 3) of its 32, so g = e & 1.  Sweep 1 replaces what must not count (rows beyond M or of a masked object,
-            // columns beyond N) by -inf and takes the maxima; sweep 2 is one FMA and one v_exp_f32 per element: exp2(x log2e - max log2e).
+            // Softmax partials of this wave's 64 x 96 outputs.  Register e of a tile is row 8 (e >> 2) + 4 h + (e & 3) of its 32, so g = e & 1.
+            // Two sweeps over the accumulators -- maxima, then one FMA and one v_exp_f32 per element: exp2(x log2e - max log2e) -- skipping what
+            // must not count (rows beyond M or of a masked object, columns beyond N).
             constexpr float L2E = 1.4426950408889634f;
             const float ninf = -__builtin_huge_valf();
             float mx[2] = {ninf, ninf}, sum[2] = {0.f, 0.f};
-            f32x16 x[TM][TN];
             bool cok[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) cok[j] = cn0 + (wn * TN + j) * 32 + r < p.N;
-            // one (v,q) row -- a pair of registers per tile -- at a time, its predicate kept in a VGPR (sixteen live lane masks cost the K loop
-            // its scalar registers: 118 spill moves per block, measured)
+            // row predicates (one per (v,q) row = pair of registers per tile), kept as VGPR integers and compared where they are used: sixteen
+            // live lane masks cost the K loop its scalar registers.  The mask bytes are loaded unconditionally (clamped row).
+            int okv[TM][4][2];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -148,27 +147,25 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         const int m = cm0 + (wm * TM + i) * 32 + 8 * eg + 4 * h + 2 * pr;
-                        const unsigned mc = (unsigned)min(m, p.M - 1);         // (the load is unconditional: sixteen divergent branches hold sixteen saved exec masks)
+                        const unsigned mc = (unsigned)min(m, p.M - 1);
                         const uint8_t mb = p.sm_mask[(int64_t)z * p.sm_objs + (p.sm_magic ? __umulhi(mc, p.sm_magic) : mc)];
-                        int okv = (int)(m < p.M) & (int)(mb == 0);
-                        asm volatile("" : "+v"(okv));               // held as a VGPR value, compared where it is used
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int g = 0; g < 2; ++g) {
-                                const int e = eg * 4 + pr * 2 + g;
-                                const float v = (okv != 0 && cok[j]) ? acc[i][j][e] : ninf;
-                                x[i][j][e] = v;
-                                mx[g] = fmaxf(mx[g], v);
-                            }
+                        okv[i][eg][pr] = (int)(m < p.M) & (int)(mb == 0);
                     }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (okv[i][e >> 2][(e >> 1) & 1] != 0 && cok[j]) mx[e & 1] = fmaxf(mx[e & 1], acc[i][j][e]);
             const float sh[2] = {mx[0] == ninf ? 0.f : mx[0] * L2E, mx[1] == ninf ? 0.f : mx[1] * L2E};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sum[e & 1] += __builtin_amdgcn_exp2f(fmaf(x[i][j][e], L2E, -sh[e & 1]));
+                    for (int e = 0; e < 16; ++e)
+                        if (okv[i][e >> 2][(e >> 1) & 1] != 0 && cok[j]) sum[e & 1] += __builtin_amdgcn_exp2f(fmaf(acc[i][j][e], L2E, -sh[e & 1]));
             float* o = p.sm_part + (((int64_t)z * tiles_per_batch + tile_in_batch) * G::NW + wm * G::WN + wn) * 4;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -352,8 +349,11 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     // stream's next block is issued into the freed slot -> fragments -> MFMAs; after a tile's last block its epilogue.
     // TILE BOUNDARY: the vmcnt wait that the first barrier after an epilogue needs is taken BEFORE the stores (the block in question was
     // issued two K blocks earlier), so that no wave waits for its stores to retire before the next tile's first MFMAs.
-    // (Measured and dropped with the continuous stream in place, each within +-1 %: a half-block stagger of the two waves of a SIMD,
-    // spreading the workgroups' start times over one tile, issuing the refill behind the MFMAs.)
+    // (Measured and dropped with the continuous stream in place, each within +-2 %: a half-block stagger of the two waves of a SIMD,
+    // spreading the workgroups' start times over one tile, issuing the refill behind the MFMAs, and reloading operands in place as they die
+    // so that block b + 1's reads and conversions run under block b's MFMAs (2.08 against 2.00 ms): the partner wave of the SIMD was
+    // already filling those gaps.  tools/mb/mb_issue.hip: 18 MFMAs + 100 VALU + 5 conversions per wave in registers take 1.09 us per
+    // block against 0.84 for the MFMAs alone; this loop takes 1.56 with LDS reads, DMA and barriers on top.)
     // Fragments of one K block.  A lane (row r of a 32-row tile, SIMD half h) reads its 2 x 8 f16 values (k = 8h .. 8h+7 and 16+8h .. 16+8h+7),
     // converts them to fp6 under the row's hi scale, and trades with its partner lane: v_permlane32_swap(X, Y) exchanges X's upper lanes
     // with Y's lower lanes.  A operand: X = own codes, Y = the lane's half of the lo codes from LDS; after the swap the lower lanes hold
