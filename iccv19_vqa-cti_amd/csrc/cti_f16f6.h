@@ -19,7 +19,8 @@
 // PLANES of an operand X (rows x K), Kb = ceil(K / 32) blocks, block-major like the bf16 planes (one K block of a GEMM tile is a
 // contiguous run of rows):
 //   H   f16   [Kb][rows_alloc][32]      hi part, saturated to +-65504                        64 B per (row, block)
-//   FL  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of (x - H) / 2^el, position p at bits 6p   24 B
+//   FL  e2m3  [Kb][rows_alloc][24 B]    fp6 codes of (x - H) / 2^el, position p at bits 6p of the row's six dwords, which are       24 B
+//                                      STORED in the order [0 1 3 4 2 5]: a GEMM lane half reads dwords (0,1,2) or (3,4,5) as one aligned 8-B and one 4-B load
 //   S   e8m0  [Kb][rows_allocS][2]      byte 0 = eh + 127, byte 1 = el + 127                  2 B     (2.81 B per element in all)
 // eh / el are the smallest exponents with max|.| / 2^e <= 7.5 (the largest e2m3 value) over the block (eh: of the hi part, which the GEMM
 // needs to derive its codes).  FL holds the block in the ORDER THE GEMM'S LANES MEET IT, position p <-> element k = F6_PI(p): a lane of the
@@ -162,7 +163,7 @@ __device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Pl
     for (int i = 0; i < 16; ++i) { le[i] = lf[f6_pi(2 * i)]; lo[i] = lf[f6_pi(2 * i + 1)]; }
     const f6_u32x6 fl = f6_hw_codes(le, lo, __builtin_bit_cast(float, (unsigned)sl << 23));     // 2^(byte - 127)
     uint2* fd = reinterpret_cast<uint2*>(p.FL + o * 24);
-    fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[2], fl[3]); fd[2] = make_uint2(fl[4], fl[5]);
+    fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[3], fl[4]); fd[2] = make_uint2(fl[2], fl[5]);     // dword order [0 1 3 4 2 5]: see the format notes
     *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
 }
 #endif

@@ -11,7 +11,7 @@
 // bytes), counted vmcnt and one raw s_barrier per block, persistent XCD-aware tile walk.  A workgroup's tiles are ONE stream of K
 // blocks: the ring is refilled across tile boundaries and the epilogue's stores overlap with loads in flight.  LDS images: the f16
 // rows are XOR-swizzled at the SOURCE (16-B chunk c of row r lands at chunk c ^ ((r >> 2) & 3)): conflict-free ds_read_b128
-// fragments; the fp6 rows are linear (24-B pitch, each lane half reads 12 B: conflict-free).
+// fragments; the fp6 rows are linear (24-B pitch, each lane half reads 12 B as one 8-B and one 4-B load: conflict-free).
 // What bounds it (round-2 measurements): a wave issues at most one instruction per four cycles and needs ~250 of them per
 // K block beside its 18 MFMAs; with two waves per SIMD the matrix pipe is busy ~45 % of the time.  Removing any one of DMA, MFMAs,
 // conversions or stores takes 10-18 % off; no single phase dominates.
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     const int c0 = ((0 + h) ^ sw) << 4, c1 = ((2 + h) ^ sw) << 4;   // swizzled chunk offsets of k-steps 0 and 1
     const int rowA = wm * TM * 32 + r, rowB = wn * TN * 32 + r;
     const int aH0 = G::OFF_AH + rowA * 64 + c0, aH1 = G::OFF_AH + rowA * 64 + c1, bH0 = G::OFF_BH + rowB * 64 + c0, bH1 = G::OFF_BH + rowB * 64 + c1;
-    const int aF = G::OFF_AFL + rowA * 24 + 12 * h, bF = G::OFF_BFL + rowB * 24 + 12 * h;
+    const int aF = G::OFF_AFL + rowA * 24 + 8 * h, bF = G::OFF_BFL + rowB * 24 + 8 * h;           // dwords (0,1) / (3,4) of the row as stored [0 1 3 4 2 5]
+    const int aF2 = G::OFF_AFL + rowA * 24 + 16 + 4 * h, bF2 = G::OFF_BFL + rowB * 24 + 16 + 4 * h;  // dword 2 / 5
     const int aS = G::OFF_AS + ((rowA * 2) & ~3), bS = G::OFF_BS + ((rowB * 2) & ~3);
     const int shS = (r & 1) * 16;                                   // the row's (hi, lo) scale bytes inside that dword (tile rows are even offsets apart)
     const int shA = shS + h * 8, shB = shS + (1 - h) * 8;           // the byte the MFMA takes: A lower lanes hi / upper lo, B the other way round
@@ -368,16 +369,19 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     f16x8 a16[TM][2], b16[TN][2]; i32x8 a6[TM], b6[TN]; int sa[TM], sb[TN]; int fa[TM][3], fb[TN][3], spa[TM], spb[TN];               \
     {                                                                                                                                 \
         const char *s_a0 = (s) + aH0, *s_a1 = (s) + aH1, *s_b0 = (s) + bH0, *s_b1 = (s) + bH1, *s_af = (s) + aF, *s_bf = (s) + bF, *s_as = (s) + aS, *s_bs = (s) + bS; \
+        const char *s_af2 = (s) + aF2, *s_bf2 = (s) + bF2;                                                                            \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {         /* every LDS read of the block first: one latency, not five */        \
             a16[i][0] = *reinterpret_cast<const f16x8*>(s_a0 + i * 2048);                                                             \
             a16[i][1] = *reinterpret_cast<const f16x8*>(s_a1 + i * 2048);                                                             \
-            _Pragma("unroll") for (int d = 0; d < 3; ++d) fa[i][d] = *reinterpret_cast<const int*>(s_af + i * 768 + 4 * d);           \
+            { const u32x2 f01 = *reinterpret_cast<const u32x2*>(s_af + i * 768); fa[i][0] = f01.x; fa[i][1] = f01.y; }                  \
+            fa[i][2] = *reinterpret_cast<const int*>(s_af2 + i * 768);                                                                \
             spa[i] = *reinterpret_cast<const int*>(s_as + i * 64);                                                                    \
         }                                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                              \
             b16[j][0] = *reinterpret_cast<const f16x8*>(s_b0 + j * 2048);                                                             \
             b16[j][1] = *reinterpret_cast<const f16x8*>(s_b1 + j * 2048);                                                             \
-            _Pragma("unroll") for (int d = 0; d < 3; ++d) fb[j][d] = *reinterpret_cast<const int*>(s_bf + j * 768 + 4 * d);           \
+            { const u32x2 f01 = *reinterpret_cast<const u32x2*>(s_bf + j * 768); fb[j][0] = f01.x; fb[j][1] = f01.y; }                  \
+            fb[j][2] = *reinterpret_cast<const int*>(s_bf2 + j * 768);                                                                \
             spb[j] = *reinterpret_cast<const int*>(s_bs + j * 64);                                                                    \
         }                                                                                                                             \
     }                                                                                                                                 \

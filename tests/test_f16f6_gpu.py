@@ -65,7 +65,8 @@ def unpack(block, rows, K, batch_rows=0):
     prow = np.arange(rows) if not batch_rows else (np.arange(rows) // batch_rows) * r8(batch_rows) + np.arange(rows) % batch_rows
 
     def codes(F):
-        bits = np.unpackbits(F[:, prow, :], axis=-1, bitorder="little").reshape(Kb, rows, 32, 6)
+        Fd = F[:, prow, :].reshape(Kb, rows, 6, 4)[:, :, [0, 1, 4, 2, 3, 5], :].reshape(Kb, rows, 24)     # the six dwords are stored in the order [0 1 3 4 2 5]
+        bits = np.unpackbits(Fd, axis=-1, bitorder="little").reshape(Kb, rows, 32, 6)
         by_position = (bits * (1 << np.arange(6))).sum(-1).astype(np.uint8)
         return by_position[:, :, PI].transpose(1, 0, 2).reshape(rows, Kb * 32)       # PI is an involution: element k sits at position PI[k]
     return (H[:, prow, :].transpose(1, 0, 2).reshape(rows, Kb * 32), codes(FL), S[:, prow, 0].T, S[:, prow, 1].T)
