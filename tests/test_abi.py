@@ -52,6 +52,25 @@ def test_tuning_rejects_bad_values_and_defaults_to_auto():
     assert lib.cti_get_tuning(1) == -1 and lib.cti_get_tuning(2) == 0
 
 
+def test_softmax_partials_contract_on_the_host():
+    """cti_tcnet_softmax_partials_bytes says where the fused partial pass exists (f16f6, glimpse 2, h % 32 == 0) and how large its block is:
+    [B][tiles of 256 x 192 over (V*Q*G) x A][8 waves][G][2] floats; the consumer refuses blocks that are not a whole number of (B, G) pairs."""
+    lib = L.lib()
+    B, V, Q, A, h = 256, 36, 14, 3129, 512
+    tiles = ((V * Q * 2 + 255) // 256) * ((A + 191) // 192)
+    assert lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, 2, L.PREC_F16F6) == B * tiles * 8 * 2 * 2 * 4
+    assert lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, 2, L.PREC_BF16X3) == 0          # other arithmetic: the two-pass softmax
+    assert lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, 3, L.PREC_F16F6) == 0           # other glimpse counts
+    assert lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, 48, 2, L.PREC_F16F6) == 0          # h not a multiple of the K block
+    assert lib.cti_tcnet_softmax_partials_bytes(0, V, Q, A, h, 2, L.PREC_F16F6) == 0
+    one = 8                                                                                   # any non-NULL addresses: nothing is dereferenced before the checks
+    assert lib.cti_masked_softmax_tri_from_partials_fwd(None, one, one, 64, one, 2, 3, 4, 2, one, 64, None) == -1          # NULL logits
+    assert lib.cti_masked_softmax_tri_from_partials_fwd(one, one, one, 64, one, 2, 3, 4, 3, one, 64, None) == -4           # G != 2
+    assert lib.cti_masked_softmax_tri_from_partials_fwd(one, one, one, 40, one, 2, 3, 4, 2, one, 64, None) == -2           # 40 bytes: not whole (B, G) pairs
+    assert lib.cti_masked_softmax_tri_from_partials_fwd(one, one, one, 64, one, 2, 3, 4, 2, one, 16, None) == -5           # workspace too small
+    assert b"workspace" in lib.cti_last_error_string()
+
+
 def test_ops_refuse_cpu_tensors():
     with pytest.raises(cti_amd.CtiError):
         cti_amd.ops.zero_row_mask(torch.zeros(2, 3, 4))

@@ -29,5 +29,7 @@ timeout 300 python tools/graph_train.py ffoe_cti 30 > $E/graph_train.jsonl 2>/de
 timeout 300 python tools/bench_pools.py 30 2>/dev/null | grep kernel > $E/hbm_kernels.jsonl
 timeout 300 python tools/bench_f16f6.py 256 20 > $E/mode3_f16f6_vs_bf16x3.json 2>/dev/null
 timeout 120 ./tools/mb/mb_f16f6 > $E/mb_f16f6.txt 2>&1
+timeout 120 ./tools/mb/mb_issue > $E/mb_issue.txt 2>&1
+timeout 300 python tools/f16f6_ksweep.py > $E/f16f6_ksweep.txt 2>/dev/null
 fi
 find $E -name "*.csv" | head -20; du -sh $E

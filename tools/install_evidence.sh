@@ -7,14 +7,14 @@ cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
 for f in f16f6 bf16x3 fp32 bf16 train c3 c4 rccl_world1; do [ -s $E/bench_$f.log ] && tail -1 $E/bench_$f.log > profiles/${R}_bench_$f.json; done
 cp $E/stats/fwd_kernel_stats.csv profiles/${R}_rocprof_kernel_stats_f16f6.csv
 cat $E/model_fwd.jsonl $E/model_train.jsonl $E/model_fwd_bf16.jsonl > profiles/${R}_model_bench.jsonl 2>/dev/null || true
-for f in graph_train.jsonl hbm_kernels.jsonl mode3_f16f6_vs_bf16x3.json mb_f16f6.txt; do [ -s $E/$f ] && cp $E/$f profiles/${R}_$f; done
+for f in graph_train.jsonl hbm_kernels.jsonl mode3_f16f6_vs_bf16x3.json mb_f16f6.txt mb_issue.txt f16f6_ksweep.txt; do [ -s $E/$f ] && cp $E/$f profiles/${R}_$f; done
 python tools/pmc_summary.py profiles/${R}_pmc_summary.json $E profiles/${R}_rocprof_kernel_stats_f16f6.csv > /dev/null
 python - "$R" <<'PY'
 import json, sys
 R = sys.argv[1]
 d = json.load(open('profiles/%s_pmc_summary.json' % R))
 k = [v for n, v in d['kernels'].items() if n.startswith('gemm_f16f6_kernel<2')][0]
-out = {"kernel": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x192, 3-slot ring of 32-deep K blocks> (mode-3 GEMM of TCNet.forward, f16f6 mode)",
+out = {"kernel": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x192, 4-slot ring of 32-deep K blocks, continuous stream> (mode-3 GEMM of TCNet.forward, f16f6 mode)",
        "variant": "gemm_f16f6_kernel<epi=INTERLEAVE2, tile 256x192>", "batch": 256,
        "hbm_bytes_per_launch": k['hbm_read_bytes_corrected'] + k['hbm_write_bytes'], "read_bytes": k['hbm_read_bytes_corrected'],
        "write_bytes": k['hbm_write_bytes'], "l2_hit_rate": k.get('l2_hit_rate'), "effective_clock_ghz": k.get('effective_clock_ghz'),
