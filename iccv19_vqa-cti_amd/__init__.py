@@ -16,6 +16,7 @@ from .graph import GraphedTrainStep                            # noqa: F401
 from .language_model import WordEmbedding, QuestionEmbedding   # noqa: F401
 from .classifier import SimpleClassifier                       # noqa: F401
 from .loss_function import BCEWithLogitsSum, Distillation_Loss # noqa: F401
+from .teacher_logits import make_json_with_logits, dump_teacher_logits, load_teacher_logits, teacher_logit_batch   # noqa: F401
 from . import base_model                                       # noqa: F401
 from .base_model import BanModel, CTIModel, TanModel, MCBanModel, build_ban, build_cti, build_mc_cti, build_mc_ban   # noqa: F401
 
