@@ -1267,7 +1267,7 @@ extern "C" int cti_masked_softmax_tri_from_partials_fwd(float* logits, const uin
     hipLaunchKernelGGL(tri_combine_kernel, dim3(B, G), dim3(64), 0, st, partials, stats, G, nchunk);
     int rc = launch_status("cti_masked_softmax_tri_from_partials_fwd/combine"); if (rc) return rc;
     const int64_t N = (int64_t)V * QA;
-    int64_t cn = 16384;                                              // positions per workgroup (even): 32 trips of 512
+    int64_t cn = tuning_tri_chunk() > 0 ? (tuning_tri_chunk() + 1) & ~(int64_t)1 : 2048;      // positions per workgroup (even).  Measured at C2, B = 64: 2048 -> 328 us, 16384 -> 376, 65536 -> 403 (a plain copy of the logits: 308)
     const int64_t nc = (N + cn - 1) / cn;
     hipLaunchKernelGGL(tri_normalise_mask_g2_kernel, dim3((unsigned)nc, B), dim3(SM_THREADS), 0, st, logits, mask, stats, p, V, QA, cn);
     return launch_status("cti_masked_softmax_tri_from_partials_fwd/normalise");

@@ -38,7 +38,7 @@
 namespace cti {
 
 constexpr int F6_BLK = 32;                       // K elements per scale block
-constexpr int F6_SLACK_ROWS = 256;               // H / FH / FL rows a tile may over-read
+constexpr int F6_SLACK_ROWS = 256;               // H / FL rows a tile may over-read
 constexpr int F6_SLACK_ROWS_S = 512;             // S rows a tile may over-read (its DMA always moves 1 KiB = 512 rows of scales)
 
 // Rows: a producer maps logical row m of its (flat) matrix to plane row (m / rdiv) * rstride + m % rdiv -- batches of rdiv rows start at

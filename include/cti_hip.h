@@ -232,8 +232,9 @@ int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1
                    const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
 
-/* The "f16f6" operand format (csrc/cti_f16f6.h): an fp32 matrix as an f16 hi plane plus two block-scaled fp6 (e2m3) planes -- codes of the hi
- * part and of the residual, one E8M0 scale per 32 elements each -- so that a product costs one f16 MFMA and half a (4x-rate) fp6 MFMA:
+/* The "f16f6" operand format (csrc/cti_f16f6.h): an fp32 matrix as an f16 hi plane plus ONE block-scaled fp6 (e2m3) plane -- the codes of the
+ * residual -- and two E8M0 scales per 32 elements (of the hi part, whose fp6 codes the GEMM derives in registers, and of the residual): 2.81
+ * bytes per element -- so that a product costs one f16 MFMA and half a (4x-rate) fp6 MFMA:
  * a*b ~= a16*b16 + fp6(a16)*fp6(b - b16) + fp6(a - a16)*fp6(b16), fp32 accumulate (fp32-grade: ~2e-5 normalised on the mode-3 product).
  * cti_quantize_f16f6 encodes `rows` x K fp32 (row stride ld) into a caller-owned block of cti_f16f6_planes_bytes (256-B aligned);
  * batch_rows > 0 places every batch of batch_rows rows at a multiple of 8 plane rows (what batched products need), 0 = one matrix.
