@@ -70,6 +70,9 @@ struct F6P {
     const float* scale; int scale_div; const float* bias; int relu;
     float* sm_part; const uint8_t* sm_mask; int sm_rows_per_obj, sm_objs; unsigned sm_magic;      // row / rows_per_obj = umulhi(row, magic) (rows < 2^24)
 };
+// the kernels' only parameter, as it sits at the head of the kernel-argument segment (constant address space: scalar loads)
+typedef const __attribute__((address_space(4))) F6P F6P_K;
+__device__ __forceinline__ const F6P_K* f6_kernarg() { return __builtin_bit_cast(const F6P_K*, __builtin_amdgcn_kernarg_segment_ptr()); }
 enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_INTERLEAVE2_SM = 5 };   // _SM: + softmax partials
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -134,6 +137,10 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
             constexpr float L2E = 1.4426950408889634f;
             const float ninf = -__builtin_huge_valf();
             float mx[2] = {ninf, ninf}, sum[2] = {0.f, 0.f};
+            const F6P_K* q = f6_kernarg();                          // the partials' own parameters, loaded here rather than held across the K loops
+            asm volatile("" : "+s"(q));
+            const uint8_t* sm_mask = q->sm_mask + (int64_t)z * q->sm_objs;
+            const unsigned sm_magic = q->sm_magic;
             bool cok[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) cok[j] = cn0 + (wn * TN + j) * 32 + r < p.N;
@@ -148,7 +155,7 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
                     for (int pr = 0; pr < 2; ++pr) {
                         const int m = cm0 + (wm * TM + i) * 32 + 8 * eg + 4 * h + 2 * pr;
                         const unsigned mc = (unsigned)min(m, p.M - 1);
-                        const uint8_t mb = p.sm_mask[(int64_t)z * p.sm_objs + (p.sm_magic ? __umulhi(mc, p.sm_magic) : mc)];
+                        const uint8_t mb = sm_mask[sm_magic ? __umulhi(mc, sm_magic) : mc];
                         okv[i][eg][pr] = (int)(m < p.M) & (int)(mb == 0);
                     }
 #pragma unroll
@@ -166,7 +173,7 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         if (okv[i][e >> 2][(e >> 1) & 1] != 0 && cok[j]) sum[e & 1] += __builtin_amdgcn_exp2f(fmaf(acc[i][j][e], L2E, -sh[e & 1]));
-            float* o = p.sm_part + (((int64_t)z * tiles_per_batch + tile_in_batch) * G::NW + wm * G::WN + wn) * 4;
+            float* o = q->sm_part + (((int64_t)z * tiles_per_batch + tile_in_batch) * G::NW + wm * G::WN + wn) * 4;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float wmx = wave_max(mx[g]);
@@ -264,22 +271,26 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     const int64_t vks_last = (shared_piece_wave && h) ? p.pAS * 2 : kstride[CNT - 1];       // per lane: the shared piece's halves walk different planes
     int iss_tile = blockIdx.x, iss_kb = 0, issued = 0;
     auto issue_tile_setup = [&]() {
+        // The plane pointers and batch strides are needed once per tile: they are re-read from the kernel-argument segment here (scalar loads
+        // through a pointer the optimiser cannot see through) instead of living in ~24 scalar registers across every K block.
+        const F6P_K* q = f6_kernarg();
+        asm volatile("" : "+s"(q));
         int zz, tm, tn;
         tile_coords(iss_tile, p.total_tiles, tiles_m, tiles_n, zz, tm, tn);
-        const int64_t ra = (int64_t)zz * p.rA + tm * BM, rb = (int64_t)zz * p.rB + tn * BN;
+        const int64_t ra = (int64_t)zz * q->rA + tm * BM, rb = (int64_t)zz * q->rB + tn * BN;
         int w = wid;
         asm volatile("" : "+s"(w));                                 // (keeps the descriptor arithmetic below out of the K loop's live registers)
         const unsigned hoff = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4)), loff = (unsigned)lane * 16u;
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
             int g = w + u * NW;
-            if (g < G::PAH)                   vp[u] = p.AH + (ra + g * 16) * 64 + hoff;
-            else if ((g -= G::PAH) < G::PBH)  vp[u] = p.BH + (rb + g * 16) * 64 + hoff;
-            else if ((g -= G::PBH) < G::PAF)  vp[u] = p.AFL + ra * 24 + g * 1024 + loff;
-            else if ((g -= G::PAF) <= G::PBF) vp[u] = p.BFL + rb * 24 + g * 1024 + loff;
-            else                              vp[u] = p.BS + rb * 2 + loff;
+            if (g < G::PAH)                   vp[u] = q->AH + (ra + g * 16) * 64 + hoff;
+            else if ((g -= G::PAH) < G::PBH)  vp[u] = q->BH + (rb + g * 16) * 64 + hoff;
+            else if ((g -= G::PBH) < G::PAF)  vp[u] = q->AFL + ra * 24 + g * 1024 + loff;
+            else if ((g -= G::PAF) <= G::PBF) vp[u] = q->BFL + rb * 24 + g * 1024 + loff;
+            else                              vp[u] = q->BS + rb * 2 + loff;
         }
-        if (shared_piece_wave && h) vp[CNT - 1] = p.AS + ra * 2 - 512 + loff;       // upper 32 lanes: the A scales, 16 B per lane from lane 32 on
+        if (shared_piece_wave && h) vp[CNT - 1] = q->AS + ra * 2 - 512 + loff;      // upper 32 lanes: the A scales, 16 B per lane from lane 32 on
     };
     auto issue_next = [&](int pos) {                                // the stream's next K block into ring slot `pos`
         if (issued >= nblk || (CTI_F6_ABL & 1)) return;
