@@ -129,3 +129,26 @@ def test_gemm_epilogue_scale_bias_relu_and_dynamic_range():
     ref = torch.relu((A.double() @ B.double().T) * scale.double().repeat_interleave(10)[None, :] + bias.double()[None, :]).numpy()
     rowmax = (A.double() @ B.double().T).abs().max(1, keepdim=True).values.numpy()
     assert np.max(np.abs(C - ref) / rowmax) < 1e-4                                             # per-row normalisation: every row keeps its accuracy
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_random_shapes_cover_the_stream_protocol(seed):
+    """Randomised shapes around the kernel's protocol edges: one K block per tile (K = 32), fewer blocks than ring slots, several tiles per
+    workgroup with 1-3 blocks each (total tiles > 256 CUs: the continuous stream crosses tile boundaries every few barriers), partial edge
+    tiles in both dimensions, batch strides that are not multiples of the tile."""
+    rs = np.random.RandomState(1000 + seed)
+    K = int(rs.choice([32, 64, 96, 128, 160]))
+    gdiv = int(rs.choice([1, 2]))
+    if seed % 3 == 0:                                              # many small tiles: > 256 tiles, several per workgroup
+        nb, M, N = int(rs.randint(40, 90)), int(rs.randint(130, 520)) // gdiv * gdiv, int(rs.randint(100, 400))
+    elif seed % 3 == 1:                                            # one batch, odd sizes
+        nb, M, N = 1, int(rs.randint(1, 1500)) // gdiv * gdiv + gdiv, int(rs.randint(1, 900))
+    else:
+        nb, M, N = int(rs.randint(2, 9)), int(rs.randint(200, 700)) // gdiv * gdiv, int(rs.randint(150, 650))
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(nb * M, K, generator=g) * 2.0
+    B = torch.randn(nb * N, K, generator=g)
+    C = ops.gemm_nt_f16f6(A.to(DEV), B.to(DEV), nb=nb, M=M, N=N, gdiv=gdiv).cpu().numpy()
+    ref = _ref(A, B, nb, M, N, gdiv)
+    err = np.abs(C - ref).max() / np.abs(ref).max()
+    assert err < 5e-5, "nb=%d M=%d N=%d K=%d gdiv=%d: %.3g" % (nb, M, N, K, gdiv, err)
