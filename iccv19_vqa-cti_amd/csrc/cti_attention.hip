@@ -1431,7 +1431,7 @@ extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float*
     CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && A > 0 && D > 0, CTI_E_SHAPE, "cti_pool_dw_mfma: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
     if (D % 16 != 0 || !aligned16(dout) || !aligned16(vt) || !aligned16(qt) || (at && !aligned16(at))) return CTI_E_UNSUPPORTED;
     const int MT = (V + 31) / 32, NT = (Q * A + 31) / 32;
-    const int KS = D >= 512 ? 2 : 1;
+    const int KS = D >= 512 ? 2 : 1;                               // at most TWO addends meet by atomicAdd on the zero-filled output: a + b in either order, the same bits
     const int dper = ((D / 16 + KS - 1) / KS) * 16;
     int rcz = zero_fill(dw, (int64_t)B * V * Q * A, as_stream(stream)); if (rcz) return rcz;
     hipLaunchKernelGGL(pool_dw_mfma_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), dout, vt, qt, at, dw, V, Q, A, D, MT, NT, dper);

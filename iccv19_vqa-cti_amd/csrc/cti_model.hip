@@ -22,13 +22,50 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ tok, const floa
     }
 }
 
-// dtable[tok[i], c] += dout[i, col_off + c]; the padding row receives nothing (nn.Embedding(padding_idx))
-__global__ void embedding_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dout, int64_t ld, int col_off,
-                                     float* __restrict__ dtable, int64_t n, int dim, int64_t rows, int64_t pad) {
+// dtable[tok[i], c] += dout[i, col_off + c]; the padding row receives nothing (nn.Embedding(padding_idx)).
+// DETERMINISTIC: no atomics.  The workgroup of position i scans the token list in chunks of 256 (one ballot per wave, the four masks shared
+// through LDS); if the first occurrence of its token is not i it has nothing to do, otherwise it alone owns table row tok[i] and adds the
+// gradient rows of every occurrence in ascending position order: dtable[k] += ((g_j1 + g_j2) + g_j3) + ...  -- the same bits on every run
+// and for every grid size (a few thousand tokens per step: the scans cost ~14 chunk iterations per workgroup).
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dout, int64_t ld, int col_off,
+                                                            float* __restrict__ dtable, int64_t n, int dim, int64_t rows, int64_t pad) {
+    __shared__ unsigned long long masks[2][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         const int64_t k = tok[i];
-        if (k < 0 || k >= rows || k == pad) continue;
-        for (int c = threadIdx.x; c < dim; c += blockDim.x) atomicAdd(dtable + k * dim + c, dout[i * ld + col_off + c]);
+        if (k < 0 || k >= rows || k == pad) continue;                // (block-uniform)
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};                         // columns t, t + 256, ... (dim <= 1024 takes one pass; wider tables loop below)
+        for (int c0 = 0; c0 < dim; c0 += 1024) {
+            bool first_seen = false, mine = true;
+            int buf = 0;
+            for (int64_t j0 = 0; j0 < n && mine; j0 += 256, buf ^= 1) {
+                const int64_t j = j0 + t;
+                const unsigned long long m = __ballot(j < n && tok[j] == k);
+                if (lane == 0) masks[buf][w] = m;
+                __syncthreads();                                     // (two buffers: the next chunk's writes cannot overtake this chunk's readers)
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    unsigned long long mm = masks[buf][ww];
+                    while (mm) {
+                        const int64_t jj = j0 + ww * 64 + __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        if (!first_seen) { first_seen = true; if (jj != i) { mine = false; break; } }
+                        const float* g = dout + jj * ld + col_off + c0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (c0 + t + u * 256 < dim) acc[u] += g[t + u * 256];
+                    }
+                    if (!mine) break;
+                }
+            }
+            if (mine) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (c0 + t + u * 256 < dim) { dtable[k * dim + c0 + t + u * 256] += acc[u]; acc[u] = 0.f; }
+            } else {
+                break;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
     }
 }
 
