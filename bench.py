@@ -232,7 +232,19 @@ def run_train(args, world, rank, dev, dist):
         loss.backward()
         opt.step()
 
-    el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+    # One rank, no collective: the step is captured into a hipGraph (cti_amd.GraphedTrainStep) and replayed -- eagerly its ~300 launches
+    # take the host about as long to issue as the GPU takes to run them, and the line would time the box's CPU.  With a process group
+    # (several ranks, or CTI_BENCH_FORCE_DIST=1) the step runs eagerly: capturing the RCCL all-reduce aborted the process on this stack
+    # (ROCm 7.0 / torch 2.10, one rank); --graph asks for the capture anyway.
+    graphed = (world == 1 and not dist.is_initialized()) or args.graph
+    if args.no_graph:
+        graphed = False
+    if graphed:
+        gs = cti_amd.GraphedTrainStep(model, opt, lambda out, tgt: crit(out, tgt) / B, (v, q, a), y, warmup=3)
+        step_fn = lambda: gs.graph.replay()                      # noqa: E731  (the inputs are resident: nothing to copy per step)
+    else:
+        step_fn = step
+    el = measure(step_fn, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
     if dist.is_initialized():                                   # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
@@ -244,7 +256,8 @@ def run_train(args, world, rank, dev, dist):
                           "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
                           "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + SimpleClassifier "
                                                  "+ BCE, train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
-                                     "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world, "collective": coll}}))
+                                     "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world, "collective": coll,
+                                     "launch": "hipGraph replay of the captured step" if graphed else "eager (one launch per kernel)"}}))
 
 
 # ---- full-model forwards: BASELINE configs[2] (c3: MC CTI, Visual7W shapes) and configs[3] (c4: FFOE BAN + CTI teacher) ---------------
@@ -335,8 +348,25 @@ def run_model(args, world, rank, dev, dist):
     def step():
         holder["out"] = fwd()
 
+    # The forward is ~190 launches for 1.3-3.2 ms of GPU work: issued eagerly it times the box's CPU as much as the GPU (74 k and 81 k samples/s
+    # for c4 on two boxes).  It contains no collective, allocates nothing and never synchronises, so it is captured into a hipGraph once and
+    # replayed (tools/graph_model.py checks replay == eager); --no-graph keeps the eager launches.
+    graphed = not args.no_graph
     with torch.no_grad():
-        el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+        if graphed:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gr, stream=side):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            el = measure(gr.replay, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+        else:
+            el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
     out = holder["out"]
     out0 = out[0] if isinstance(out, tuple) else out
     assert tuple(out0.shape) == out_shape and bool(torch.isfinite(out0).all())
@@ -351,7 +381,7 @@ def run_model(args, world, rank, dev, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[prec], "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "precision": prec, "parallelism": "replicas x%d" % world,
-                       "gflop_per_batch": round(flops / 1e9, 3)},
+                       "gflop_per_batch": round(flops / 1e9, 3), "launch": "hipGraph replay of the captured forward" if graphed else "eager"},
             "roofline": {"bound": "mfma", "kernel": "whole forward (launch sequence; dominant kernels are the projection GEMMs)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "note": "algorithmic flops of SURVEY.md 8(d) summed over the module calls / wall time of the forward"}}), flush=True)
@@ -482,6 +512,8 @@ def main():
                     help="f16f6 (default of the headline line): mode-3 product as f16 hi x hi + one block-scaled fp6 MFMA for both cross terms, every "
                          "other GEMM bf16x3 -- fp32-grade (3e-5 vs the float64 oracle at the configs[1] shape, tolerance 1e-4); bf16x3: 3-term split-bf16 "
                          "everywhere (1.5e-5); fp32: exact fp32 MFMA")
+    ap.add_argument("--graph", action="store_true", help="--mode train with several ranks: capture the step (incl. the all-reduce) into a hipGraph, as one rank does by default")
+    ap.add_argument("--no-graph", action="store_true", help="--mode train: eager launches even on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the 4-step exact-fp32 sub-record of the default line")
     ap.add_argument("--cpu-budget", type=float, default=20.0)

@@ -4,8 +4,10 @@ The FFOE CTI training step is ~500 kernel launches issued by ~7 ms of host Pytho
 `GraphedTrainStep` captures forward + loss + backward + FlatAdamaxDP.step() ONCE (torch.cuda.CUDAGraph = hipGraph) and replays it per batch:
 the host then issues one hipGraphLaunch per step.  What makes the step capturable is that nothing that changes from step to step is a kernel
 ARGUMENT: the learning rate, the completed-step count of Adamax' bias correction and the dropout streams' step counter live in device memory
-(cti_adamax_step_g / cti_dropout_g / cti_counter_add), the library allocates nothing and never synchronises, and the one collective
-(the all-reduce of the flat gradient buffer) is an RCCL call, which is capturable.  Batches are fed by copying into static input tensors."""
+(cti_adamax_step_g / cti_dropout_g / cti_counter_add), and the library allocates nothing and never synchronises.  Single-rank steps (no
+collective) are what is captured and tested; capturing the RCCL all-reduce of a process group aborted the process on this stack (ROCm 7.0 /
+torch 2.10, `bench.py --mode train --graph` with CTI_BENCH_FORCE_DIST=1), so multi-rank steps are launched eagerly.  Batches are fed by
+copying into static input tensors."""
 import torch
 
 from . import ops
