@@ -73,6 +73,8 @@ SIGNATURES = {
     "cti_f16f6_planes_bytes": (_sz, [_i64, _int, _i64]),
     "cti_quantize_f16f6": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _sz, _vp]),
     "cti_gemm_nt_f16f6": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _vp]),
+    "cti_gemm_nt_f16f6_planes": (_int, [_vp, _i64, _vp, _i64, _vp, _sz, _i64, _int, _int, _int, _vp, _int, _vp]),
+    "cti_quantize_f16f6_scaled": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _int, _vp, _sz, _vp]),
     "cti_gemm_tn": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "cti_gemm_nn": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _int, _vp, _sz, _vp]),
     "cti_gemm_nn_workspace_bytes": (_sz, [_i64, _int, _int, _int]),

@@ -116,10 +116,17 @@ struct F6GemmArgs {
     // not masked -- row m belongs to object m / sm_rows_per_obj, masked iff sm_mask[z * sm_objs + object] != 0 -- to
     // sm_part[((z * f6_sm_chunks(M, N) + chunk) * 2 + g) * 2 + {0, 1}]: the layout of the softmax's own partial pass.
     float* sm_part; const uint8_t* sm_mask; int sm_rows_per_obj, sm_objs;
+    // epi 6 ("transposed planes"): the product is taken with the roles swapped -- A = the layer's weight (M = output features, a multiple of 32),
+    // B = the activations (N = their rows) -- and act(acc + bias[m]) of column n is written as f16f6 planes of a (N rows x M features)
+    // matrix: plane row f6_prow(*out, n), K block m / 32.  In that orientation a lane PAIR of the MFMA accumulator holds the 32 features of
+    // one row's block, so the encoder runs in registers and the tile stream never pauses for LDS (cti_gemm_f16f6.hip).  The bias enters as
+    // the accumulators' initial value; a weight-norm scale belongs in the weight planes (quantize_f16f6's row_scale).  nb = 1.
+    const F6Planes* out;
 };
 int f6_sm_chunks(int M, int N);                // partial (max, sum) pairs per batch and g that gemm_nt_f16f6 writes for an M x N product
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);
-int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st);
+// row_scale != NULL: row m is multiplied by row_scale[m / scale_div] on the way in (a weight-normalised layer's g / ||V|| per matrix)
+int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st, const float* row_scale = nullptr, int scale_div = 1);
 #if defined(__HIPCC__)
 // Encode and store one (row, block) whose 32 fp32 values sit in LDS (16-B aligned, contiguous) -- the form GEMM epilogues and the encoder
 // kernel use: two streaming passes over the LDS copy instead of 32 + 32 + 32 live registers (pass 1: f16 hi part stored 8 values at a time,
@@ -165,6 +172,64 @@ __device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Pl
     uint2* fd = reinterpret_cast<uint2*>(p.FL + o * 24);
     fd[0] = make_uint2(fl[0], fl[1]); fd[1] = make_uint2(fl[3], fl[4]); fd[2] = make_uint2(fl[2], fl[5]);     // dword order [0 1 3 4 2 5]: see the format notes
     *reinterpret_cast<unsigned short*>(p.S + ((int64_t)kb * p.rows_allocS + prow) * 2) = (unsigned short)(sh | (sl << 8));
+}
+// The same (row, block) item from 32 values a lane holds in registers (element order) -- the register-only epilogue of the transposed
+// f16f6 GEMM -- with max(x, lo_bound) applied first (lo_bound = 0: ReLU; -inf: none).  Same planes, bit for bit, as f6_encode_row32_lds on
+// max(x, lo_bound), in ~4.5 VALU instructions per element: v_med3_f32 (lower bound and f16 saturation in one), v_cvt_pk_f16_f32 (gfx950: two
+// values per instruction, round to nearest even), the residual as a packed fp32 subtraction, the hi maximum as an integer maximum of the
+// packed |f16| bit patterns.  A block that holds a saturated value (|x| >= 65504, outside the format's domain) recomputes its residuals from the
+// unsaturated values in a rarely taken branch.  Plain vector stores (no HIP structs): nothing here may alias the GEMM's LDS-DMA ring,
+// which stays in flight around it.
+typedef unsigned f6_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned f6_u32x2 __attribute__((ext_vector_type(2)));
+typedef float f6_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f6_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short f6_u16x2 __attribute__((ext_vector_type(2)));
+#ifndef CTI_F6_ABL
+#define CTI_F6_ABL 0
+#endif
+__device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float lo_bound, char* Hrow, char* FLrow, char* Srow) {
+    if ((CTI_F6_ABL & 16) && x[31] != 12345.f) { Hrow = FLrow = Srow = nullptr; }      // timing-only ablation: the arithmetic without the stores
+    const float lo_sat = fmaxf(lo_bound, -65504.f);
+    float ml = 0.f;
+    f6_u16x2 mh2 = {0, 0};
+    float lf[32];
+    unsigned hw[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        f6_f32x2 v = {__builtin_amdgcn_fmed3f(x[2 * u], lo_sat, 65504.f), __builtin_amdgcn_fmed3f(x[2 * u + 1], lo_sat, 65504.f)};
+        const f6_f16x2 h = __builtin_convertvector(v, f6_f16x2);
+        const f6_f32x2 l = v - __builtin_convertvector(h, f6_f32x2);
+        lf[2 * u] = l[0]; lf[2 * u + 1] = l[1];
+        ml = fmaxf(ml, fmaxf(fabsf(l[0]), fabsf(l[1])));
+        hw[u] = __builtin_bit_cast(unsigned, h);
+        mh2 = __builtin_elementwise_max(mh2, __builtin_bit_cast(f6_u16x2, hw[u] & 0x7fff7fffu));
+    }
+    const unsigned short mhb = mh2[0] > mh2[1] ? mh2[0] : mh2[1];
+    if (mhb >= 0x7bffu) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)
+        ml = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const f6_f32x2 hf = __builtin_convertvector(__builtin_bit_cast(f6_f16x2, hw[u]), f6_f32x2);
+            lf[2 * u] = fmaxf(x[2 * u], lo_bound) - hf[0]; lf[2 * u + 1] = fmaxf(x[2 * u + 1], lo_bound) - hf[1];
+            ml = fmaxf(ml, fmaxf(fabsf(lf[2 * u]), fabsf(lf[2 * u + 1])));
+        }
+        if (!(ml < 3.0e38f)) ml = 0.f;
+    }
+    if (!(CTI_F6_ABL & 16) || Hrow) {
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) reinterpret_cast<f6_u32x4*>(Hrow)[q8] = f6_u32x4{hw[4 * q8], hw[4 * q8 + 1], hw[4 * q8 + 2], hw[4 * q8 + 3]};
+    }
+    const float mh = static_cast<float>(__builtin_bit_cast(_Float16, mhb));
+    const int sh = f6_scale_byte(mh), sl = f6_scale_byte(ml);
+    f6_f32x16 le, lo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { le[i] = lf[f6_pi(2 * i)]; lo[i] = lf[f6_pi(2 * i + 1)]; }
+    const f6_u32x6 fl = f6_hw_codes(le, lo, __builtin_bit_cast(float, (unsigned)sl << 23));
+    if ((CTI_F6_ABL & 16) && !Hrow) { if (fl[0] == 0x12345u && sh == 77) *reinterpret_cast<volatile unsigned*>(16) = fl[5] + sl; return; }
+    f6_u32x2* fd = reinterpret_cast<f6_u32x2*>(FLrow);
+    fd[0] = f6_u32x2{fl[0], fl[1]}; fd[1] = f6_u32x2{fl[3], fl[4]}; fd[2] = f6_u32x2{fl[2], fl[5]};
+    *reinterpret_cast<unsigned short*>(Srow) = (unsigned short)(sh | (sl << 8));
 }
 #endif
 

@@ -30,7 +30,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // 8-B LDS loads. 
 // ---- encoder: fp32 rows -> f16f6 planes.  A wave stages a 64-row x 32-column tile through a private LDS patch: the global loads are
 // coalesced (8 lanes x 16 B = one row's block, 8 rows per instruction), then every lane encodes one row from LDS (pitch 36 floats:
 // conflict-free 16-B row reads) with the streaming encoder the GEMM epilogues use.
-__global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, F6Planes p) {
+__global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int K, F6Planes p,
+                                                              const float* __restrict__ row_scale, int scale_div) {
     __shared__ __attribute__((aligned(16))) float patch[4][64 * 36];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int kb = blockIdx.y, k0 = kb * 32;
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __rest
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (k0 + c4 * 4 + u < K) v[u] = src[u];
             }
+            if (row_scale) v *= row_scale[row / scale_div];
         }
         *reinterpret_cast<f6_f32x4*>(st + rr * 36 + c4 * 4) = v;
     }
@@ -69,11 +71,12 @@ struct F6P {
     float* C; int64_t ldc_m, ldc_n, sC; int gdiv;
     const float* scale; int scale_div; const float* bias; int relu;
     float* sm_part; const uint8_t* sm_mask; int sm_rows_per_obj, sm_objs; unsigned sm_magic;      // row / rows_per_obj = umulhi(row, magic) (rows < 2^24)
+    char* oH; char* oFL; char* oS; int64_t o_ra, o_ras; int o_rdiv, o_rstride;                    // F6_EPI_PLANES_T: the output planes
 };
 // the kernels' only parameter, as it sits at the head of the kernel-argument segment (constant address space: scalar loads)
 typedef const __attribute__((address_space(4))) F6P F6P_K;
 __device__ __forceinline__ const F6P_K* f6_kernarg() { return __builtin_bit_cast(const F6P_K*, __builtin_amdgcn_kernarg_segment_ptr()); }
-enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_INTERLEAVE2_SM = 5 };   // _SM: + softmax partials
+enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_INTERLEAVE2_SM = 5, F6_EPI_PLANES_T = 6 };   // _SM: + softmax partials; _T: see F6GemmArgs
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -128,6 +131,47 @@ template <int EPI, class G>
 __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], const F6P& p, int z, int cm0, int cn0, int wm, int wn, int lane, int tile_in_batch, int tiles_per_batch) {
     constexpr int TM = G::TM, TN = G::TN;
     const int r = lane & 31, h = lane >> 5;
+    if (EPI == F6_EPI_PLANES_T) {
+        // Transposed product: GEMM rows m = output features, columns n = activation rows; the result leaves as f16f6 planes of the
+        // (N x M) matrix.  Register e of a 32 x 32 accumulator tile is feature 8 (e >> 2) + 4 h + (e & 3) of column r = lane & 31, so a
+        // lane and its SIMD-half partner hold all 32 features of one (row, block) item between them -- and the wave's two row tiles are
+        // two such blocks.  Sixteen v_permlane32_swap(tile 0 register, tile 1 register) hand the lower lanes all of tile 0 and the upper
+        // lanes all of tile 1: every lane then encodes ONE complete item in registers (f6_encode_row32_regs).  No LDS, and NO global loads
+        // (the bias came in as the accumulators' initial value): the ring keeps streaming the next tile's K blocks underneath, and nothing
+        // here waits on vmcnt -- a load's wait would also wait for the previous item's stores.
+        static_assert(EPI != F6_EPI_PLANES_T || TM == 2, "a lane pair owns the wave's two row tiles");
+        const F6P_K* q = f6_kernarg();
+        asm volatile("" : "+s"(q));
+        const int mblk = cm0 + (wm * TM + h) * 32;                  // first feature of this lane's block
+        const int kb = mblk >> 5;
+        char* const oH = q->oH; char* const oFL = q->oFL; char* const oS = q->oS;
+        const int64_t o_ra = q->o_ra, o_ras = q->o_ras;
+        const int o_rdiv = q->o_rdiv, o_rstride = q->o_rstride;
+        const bool mok = mblk < p.M;                                // M % 32 == 0: a block is all real or all padding
+        const float lo_bound = p.relu ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 t0 = acc[0][j], t1 = acc[1][j];
+            asm volatile("" : "+v"(t0), "+v"(t1));
+            float x[32];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // (inline asm: given vector elements, the builtin form of this swap was folded to ONE instruction for all sixteen registers)
+                float lo_ = t0[e], hi_ = t1[e];
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo_), "+v"(hi_));
+                const int k = 8 * (e >> 2) + (e & 3);                // lo_: the lower-lane register (features k), hi_: the upper-lane one (k + 4)
+                x[k] = lo_; x[k + 4] = hi_;
+            }
+            const int n = cn0 + (wn * TN + j) * 32 + r;
+            if (n >= p.N || !mok || ((CTI_F6_ABL & 8) && x[0] != 12345.f)) continue;
+            const unsigned un = (unsigned)n, ub = o_rdiv > 0 ? un / (unsigned)o_rdiv : 0u;
+            const int64_t prow = o_rdiv > 0 ? (int64_t)ub * o_rstride + (un - ub * (unsigned)o_rdiv) : (int64_t)n;
+            const int64_t o = (int64_t)kb * o_ra + prow;
+            f6_encode_row32_regs(x, lo_bound, oH + o * 64, oFL + o * 24, oS + ((int64_t)kb * o_ras + prow) * 2);
+        }
+        return;
+    }
     float* C = p.C + (int64_t)z * p.sC;
     if (EPI == F6_EPI_INTERLEAVE2 || EPI == F6_EPI_INTERLEAVE2_SM) {
         if (EPI == F6_EPI_INTERLEAVE2_SM) {
@@ -332,13 +376,41 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     };
     compute_tile_setup();
     f32x16 acc[TM][TN];
+    // F6_EPI_PLANES_T: the accumulators start from the bias of their GEMM row (register e of row tile i: row 8 (e >> 2) + 4 h + (e & 3)), held in
+    // registers for as long as the workgroup's row tile stays the same -- with a power-of-two number of row tiles <= 32 it never changes.
+    f32x16 bv[EPI == F6_EPI_PLANES_T ? TM : 1];
+    int bv_m0 = -1;
+    auto load_bias = [&]() {
+        if (EPI != F6_EPI_PLANES_T || bv_m0 == m0) return;
+        const bool first = bv_m0 < 0;
+        bv_m0 = m0;
+#pragma unroll
+        for (int i = 0; i < (EPI == F6_EPI_PLANES_T ? TM : 1); ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const int m = m0 + (wm * TM + i) * 32 + 8 * g4 + 4 * h;
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && m < p.M) {
+                    const float* src = p.bias + m;
+                    if (first) { b4[0] = src[0]; b4[1] = src[1]; b4[2] = src[2]; b4[3] = src[3]; }
+                    else       // mid-stream: opaque loads with their own wait, so that the compiler's vmcnt bookkeeping of the tile loop stays as it is
+                        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
+                                     "global_load_dword %3, %4, off offset:12\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(src) : "memory");
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[i][4 * g4 + u] = b4[u];
+            }
+    };
     auto zero_acc = [&]() {
+        load_bias();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = EPI == F6_EPI_PLANES_T ? bv[i][e] : 0.f;
     };
     zero_acc();
 
@@ -478,11 +550,11 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
 
 }  // namespace
 
-int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st) {
+int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st, const float* row_scale, int scale_div) {
     if (rows <= 0 || K <= 0) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d", (long long)rows, K);
     const int64_t bx = (rows + 255) / 256;
     if (bx > 0x7fffffffLL || p.Kb > 65535) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d exceed the grid", (long long)rows, K);
-    hipLaunchKernelGGL(quantize_f16f6_kernel, dim3((unsigned)bx, (unsigned)p.Kb), dim3(256), 0, st, x, ld, rows, K, p);
+    hipLaunchKernelGGL(quantize_f16f6_kernel, dim3((unsigned)bx, (unsigned)p.Kb), dim3(256), 0, st, x, ld, rows, K, p, row_scale, scale_div > 0 ? scale_div : 1);
     return launch_status("quantize_f16f6");
 }
 
@@ -509,6 +581,12 @@ int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st) {
             if (a.sm_part && !(p.gdiv == 2 && a.ldc_n == 2 && a.sm_mask)) return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: softmax partials need gdiv = 2, ldc_n = 2 and a mask");
             if (p.gdiv == 2 && a.ldc_n == 2) return a.sm_part ? launch_f6<F6_EPI_INTERLEAVE2_SM>(p, a.nb, a.N, st) : launch_f6<F6_EPI_INTERLEAVE2>(p, a.nb, a.N, st);
             return launch_f6<F6_EPI_INTERLEAVE>(p, a.nb, a.N, st);
+        case 6:
+            if (!a.out || a.nb != 1 || a.M % 32 != 0 || a.scale || a.out->Kb * 32 < a.M || a.N >= (1 << 30))
+                return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: transposed planes output needs nb = 1, M %% 32 == 0, no epilogue scale and planes of >= M features");
+            p.oH = reinterpret_cast<char*>(a.out->H); p.oFL = reinterpret_cast<char*>(a.out->FL); p.oS = reinterpret_cast<char*>(a.out->S);
+            p.o_ra = a.out->rows_alloc; p.o_ras = a.out->rows_allocS; p.o_rdiv = (int)a.out->rdiv; p.o_rstride = (int)a.out->rstride; p.gdiv = 1;
+            return launch_f6<F6_EPI_PLANES_T>(p, a.nb, a.N, st);
         default: return fail(CTI_E_UNSUPPORTED, "gemm_nt_f16f6: epi=%d", a.epi);
     }
 }
@@ -545,4 +623,30 @@ extern "C" int cti_gemm_nt_f16f6(const void* A_planes, int64_t rowsA_total, int6
     g.epi = gdiv > 1 ? 3 : 0; g.C = C; g.ldc_m = ldc_m; g.ldc_n = ldc_n; g.sC = sC; g.gdiv = gdiv;
     g.scale = scale; g.scale_div = scale_div; g.bias = bias; g.relu = act == CTI_ACT_RELU;
     return gemm_nt_f16f6(g, as_stream(stream));
+}
+
+extern "C" int cti_gemm_nt_f16f6_planes(const void* W_planes, int64_t rowsW_total, const void* X_planes, int64_t rowsX_total, void* Y_planes, size_t Y_bytes,
+                                        int64_t batch_rows_out, int M, int N, int K, const float* bias, int act, void* stream) {
+    CTI_REQUIRE_PTR(W_planes); CTI_REQUIRE_PTR(X_planes); CTI_REQUIRE_PTR(Y_planes);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && M <= rowsW_total && N <= rowsX_total && batch_rows_out >= 0, CTI_E_SHAPE, "cti_gemm_nt_f16f6_planes: M=%d N=%d K=%d", M, N, K);
+    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_gemm_nt_f16f6_planes: act=%d", act);
+    CTI_REQUIRE(Y_bytes >= f6_planes_bytes(N, M, batch_rows_out), CTI_E_WORKSPACE, "cti_gemm_nt_f16f6_planes: output block %zu < %zu", Y_bytes, f6_planes_bytes(N, M, batch_rows_out));
+    CTI_REQUIRE((reinterpret_cast<uintptr_t>(Y_planes) & 255) == 0, CTI_E_ALIGN, "cti_gemm_nt_f16f6_planes: the output block must be 256-B aligned");
+    F6GemmArgs g{};
+    g.A = f6_carve(const_cast<void*>(W_planes), rowsW_total, K, 0); g.B = f6_carve(const_cast<void*>(X_planes), rowsX_total, K, 0);
+    const F6Planes out = f6_carve(Y_planes, N, M, batch_rows_out);
+    g.nb = 1; g.M = M; g.N = N; g.epi = 6; g.out = &out;
+    g.bias = bias; g.relu = act == CTI_ACT_RELU;
+    return gemm_nt_f16f6(g, as_stream(stream));
+}
+
+extern "C" int cti_quantize_f16f6_scaled(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, const float* row_scale, int scale_div, void* planes,
+                                         size_t planes_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(planes); CTI_REQUIRE_PTR(row_scale);
+    CTI_REQUIRE(rows > 0 && K > 0 && ld >= K && batch_rows >= 0 && scale_div > 0, CTI_E_SHAPE, "cti_quantize_f16f6_scaled: rows=%lld K=%d ld=%lld batch_rows=%lld scale_div=%d", (long long)rows, K, (long long)ld, (long long)batch_rows, scale_div);
+    CTI_REQUIRE(planes_bytes >= f6_planes_bytes(rows, K, batch_rows), CTI_E_WORKSPACE, "cti_quantize_f16f6_scaled: block %zu < %zu", planes_bytes, f6_planes_bytes(rows, K, batch_rows));
+    CTI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 255) == 0, CTI_E_ALIGN, "cti_quantize_f16f6_scaled: the plane block must be 256-B aligned");
+    hipError_t e = hipMemsetAsync(planes, 0, f6_planes_bytes(rows, K, batch_rows), as_stream(stream));
+    if (e != hipSuccess) return fail((int)e, "cti_quantize_f16f6_scaled: hipMemsetAsync: %s", hipGetErrorString(e));
+    return quantize_f16f6(x, ld, rows, K, f6_carve(planes, rows, K, batch_rows), as_stream(stream), row_scale, scale_div);
 }

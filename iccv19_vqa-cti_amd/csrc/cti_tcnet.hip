@@ -72,6 +72,9 @@ struct Plan {
     // f16f6 mode: the mode-3 product runs on f16 + fp6 planes (cti_f16f6.h) written by the rank GEMM's epilogue (A^) and an encoding pass (M);
     // every other GEMM stays on bf16x3
     F6Planes f_Arp, f_Mp; float* Mf32;
+    // ... and so do the a-side rank nets (A >= 7): the Tucker GEMM's epilogue encodes a~ (f_At), the rank nets run as one transposed f16f6 product
+    // whose register epilogue encodes A^ (gemm_nt_f16f6 epi 6) against the rank weights' block f_wra (weight-norm scale folded in; prepared)
+    F6Planes f_At, f_wra;
     size_t bytes;
 };
 
@@ -91,6 +94,7 @@ void carve_prep(const Dims& d, int prec, Bump& w, Plan& p) {
     }
     if (prec != CTI_PREC_F32)
         for (int s = 0; s < 3; ++s) { p.wt[s] = take_planes(w, d.h, in[s]); p.wr[s] = take_planes(w, d.h, d.h); }
+    if (prec == CTI_PREC_F16F6) p.f_wra = f6_carve(w.take(f6_planes_bytes(d.h, d.h, 0)), d.h, d.h, 0);
 }
 
 Plan carve(const Dims& d, int prec, void* ws) {
@@ -111,7 +115,8 @@ Plan carve(const Dims& d, int prec, void* ws) {
         for (int s = 0; s < 3; ++s) {
             if (!af32_side(prec, in[s])) p.xin[s] = take_planes(w, rows[s], in[s]);
             else { p.xin[s] = Planes{}; p.xin[s].Kp = planes_kp(in[s]); p.xin[s].rows_alloc = rows[s] + PLANE_SLACK_ROWS; }
-            p.tp[s] = take_planes(w, rows[s], d.h);
+            if (s == 2 && f6 && !small_a(d)) p.f_At = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, 0)), rows[2], d.h, 0);
+            else p.tp[s] = take_planes(w, rows[s], d.h);
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
         p.Qr = static_cast<float*>(w.take(sizeof(float) * rows[1] * d.h));
@@ -138,6 +143,14 @@ int check_dims(const Dims& d) {
     return CTI_OK;
 }
 
+// the a-side rank weights (R matrices of hr x h = one h x h matrix) as an f16f6 block with their weight-norm scales folded in; the block's
+// slack rows are zeroed (defined scales, zero codes)
+int quantize_rank_a(const Dims& d, const Plan& p, const float* rank_wv_a, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(p.f_wra.H, 0, f6_planes_bytes(d.h, d.h, 0), st);      // (H is the block's first plane)
+    if (e != hipSuccess) return fail((int)e, "cti_tcnet: hipMemsetAsync: %s", hipGetErrorString(e));
+    return quantize_f16f6(rank_wv_a, d.h, d.h, d.h, p.f_wra, st, p.scale_r[2], d.h / d.R);
+}
+
 // scales of the six weight-normalised layers, T_eff (and its transposed copy), and -- planes modes -- the weights' operand planes
 int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tucker_wv, const float* const* tucker_g, const float* const* rank_wv,
                 const float* const* rank_g, const float* T_g, bool weight_planes, void* stream) {
@@ -161,6 +174,7 @@ int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tuck
                 rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
                 rc = split_planes(rank_wv[s], d.h, d.h, d.h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
             }
+            if (prec == CTI_PREC_F16F6) { rc = quantize_rank_a(d, p, rank_wv[2], st); if (rc) return rc; }
         }
     }
     return CTI_OK;
@@ -317,15 +331,24 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
             r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
             r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
+            if (s == 2 && f6) { r_ = quantize_rank_a(d, p, rank_wv[2], ss); if (r_) return r_; }
         }
+        const bool f6_side = s == 2 && f6 && !fused_core;       // a side of the f16f6 mode: Tucker -> f16f6 planes -> transposed f16f6 rank product -> planes
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
         if (af32) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
         g.rows_allocA = p.xin[s].rows_alloc; g.rows_allocB = p.wt[s].rows_alloc; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
         g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.rows_allocP = p.tp[s].rows_alloc; g.Np = Kh;
+        if (f6_side) { g.epi = 4; g.f6out = &p.f_At; g.Np = h; }
         g.scale = p.scale_t[s]; g.scale_div = h; g.bias = tucker_b[s]; g.relu = relu;
         r_ = gemm_nt_planes(g, ss); if (r_) return r_;
+        if (f6_side) {
+            F6GemmArgs t{};                                  // A^^T = W_r a~^T: rows = the R * hr = h rank features, columns = the B * A answer tokens
+            t.A = p.f_wra; t.B = p.f_At; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_Arp;
+            t.bias = rank_b[2]; t.relu = relu;
+            return gemm_nt_f16f6(t, ss);
+        }
         PlaneGemmArgs r{};                                   // packed rank nets: planes -> fp32 (v, q) or planes (a)
         r.Ah = p.tp[s].hi; r.Al = p.tp[s].lo; r.Bh = p.wr[s].hi; r.Bl = p.wr[s].lo;
         r.rows_allocA = p.tp[s].rows_alloc; r.rows_allocB = p.wr[s].rows_alloc; r.nb1 = 1; r.nb2 = 1;

@@ -608,15 +608,20 @@ def split_operand(w, prec=None):
     return block
 
 
-def quantize_f16f6(x, batch_rows=0):
+def quantize_f16f6(x, batch_rows=0, row_scale=None, scale_div=1):
     """(rows, K) fp32 -> the f16f6 operand planes (one uint8 block): f16 hi plane + block-scaled fp6 codes of the hi part and of the residual.
-    batch_rows > 0: every batch of batch_rows rows starts at a multiple of 8 plane rows (for batched products)."""
+    batch_rows > 0: every batch of batch_rows rows starts at a multiple of 8 plane rows (for batched products).  row_scale: row m is
+    multiplied by row_scale[m // scale_div] on the way in (a weight-normalised layer's g / ||V||)."""
     _req(x, "x")
     x2, ld = _rows2d(x)
     rows, K = x2.shape
     lib = L.lib()
     nb = lib.cti_f16f6_planes_bytes(rows, K, int(batch_rows))
     block = torch.empty(nb, device=x.device, dtype=torch.uint8)
+    if row_scale is not None:
+        L.check(lib.cti_quantize_f16f6_scaled(x2.data_ptr(), ld, rows, K, int(batch_rows), row_scale.data_ptr(), int(scale_div), block.data_ptr(), nb, _stream()),
+                "cti_quantize_f16f6_scaled")
+        return block
     L.check(lib.cti_quantize_f16f6(x2.data_ptr(), ld, rows, K, int(batch_rows), block.data_ptr(), nb, _stream()), "cti_quantize_f16f6")
     return block
 
@@ -642,6 +647,18 @@ def gemm_nt_f16f6(A, B, nb=1, M=None, N=None, gdiv=1, scale=None, scale_div=1, b
                                           ldc_m, ldc_n, sC, gdiv, nb, M, N, K, _ptr(scale), int(scale_div), _ptr(bias),
                                           L.ACT_RELU if relu else L.ACT_NONE, _stream()), "cti_gemm_nt_f16f6")
     return C
+
+
+def linear_f16f6_planes(x_planes, rows, w_planes, M, K, batch_rows_out=0, bias=None, relu=False):
+    """act(x @ w.T + bias) between f16f6 blocks: x (rows, K) and w (M, K) as blocks of quantize_f16f6 -> the block of the (rows, M) result.
+    A weight-norm scale belongs in w's block (quantize_f16f6(w, row_scale=..., scale_div=...))."""
+    lib = L.lib()
+    nb = lib.cti_f16f6_planes_bytes(rows, M, int(batch_rows_out))
+    y = torch.zeros(nb, device=x_planes.device, dtype=torch.uint8)
+    with _timed("gemm_nt_f16f6_planes"):
+        L.check(lib.cti_gemm_nt_f16f6_planes(w_planes.data_ptr(), M, x_planes.data_ptr(), rows, y.data_ptr(), nb, int(batch_rows_out), M, rows, K,
+                                             _ptr(bias), L.ACT_RELU if relu else L.ACT_NONE, _stream()), "cti_gemm_nt_f16f6_planes")
+    return y
 
 
 def transpose(src, rows, cols, batch=1, s_src=0, ld_src=None, dst=None, s_dst=0, ld_dst=None):

@@ -245,6 +245,16 @@ int cti_quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, int64_t 
 int cti_gemm_nt_f16f6(const void* A_planes, int64_t rowsA_total, int64_t batch_rowsA, const void* B_planes, int64_t rowsB_total, int64_t batch_rowsB,
                       float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC, int gdiv, int nb, int M, int N, int K, const float* scale, int scale_div,
                       const float* bias, int act, void* stream);
+/* A weight-normalised Linear layer between two f16f6 operands (src/fc.py:22-29 as the a-side rank nets of src/tc.py:46 run it in the f16f6
+ * mode): Y = act(X W^T + bias[m]) for X (N rows x K) and W (M features x K) given as f16f6 blocks, Y (N x M) written as an f16f6 block
+ * (cti_f16f6_planes_bytes(N, M, batch_rows_out); batches of batch_rows_out rows start at multiples of 8 plane rows).  The product is taken
+ * as W X^T so that a lane pair of the accumulator holds one row's 32-feature block and the encoder runs in registers; the bias is the
+ * accumulators' initial value.  The weight-norm scale g / ||V|| belongs in W's block: cti_quantize_f16f6_scaled multiplies row m by
+ * row_scale[m / scale_div] while encoding.  M % 32 == 0; slack / padding rows of Y are left untouched. */
+int cti_gemm_nt_f16f6_planes(const void* W_planes, int64_t rowsW_total, const void* X_planes, int64_t rowsX_total, void* Y_planes, size_t Y_bytes,
+                             int64_t batch_rows_out, int M, int N, int K, const float* bias, int act, void* stream);
+int cti_quantize_f16f6_scaled(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, const float* row_scale, int scale_div, void* planes,
+                              size_t planes_bytes, void* stream);
 
 /* C (N x K, contiguous) = a^T b for a (M x N, row stride lda) and b (M x K, row stride ldb): the weight-gradient contraction over the
  * ROW axis (dW = dz^T x; src/fc.py:22-29 under autograd).  Both operands are written straight to transposed bf16 hi/lo planes, the M axis

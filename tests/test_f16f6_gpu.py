@@ -152,3 +152,70 @@ def test_gemm_random_shapes_cover_the_stream_protocol(seed):
     ref = _ref(A, B, nb, M, N, gdiv)
     err = np.abs(C - ref).max() / np.abs(ref).max()
     assert err < 5e-5, "nb=%d M=%d N=%d K=%d gdiv=%d: %.3g" % (nb, M, N, K, gdiv, err)
+
+
+def _decode(H, CL, SL):
+    grid = e2m3_grid()
+    return H.astype(np.float64) + np.where(CL & 32, -1.0, 1.0) * grid[CL & 31] * np.repeat(2.0 ** (SL.astype(np.float64) - 127), 32, axis=1)
+
+
+@pytest.mark.parametrize("rows,M,K,batch", [(500, 64, 64, 0), (192 * 3, 512, 512, 0), (1000, 96, 160, 125), (37, 32, 32, 0), (3129 * 2, 512, 512, 3129)])
+def test_planes_to_planes_linear_is_the_encoder_applied_to_the_f32_product(rows, M, K, batch):
+    """cti_gemm_nt_f16f6_planes without scale / bias / activation: its planes are, bit for bit, the encoder's output on the fp32 result of the
+    same product taken in the same orientation (W X^T written transposed) -- the register epilogue's lane-pair exchange, block / row
+    addressing and batch padding under one exact check."""
+    g = torch.Generator().manual_seed(rows + M + K)
+    x = torch.relu(torch.randn(rows, K, generator=g)) * 2.0
+    w = torch.randn(M, K, generator=g) * 0.3
+    px, pw = ops.quantize_f16f6(x.to(DEV)), ops.quantize_f16f6(w.to(DEV))
+    y = ops.linear_f16f6_planes(px, rows, pw, M, K, batch_rows_out=batch)
+    # the same accumulators as fp32: C^T[m, n] stored at n * M + m
+    C = torch.empty(rows, M, device=DEV)
+    L = cti_amd.pkg._lib
+    L.check(L.lib().cti_gemm_nt_f16f6(pw.data_ptr(), M, 0, px.data_ptr(), rows, 0, C.data_ptr(), 1, M, 0, 1, 1, M, rows, K, 0, 1, 0, 0, ops._stream()), "g")
+    ref = ops.quantize_f16f6(C, batch)
+    got, want = unpack(y, rows, M, batch), unpack(ref, rows, M, batch)
+    for a, b, name in zip(got, want, ("H", "lo codes", "hi scales", "lo scales")):
+        assert np.array_equal(a.view(np.uint16) if a.dtype == np.float16 else a, b.view(np.uint16) if b.dtype == np.float16 else b), name
+    err = np.abs(C.cpu().numpy() - (x.double() @ w.double().T).numpy()).max() / float((x.double() @ w.double().T).abs().max())
+    assert err < 5e-5
+
+
+@pytest.mark.parametrize("rows,M,K,hr", [(700, 128, 96, 16), (40000, 768, 64, 48)])
+def test_planes_to_planes_linear_scale_bias_relu(rows, M, K, hr):
+    """(the second shape has three row tiles and more tiles than workgroups: a workgroup's row tile changes mid-stream and it reloads its bias registers)"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.relu(torch.randn(rows, K, generator=g))
+    w = torch.randn(M, K, generator=g) * 0.2
+    scale = torch.rand(M // hr, generator=g) + 0.5
+    bias = torch.randn(M, generator=g) * 0.5
+    pw = ops.quantize_f16f6(w.to(DEV), row_scale=scale.to(DEV), scale_div=hr)          # the weight-norm scale rides in the weight's block
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(unpack(pw, M, K), unpack(ops.quantize_f16f6((w * scale.repeat_interleave(hr)[:, None]).to(DEV)), M, K)))
+    y = ops.linear_f16f6_planes(ops.quantize_f16f6(x.to(DEV)), rows, pw, M, K, batch_rows_out=70, bias=bias.to(DEV), relu=True)
+    H, CL, SH, SL = unpack(y, rows, M, 70)
+    ref = torch.relu((x.double() @ w.double().T) * scale.double().repeat_interleave(hr)[None, :] + bias.double()[None, :]).numpy()
+    err = np.abs(_decode(H, CL, SL) - ref).max() / np.abs(ref).max()
+    print("planes -> planes linear: normalised max error %.3g" % err)
+    assert err < 5e-5
+    assert (H >= 0).all()                                            # ReLU
+
+
+def test_planes_to_planes_linear_out_of_range_values_match_the_encoder():
+    """Values beyond f16's range (outside the format's domain): the register encoder's rarely taken branch gives the same planes as the
+    stand-alone encoder -- hi part saturated, the excess in the residual's codes."""
+    rows, M, K = 64, 32, 32
+    x = torch.full((rows, K), 300.0)
+    x[::3] = 0.01
+    w = torch.full((M, K), 40.0)
+    w[1::2] = -40.0
+    px, pw = ops.quantize_f16f6(x.to(DEV)), ops.quantize_f16f6(w.to(DEV))
+    y = ops.linear_f16f6_planes(px, rows, pw, M, K)
+    C = torch.empty(rows, M, device=DEV)
+    L = cti_amd.pkg._lib
+    L.check(L.lib().cti_gemm_nt_f16f6(pw.data_ptr(), M, 0, px.data_ptr(), rows, 0, C.data_ptr(), 1, M, 0, 1, 1, M, rows, K, 0, 1, 0, 0, ops._stream()), "g")
+    assert float(C.abs().max()) > 65504
+    for a_, b_ in zip(unpack(y, rows, M), unpack(ops.quantize_f16f6(C), rows, M)):
+        assert np.array_equal(a_.view(np.uint16) if a_.dtype == np.float16 else a_, b_.view(np.uint16) if b_.dtype == np.float16 else b_)
+    yr = ops.linear_f16f6_planes(px, rows, pw, M, K, relu=True)
+    for a_, b_ in zip(unpack(yr, rows, M), unpack(ops.quantize_f16f6(torch.relu(C)), rows, M)):
+        assert np.array_equal(a_.view(np.uint16) if a_.dtype == np.float16 else a_, b_.view(np.uint16) if b_.dtype == np.float16 else b_)

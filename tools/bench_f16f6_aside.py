@@ -30,3 +30,15 @@ for K in (300, 512):
     out = torch.empty(rows, 512, device=dev)
     tg = t(lambda: L.check(lib.cti_gemm_nt_f16f6(px.data_ptr(), rows, 0, pw.data_ptr(), 512, 0, out.data_ptr(), 512, 1, 0, 1, 1, rows, 512, K, 0, 1, 0, 0, st), "g"))
     print(json.dumps({"K": K, "quantize_ms": round(tq, 3), "gemm_f32out_ms": round(tg, 3), "gemm_tflops": round(2.0 * rows * 512 * K / tg / 1e9, 1)}))
+
+# the a-side rank nets as they run in the f16f6 mode: planes -> planes, transposed product, register epilogue
+K, M = 512, 512
+x = torch.relu(torch.randn(rows, K, device=dev))
+w = torch.randn(M, K, device=dev) * 0.05
+sc = torch.rand(32, device=dev) + 0.5
+bi = torch.randn(M, device=dev)
+px, pw = ops.quantize_f16f6(x), ops.quantize_f16f6(w)
+nby = lib.cti_f16f6_planes_bytes(rows, M, 3129)
+y = torch.zeros(nby, device=dev, dtype=torch.uint8)
+tp = t(lambda: L.check(lib.cti_gemm_nt_f16f6_planes(pw.data_ptr(), M, px.data_ptr(), rows, y.data_ptr(), nby, 3129, M, rows, K, bi.data_ptr(), 1, st), "p"), n=10)
+print(json.dumps({"planes_to_planes_ms": round(tp, 3), "tflops": round(2.0 * rows * M * K / tp / 1e9, 1)}))
