@@ -23,6 +23,7 @@ SIGNATURES = {
     "cti_teff_scramble": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_planes_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _i64, _vp]),
+    "cti_paralind_mbuild_f16f6_fwd": (_int, [_vp, _vp, _vp, _vp, _sz, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_core_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_paralind_core_workspace_bytes": (_sz, [_int, _int, _int, _int, _int, _int]),
     "cti_event_create": (_vp, []),

@@ -188,6 +188,9 @@ typedef unsigned short f6_u16x2 __attribute__((ext_vector_type(2)));
 #ifndef CTI_F6_ABL
 #define CTI_F6_ABL 0
 #endif
+// SAT_EXCESS = false drops that branch (a saturated value then decodes to +-65504): for callers at their register ceiling -- the branch keeps
+// all 32 inputs and the 16 packed hi words alive to the end.
+template <bool SAT_EXCESS = true>
 __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float lo_bound, char* Hrow, char* FLrow, char* Srow) {
     if ((CTI_F6_ABL & 16) && x[31] != 12345.f) { Hrow = FLrow = Srow = nullptr; }      // timing-only ablation: the arithmetic without the stores
     const float lo_sat = fmaxf(lo_bound, -65504.f);
@@ -204,9 +207,10 @@ __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float
         ml = fmaxf(ml, fmaxf(fabsf(l[0]), fabsf(l[1])));
         hw[u] = __builtin_bit_cast(unsigned, h);
         mh2 = __builtin_elementwise_max(mh2, __builtin_bit_cast(f6_u16x2, hw[u] & 0x7fff7fffu));
+        if ((u & 3) == 3 && (!(CTI_F6_ABL & 16) || Hrow)) reinterpret_cast<f6_u32x4*>(Hrow)[u >> 2] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
     }
     const unsigned short mhb = mh2[0] > mh2[1] ? mh2[0] : mh2[1];
-    if (mhb >= 0x7bffu) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)
+    if (SAT_EXCESS && mhb >= 0x7bffu) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)
         ml = 0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -215,10 +219,6 @@ __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float
             ml = fmaxf(ml, fmaxf(fabsf(lf[2 * u]), fabsf(lf[2 * u + 1])));
         }
         if (!(ml < 3.0e38f)) ml = 0.f;
-    }
-    if (!(CTI_F6_ABL & 16) || Hrow) {
-#pragma unroll
-        for (int q8 = 0; q8 < 4; ++q8) reinterpret_cast<f6_u32x4*>(Hrow)[q8] = f6_u32x4{hw[4 * q8], hw[4 * q8 + 1], hw[4 * q8 + 2], hw[4 * q8 + 3]};
     }
     const float mh = static_cast<float>(__builtin_bit_cast(_Float16, mhb));
     const int sh = f6_scale_byte(mh), sl = f6_scale_byte(ml);

@@ -10,6 +10,7 @@
 // 2 x 4) 16-B pieces, i.e. 64/128 contiguous bytes: M is written exactly once, in the layout the mode-3 GEMM DMA reads.
 // 35 MFLOP/sample at C2, fp32 VALU (exact), HBM traffic = the M planes (2 MB/sample) + Vr/Qr (0.1 MB/sample).
 #include "cti_common.h"
+#include "cti_f16f6.h"
 
 namespace cti {
 namespace {
@@ -397,6 +398,145 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
 }
 
 // =====================================================================================================
+// The same M build writing the f16f6 operand planes of the mode-3 product DIRECTLY (cti_f16f6.h): no fp32 M in HBM (528 MB written and read
+// back at BASELINE configs[1]) and no encoding pass.  A scale block is 32 consecutive K = TWO ranks of one output row (v, q, g), and a
+// step-2 tile holds one rank's 16 k for both g, spread over a lane pair exactly like the transposed GEMM's accumulators: eight
+// v_permlane32_swap hand the lower lanes the 16 values of (v, q, g = 0) and the upper lanes those of g = 1.  The even rank's values wait
+// in a wave-private LDS buffer (hold[v][4 chunks][(g, q)][4 floats]: a lane's four 16-B pieces are 16 B apart across lanes -- conflict-free;
+// LDS has no room for a second rank of X), the odd rank's stay in registers, and every lane with a real q encodes one whole (row, block)
+// item in registers (f6_encode_row32_regs; without the saturation-excess branch -- M values beyond f16's range, outside the format's
+// domain, clamp to +-65504 here).  LDS: X2 + hold = (2560 + 128 Q) V bytes <= 160 KiB (configs[1]: 153 KiB).
+#ifndef CTI_MBF6_PREFETCH_EARLY
+#define CTI_MBF6_PREFETCH_EARLY 1
+#endif
+__global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr, const float* __restrict__ Tt,
+                                                              F6Planes P, int V, int Q, int R) {
+    constexpr int HR = 16, G = 2, INNER = HR * HR * G;
+    extern __shared__ __attribute__((aligned(16))) float X2[];
+    float* hold = X2 + (size_t)V * G * HR * MB_XP;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int K = R * HR;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vb = Vr + (int64_t)b * V * K + kg * 8;
+    const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
+    const int v0 = l31, v1 = 32 + l31;
+    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
+    const int c1 = wid * 32 + l31;
+    const int xk = l31 >> 1, xg = l31 & 1;
+    const int64_t rows_b = (int64_t)b * V * Q * G;
+    typedef float mbf_f32x4 __attribute__((ext_vector_type(4)));
+    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
+#define CTI_MM_LOAD(rr)                                                                                             \
+    {                                                                                                               \
+        const int o_ = (rr) * HR;                                                                                   \
+        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
+        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
+        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_); q1 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_ + 4); } \
+        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
+        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
+    }
+    CTI_MM_LOAD(0)
+    for (int r = 0; r < R; ++r) {
+        mb_bf16x8 ah0, al0, ah1, al1, th, tl, qh, ql;
+        mb_split8(a00, a01, ah0, al0);
+        mb_split8(a10, a11, ah1, al1);
+        mb_split8(t0, t1, th, tl);
+        mb_split8(q0, q1, qh, ql);
+#if CTI_MBF6_PREFETCH_EARLY
+        if (r + 1 < R) CTI_MM_LOAD(r + 1)
+#endif
+        mb_f32x16 x0, x1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, th, x0, 0, 0, 0);
+        if (V > 32) {
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
+        }
+        __syncthreads();
+        {
+            // X -> LDS without branches and without 32 hoisted per-lane addresses (which the allocator then spills): one base per row tile,
+            // re-derived every rank behind an opaque barrier, compile-time offsets, and rows beyond V redirected to a pad column of row 0
+            float* xw = X2 + ((4 * kg * G + xg) * HR + xk) * MB_XP + wid;
+            asm volatile("" : "+v"(xw));
+            float* const trash = X2 + 16 + (lane & 3);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg;
+                float* d0 = xw + vo * (G * HR * MB_XP);
+                if (V < 32) d0 = vv < V ? d0 : trash;
+                *d0 = x0[e];
+            }
+            if (V > 32) {
+                float* xw1 = xw + 32 * (G * HR * MB_XP);
+                asm volatile("" : "+v"(xw1));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg + 32;
+                    float* d1 = xw1 + vo * (G * HR * MB_XP);
+                    d1 = vv < V ? d1 : trash;
+                    *d1 = x1[e];
+                }
+            }
+        }
+        __syncthreads();
+        const int sg = l31 >> 4, sk = l31 & 15;
+        const bool odd = r & 1;
+        for (int v = wid; v < V; v += 16) {
+            const float* xr = X2 + ((v * G + sg) * HR + sk) * MB_XP + kg * 8;
+            mb_bf16x8 xh, xl;
+            mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
+            mb_f32x16 m;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = 0.f;
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, qh, m, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ql, m, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, qh, m, 0, 0, 0);
+            // register 4 eg + t of lane (q, kg) is rho = 8 eg + 4 kg + t = (g = eg >> 1, k = 8 (eg & 1) + 4 kg + t): the swaps of (eg 0, eg 2) and
+            // (eg 1, eg 3) leave lane half g with y[k], k = 0 .. 15, of output row (v, q, g)
+            float y[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float xa = m[t], ya = m[8 + t], xb = m[4 + t], yb = m[12 + t];
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(xa), "+v"(ya));
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(xb), "+v"(yb));
+                y[t] = xa; y[4 + t] = ya; y[8 + t] = xb; y[12 + t] = yb;
+            }
+            if (!qok) continue;
+            float* hp = hold + ((size_t)v * 4 * (2 * Q) + kg * Q + l31) * 4;           // chunk c at + c * 2Q * 4 floats
+            if (!odd) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<mbf_f32x4*>(hp + c * (2 * Q) * 4) = mbf_f32x4{y[4 * c], y[4 * c + 1], y[4 * c + 2], y[4 * c + 3]};
+                continue;
+            }
+            float x[32];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const mbf_f32x4 hv = *reinterpret_cast<const mbf_f32x4*>(hp + c * (2 * Q) * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[4 * c + u] = hv[u];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[16 + k] = y[k];
+            const int64_t prow = f6_prow(P, rows_b + ((int64_t)v * Q + l31) * G + kg);
+            const int kb = r >> 1;
+            const int64_t o = (int64_t)kb * P.rows_alloc + prow;
+            f6_encode_row32_regs<false>(x, -__builtin_huge_valf(), reinterpret_cast<char*>(P.H) + o * 64, reinterpret_cast<char*>(P.FL) + o * 24,
+                                 reinterpret_cast<char*>(P.S) + ((int64_t)kb * P.rows_allocS + prow) * 2);
+        }
+#if !CTI_MBF6_PREFETCH_EARLY
+        if (r + 1 < R) CTI_MM_LOAD(r + 1)                      // (behind step 2: its 32 registers are the encoder's while that runs)
+#endif
+    }
+#undef CTI_MM_LOAD
+}
+
+// =====================================================================================================
 // Modes 1 + 2 + 3 in ONE kernel for FEW answer tokens (A <= 6: the FFOE / MC models, A = 3 / 6): the M tile of a rank never leaves the
 // registers.  Same two MFMA steps as mbuild_mfma_kernel; instead of splitting the step-2 tile to planes and handing 528 MB of M to a GEMM
 // whose N is 3 (98 % padding), every lane contracts the 16 (g, k) values it holds for its column q with the matching entries of Ar[a]
@@ -544,6 +684,28 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
     if (Mf) hipLaunchKernelGGL(mbuild_mfma_kernel<true>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
     else    hipLaunchKernelGGL(mbuild_mfma_kernel<false>, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Mh, Ml, Mf, V, Q, R, pitchM);
     return launch_status("mbuild_mfma");
+}
+
+// M straight into the f16f6 planes P of the mode-3 product (rows (b, v, q, g), K = R * 16).  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2,
+// even R and the LDS budget: the caller takes mbuild_mfma -> fp32 rows -> quantize_f16f6.
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st) {
+#if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
+    return CTI_E_UNSUPPORTED;
+#endif
+    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || P.Kb * 32 != R * hr) return CTI_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)V * 4 * (2 * Q) * 4);
+    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mbuild_mfma_f6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "mbuild_mfma_f6: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(mbuild_mfma_f6_kernel, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, P, V, Q, R);
+    return launch_status("mbuild_mfma_f6");
 }
 
 // Modes 1 + 2 + 3 for few answer tokens, out (B,V,Q,A,G) fp32.  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2, V <= 64, Q <= 16, A <= 6:

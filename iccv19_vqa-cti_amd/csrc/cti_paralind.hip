@@ -2,6 +2,7 @@
 // of the PARALIND core.  All HBM/L2-bound helpers: coalesced loads along the innermost axis, wave-shuffle
 // reductions (64-wide), no GEMM reshaping.
 #include "cti_common.h"
+#include "cti_f16f6.h"
 
 namespace cti {
 namespace {
@@ -266,6 +267,23 @@ extern "C" int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, 
     if (Teff_t) rc = mbuild_mfma(Vr, Qr, Teff_t, Mh, Ml, nullptr, B, V, Q, R, hr, G, rows_alloc * 16, as_stream(stream));
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(Vr, Qr, Teff, nullptr, Mh, Ml, B, V, Q, R, hr, G, rows_alloc * 16, as_stream(stream));
     if (rc == CTI_E_UNSUPPORTED) return fail(CTI_E_UNSUPPORTED, "cti_paralind_mbuild_planes_fwd: h/rank=%d G=%d V=%d Q=%d is outside the plane-writing M-build kernels", hr, G, V, Q);
+    return rc;
+}
+
+namespace cti {
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
+}
+
+extern "C" int cti_paralind_mbuild_f16f6_fwd(const float* Vr, const float* Qr, const float* Teff_t, void* planes, size_t planes_bytes, int B, int V, int Q,
+                                             int R, int hr, int G, void* stream) {
+    CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff_t); CTI_REQUIRE_PTR(planes);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && hr > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_f16f6_fwd: B=%d V=%d Q=%d R=%d hr=%d G=%d", B, V, Q, R, hr, G);
+    const int64_t rows = (int64_t)B * V * Q * G, rpb = (int64_t)V * Q * G;
+    CTI_REQUIRE((R * hr) % 32 == 0, CTI_E_UNSUPPORTED, "cti_paralind_mbuild_f16f6_fwd: R*hr = %d is not a multiple of 32", R * hr);
+    CTI_REQUIRE(planes_bytes >= f6_planes_bytes(rows, R * hr, rpb), CTI_E_WORKSPACE, "cti_paralind_mbuild_f16f6_fwd: block %zu < %zu", planes_bytes, f6_planes_bytes(rows, R * hr, rpb));
+    CTI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 255) == 0, CTI_E_ALIGN, "cti_paralind_mbuild_f16f6_fwd: the plane block must be 256-B aligned");
+    const int rc = mbuild_mfma_f6(Vr, Qr, Teff_t, f6_carve(planes, rows, R * hr, rpb), B, V, Q, R, hr, G, as_stream(stream));
+    if (rc == CTI_E_UNSUPPORTED) return fail(CTI_E_UNSUPPORTED, "cti_paralind_mbuild_f16f6_fwd: h/rank=%d G=%d V=%d Q=%d R=%d is outside the direct-encoding M build (use cti_paralind_mbuild_fwd + cti_quantize_f16f6)", hr, G, V, Q, R);
     return rc;
 }
 

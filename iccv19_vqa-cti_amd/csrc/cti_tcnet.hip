@@ -10,6 +10,7 @@
 namespace cti {
 int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
                       hipStream_t st);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
@@ -376,11 +377,14 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     if (f6) {
         // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
         // start at multiples of 8 rows
-        rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, nullptr, nullptr, p.Mf32, B, V, Q, R, hr, G, h, sb);
-        if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, p.Mf32, nullptr, nullptr, B, V, Q, R, hr, G, h, sb);
-        if (rc == CTI_E_UNSUPPORTED) rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, p.Mf32, B, V, Q, R, hr, hr, hr, G, sb);
-        if (rc) return finish(rc);
-        rc = quantize_f16f6(p.Mf32, h, (int64_t)B * mrows_per_b, h, p.f_Mp, sb);
+        rc = mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb);       // the planes directly (hr = 16, glimpse 2, X + hold buffer fit the LDS)
+        if (rc == CTI_E_UNSUPPORTED) {
+            rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, nullptr, nullptr, p.Mf32, B, V, Q, R, hr, G, h, sb);
+            if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, p.Mf32, nullptr, nullptr, B, V, Q, R, hr, G, h, sb);
+            if (rc == CTI_E_UNSUPPORTED) rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, p.Mf32, B, V, Q, R, hr, hr, hr, G, sb);
+            if (rc) return finish(rc);
+            rc = quantize_f16f6(p.Mf32, h, (int64_t)B * mrows_per_b, h, p.f_Mp, sb);
+        }
     } else {
     rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, nullptr, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);

@@ -297,6 +297,22 @@ def paralind_mbuild_planes(Vr, Qr, Teff, use_mfma=True):
     return Mh, Ml
 
 
+def paralind_mbuild_f16f6(Vr, Qr, Teff):
+    """The same M as the f16f6 operand block of the mode-3 product (rows (b,v,q,g) in batches of V*Q*G), encoded inside the M build."""
+    _req(Vr, "Vr"); _req(Qr, "Qr"); _req(Teff, "Teff")
+    R, I, J, K, G = Teff.shape
+    B, V, _ = Vr.shape
+    Q = Qr.shape[1]
+    Vr, Qr, Teff = Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
+    Tt = transpose(Teff, I, J * K * G, batch=R, s_src=I * J * K * G, ld_src=J * K * G, s_dst=I * J * K * G, ld_dst=I).view(R, J * K * G, I)
+    lib = L.lib()
+    nb = lib.cti_f16f6_planes_bytes(B * V * Q * G, R * K, V * Q * G)
+    block = torch.zeros(nb, device=Vr.device, dtype=torch.uint8)
+    L.check(lib.cti_paralind_mbuild_f16f6_fwd(Vr.data_ptr(), Qr.data_ptr(), Tt.data_ptr(), block.data_ptr(), nb, B, V, Q, R, I, G, _stream()),
+            "cti_paralind_mbuild_f16f6_fwd")
+    return block
+
+
 def paralind_core(M, Ar, prec=None):
     """M (B,V,Q,G,K), Ar (B,A,K) -> out (B,V,Q,A,G) contiguous."""
     _req(M, "M"); _req(Ar, "Ar")

@@ -113,6 +113,13 @@ int cti_paralind_mbuild_fwd(const float* Vr, const float* Qr, const float* Teff,
 int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, const float* Teff, const float* Teff_t, unsigned short* Mh,
                                    unsigned short* Ml, int B, int V, int Q, int R, int hr, int G, int64_t rows_alloc, void* stream);
 
+/* The same M, written directly as the f16f6 operand block of the mode-3 product in the f16f6 mode (below: cti_f16f6_planes_bytes(B*V*Q*G, R*hr,
+ * V*Q*G); rows (b,v,q,g) in batches of V*Q*G).  Teff_t as above (required).  hr = 16, G = 2, even R and (2560 + 128 Q) V <= 160 KiB of LDS
+ * (BASELINE configs[1]: V = 36, Q = 14); CTI_E_UNSUPPORTED otherwise (cti_paralind_mbuild_fwd + cti_quantize_f16f6 give the same block).
+ * Slack / padding rows are left untouched; values beyond f16's range (outside the format's domain) clamp to +-65504. */
+int cti_paralind_mbuild_f16f6_fwd(const float* Vr, const float* Qr, const float* Teff_t, void* planes, size_t planes_bytes, int B, int V, int Q,
+                                  int R, int hr, int G, void* stream);
+
 /* out[b,vq,a,g] = sum_K M[b,vq,g,K] * Ar[b,a,K]   (mode-3 product + the sum over ranks, src/Tensor.py:16-20 and the
  * running `+ f_emb` of src/tc.py:50).  M: (B,VQ,G,K); Ar: (B,A,K); out: (B,VQ,A,G) contiguous = the logical
  * (B,V,Q,A,G) tensor TCNet.forward returns.  prec / workspace as for cti_wn_linear_fwd. */

@@ -219,3 +219,26 @@ def test_planes_to_planes_linear_out_of_range_values_match_the_encoder():
     yr = ops.linear_f16f6_planes(px, rows, pw, M, K, relu=True)
     for a_, b_ in zip(unpack(yr, rows, M), unpack(ops.quantize_f16f6(torch.relu(C)), rows, M)):
         assert np.array_equal(a_.view(np.uint16) if a_.dtype == np.float16 else a_, b_.view(np.uint16) if b_.dtype == np.float16 else b_)
+
+
+@pytest.mark.parametrize("B,V,Q,R", [(3, 36, 14, 32), (2, 9, 5, 4), (5, 33, 16, 2), (1, 40, 8, 6)])
+def test_m_build_encodes_its_planes_itself(B, V, Q, R):
+    """cti_paralind_mbuild_f16f6_fwd (modes 1 + 2 of src/Tensor.py:6-13 straight into the mode-3 product's f16f6 block: two ranks per scale
+    block, lane-pair exchange, wave-private hold buffer) against the exact-fp32 M build: hi + decoded lo within the format's 2^-15 of the
+    block maximum plus the three-product bf16 arithmetic of the build, scales consistent with the decoded block, batches padded to 8 rows."""
+    hr, G = 16, 2
+    g = torch.Generator().manual_seed(B * 100 + V + Q + R)
+    Vr = torch.relu(torch.randn(B, V, R * hr, generator=g)).to(DEV)
+    Qr = torch.relu(torch.randn(B, Q, R * hr, generator=g)).to(DEV)
+    Teff = torch.randn(R, hr, hr, hr, G, generator=g).to(DEV)
+    M = ops.paralind_mbuild(Vr, Qr, Teff).reshape(B * V * Q * G, R * hr).cpu().numpy().astype(np.float64)
+    blk = ops.paralind_mbuild_f16f6(Vr, Qr, Teff)
+    H, CL, SH, SL = unpack(blk, B * V * Q * G, R * hr, V * Q * G)
+    dec = _decode(H, CL, SL)
+    bmax = np.repeat(np.abs(M).reshape(M.shape[0], -1, 32).max(-1), 32, axis=1)
+    err = np.max(np.abs(dec - M) / np.maximum(bmax, 1e-30))
+    print("M build -> f16f6 planes B=%d V=%d Q=%d R=%d: max error / block max %.3g" % (B, V, Q, R, err))
+    assert err < 6e-5
+    # the stored scales are the encoder's for the values actually stored
+    h, ch, cl, sh, sl = np_encode(H.astype(np.float32))
+    assert np.array_equal(SH, sh)
