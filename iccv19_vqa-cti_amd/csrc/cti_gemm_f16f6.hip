@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __rest
                                                               const float* __restrict__ row_scale, int scale_div) {
     __shared__ __attribute__((aligned(16))) float patch[4][64 * 36];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int kb = blockIdx.y, k0 = kb * 32;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * 64;
+    // the K block is the FAST grid axis: workgroups dispatched together read adjacent 128-B pieces of the same 256 rows (whole DRAM pages and
+    // shared cache lines when the row length is not a multiple of 128 B) instead of one piece of every row per pass over the matrix
+    const int kb = blockIdx.x, k0 = kb * 32;
+    const int64_t row0 = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 4 + wid) * 64;
     if (row0 >= rows) return;
     float* st = patch[wid];
     const int c4 = lane & 7, rsub = lane >> 3;
@@ -553,8 +555,9 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
 int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st, const float* row_scale, int scale_div) {
     if (rows <= 0 || K <= 0) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d", (long long)rows, K);
     const int64_t bx = (rows + 255) / 256;
-    if (bx > 0x7fffffffLL || p.Kb > 65535) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d exceed the grid", (long long)rows, K);
-    hipLaunchKernelGGL(quantize_f16f6_kernel, dim3((unsigned)bx, (unsigned)p.Kb), dim3(256), 0, st, x, ld, rows, K, p, row_scale, scale_div > 0 ? scale_div : 1);
+    const int64_t gz = (bx + 65534) / 65535, gy = (bx + gz - 1) / gz;          // row blocks spread over (y, z): y <= 65535
+    if (gz > 65535) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d exceed the grid", (long long)rows, K);
+    hipLaunchKernelGGL(quantize_f16f6_kernel, dim3((unsigned)p.Kb, (unsigned)gy, (unsigned)gz), dim3(256), 0, st, x, ld, rows, K, p, row_scale, scale_div > 0 ? scale_div : 1);
     return launch_status("quantize_f16f6");
 }
 

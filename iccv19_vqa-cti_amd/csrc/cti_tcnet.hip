@@ -76,6 +76,9 @@ struct Plan {
     // ... and so do the a-side rank nets (A >= 7): the Tucker GEMM's epilogue encodes a~ (f_At), the rank nets run as one transposed f16f6 product
     // whose register epilogue encodes A^ (gemm_nt_f16f6 epi 6) against the rank weights' block f_wra (weight-norm scale folded in; prepared)
     F6Planes f_At, f_wra;
+    // ... and the a-side Tucker projection: `a` is encoded once (f_Ain) and multiplied with the Tucker weight's block f_wta (scale folded in; prepared)
+    // in the same transposed form
+    F6Planes f_Ain, f_wta;
     size_t bytes;
 };
 
@@ -95,7 +98,10 @@ void carve_prep(const Dims& d, int prec, Bump& w, Plan& p) {
     }
     if (prec != CTI_PREC_F32)
         for (int s = 0; s < 3; ++s) { p.wt[s] = take_planes(w, d.h, in[s]); p.wr[s] = take_planes(w, d.h, d.h); }
-    if (prec == CTI_PREC_F16F6) p.f_wra = f6_carve(w.take(f6_planes_bytes(d.h, d.h, 0)), d.h, d.h, 0);
+    if (prec == CTI_PREC_F16F6) {
+        p.f_wra = f6_carve(w.take(f6_planes_bytes(d.h, d.h, 0)), d.h, d.h, 0);
+        p.f_wta = f6_carve(w.take(f6_planes_bytes(d.h, d.ad, 0)), d.h, d.ad, 0);
+    }
 }
 
 Plan carve(const Dims& d, int prec, void* ws) {
@@ -114,9 +120,13 @@ Plan carve(const Dims& d, int prec, void* ws) {
     } else {
         const bool f6 = prec == CTI_PREC_F16F6;
         for (int s = 0; s < 3; ++s) {
-            if (!af32_side(prec, in[s])) p.xin[s] = take_planes(w, rows[s], in[s]);
+            if (s == 2 && f6 && !small_a(d)) p.xin[s] = Planes{};
+            else if (!af32_side(prec, in[s])) p.xin[s] = take_planes(w, rows[s], in[s]);
             else { p.xin[s] = Planes{}; p.xin[s].Kp = planes_kp(in[s]); p.xin[s].rows_alloc = rows[s] + PLANE_SLACK_ROWS; }
-            if (s == 2 && f6 && !small_a(d)) p.f_At = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, 0)), rows[2], d.h, 0);
+            if (s == 2 && f6 && !small_a(d)) {
+                p.f_Ain = f6_carve(w.take(f6_planes_bytes(rows[2], d.ad, 0)), rows[2], d.ad, 0);
+                p.f_At = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, 0)), rows[2], d.h, 0);
+            }
             else p.tp[s] = take_planes(w, rows[s], d.h);
         }
         p.Vr = static_cast<float*>(w.take(sizeof(float) * rows[0] * d.h));
@@ -144,12 +154,14 @@ int check_dims(const Dims& d) {
     return CTI_OK;
 }
 
-// the a-side rank weights (R matrices of hr x h = one h x h matrix) as an f16f6 block with their weight-norm scales folded in; the block's
-// slack rows are zeroed (defined scales, zero codes)
-int quantize_rank_a(const Dims& d, const Plan& p, const float* rank_wv_a, hipStream_t st) {
+// the a-side rank weights (R matrices of hr x h = one h x h matrix) and Tucker weight as f16f6 blocks with their weight-norm scales folded in;
+// the blocks' slack rows are zeroed (defined scales, zero codes)
+int quantize_rank_a(const Dims& d, const Plan& p, const float* rank_wv_a, const float* tucker_wv_a, hipStream_t st) {
     hipError_t e = hipMemsetAsync(p.f_wra.H, 0, f6_planes_bytes(d.h, d.h, 0), st);      // (H is the block's first plane)
+    if (e == hipSuccess) e = hipMemsetAsync(p.f_wta.H, 0, f6_planes_bytes(d.h, d.ad, 0), st);
     if (e != hipSuccess) return fail((int)e, "cti_tcnet: hipMemsetAsync: %s", hipGetErrorString(e));
-    return quantize_f16f6(rank_wv_a, d.h, d.h, d.h, p.f_wra, st, p.scale_r[2], d.h / d.R);
+    int rc = quantize_f16f6(rank_wv_a, d.h, d.h, d.h, p.f_wra, st, p.scale_r[2], d.h / d.R); if (rc) return rc;
+    return quantize_f16f6(tucker_wv_a, d.ad, d.h, d.ad, p.f_wta, st, p.scale_t[2], d.h);
 }
 
 // scales of the six weight-normalised layers, T_eff (and its transposed copy), and -- planes modes -- the weights' operand planes
@@ -175,7 +187,7 @@ int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tuck
                 rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
                 rc = split_planes(rank_wv[s], d.h, d.h, d.h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, st); if (rc) return rc;
             }
-            if (prec == CTI_PREC_F16F6) { rc = quantize_rank_a(d, p, rank_wv[2], st); if (rc) return rc; }
+            if (prec == CTI_PREC_F16F6) { rc = quantize_rank_a(d, p, rank_wv[2], tucker_wv[2], st); if (rc) return rc; }
         }
     }
     return CTI_OK;
@@ -325,31 +337,36 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     };
     const int Kh = planes_kp(h);
     auto side = [&](int s, hipStream_t ss) -> int {
-        const bool af32 = af32_side(prec, in[s]);
+        const bool f6_side = s == 2 && f6 && !fused_core;       // a side of the f16f6 mode: encode a -> transposed f16f6 Tucker product -> planes -> transposed f16f6 rank product -> planes
+        const bool af32 = !f6_side && af32_side(prec, in[s]);
         if (af32 && (reinterpret_cast<uintptr_t>(x[s]) & 15)) return fail(CTI_E_ALIGN, "cti_tcnet_forward: input %d must be 16-B aligned (its rows are DMA'd as fp32)", s);
         int r_;
-        if (!af32) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
+        if (!af32 && !f6_side) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
         if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
             r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
             r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
-            if (s == 2 && f6) { r_ = quantize_rank_a(d, p, rank_wv[2], ss); if (r_) return r_; }
+            if (s == 2 && f6) { r_ = quantize_rank_a(d, p, rank_wv[2], tucker_wv[2], ss); if (r_) return r_; }
         }
-        const bool f6_side = s == 2 && f6 && !fused_core;       // a side of the f16f6 mode: Tucker -> f16f6 planes -> transposed f16f6 rank product -> planes
+        if (f6_side) {
+            r_ = quantize_f16f6(x[2], in[2], rows[2], in[2], p.f_Ain, ss); if (r_) return r_;
+            // (Measured and dropped: joining chain B HERE, behind the encoding pass, instead of in front of the mode-3 product.  Its kernels then run
+            // unstarved -- the M build 0.36 ms of wall time instead of 1.2 -- but the step takes 4.72 instead of 4.60 ms: starved as they are, they
+            // fill the tails of the persistent GEMMs' last tile rounds.)
+            F6GemmArgs t{};                                  // a~^T = W_t a^T, then A^^T = W_r a~^T: rows = features, columns = the B * A answer tokens
+            t.A = p.f_wta; t.B = p.f_Ain; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_At; t.bias = tucker_b[2]; t.relu = relu;
+            r_ = gemm_nt_f16f6(t, ss); if (r_) return r_;
+            t.A = p.f_wra; t.B = p.f_At; t.out = &p.f_Arp; t.bias = rank_b[2];
+            return gemm_nt_f16f6(t, ss);
+        }
         PlaneGemmArgs g{};                                   // Tucker: planes -> planes
         g.Ah = p.xin[s].hi; g.Al = p.xin[s].lo; g.Bh = p.wt[s].hi; g.Bl = p.wt[s].lo;
         if (af32) { g.Af = x[s]; g.ldaf = in[s]; g.Kreal = in[s]; }
         g.rows_allocA = p.xin[s].rows_alloc; g.rows_allocB = p.wt[s].rows_alloc; g.nb1 = 1; g.nb2 = 1;
         g.M = (int)rows[s]; g.N = h; g.Kp = p.xin[s].Kp; g.terms = terms; g.epi = 1;
         g.Ph = p.tp[s].hi; g.Pl = p.tp[s].lo; g.rows_allocP = p.tp[s].rows_alloc; g.Np = Kh;
-        if (f6_side) { g.epi = 4; g.f6out = &p.f_At; g.Np = h; }
+
         g.scale = p.scale_t[s]; g.scale_div = h; g.bias = tucker_b[s]; g.relu = relu;
         r_ = gemm_nt_planes(g, ss); if (r_) return r_;
-        if (f6_side) {
-            F6GemmArgs t{};                                  // A^^T = W_r a~^T: rows = the R * hr = h rank features, columns = the B * A answer tokens
-            t.A = p.f_wra; t.B = p.f_At; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_Arp;
-            t.bias = rank_b[2]; t.relu = relu;
-            return gemm_nt_f16f6(t, ss);
-        }
         PlaneGemmArgs r{};                                   // packed rank nets: planes -> fp32 (v, q) or planes (a)
         r.Ah = p.tp[s].hi; r.Al = p.tp[s].lo; r.Bh = p.wr[s].hi; r.Bl = p.wr[s].lo;
         r.rows_allocA = p.tp[s].rows_alloc; r.rows_allocB = p.wr[s].rows_alloc; r.nb1 = 1; r.nb2 = 1;
