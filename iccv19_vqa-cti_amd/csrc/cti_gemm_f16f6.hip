@@ -526,6 +526,9 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #endif
 }
 
+#ifndef CTI_F6_OVERSUB_DEFAULT
+#define CTI_F6_OVERSUB_DEFAULT 1
+#endif
 template <int EPI>
 int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
     using G = GeoF6;
@@ -544,7 +547,12 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
     p.total_tiles = (int)total;
     static thread_local int n_cu = 0;
     if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    long long grid = n_cu;
+    // Workgroups per CU.  One = fully persistent: every workgroup walks total / n_cu tiles, assigned statically -- a CU that starts late because a
+    // kernel of the other stream sat on it (the M build: one workgroup per CU, all of its LDS) finishes late, and the stream-ordered GEMM behind
+    // this one waits for it.  With a few workgroups per CU the hardware dispatcher balances that: a delayed CU simply takes fewer of them; the
+    // price is one ring refill per workgroup.  CTI_F6_OVERSUB overrides (experiments).
+    static const int oversub = [] { const char* e = getenv("CTI_F6_OVERSUB"); const int v = e ? atoi(e) : CTI_F6_OVERSUB_DEFAULT; return v < 1 ? 1 : v; }();
+    long long grid = (long long)n_cu * oversub;
     if (grid > total) grid = total;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NTHR), G::LDS, st, p);
     return launch_status("gemm_nt_f16f6");

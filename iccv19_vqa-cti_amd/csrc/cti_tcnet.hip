@@ -61,6 +61,15 @@ static bool small_a(const Dims& d) {
     return d.h / d.R == 16 && d.G == 2 && d.V <= 64 && d.Q <= 16 && d.A <= 6 && (d.R & 1) == 0 && d.B <= 65535;
 }
 
+// f16f6 mode: the M build encodes the mode-3 product's planes itself (mbuild_mfma_f6's own shape test, by sizes only -- the workspace then
+// holds no fp32 M); other shapes build fp32 rows and run the encoding pass.
+static bool direct_m(const Dims& d) {
+#if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
+    return false;
+#endif
+    return d.h / d.R == 16 && d.G == 2 && d.V <= 64 && d.Q <= 16 && (d.R & 1) == 0 && d.B <= 65535 && (size_t)(2560 + 128 * d.Q) * d.V <= 160 * 1024;
+}
+
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
     float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* wn_partial;
@@ -139,7 +148,7 @@ Plan carve(const Dims& d, int prec, void* ws) {
         } else {
             const int64_t mpb = (int64_t)d.V * d.Q * d.G;
             p.f_Arp = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, d.A)), rows[2], d.h, d.A);
-            p.Mf32 = static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
+            p.Mf32 = direct_m(d) ? nullptr : static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
             p.f_Mp = f6_carve(w.take(f6_planes_bytes(mrows, d.h, mpb)), mrows, d.h, mpb);
         }
     }
@@ -394,7 +403,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     if (f6) {
         // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
         // start at multiples of 8 rows
-        rc = mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb);       // the planes directly (hr = 16, glimpse 2, X + hold buffer fit the LDS)
+        rc = p.Mf32 ? CTI_E_UNSUPPORTED : mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb);       // the planes directly (hr = 16, glimpse 2, X + hold buffer fit the LDS)
+        if (rc == CTI_E_UNSUPPORTED && !p.Mf32) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: the direct-encoding M build refused a shape its plan accepted"));
         if (rc == CTI_E_UNSUPPORTED) {
             rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, nullptr, nullptr, p.Mf32, B, V, Q, R, hr, G, h, sb);
             if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, p.Mf32, nullptr, nullptr, B, V, Q, R, hr, G, h, sb);
