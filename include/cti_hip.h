@@ -41,9 +41,9 @@ enum {
     CTI_PREC_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate                      */
     CTI_PREC_BF16X3 = 1,  /* fp32 operands split into bf16 hi+lo planes, 3 bf16 MFMAs per product, fp32 acc.   */
     CTI_PREC_BF16 = 2,    /* operands rounded to bf16 once, 1 MFMA per product, fp32 accumulate                 */
-    CTI_PREC_F16F6 = 3    /* cti_tcnet_forward only: the mode-3 product (the dominant GEMM) as f16 hi x hi + ONE block-scaled fp6 MFMA for both
-                             cross terms (csrc/cti_f16f6.h), fp32 accumulate: fp32-grade at half the MFMA cycles of CTI_PREC_BF16X3, which the
-                             projection GEMMs keep */
+    CTI_PREC_F16F6 = 3    /* cti_tcnet_forward only: the mode-3 product (the dominant GEMM) and, for more than 6 answer tokens, the a side's Tucker
+                             projection and rank nets as f16 hi x hi + ONE block-scaled fp6 MFMA for both cross terms (csrc/cti_f16f6.h), fp32
+                             accumulate: fp32-grade at half the MFMA cycles of CTI_PREC_BF16X3, which the v / q sides keep */
 };
 
 enum { CTI_ACT_NONE = 0, CTI_ACT_RELU = 1 };

@@ -229,3 +229,35 @@ def test_softmax_partials_from_the_gemm_epilogue_match_the_two_pass_softmax():
         assert used >= 1                                           # (the reduced fixtures have A = 5: the few-answer path, which leaves no partials)
     finally:
         cti_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("B,V,Q,A,vd,qd,ad,h,R", [
+    (2, 44, 16, 9, 96, 64, 48, 64, 4),        # hr = 16, but X + hold buffer exceed the LDS: fp32 M + encoding pass; a side on f16f6 products
+    (3, 10, 6, 7, 40, 24, 30, 32, 2),         # direct-encoding M build at its smallest; a_dim % 4 != 0 (the encoder's scalar loads); h = one K block
+    (2, 12, 5, 40, 64, 32, 52, 64, 16),       # hr = 4: VALU M build + encoding pass
+    (2, 36, 14, 200, 64, 48, 300, 96, 6),     # h = 96: a partial row tile of the transposed a-side products (feature blocks beyond h are skipped), K = 300 -> 10 blocks
+])
+def test_f16f6_forward_around_its_fast_paths(B, V, Q, A, vd, qd, ad, h, R):
+    """precision='f16f6', fused TCNet.forward (src/tc.py:41-52) with more than 6 answer tokens at shapes on either side of every shape test
+    of its a-side / M-build / mode-3 chain, against the float64 oracle: <= 1e-4 normalised (north_star)."""
+    torch.manual_seed(B * 1000 + V + A)
+    net = cti_amd.TCNet(vd, qd, ad, h, 1, R, 2).to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(B, V, vd, generator=g).abs()
+    v[0, V - 2:] = 0
+    q = torch.tanh(torch.randn(B, Q, qd, generator=g))
+    a = torch.tanh(torch.randn(B, A, ad, generator=g))
+    params = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
+    ref = O.tcnet_forward(v.numpy(), q.numpy(), a.numpy(), params, dtype=np.float64)
+    old = cti_amd.get_precision()
+    try:
+        outs = {}
+        for prec in ("bf16x3", "f16f6"):
+            cti_amd.set_precision(prec)
+            with torch.no_grad():
+                outs[prec] = net(v.to(DEV), q.to(DEV), a.to(DEV)).cpu().numpy()
+    finally:
+        cti_amd.set_precision(old)
+    e3, e6 = O.norm_max_err(outs["bf16x3"], ref), O.norm_max_err(outs["f16f6"], ref)
+    print("TCNet.forward B=%d V=%d Q=%d A=%d h=%d R=%d: bf16x3 %.3g, f16f6 %.3g vs float64" % (B, V, Q, A, h, R, e3, e6))
+    assert e3 < TOL and e6 < TOL
