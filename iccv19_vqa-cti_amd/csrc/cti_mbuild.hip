@@ -290,6 +290,34 @@ __device__ __forceinline__ uint4 mb_pack8(const unsigned short* h) {
 constexpr int MB_SP = 36;                       // pitch of the wave-private output patch [q][32 rho + 4 pad]
 constexpr int MB_XP = 20;                       // X row pitch in floats (16 j + 4 pad: 80-B rows, 16-B aligned, conflict-free)
 
+// X (the step-1 accumulators of both row tiles) -> LDS, branch-free: one base per row tile, re-derived every rank behind an opaque barrier,
+// compile-time offsets, rows beyond V redirected to a pad column of row 0.  (The straightforward form -- 32 guarded scalar stores -- makes hipcc
+// hoist 32 per-lane addresses out of the rank loop and spill them, and costs 32 exec branches per rank.)
+__device__ __forceinline__ void mb_store_x(float* X2, const mb_f32x16& x0, const mb_f32x16& x1, int V, int kg, int xg, int xk, int wid, int lane) {
+    constexpr int HR = 16, G = 2;
+    float* xw = X2 + ((4 * kg * G + xg) * HR + xk) * MB_XP + wid;
+    asm volatile("" : "+v"(xw));
+    float* const trash = X2 + 16 + (lane & 3);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg;
+        float* d0 = xw + vo * (G * HR * MB_XP);
+        if (V < 32) d0 = vv < V ? d0 : trash;
+        *d0 = x0[e];
+    }
+    if (V > 32) {
+        float* xw1 = xw + 32 * (G * HR * MB_XP);
+        asm volatile("" : "+v"(xw1));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg + 32;
+            float* d1 = xw1 + vo * (G * HR * MB_XP);
+            d1 = vv < V ? d1 : trash;
+            *d1 = x1[e];
+        }
+    }
+}
+
 // F32OUT: the rows are written as fp32 (row stride pitchM floats) instead of bf16 hi/lo planes -- the f16f6 mode encodes them in one pass
 template <bool F32OUT>
 __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
@@ -344,13 +372,8 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
         }
         __syncthreads();                                        // step-2 readers of the previous rank are done with X2
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int vv = (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (CTI_MM_SKIP & 2) { if (x0[e] == 12345.f) X2[e] = x1[e]; continue; }
-            if (vv < V) X2[((vv * G + xg) * HR + xk) * MB_XP + wid] = x0[e];
-            if (vv + 32 < V) X2[(((vv + 32) * G + xg) * HR + xk) * MB_XP + wid] = x1[e];
-        }
+        if (CTI_MM_SKIP & 2) { if (x0[0] == 12345.f) X2[0] = x1[0]; }
+        else mb_store_x(X2, x0, x1, V, kg, xg, xk, wid, lane);
         __syncthreads();
         // ---- step 2: one tile per v: rows rho = g*16 + k, columns q ------------------------------------------------------
         const int sg = l31 >> 4, sk = l31 & 15;
@@ -459,31 +482,7 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
         }
         __syncthreads();
-        {
-            // X -> LDS without branches and without 32 hoisted per-lane addresses (which the allocator then spills): one base per row tile,
-            // re-derived every rank behind an opaque barrier, compile-time offsets, and rows beyond V redirected to a pad column of row 0
-            float* xw = X2 + ((4 * kg * G + xg) * HR + xk) * MB_XP + wid;
-            asm volatile("" : "+v"(xw));
-            float* const trash = X2 + 16 + (lane & 3);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg;
-                float* d0 = xw + vo * (G * HR * MB_XP);
-                if (V < 32) d0 = vv < V ? d0 : trash;
-                *d0 = x0[e];
-            }
-            if (V > 32) {
-                float* xw1 = xw + 32 * (G * HR * MB_XP);
-                asm volatile("" : "+v"(xw1));
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int vo = (e & 3) + 8 * (e >> 2), vv = vo + 4 * kg + 32;
-                    float* d1 = xw1 + vo * (G * HR * MB_XP);
-                    d1 = vv < V ? d1 : trash;
-                    *d1 = x1[e];
-                }
-            }
-        }
+        mb_store_x(X2, x0, x1, V, kg, xg, xk, wid, lane);
         __syncthreads();
         const int sg = l31 >> 4, sk = l31 & 15;
         const bool odd = r & 1;
@@ -601,12 +600,7 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
         }
         __syncthreads();                                        // step-2 readers of the previous rank are done with X2 (and Ar[b] is staged)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int vv = (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (vv < V) X2[((vv * G + xg) * HR + xk) * MB_XP + wid] = x0[e];
-            if (vv + 32 < V) X2[(((vv + 32) * G + xg) * HR + xk) * MB_XP + wid] = x1[e];
-        }
+        mb_store_x(X2, x0, x1, V, kg, xg, xk, wid, lane);
         __syncthreads();
         // the Ar entries this lane half meets in rank r: k = 4 kg + {0-3} and 8 + 4 kg + {0-3} (register e of the step-2 tile is row rho = (e & 3) + 8 (e >> 2)
         // + 4 kg = g * 16 + k: registers 0-7 are g = 0, 8-15 are g = 1, each (k = 4 kg .. +3, 8 + 4 kg .. +3))

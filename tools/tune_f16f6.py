@@ -21,7 +21,8 @@ def run(rounds=5, B=256, K=512):
     import cti_amd
     L, ops = cti_amd.pkg._lib, cti_amd.ops
     libs = {}
-    for f in sorted(glob.glob(os.path.join(VDIR, "*.so")), key=lambda x: (not os.path.basename(x).startswith("libcti_hip_base"), x)):
+    C.CDLL(os.path.join(ROOT, "iccv19_vqa-cti_amd", "lib", "libcti_hip.so"), mode=C.RTLD_GLOBAL)
+    for f in sorted(glob.glob(os.path.join(VDIR, "libcti_hip_*.so")), key=lambda x: (not os.path.basename(x).startswith("libcti_hip_base"), x)):
         l = C.CDLL(f)
         for name in ("cti_gemm_nt_f16f6", "cti_last_error_string"):
             fn = getattr(l, name)
@@ -63,8 +64,21 @@ def run(rounds=5, B=256, K=512):
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        import tune_gemm
-        tune_gemm.build(sys.argv[2:])
+        # light variants: the GEMM's own source + cti_api.hip, -Bsymbolic (internal calls stay inside the variant), everything else resolves
+        # against the main library, which run() loads RTLD_GLOBAL first
+        import subprocess
+        os.makedirs(VDIR, exist_ok=True)
+        for f in glob.glob(os.path.join(VDIR, "*.so")):
+            os.remove(f)
+        procs = []
+        for spec in sys.argv[2:]:
+            name, _, flags = spec.partition(":")
+            cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-Wno-unused-result"] + flags.split() + [
+                "-o", os.path.join(VDIR, "libcti_hip_%s.so" % name)] + [os.path.join(ROOT, "iccv19_vqa-cti_amd", "csrc", f) for f in ("cti_gemm_f16f6.hip", "cti_api.hip")]
+            procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for n, pr in procs:
+            o, _ = pr.communicate()
+            print(n, "rc", pr.returncode, o[-600:] if pr.returncode else "")
     else:
         for K in ([int(k) for k in sys.argv[4].split(",")] if len(sys.argv) > 4 else [512]):
             run(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 256, K)
