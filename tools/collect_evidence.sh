@@ -31,5 +31,6 @@ timeout 300 python tools/bench_f16f6.py 256 20 > $E/mode3_f16f6_vs_bf16x3.json 2
 timeout 120 ./tools/mb/mb_f16f6 > $E/mb_f16f6.txt 2>&1
 timeout 120 ./tools/mb/mb_issue > $E/mb_issue.txt 2>&1
 timeout 300 python tools/f16f6_ksweep.py > $E/f16f6_ksweep.txt 2>/dev/null
+timeout 300 python tools/bench_f16f6_aside.py 2>/dev/null | grep '^{' > $E/aside_f16f6.jsonl
 fi
 find $E -name "*.csv" | head -20; du -sh $E
