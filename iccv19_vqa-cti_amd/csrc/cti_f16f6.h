@@ -176,7 +176,7 @@ __device__ __forceinline__ void f6_encode_row32_lds(const float* src, const F6Pl
 // The same (row, block) item from 32 values a lane holds in registers (element order) -- the register-only epilogue of the transposed
 // f16f6 GEMM -- with max(x, lo_bound) applied first (lo_bound = 0: ReLU; -inf: none).  Same planes, bit for bit, as f6_encode_row32_lds on
 // max(x, lo_bound), in ~4 VALU instructions per element: v_med3_f32 (lower bound and f16 saturation in one), v_cvt_pk_f16_f32 (gfx950: two
-// values per instruction, round to nearest even), the residual as a packed fp32 subtraction, the hi maximum as f16(max |x|) (rounding is monotone).  A block that holds a saturated value (|x| >= 65504, outside the format's domain) recomputes its residuals from the
+// values per instruction, round to nearest even), the residual as a packed fp32 subtraction, both maxima as v_max3 with |.| modifiers.  A block that holds a saturated value (|x| >= 65504, outside the format's domain) recomputes its residuals from the
 // unsaturated values in a rarely taken branch.  Plain vector stores (no HIP structs): nothing here may alias the GEMM's LDS-DMA ring,
 // which stays in flight around it.
 typedef unsigned f6_u32x4 __attribute__((ext_vector_type(4)));
@@ -193,21 +193,22 @@ template <bool SAT_EXCESS = true>
 __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float lo_bound, char* Hrow, char* FLrow, char* Srow) {
     if ((CTI_F6_ABL & 16) && x[31] != 12345.f) { Hrow = FLrow = Srow = nullptr; }      // timing-only ablation: the arithmetic without the stores
     const float lo_sat = fmaxf(lo_bound, -65504.f);
-    float ml = 0.f, mx = 0.f;                                       // mx: max |saturated x|; rounding to f16 is monotone, so max |h| = f16(mx)
+    float ml = 0.f, mx = 0.f;                                       // mx: max |hi part|
     float lf[32];
     unsigned hw[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         f6_f32x2 v = {__builtin_amdgcn_fmed3f(x[2 * u], lo_sat, 65504.f), __builtin_amdgcn_fmed3f(x[2 * u + 1], lo_sat, 65504.f)};
         const f6_f16x2 h = __builtin_convertvector(v, f6_f16x2);
-        const f6_f32x2 l = v - __builtin_convertvector(h, f6_f32x2);
+        const f6_f32x2 hf = __builtin_convertvector(h, f6_f32x2);
+        const f6_f32x2 l = v - hf;
         lf[2 * u] = l[0]; lf[2 * u + 1] = l[1];
-        ml = fmaxf(ml, fmaxf(fabsf(l[0]), fabsf(l[1])));
-        mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
+        ml = fmaxf(fmaxf(ml, fabsf(l[0])), fabsf(l[1]));            // (this nesting becomes ONE v_max3_f32 with |.| modifiers)
+        mx = fmaxf(fmaxf(mx, fabsf(hf[0])), fabsf(hf[1]));
         hw[u] = __builtin_bit_cast(unsigned, h);
         if ((u & 3) == 3 && (!(CTI_F6_ABL & 16) || Hrow)) reinterpret_cast<f6_u32x4*>(Hrow)[u >> 2] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
     }
-    const float mh = static_cast<float>(static_cast<_Float16>(mx));
+    const float mh = mx;
     if (SAT_EXCESS && mh >= 65504.f) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)
         ml = 0.f;
 #pragma unroll
