@@ -204,11 +204,12 @@ __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float
         const f6_f32x2 l = v - hf;
         lf[2 * u] = l[0]; lf[2 * u + 1] = l[1];
         ml = fmaxf(fmaxf(ml, fabsf(l[0])), fabsf(l[1]));            // (this nesting becomes ONE v_max3_f32 with |.| modifiers)
-        mx = fmaxf(fmaxf(mx, fabsf(hf[0])), fabsf(hf[1]));
+        if (SAT_EXCESS) mx = fmaxf(fmaxf(mx, fabsf(hf[0])), fabsf(hf[1]));
+        else            mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));   // (of the inputs: rounding is monotone; frees the converted pair earlier -- the M build's ceiling)
         hw[u] = __builtin_bit_cast(unsigned, h);
         if ((u & 3) == 3 && (!(CTI_F6_ABL & 16) || Hrow)) reinterpret_cast<f6_u32x4*>(Hrow)[u >> 2] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
     }
-    const float mh = mx;
+    const float mh = SAT_EXCESS ? mx : static_cast<float>(static_cast<_Float16>(mx));
     if (SAT_EXCESS && mh >= 65504.f) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)
         ml = 0.f;
 #pragma unroll
