@@ -151,6 +151,7 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
         const int o_rdiv = q->o_rdiv, o_rstride = q->o_rstride;
         const bool mok = mblk < p.M;                                // M % 32 == 0: a block is all real or all padding
         const float lo_bound = p.relu ? 0.f : -__builtin_huge_valf();
+        unsigned nq = 0, nr = 0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             __builtin_amdgcn_sched_barrier(0);
@@ -167,8 +168,15 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
             }
             const int n = cn0 + (wn * TN + j) * 32 + r;
             if (n >= p.N || !mok || ((CTI_F6_ABL & 8) && x[0] != 12345.f)) continue;
-            const unsigned un = (unsigned)n, ub = o_rdiv > 0 ? un / (unsigned)o_rdiv : 0u;
-            const int64_t prow = o_rdiv > 0 ? (int64_t)ub * o_rstride + (un - ub * (unsigned)o_rdiv) : (int64_t)n;
+            // plane row of n: batches of o_rdiv rows start at multiples of o_rstride.  One division per tile (column tile 0); the wave's other column
+            // tiles are 32 rows further on -- at most one batch boundary when a batch has 32 rows or more
+            if (j == 0 || o_rdiv < 32) {
+                nq = o_rdiv > 0 ? (unsigned)n / (unsigned)o_rdiv : 0u; nr = o_rdiv > 0 ? (unsigned)n - nq * (unsigned)o_rdiv : (unsigned)n;
+            } else {
+                nr += 32u;
+                if (nr >= (unsigned)o_rdiv) { nr -= (unsigned)o_rdiv; ++nq; }
+            }
+            const int64_t prow = (int64_t)nq * o_rstride + nr;
             const int64_t o = (int64_t)kb * o_ra + prow;
             f6_encode_row32_regs(x, lo_bound, oH + o * 64, oFL + o * 24, oS + ((int64_t)kb * o_ras + prow) * 2);
         }

@@ -442,8 +442,10 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
     const int l31 = lane & 31, kg = lane >> 5;
     const int K = R * HR;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* vb = Vr + (int64_t)b * V * K + kg * 8;
-    const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
+    // uniform bases + 32-bit per-lane element offsets (global loads with an SGPR base): four 64-bit per-lane pointers less in a kernel at its register ceiling
+    const float* vb = Vr + (int64_t)b * V * K;
+    const float* qb = Qr + (int64_t)b * Q * K;
+    const unsigned ov0 = (unsigned)(l31 * K + kg * 8), ov1 = (unsigned)((32 + l31) * K + kg * 8), ot = (unsigned)((wid * 32 + l31) * HR + kg * 8);
     const int v0 = l31, v1 = 32 + l31;
     const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
     const int c1 = wid * 32 + l31;
@@ -453,12 +455,12 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
     float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
 #define CTI_MM_LOAD(rr)                                                                                             \
     {                                                                                                               \
-        const int o_ = (rr) * HR;                                                                                   \
-        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
-        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
-        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_); q1 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_ + 4); } \
-        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
-        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
+        const unsigned o_ = (unsigned)((rr) * HR);                                                                  \
+        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (ov0 + o_)); a01 = *reinterpret_cast<const float4*>(vb + (ov0 + o_ + 4)); } \
+        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (ov1 + o_)); a11 = *reinterpret_cast<const float4*>(vb + (ov1 + o_ + 4)); } \
+        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (ov0 + o_)); q1 = *reinterpret_cast<const float4*>(qb + (ov0 + o_ + 4)); } \
+        const float* tp_ = Tt + (size_t)(rr) * INNER * HR;                                                          \
+        t0 = *reinterpret_cast<const float4*>(tp_ + ot); t1 = *reinterpret_cast<const float4*>(tp_ + (ot + 4));     \
     }
     CTI_MM_LOAD(0)
     for (int r = 0; r < R; ++r) {
