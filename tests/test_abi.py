@@ -71,6 +71,39 @@ def test_softmax_partials_contract_on_the_host():
     assert b"workspace" in lib.cti_last_error_string()
 
 
+def test_f16f6_block_producers_contract_on_the_host():
+    """The f16f6 mode's block-in / block-out entry points (cti_gemm_nt_f16f6_planes, cti_quantize_f16f6_scaled, cti_paralind_mbuild_f16f6_fwd) check
+    their arguments before anything is launched: NULL, sizes, the output block's size / alignment, the activation code, the shapes the
+    direct-encoding M build accepts."""
+    lib = L.lib()
+    one, al = 8, 256                                                                          # non-NULL addresses; nothing is dereferenced before the checks
+    rows, M, K = 1000, 64, 96
+    need = lib.cti_f16f6_planes_bytes(rows, M, 0)
+    assert need == 2 * ((rows + 256) * 64 + (rows + 256) * 24 + (rows + 512) * 2) + 3 * 256   # Kb = 2 blocks of (H 64 B + FL 24 B per row, S 2 B per row) + slack rows
+    assert lib.cti_gemm_nt_f16f6_planes(None, M, one, rows, al, need, 0, M, rows, K, None, 0, None) == -1                # NULL weight block
+    assert lib.cti_gemm_nt_f16f6_planes(one, M, one, rows, al, need, 0, M, rows + 1, K, None, 0, None) == -2            # more rows than the operand has
+    assert lib.cti_gemm_nt_f16f6_planes(one, M, one, rows, al, need, 0, M, rows, K, None, 7, None) == -4                # activation code
+    assert lib.cti_gemm_nt_f16f6_planes(one, M, one, rows, al, need - 1, 0, M, rows, K, None, 0, None) == -5            # output block too small
+    assert lib.cti_gemm_nt_f16f6_planes(one, M, one, rows, al + 16, need, 0, M, rows, K, None, 0, None) == -3           # output block not 256-B aligned
+    assert lib.cti_gemm_nt_f16f6_planes(one, 48, one, rows, al, lib.cti_f16f6_planes_bytes(rows, 48, 0), 0, 48, rows, K, None, 0, None) == -4   # features not whole K blocks
+    assert b"M % 32" in lib.cti_last_error_string()
+    nq = lib.cti_f16f6_planes_bytes(rows, K, 0)
+    assert lib.cti_quantize_f16f6_scaled(one, K, rows, K, 0, None, 16, al, nq, None) == -1                                # NULL scales
+    assert lib.cti_quantize_f16f6_scaled(one, K, rows, K, 0, one, 0, al, nq, None) == -2                                  # scale_div = 0
+    assert lib.cti_quantize_f16f6_scaled(one, K, rows, K, 0, one, 16, al, nq - 1, None) == -5
+    B, V, Q, R, hr, G = 4, 36, 14, 32, 16, 2
+    nm = lib.cti_f16f6_planes_bytes(B * V * Q * G, R * hr, V * Q * G)
+    assert lib.cti_paralind_mbuild_f16f6_fwd(one, one, None, al, nm, B, V, Q, R, hr, G, None) == -1                      # the transposed core is required
+    assert lib.cti_paralind_mbuild_f16f6_fwd(one, one, one, al, nm - 1, B, V, Q, R, hr, G, None) == -5
+    assert lib.cti_paralind_mbuild_f16f6_fwd(one, one, one, al, lib.cti_f16f6_planes_bytes(B * V * Q * G, 3 * 8, V * Q * G), B, V, Q, 3, 8, G, None) == -4   # R * hr not whole K blocks
+    assert lib.cti_paralind_mbuild_f16f6_fwd(al, al, al, al, lib.cti_f16f6_planes_bytes(B * 48 * 16 * G, R * hr, 48 * 16 * G), B, 48, 16, R, hr, G, None) == -4   # X + hold buffer exceed the LDS
+    assert b"direct-encoding" in lib.cti_last_error_string()
+    # the fused forward's workspace: the f16f6 mode holds no fp32 M where the direct-encoding build applies
+    w_direct = lib.cti_tcnet_forward_workspace_bytes(8, 36, 14, 200, 256, 128, 96, 512, 32, 2, L.PREC_F16F6)
+    w_fallback = lib.cti_tcnet_forward_workspace_bytes(8, 48, 16, 200, 256, 128, 96, 512, 32, 2, L.PREC_F16F6)
+    assert w_fallback - w_direct > 8 * 48 * 16 * 2 * 512 * 4                                   # (more rows AND the fp32 M of the 48 x 16 shape)
+
+
 def test_ops_refuse_cpu_tensors():
     with pytest.raises(cti_amd.CtiError):
         cti_amd.ops.zero_row_mask(torch.zeros(2, 3, 4))
