@@ -232,19 +232,28 @@ def run_train(args, world, rank, dev, dist):
         loss.backward()
         opt.step()
 
-    # One rank, no collective: the step is captured into a hipGraph (cti_amd.GraphedTrainStep) and replayed -- eagerly its ~300 launches
-    # take the host about as long to issue as the GPU takes to run them, and the line would time the box's CPU.  With a process group
-    # (several ranks, or CTI_BENCH_FORCE_DIST=1) the step runs eagerly: capturing the RCCL all-reduce aborted the process on this stack
-    # (ROCm 7.0 / torch 2.10, one rank); --graph asks for the capture anyway.
-    graphed = (world == 1 and not dist.is_initialized()) or args.graph
-    if args.no_graph:
-        graphed = False
+    # The step is captured (cti_amd.GraphedTrainStep) and replayed -- eagerly its ~300 launches take the host about as long to issue as the
+    # GPU takes to run them, and the line would time the box's CPU.  One rank, no collective: ONE hipGraph.  With a process group (several
+    # ranks, or CTI_BENCH_FORCE_DIST=1): TWO graphs -- forward + backward + gradient gather | clip + Adamax -- with the RCCL all-reduce issued
+    # eagerly between them (capturing the collective itself aborted the process on this stack; --graph asks for that one-graph form anyway).
+    graphed = not args.no_graph
     if graphed:
-        gs = cti_amd.GraphedTrainStep(model, opt, lambda out, tgt: crit(out, tgt) / B, (v, q, a), y, warmup=3)
-        step_fn = lambda: gs.graph.replay()                      # noqa: E731  (the inputs are resident: nothing to copy per step)
+        gs = cti_amd.GraphedTrainStep(model, opt, lambda out, tgt: crit(out, tgt) / B, (v, q, a), y, warmup=3,
+                                      split_collective=False if args.graph else None)
+        step_fn = gs.replay                                      # (the inputs are resident: nothing to copy per step)
+        launch = ("two hipGraphs (fwd + bwd + gather | clip + Adamax) around one eager RCCL all-reduce" if gs.split
+                  else "hipGraph replay of the captured step")
     else:
         step_fn = step
+        launch = "eager (one launch per kernel)"
     el = measure(step_fn, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+    # host time to ISSUE a step (no device sync inside the loop): what the ranks' CPUs spend per step
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step_fn()
+    host_ms = (time.perf_counter() - t0) / 10 * 1e3
+    torch.cuda.synchronize()
     if dist.is_initialized():                                   # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
@@ -257,7 +266,7 @@ def run_train(args, world, rank, dev, dist):
                           "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + SimpleClassifier "
                                                  "+ BCE, train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
                                      "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world, "collective": coll,
-                                     "launch": "hipGraph replay of the captured step" if graphed else "eager (one launch per kernel)"}}))
+                                     "launch": launch, "host_issue_ms_per_step": round(host_ms, 3)}}))
 
 
 # ---- full-model forwards: BASELINE configs[2] (c3: MC CTI, Visual7W shapes) and configs[3] (c4: FFOE BAN + CTI teacher) ---------------
@@ -512,7 +521,7 @@ def main():
                     help="f16f6 (default of the headline line): mode-3 product as f16 hi x hi + one block-scaled fp6 MFMA for both cross terms, every "
                          "other GEMM bf16x3 -- fp32-grade (3e-5 vs the float64 oracle at the configs[1] shape, tolerance 1e-4); bf16x3: 3-term split-bf16 "
                          "everywhere (1.5e-5); fp32: exact fp32 MFMA")
-    ap.add_argument("--graph", action="store_true", help="--mode train with several ranks: capture the step (incl. the all-reduce) into a hipGraph, as one rank does by default")
+    ap.add_argument("--graph", action="store_true", help="--mode train with a process group: capture the whole step INCLUDING the all-reduce into one hipGraph (aborts on ROCm 7.0 / torch 2.10; the default there is two graphs around an eager all-reduce)")
     ap.add_argument("--no-graph", action="store_true", help="--mode train: eager launches even on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the 4-step exact-fp32 sub-record of the default line")

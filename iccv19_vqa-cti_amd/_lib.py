@@ -33,6 +33,8 @@ SIGNATURES = {
     "cti_tcnet_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "cti_tcnet_forward_sm": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz]),
     "cti_tcnet_softmax_partials_bytes": (_sz, [_int] * 7),
+    "cti_tcnet_forward_guard_bytes": (_sz, [_int] * 11),
+    "cti_guard_read": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "cti_masked_softmax_tri_from_partials_fwd": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_tcnet_prepare": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _sz, _vp]),
     "cti_tcnet_prepared_bytes": (_sz, [_int] * 7),
@@ -116,6 +118,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3
 E_UNSUPPORTED = -4                                   # CTI_E_UNSUPPORTED: shape / mode outside a specialised kernel
 ACT_NONE, ACT_RELU = 0, 1
 TUNE_GEMM_CFG, TUNE_TRI_CHUNK = 1, 2                # cti_set_tuning keys
+GUARD_SATURATED, GUARD_UNDERFLOW, GUARD_NONFINITE = 1, 2, 4     # status bits of the f16f6 range guard (cti_guard_read)
 
 _lib = None
 

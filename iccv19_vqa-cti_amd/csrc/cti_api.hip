@@ -18,10 +18,12 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-static std::atomic<int> g_gemm_cfg{-1};
-static std::atomic<long long> g_tri_chunk{0};
-int tuning_gemm_cfg() { return g_gemm_cfg.load(std::memory_order_relaxed); }
-int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk.load(std::memory_order_relaxed); }
+// Tuning overrides are THREAD-LOCAL, like the error string: the header promises no process-wide mutable state, and a test thread that forces a
+// tile geometry must not change what another thread's production call launches.
+static thread_local int g_gemm_cfg = -1;
+static thread_local long long g_tri_chunk = 0;
+int tuning_gemm_cfg() { return g_gemm_cfg; }
+int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk; }
 
 }  // namespace cti
 
@@ -31,11 +33,11 @@ extern "C" int cti_set_tuning(int key, int64_t value) {
     switch (key) {
         case CTI_TUNE_GEMM_CFG:
             CTI_REQUIRE(value >= -1 && value <= 2, CTI_E_SHAPE, "cti_set_tuning: GEMM_CFG must be -1 (auto), 0, 1 or 2, got %lld", (long long)value);
-            g_gemm_cfg.store((int)value); return CTI_OK;
+            g_gemm_cfg = (int)value; return CTI_OK;
         case CTI_TUNE_TRI_CHUNK:
             CTI_REQUIRE(value == 0 || (value >= 4 && value <= (1ll << 30) && value % 4 == 0), CTI_E_SHAPE,
                         "cti_set_tuning: TRI_CHUNK must be 0 (auto) or a multiple of 4 in [4, 2^30], got %lld", (long long)value);
-            g_tri_chunk.store((long long)value); return CTI_OK;
+            g_tri_chunk = (long long)value; return CTI_OK;
         default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
     }
 }

@@ -187,7 +187,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
                                                       int64_t n, float p, unsigned long long seed, unsigned long long offset, int use_mask,
                                                       int64_t period, int vec, const unsigned long long* __restrict__ rng_dev) {
-    if (rng_dev) seed += rng_dev[0] * 0x9E3779B97F4A7C15ull;            // device-resident step counter: a replayed hipGraph draws fresh masks
+    // device-resident step counter: a replayed hipGraph draws fresh masks.  Its multiplier differs from the one the host applies to the SEED
+    // ((seed0 * PHI + call) on the host): with the same constant, step s of a run seeded S drew the masks of step 0 of a run seeded S + s.
+    if (rng_dev) seed += rng_dev[0] * 0xD1B54A32D192ED03ull;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 4 elements
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 // stores of the general kernel wrote the 151 MB mask of the visual rank nets at 1.9 TB/s
 __global__ __launch_bounds__(256) void dropout_mask16_kernel(uint8_t* __restrict__ mask, int64_t n16, float p, unsigned long long seed,
                                                              unsigned long long offset, const unsigned long long* __restrict__ rng_dev) {
-    if (rng_dev) seed += rng_dev[0] * 0x9E3779B97F4A7C15ull;
+    if (rng_dev) seed += rng_dev[0] * 0xD1B54A32D192ED03ull;               // (see dropout_kernel)
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // group of 16 elements
     if (t >= n16) return;
     const unsigned thr = (unsigned)fminf(4294967295.f, p * 4294967296.f);

@@ -123,6 +123,27 @@ struct F6GemmArgs {
     // the accumulators' initial value; a weight-norm scale belongs in the weight planes (quantize_f16f6's row_scale).  nb = 1.
     const F6Planes* out;
 };
+// ---- range guard (cti_f16f6_guard.hip): the guard block is GUARD_WORDS uint32 at the head of cti_tcnet_forward's workspace
+constexpr int GUARD_WORDS = 64, GUARD_W_STATUS = 0, GUARD_W_DONE = 1, GUARD_W_SEG = 4, GUARD_MAX_SEG = 12;
+struct GuardSeg {
+    const void* p;                             // kind 0: an S plane ([Kb][rows_allocS][2 B]); kind 1: fp32 values
+    int kind, Kb;
+    int64_t rows_allocS, nb, rdiv, rstride;    // kind 0: nb batches of rdiv real rows starting at multiples of rstride
+    int64_t n;                                 // kind 1: element count
+};
+struct GuardArgs { GuardSeg seg[GUARD_MAX_SEG]; int nseg; unsigned* words; };
+inline GuardSeg guard_seg_planes(const F6Planes& P, int64_t rows) {
+    GuardSeg s{};
+    s.p = P.S; s.kind = 0; s.Kb = P.Kb; s.rows_allocS = P.rows_allocS;
+    if (P.rdiv > 0) { s.nb = (rows + P.rdiv - 1) / P.rdiv; s.rdiv = P.rdiv; s.rstride = P.rstride; }
+    else            { s.nb = 1; s.rdiv = rows; s.rstride = 0; }
+    return s;
+}
+inline GuardSeg guard_seg_f32(const float* x, int64_t n) { GuardSeg s{}; s.p = x; s.kind = 1; s.n = n; return s; }
+int guard_reset(unsigned* words, hipStream_t st);
+int guard_scan(const GuardArgs& g, hipStream_t st);
+int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st);
+
 int f6_sm_chunks(int M, int N);                // partial (max, sum) pairs per batch and g that gemm_nt_f16f6 writes for an M x N product
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);
 // row_scale != NULL: row m is multiplied by row_scale[m / scale_div] on the way in (a weight-normalised layer's g / ||V|| per matrix)

@@ -1,0 +1,133 @@
+// cti_f16f6_guard.hip -- range guard of the f16f6 forward (reference src/Tensor.py:12,18: the reference multiplies in full-range fp32).
+//
+// The f16f6 operand format (cti_f16f6.h) is exact-to-11-bits in its f16 hi part only for 6.1e-5 <= |x| <= 65504: larger values saturate, a
+// tensor whose magnitudes sit below the f16 subnormal knee loses its hi part, and the register encoders map NaN to a finite value.  None of
+// that may reach a caller silently.  Every encoder already writes, per (row, 32-wide K block), the E8M0 byte of the block's hi maximum into the
+// S plane (byte 0 = eh + 127; saturated and non-finite blocks come out as 141 = the byte of 65504), so the guard is ONE small kernel over the
+// S planes of everything the f16f6 kernels read -- 2 B per 32 elements, ~75 MB at BASELINE configs[1] -- plus a non-finite scan of the fp32
+// rows that feed the direct-encoding M build:
+//
+//   guard_reset  (first kernel of the call)        zeroes the guard block at the head of the workspace
+//   guard_scan   (before the mode-3 product)       per tensor: max eh byte over its REAL rows (padding rows between batches hold stale bytes);
+//                                                   the last workgroup to finish evaluates the status word
+//   guard_poison (after the mode-3 product)        status != 0: the output is overwritten with NaN -- never a finite, plausible, wrong number
+//
+// status bits: 1 = a block at or beyond the f16 range (|x| > 61440, incl. inf / NaN in an encoded tensor), 2 = a tensor that is not all zero
+// but whose largest block lies below 2^-12 (hi parts subnormal: absolute error 2^-29 stops being small against the tensor), 4 = non-finite
+// values in V^ / Q^ / T_eff (the M build's encoder would swallow them).  The host reads the word after ev_core_begin (cti_guard_read) and
+// re-runs the call in the bf16x3 mode; under hipGraph capture, where the host cannot look, the NaN fill is the signal.
+#include "cti_common.h"
+#include "cti_f16f6.h"
+
+namespace cti {
+
+namespace {
+
+constexpr int GUARD_SAT_BYTE = 141;            // f6_scale_byte(m) for 61440 < m <= 65504 (and what the encoders write for non-finite maxima)
+constexpr int GUARD_KNEE_BYTE = 113;           // f6_scale_byte(2^-12)
+
+__global__ __launch_bounds__(64) void guard_reset_kernel(unsigned* words) { words[threadIdx.x] = 0u; }
+
+// one wave-wide maximum of small non-negative integers
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, o, 64));
+    return x;
+}
+
+__global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
+    const unsigned tid = blockIdx.x * 256u + threadIdx.x, nthr = gridDim.x * 256u;
+    const int lane = threadIdx.x & 63;
+    for (int s = 0; s < g.nseg; ++s) {
+        const GuardSeg sg = g.seg[s];
+        unsigned mx = 0u;
+        if (sg.kind == 0) {
+            // S plane: [Kb][rows_allocS][2 B]; real rows = nb batches of rdiv rows starting at multiples of rstride (a multiple of 8).  One item
+            // = four consecutive rows of one (K block, batch): an aligned 8-B load; rows beyond the batch are skipped.
+            const unsigned rows4 = (unsigned)((sg.rdiv + 3) >> 2), per_kb = (unsigned)sg.nb * rows4, items = (unsigned)sg.Kb * per_kb;
+            for (unsigned i = tid; i < items; i += nthr) {
+                const unsigned kb = i / per_kb, rem = i - kb * per_kb, b = rem / rows4, r4 = rem - b * rows4;
+                const int64_t prow = (int64_t)b * sg.rstride + (int64_t)r4 * 4;
+                const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(sg.p) + ((int64_t)kb * sg.rows_allocS + prow) * 2);
+                const int left = (int)sg.rdiv - (int)r4 * 4;                                   // real rows in this item (>= 1)
+                mx = max(mx, w.x & 0xffu);
+                if (left > 1) mx = max(mx, (w.x >> 16) & 0xffu);
+                if (left > 2) mx = max(mx, w.y & 0xffu);
+                if (left > 3) mx = max(mx, (w.y >> 16) & 0xffu);
+            }
+        } else {
+            // fp32 rows: any inf / NaN (exponent field all ones)
+            const float* x = static_cast<const float*>(sg.p);
+            const int64_t n4 = sg.n >> 2;
+            for (int64_t i = tid; i < n4; i += nthr) {
+                const uint4 w = reinterpret_cast<const uint4*>(x)[i];
+                const unsigned e = 0x7f800000u;
+                if ((w.x & e) == e || (w.y & e) == e || (w.z & e) == e || (w.w & e) == e) mx = 1u;
+            }
+            for (int64_t i = (n4 << 2) + tid; i < sg.n; i += nthr)
+                if ((__builtin_bit_cast(unsigned, x[i]) & 0x7f800000u) == 0x7f800000u) mx = 1u;
+        }
+        mx = wave_max_u32(mx);
+        if (lane == 0 && mx) atomicMax(&g.words[GUARD_W_SEG + s], mx);
+    }
+    // last workgroup out: evaluate.  (Device-scope atomics execute at the memory side on gfx950: every workgroup's maxima are visible to the
+    // atomic reads below once its own fence + counter increment have been performed.)
+    __shared__ bool last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&g.words[GUARD_W_DONE], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    unsigned status = 0u;
+    for (int s = 0; s < g.nseg; ++s) {
+        const unsigned m = atomicOr(&g.words[GUARD_W_SEG + s], 0u);
+        if (g.seg[s].kind == 0) {
+            if (m >= (unsigned)GUARD_SAT_BYTE) status |= CTI_GUARD_SATURATED;
+            if (m > 1u && m < (unsigned)GUARD_KNEE_BYTE) status |= CTI_GUARD_UNDERFLOW;
+        } else if (m) status |= CTI_GUARD_NONFINITE;
+    }
+    atomicExch(&g.words[GUARD_W_STATUS], status);
+}
+
+__global__ __launch_bounds__(256) void guard_poison_kernel(const unsigned* words, float* out, int64_t n) {
+    if (words[GUARD_W_STATUS] == 0u) return;
+    const float nan = __builtin_nanf("");
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = nan;
+}
+
+}  // namespace
+
+int guard_reset(unsigned* words, hipStream_t st) {
+    hipLaunchKernelGGL(guard_reset_kernel, dim3(1), dim3(64), 0, st, words);
+    return launch_status("guard_reset");
+}
+
+int guard_scan(const GuardArgs& g, hipStream_t st) {
+    if (g.nseg <= 0 || g.nseg > GUARD_MAX_SEG) return fail(CTI_E_SHAPE, "guard_scan: %d segments", g.nseg);
+    for (int s = 0; s < g.nseg; ++s) {
+        const GuardSeg& sg = g.seg[s];
+        if (sg.kind == 0 && ((sg.rstride & 7) || (sg.rows_allocS & 7) || sg.rdiv <= 0 || sg.nb <= 0 ||
+                             (int64_t)sg.Kb * sg.nb * ((sg.rdiv + 3) >> 2) >= (1ll << 32) || (reinterpret_cast<uintptr_t>(sg.p) & 7)))
+            return fail(CTI_E_SHAPE, "guard_scan: segment %d (Kb=%d nb=%lld rdiv=%lld rstride=%lld)", s, sg.Kb, (long long)sg.nb, (long long)sg.rdiv, (long long)sg.rstride);
+        if (sg.kind == 1 && (reinterpret_cast<uintptr_t>(sg.p) & 15)) return fail(CTI_E_ALIGN, "guard_scan: fp32 segment %d is not 16-B aligned", s);
+    }
+    hipLaunchKernelGGL(guard_scan_kernel, dim3(1024), dim3(256), 0, st, g);
+    return launch_status("guard_scan");
+}
+
+int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(guard_poison_kernel, dim3(2048), dim3(256), 0, st, words, out, n);
+    return launch_status("guard_poison");
+}
+
+}  // namespace cti
+
+using namespace cti;
+
+extern "C" int cti_guard_read(const void* workspace, void* ev_core_begin, void* stream, uint32_t* status_host) {
+    CTI_REQUIRE_PTR(workspace); CTI_REQUIRE_PTR(ev_core_begin); CTI_REQUIRE_PTR(status_host);
+    hipError_t e = hipEventSynchronize(static_cast<hipEvent_t>(ev_core_begin));       // the scan precedes the event on the launch stream
+    if (e == hipSuccess) e = hipMemcpyAsync(status_host, static_cast<const unsigned*>(workspace) + GUARD_W_STATUS, sizeof(uint32_t), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    return e == hipSuccess ? CTI_OK : fail((int)e, "cti_guard_read: %s", hipGetErrorString(e));
+}

@@ -682,16 +682,33 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
     return launch_status("mbuild_mfma");
 }
 
+// The shape tests of the two fused kernels, by sizes only: cti_tcnet.hip plans its workspace with the SAME predicates the launchers apply
+// (a plan that accepts a shape its kernel refuses leaves the forward without M / A^ planes to fall back on).
+static size_t mbuild_mfma_f6_lds(int V, int Q, int G) { return sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)V * 4 * (2 * Q) * 4); }
+static size_t mbuild_core_small_lds(int V, int A, int R, int hr, int G) { return sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)A * R * hr); }
+bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G) {
+#if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
+    return false;
+#endif
+    return hr == 16 && G == 2 && V >= 1 && V <= 64 && Q >= 1 && Q <= 16 && (R & 1) == 0 && B <= 65535 && mbuild_mfma_f6_lds(V, Q, G) <= 160 * 1024;
+}
+bool mbuild_core_small_fits(int B, int V, int Q, int A, int R, int hr, int G) {
+#ifdef CTI_NO_MBUILD_CORE_SMALL
+    return false;
+#endif
+    return hr == 16 && G == 2 && V >= 1 && V <= 64 && Q >= 1 && Q <= 16 && A >= 1 && A <= 6 && (R & 1) == 0 && B <= 65535 &&
+           mbuild_core_small_lds(V, A, R, hr, G) <= 160 * 1024;
+}
+
 // M straight into the f16f6 planes P of the mode-3 product (rows (b, v, q, g), K = R * 16).  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2,
 // even R and the LDS budget: the caller takes mbuild_mfma -> fp32 rows -> quantize_f16f6.
 int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st) {
 #if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
     return CTI_E_UNSUPPORTED;
 #endif
-    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || P.Kb * 32 != R * hr) return CTI_E_UNSUPPORTED;
+    if (!mbuild_mfma_f6_fits(B, V, Q, R, hr, G) || !Tt || P.Kb * 32 != R * hr) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)V * 4 * (2 * Q) * 4);
-    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    const size_t lds = mbuild_mfma_f6_lds(V, Q, G);
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -711,10 +728,9 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
 #ifdef CTI_NO_MBUILD_CORE_SMALL
     return CTI_E_UNSUPPORTED;
 #endif
-    if (hr != 16 || G != 2 || V > 64 || Q > 16 || A > 6 || A < 1 || (R & 1) || B > 65535 || !Tt) return CTI_E_UNSUPPORTED;
+    if (!mbuild_core_small_fits(B, V, Q, A, R, hr, G) || !Tt) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt) | reinterpret_cast<uintptr_t>(Ar)) & 15) return CTI_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + (size_t)A * R * hr);
-    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    const size_t lds = mbuild_core_small_lds(V, A, R, hr, G);
     const int VT = (V + 15) / 16;
 #define CTI_MC_LAUNCH(AT, VTv)                                                                                                              \
     {                                                                                                                                       \

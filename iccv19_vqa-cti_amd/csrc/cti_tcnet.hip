@@ -15,6 +15,8 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
                       hipStream_t st);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
+bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
+bool mbuild_core_small_fits(int B, int V, int Q, int A, int R, int hr, int G);
 }
 using namespace cti;
 
@@ -53,22 +55,13 @@ Planes take_planes(Bump& w, int64_t rows, int K) {
 struct Dims { int B, V, Q, A, vd, qd, ad, h, R, G; };
 
 // Few answer tokens (the FFOE / MC models: A = 3 / 6): modes 1 + 2 + 3 run in ONE kernel (mbuild_core_small) and M is never written.
-// Mirrors that kernel's own shape test (hr = 16, glimpse 2, V <= 64, Q <= 16, A <= 6, even rank count).
-static bool small_a(const Dims& d) {
-#ifdef CTI_NO_MBUILD_CORE_SMALL
-    return false;
-#endif
-    return d.h / d.R == 16 && d.G == 2 && d.V <= 64 && d.Q <= 16 && d.A <= 6 && (d.R & 1) == 0 && d.B <= 65535;
-}
+// The kernel's own shape test (hr = 16, glimpse 2, V <= 64, Q <= 16, A <= 6, even rank count AND its LDS budget: X + the sample's A^ block --
+// with R = 32 that refuses V >= 62 at A = 3 and V >= 60 at A = 6, which then take the M build + planes GEMM).
+static bool small_a(const Dims& d) { return mbuild_core_small_fits(d.B, d.V, d.Q, d.A, d.R, d.h / d.R, d.G); }
 
 // f16f6 mode: the M build encodes the mode-3 product's planes itself (mbuild_mfma_f6's own shape test, by sizes only -- the workspace then
 // holds no fp32 M); other shapes build fp32 rows and run the encoding pass.
-static bool direct_m(const Dims& d) {
-#if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
-    return false;
-#endif
-    return d.h / d.R == 16 && d.G == 2 && d.V <= 64 && d.Q <= 16 && (d.R & 1) == 0 && d.B <= 65535 && (size_t)(2560 + 128 * d.Q) * d.V <= 160 * 1024;
-}
+static bool direct_m(const Dims& d) { return mbuild_mfma_f6_fits(d.B, d.V, d.Q, d.R, d.h / d.R, d.G); }
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
@@ -88,6 +81,7 @@ struct Plan {
     // ... and the a-side Tucker projection: `a` is encoded once (f_Ain) and multiplied with the Tucker weight's block f_wta (scale folded in; prepared)
     // in the same transposed form
     F6Planes f_Ain, f_wta;
+    unsigned* guard;                           // f16f6 kernels in use: the range-guard block (GUARD_WORDS uint32) at the HEAD of the per-call workspace
     size_t bytes;
 };
 
@@ -118,6 +112,7 @@ Plan carve(const Dims& d, int prec, void* ws) {
     Bump w{static_cast<char*>(ws), 0, 0};
     const int64_t rows[3] = {(int64_t)d.B * d.V, (int64_t)d.B * d.Q, (int64_t)d.B * d.A};
     const int in[3] = {d.vd, d.qd, d.ad};
+    if (prec == CTI_PREC_F16F6 && !small_a(d)) p.guard = static_cast<unsigned*>(w.take(sizeof(unsigned) * GUARD_WORDS));     // offset 0: include/cti_hip.h
     carve_prep(d, prec, w, p);
     const int64_t mrows = (int64_t)d.B * d.V * d.Q * d.G;
     if (prec == CTI_PREC_F32) {
@@ -237,6 +232,12 @@ extern "C" size_t cti_tcnet_forward_workspace_bytes(int B, int V, int Q, int A, 
     return carve(d, prec, nullptr).bytes;
 }
 
+extern "C" size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec) {
+    if (B <= 0 || V <= 0 || Q <= 0 || A <= 0 || v_dim <= 0 || q_dim <= 0 || a_dim <= 0 || h <= 0 || R <= 0 || G <= 0 || h % R || prec != CTI_PREC_F16F6 || h % 32) return 0;
+    Dims d{B, V, Q, A, v_dim, q_dim, a_dim, h, R, G};
+    return small_a(d) ? 0 : sizeof(unsigned) * GUARD_WORDS;
+}
+
 static bool sm_partials_supported(int h, int G, int prec) { return prec == CTI_PREC_F16F6 && G == 2 && h % 32 == 0; }
 
 extern "C" size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec) {
@@ -304,6 +305,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     const int64_t rows[3] = {(int64_t)B * V, (int64_t)B * Q, (int64_t)B * A};
     const int relu = act == CTI_ACT_RELU;
 
+    if (p.guard) { rc = guard_reset(p.guard, st); if (rc) return rc; }
     if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
     if (!prepared) { rc = run_prepare(d, prec, p, tucker_wv, tucker_g, rank_wv, rank_g, T_g, false, stream); if (rc) return rc; }
     const int64_t mrows_per_b = (int64_t)V * Q * G;
@@ -432,10 +434,26 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
         c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
         if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }     // the Tri softmax's partial pass, from the accumulators
+        // Range guard: everything the f16f6 kernels read is encoded by now.  The scan (scale bytes of the six encoded operands + a non-finite
+        // sweep of the fp32 rows behind the M build: ~75 MB at configs[1]) leaves the status word BEFORE ev_core_begin, so a host that waits
+        // for that event learns the verdict while the mode-3 product is still running; the NaN fill behind the product needs no host at all.
+        GuardArgs ga{};
+        ga.words = p.guard;
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2]);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2]);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2]);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h);
+        ga.seg[ga.nseg++] = guard_seg_f32(p.Vr, rows[0] * h);
+        ga.seg[ga.nseg++] = guard_seg_f32(p.Qr, rows[1] * h);
+        ga.seg[ga.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G);
+        rc = guard_scan(ga, st); if (rc) return finish(rc);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
-        return finish(rc);
+        if (rc) return finish(rc);
+        return finish(guard_poison(p.guard, out, (int64_t)B * V * Q * A * G, st));
     }
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;

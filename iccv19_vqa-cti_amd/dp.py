@@ -84,7 +84,7 @@ class FlatAdamaxDP:
 
     def broadcast_parameters(self, src=0):
         """Identical initial parameters on every rank: one broadcast of the flat buffer."""
-        if self.world > 1 or (self.force_collective and dist.is_initialized()):
+        if self.needs_collective():
             dist.broadcast(self.flat_p, src=src, group=self.pg)
             ops.invalidate_caches()                              # flat_p was overwritten behind autograd's version counters
 
@@ -124,11 +124,18 @@ class FlatAdamaxDP:
             p.grad = gv
         del keep
 
-    def step(self):
-        """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm."""
-        self.gather_grads()
-        if self.world > 1 or (self.force_collective and dist.is_initialized()):
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)     # the ONE collective of the step
+    def needs_collective(self):
+        """True when step() issues the RCCL all-reduce (more than one rank, or force_collective in an initialised one-rank group)."""
+        return self.world > 1 or (self.force_collective and dist.is_available() and dist.is_initialized())
+
+    def all_reduce_grads(self):
+        """The ONE collective of the step: all-reduce(sum) of the flat gradient buffer over xGMI (no-op without a group)."""
+        if self.needs_collective():
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def apply_update(self):
+        """scale by 1/(world*update_freq) + global norm -> clip + Adamax -> counters: three kernels on device-resident scalars, no host sync,
+        capturable (the second half of GraphedTrainStep's split form)."""
         self.step_count += 1                                     # host mirror (eager); the kernels read the device counter
         st = ops._stream()
         lib = L.lib()
@@ -141,6 +148,14 @@ class FlatAdamaxDP:
         ops.rng_advance(self.flat_p.device)                      # the next step's dropout masks differ, also when this step is a graph replay
         ops.invalidate_caches()                                  # the kernel wrote the parameters behind autograd's version counters
         return self.grad_norm
+
+    def step(self):
+        """Call after backward() of the last micro-batch.  Returns the device tensor holding the pre-clip gradient norm.
+        = gather_grads() -> all_reduce_grads() -> apply_update(); GraphedTrainStep captures the first and the last into two hipGraphs and
+        issues the collective between them."""
+        self.gather_grads()
+        self.all_reduce_grads()
+        return self.apply_update()
 
     def steps_done(self):
         """Completed steps as the device counts them (= step_count in eager use; graph replays advance only the device counter).  Synchronises."""

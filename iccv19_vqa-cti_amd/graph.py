@@ -1,27 +1,36 @@
 """hipGraph capture of a whole training step (reference src/FFOE/trainer.py:97-149,221-269).
 
 The FFOE CTI training step is ~500 kernel launches issued by ~7 ms of host Python for ~7.7 ms of GPU work: the step is host-co-limited.
-`GraphedTrainStep` captures forward + loss + backward + FlatAdamaxDP.step() ONCE (torch.cuda.CUDAGraph = hipGraph) and replays it per batch:
-the host then issues one hipGraphLaunch per step.  What makes the step capturable is that nothing that changes from step to step is a kernel
-ARGUMENT: the learning rate, the completed-step count of Adamax' bias correction and the dropout streams' step counter live in device memory
-(cti_adamax_step_g / cti_dropout_g / cti_counter_add), and the library allocates nothing and never synchronises.  Single-rank steps (no
-collective) are what is captured and tested; capturing the RCCL all-reduce of a process group aborted the process on this stack (ROCm 7.0 /
-torch 2.10, `bench.py --mode train --graph` with CTI_BENCH_FORCE_DIST=1), so multi-rank steps are launched eagerly.  Batches are fed by
-copying into static input tensors."""
+`GraphedTrainStep` captures the step ONCE (torch.cuda.CUDAGraph = hipGraph) and replays it per batch.  What makes the step capturable is that
+nothing that changes from step to step is a kernel ARGUMENT: the learning rate, the completed-step count of Adamax' bias correction and the
+dropout streams' step counter live in device memory (cti_adamax_step_g / cti_dropout_g / cti_counter_add), and the library allocates nothing
+and never synchronises.
+
+Two forms:
+  * one rank, no collective: forward + loss + backward + FlatAdamaxDP.step() are ONE graph; the host issues one hipGraphLaunch per step;
+  * with a process group (the data-parallel step of SURVEY 8e): capturing the RCCL all-reduce aborted the process on this stack (ROCm 7.0 /
+    torch 2.10), so the step is TWO graphs with the collective issued eagerly between them --
+        graph A: zero_grad, forward, loss, backward, cti_flat_gather          (everything up to the flat gradient buffer)
+        eager  : dist.all_reduce(flat_g)                                      (the ONE collective, reference trainer.py:221-232)
+        graph B: scale + norm, clip + Adamax, step / dropout counters
+    = two hipGraphLaunch + one ncclAllReduce per step from the host instead of ~500 launches, so the ranks time the GPU and the xGMI, not Python.
+Batches are fed by copying into static input tensors."""
 import torch
 
 from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_fn, example_inputs, example_target, warmup=2):
+    def __init__(self, model, optimizer, loss_fn, example_inputs, example_target, warmup=2, split_collective=None):
         """loss_fn(model_output, target) -> scalar tensor.  example_inputs: tuple of tensors (shapes / dtypes are frozen); warmup eager steps run on
         a side stream first (allocator, one-time attributes, weight-norm caches), as torch's capture rules ask.  The warm-up steps DO update the
-        parameters."""
+        parameters.  split_collective: None = the two-graph form exactly when the optimizer issues a collective; True / False force it."""
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.split = optimizer.needs_collective() if split_collective is None else bool(split_collective)
         self.static_in = tuple(t.clone() for t in example_inputs)
         self.static_tgt = example_target.clone()
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_update = torch.cuda.CUDAGraph() if self.split else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -29,21 +38,44 @@ class GraphedTrainStep:
                 self._step()
             torch.cuda.synchronize()
             ops.invalidate_caches()                      # the captured step must contain the per-step refresh of every derived cache
-            with torch.cuda.graph(self.graph, stream=s):
-                self.static_loss = self._step()
+            if not self.split:
+                with torch.cuda.graph(self.graph, stream=s):
+                    self.static_loss = self._step()
+            else:
+                with torch.cuda.graph(self.graph, stream=s):
+                    self.static_loss = self._forward_backward()
+                with torch.cuda.graph(self.graph_update, stream=s):
+                    self.opt.apply_update()
         torch.cuda.current_stream().wait_stream(s)
 
-    def _step(self):
+    def _forward_backward(self):
         self.opt.zero_grad()
         loss = self.loss_fn(self.model(*self.static_in), self.static_tgt)
         loss.backward()
-        self.opt.step()
+        self.opt.gather_grads()
         return loss.detach()
+
+    def _step(self):
+        loss = self._forward_backward()
+        self.opt.all_reduce_grads()
+        self.opt.apply_update()
+        return loss
+
+    def replay(self):
+        """The captured step on whatever the static tensors hold.  Replays rewrite the parameters on the device behind every host-side cache key
+        (weight-norm scales, operand planes of TCNet / the GRU are keyed on a package-wide epoch + storage + autograd version, none of which a
+        replay moves), so the epoch is bumped here: an eager forward between two replays must not reuse planes of the older parameters.
+        Anyone replaying `.graph` directly must call ops.invalidate_caches() as well."""
+        self.graph.replay()
+        if self.split:
+            self.opt.all_reduce_grads()                  # eager: the one collective, stream-ordered between the two graphs
+            self.graph_update.replay()
+        ops.invalidate_caches()
 
     def __call__(self, inputs, target):
         """One training step on a new batch (copied into the captured tensors); returns the loss tensor of the replay (device, no sync)."""
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
         self.static_tgt.copy_(target, non_blocking=True)
-        self.graph.replay()
+        self.replay()
         return self.static_loss

@@ -22,6 +22,39 @@ def get_precision():
     return _default_prec
 
 
+# ---- range guard of the f16f6 forward (include/cti_hip.h: cti_tcnet_forward_guard_bytes / cti_guard_read) -----------------------------
+# The reference multiplies in full-range fp32 (src/Tensor.py:12,18); the f16f6 operand format is fp32-grade only inside f16's normal range.
+# The library scans every encoded operand before the mode-3 product and NaN-fills the output when one leaves the domain.  'sync' (default):
+# the wrapper waits for that verdict -- it arrives while the mode-3 product is still running, so the launch pipeline does not drain -- and
+# re-runs the call in the bf16x3 mode: the caller always gets fp32-grade numbers.  'poison': no host wait (what hipGraph capture forces): an
+# out-of-range call returns NaN, never clamped numbers.
+_range_check = "sync"
+_range_log = {"calls": 0, "trips": 0, "last_status": 0, "consecutive": 0, "skip": 0}
+_guard_res = {}
+
+
+def set_range_check(mode):
+    global _range_check
+    if mode not in ("sync", "poison"):
+        raise ValueError("range check must be 'sync' or 'poison'")
+    _range_check = mode
+
+
+def f16f6_range_status():
+    """Counters of the f16f6 range guard in this process: guarded calls, trips (calls re-run as bf16x3), the last status word
+    (bit 0 saturation / non-finite in an encoded operand, bit 1 underflow, bit 2 non-finite V^ / Q^ / T_eff)."""
+    return dict(_range_log)
+
+
+def _guard_resources(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    r = _guard_res.get(key)
+    if r is None:
+        lib = L.lib()
+        r = _guard_res[key] = (lib.cti_event_create(), lib.cti_event_create(), torch.cuda.Stream(device=device))
+    return r
+
+
 def _prec(p, fused=False):
     """Precision code of a launch.  'f16f6' exists for the fused TCNet.forward (cti_tcnet_forward / cti_tcnet_prepare) only: every other op runs its
     bf16x3 form in that mode (same fp32-grade accuracy class)."""
@@ -431,12 +464,20 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
             raise ValueError("the prepared block was built for another precision mode")
         prep_ptr = prepared[0].data_ptr()
     lib = L.lib()
+    guarded = pr == L.PREC_F16F6 and lib.cti_tcnet_forward_guard_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr) > 0
+    wait_guard = guarded and _range_check == "sync" and not torch.cuda.is_current_stream_capturing()
+    if wait_guard and _range_log["skip"] > 0:
+        # this process keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
+        _range_log["skip"] -= 1
+        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials)
     wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
     ev0 = ev1 = None
     if _prof is not None:                       # hipEvents around the mode-3 GEMM, recorded by the library on the launch stream
         ev0, ev1 = lib.cti_event_create(), lib.cti_event_create()
         _prof.setdefault("paralind_core", []).append(_LibEventPair(ev0, ev1))
+    elif wait_guard:
+        ev0, ev1, _ = _guard_resources(v.device)
     part = None
     if want_sm_partials:
         pb = lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, pr)
@@ -452,6 +493,26 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
             L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                           _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
                                           prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
+    if guarded:
+        _range_log["calls"] += 1
+    if wait_guard:
+        import ctypes as _C
+        status = _C.c_uint32(0)
+        L.check(lib.cti_guard_read(ws.data_ptr(), ev0, _guard_resources(v.device)[2].cuda_stream, _C.byref(status)), "cti_guard_read")
+        _range_log["last_status"] = int(status.value)
+        if status.value:
+            # an operand left the f16f6 format's domain (the output of this launch has been NaN-filled on the device): the reference's
+            # full-range fp32 semantics come from the bf16x3 kernels
+            _range_log["trips"] += 1
+            _range_log["consecutive"] += 1
+            if _range_log["consecutive"] >= 2:
+                _range_log["skip"] = 64
+            if _range_log["trips"] == 1:
+                import warnings
+                warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the bf16x3 mode; see ops.f16f6_range_status()"
+                              % (status.value, ", ".join(n for b, n in ((1, "saturation / non-finite"), (2, "underflow"), (4, "non-finite V^/Q^/T")) if status.value & b)))
+            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials)
+        _range_log["consecutive"] = 0
     if want_sm_partials:
         return out, mask, part
     return (out, mask) if want_mask else out
@@ -796,6 +857,14 @@ def _rng_tensor(device):
     return t
 
 
+def _dp_rank():
+    try:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    except Exception:
+        return 0
+
+
 def _dropout_seed(device):
     seed0 = torch.initial_seed()
     if _dropout_seed_seen[0] != seed0:                       # torch.manual_seed(...) since the last call: restart the streams
@@ -804,7 +873,10 @@ def _dropout_seed(device):
         if not torch.cuda.is_current_stream_capturing():
             for t in _rng_dev.values():
                 t.zero_()
-    seed = (seed0 * 0x9E3779B97F4A7C15 + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
+    # key = seed0 * PHI + rank * C3 + call counter, advanced on the device by step * C2 (cti_dropout_g): three different odd multipliers, so
+    # neither adjacent seeds (1204, 1205, ...) nor the ranks of a data-parallel run that all call torch.manual_seed(seed) share mask streams
+    # shifted by a step / a call.
+    seed = (seed0 * 0x9E3779B97F4A7C15 + _dp_rank() * 0xA0761D6478BD642F + _dropout_calls[0]) & 0xFFFFFFFFFFFFFFFF
     _dropout_calls[0] += 1
     return seed, _rng_tensor(device).data_ptr()
 

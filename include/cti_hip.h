@@ -7,7 +7,7 @@
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller (PyTorch's caching
  *    allocator in the shipped host code), including workspaces; the library allocates nothing and keeps no
- *    mutable global state apart from a thread-local last-error string;
+ *    process-wide mutable state: the last-error string and the test-only tuning overrides (cti_set_tuning) are thread-local;
  *  - all tensors are fp32, row-major, innermost dimension contiguous unless a stride argument says otherwise;
  *  - every launch goes to the hipStream_t passed as the last argument (`void*`, 0 = the null stream); no host
  *    synchronisation, no hipMalloc/hipFree inside (safe under hipGraph capture);
@@ -51,8 +51,9 @@ enum { CTI_ACT_NONE = 0, CTI_ACT_RELU = 1 };
 int cti_abi_version(void);
 const char* cti_last_error_string(void);
 
-/* Tuning overrides -- process-wide, for tests and benchmarks only (they select among kernels that compute the same result up to fp32
- * summation order; the defaults are what production uses).  CTI_TUNE_GEMM_CFG: tile geometry of the plane GEMM (-1 = the makespan model,
+/* Tuning overrides -- PER CALLING THREAD (thread-local, like the error string), for tests and benchmarks only (they select among kernels
+ * that compute the same result up to fp32 summation order; the defaults are what production uses; a thread that never calls cti_set_tuning
+ * always gets the defaults, whatever other threads set).  CTI_TUNE_GEMM_CFG: tile geometry of the plane GEMM (-1 = the makespan model,
  * 0 = 128x128, 1 = 256x128, 2 = 256x256).  CTI_TUNE_TRI_CHUNK: positions per chunk of the two-level Tri softmax, forward and backward
  * (0 = 32768; a multiple of 4 otherwise) -- lets a small tensor run the multi-chunk combine that BASELINE configs[1] needs
  * (1.58 M positions per sample = 49 chunks).  cti_get_tuning returns INT64_MIN for an unknown key. */
@@ -163,6 +164,22 @@ int cti_tcnet_forward_sm(const float* v, const float* q, const float* a, const f
                          int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                          void* ev_core_end, void* aux_stream, void* stream, float* sm_partials, size_t sm_partials_bytes);
 size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec);
+
+/* Range guard of the CTI_PREC_F16F6 forward.  The reference multiplies in full-range fp32 (src/Tensor.py:12,18); the f16f6 operand format is
+ * fp32-grade only for magnitudes inside f16's normal range (csrc/cti_f16f6.h: 6.1e-5 <= |x| <= 65504).  Whenever cti_tcnet_forward /
+ * cti_tcnet_forward_sm run their f16f6 kernels -- cti_tcnet_forward_guard_bytes(...) != 0 -- the first that many bytes of `workspace` are
+ * the guard block: a scan of every encoded operand (`a`, its Tucker projection, A^, M, the a-side weights: the per-block scale bytes the
+ * encoders wrote) and of V^ / Q^ / T_eff for non-finite values runs on `stream` BEFORE ev_core_begin is recorded and leaves a status word
+ * (uint32 at offset 0):  0 = every operand is inside the format's domain;  CTI_GUARD_SATURATED = a block reaches beyond +-61440 (incl.
+ * inf / NaN in an encoded tensor);  CTI_GUARD_UNDERFLOW = a tensor that is not all zero has no block above 2^-12 (its f16 hi parts are
+ * subnormal);  CTI_GUARD_NONFINITE = inf / NaN in V^, Q^ or T_eff.  With a non-zero status the call still completes, but `out` is then
+ * OVERWRITTEN WITH NaN (stream-ordered, no host involvement: valid under hipGraph capture) -- a caller never receives clamped numbers.
+ * cti_guard_read waits on the HOST for ev_core_begin (i.e. while the mode-3 product is still running), copies the status word through
+ * `stream` (any stream of the caller that is idle by then, e.g. the call's aux_stream) and returns it: a non-zero value means "re-run
+ * this call with CTI_PREC_BF16X3" (what the shipped Python wrapper does).  It is the only entry point of the library that synchronises. */
+enum { CTI_GUARD_SATURATED = 1, CTI_GUARD_UNDERFLOW = 2, CTI_GUARD_NONFINITE = 4 };
+size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
+int cti_guard_read(const void* workspace, void* ev_core_begin, void* stream, uint32_t* status_host);
 /* The batch-independent part of cti_tcnet_forward, computed once per parameter update: the six weight-norm scales, T_eff (and its
  * [r][(j,k,g)][i] copy), and in the bf16 modes the hi/lo operand planes of the six weight matrices.  `prepared`: a device block of
  * cti_tcnet_prepared_bytes(...) owned by the caller; valid until a weight, T_g or the precision changes. */

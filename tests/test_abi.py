@@ -52,6 +52,23 @@ def test_tuning_rejects_bad_values_and_defaults_to_auto():
     assert lib.cti_get_tuning(1) == -1 and lib.cti_get_tuning(2) == 0
 
 
+def test_tuning_overrides_are_thread_local():
+    """include/cti_hip.h promises no process-wide mutable state: an override set on one thread is invisible to every other thread."""
+    import threading
+    lib = L.lib()
+    seen = {}
+
+    def other():
+        seen["before"] = (lib.cti_get_tuning(1), lib.cti_get_tuning(2))
+        lib.cti_set_tuning(1, 0)
+        seen["own"] = lib.cti_get_tuning(1)
+
+    with cti_amd.ops.tuning(gemm_cfg=2, tri_chunk=64):
+        t = threading.Thread(target=other); t.start(); t.join()
+        assert lib.cti_get_tuning(1) == 2 and lib.cti_get_tuning(2) == 64          # the other thread's override did not leak here
+    assert seen == {"before": (-1, 0), "own": 0}
+
+
 def test_softmax_partials_contract_on_the_host():
     """cti_tcnet_softmax_partials_bytes says where the fused partial pass exists (f16f6, glimpse 2, h % 32 == 0) and how large its block is:
     [B][tiles of 256 x 192 over (V*Q*G) x A][8 waves][G][2] floats; the consumer refuses blocks that are not a whole number of (B, G) pairs."""

@@ -87,8 +87,27 @@ def _c2_full_batch(prec):
         p, logits = m(vd, qd, ad)
         p_s, l_s = p[pick].cpu().numpy(), logits[pick].cpu().numpy()
         psum = p.view(B, -1, 2).sum(1).cpu().numpy()
-        del p, logits
+        # whole-launch statistics: per (b, g) the maximum and the log-sum-exp over the sample's 1.58 M positions (masked rows are -inf) --
+        # every tile of the persistent walk feeds one of these 512 pairs
+        lg = logits.view(B, -1, 2)
+        gmax = lg.max(1).values.cpu().numpy()
+        glse = torch.logsumexp(lg.double(), 1).cpu().numpy()
+        del p, logits, lg
     torch.cuda.empty_cache()
+    # ... against the float32 oracle on ALL 256 samples (the reference's own arithmetic class; ~20 s on the GPU box's host cores)
+    omax, olse, oabs = np.empty((B, 2)), np.empty((B, 2)), 0.0
+    for b0 in range(0, B, 8):
+        sl = slice(b0, b0 + 8)
+        r32 = O.tcnet_forward(v[sl], q[sl], a[sl], params, "TriAtt.")
+        oabs = max(oabs, float(np.max(np.abs(r32))))
+        r32 = np.where(O.zero_row_mask(v[sl]).astype(bool)[:, :, None, None, None], -np.inf, r32).reshape(r32.shape[0], -1, 2).astype(np.float64)
+        omax[sl] = r32.max(1)
+        mx = omax[sl][:, None, :]
+        olse[sl] = np.log(np.exp(r32 - mx).sum(1)) + omax[sl]
+        del r32
+    e_max, e_lse = np.max(np.abs(gmax - omax)) / oabs, np.max(np.abs(glse - olse)) / oabs
+    assert e_max < TOL and e_lse < TOL, "B=256 [%s]: per-(b,g) max %.3g / log-sum-exp %.3g vs the float32 oracle over all samples" % (prec, e_max, e_lse)
+    print("C2 B=256 [%s]: all 256 samples, per-(b,g) max err %.3g, log-sum-exp err %.3g (normalised by max |raw| = %.3g)" % (prec, e_max, e_lse, oabs))
     raw64 = O.tcnet_forward(v[pick], q[pick], a[pick], params, "TriAtt.", dtype=np.float64)
     e = check(raw_s, raw64, what="B=256 raw (samples 0/127/255) vs float64 oracle")
     p64, l64 = O.tri_attention(v[pick], q[pick], a[pick], params, dtype=np.float64)

@@ -91,6 +91,34 @@ def test_biattention_and_pool_shapes(B, V, Q, vd, qd, hd, G):
     check(pooled, O.bcnet_forward_with_weights(v, q, p_ref[:, 0], sd(net), dtype=np.float64), "pooled")
 
 
+@pytest.mark.parametrize("V,A", [(64, 3), (64, 6), (61, 3), (62, 3), (59, 6), (60, 6)])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16", "f16f6"])
+def test_fused_few_answer_kernel_at_its_lds_budget(V, A, mode):
+    """hr = 16, glimpse 2, R = 32 and 59 ... 64 objects: the fused modes-1+2+3 kernel holds X (V*2*16*20 floats) + the sample's A^ block
+    (A*512 floats) in LDS and refuses V >= 62 at A = 3, V >= 60 at A = 6.  The forward's plan must then carry M / A^ planes and take the
+    M build + GEMM pair (round-2 ADVICE: the plan ignored the budget and the call raised CTI_E_UNSUPPORTED).  Both sides of the boundary."""
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(mode)
+    try:
+        torch.manual_seed(V * 7 + A)
+        att = cti_amd.TriAttention(48, 40, 24, 512, 1, 32, 2, 1).to(DEV).eval()
+        rs = np.random.RandomState(V + A)
+        v = np.abs(rs.standard_normal((2, V, 48))).astype(np.float32)
+        v[1, V - 2:] = 0
+        q = np.tanh(rs.standard_normal((2, 13, 40))).astype(np.float32)
+        a = np.tanh(rs.standard_normal((2, A, 24))).astype(np.float32)
+        with torch.no_grad():
+            p, logits = att(T(v), T(q), T(a))
+        p_ref, l_ref = O.tri_attention(v, q, a, sd(att), dtype=np.float64)
+        fin = np.isfinite(l_ref)
+        assert np.array_equal(np.isfinite(logits.cpu().numpy()), fin)
+        tol = 2e-2 if mode == "bf16" else TOL
+        check(torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits)), np.where(fin, l_ref, 0), "logits V=%d A=%d %s" % (V, A, mode), tol)
+        check(p, p_ref, "p V=%d A=%d %s" % (V, A, mode), tol)
+    finally:
+        cti_amd.set_precision(old)
+
+
 def test_empty_batch_returns_empty_tensors():
     att = cti_amd.TriAttention(16, 16, 16, 16, 1, 4, 2, 1).to(DEV).eval()
     net = cti_amd.TCNet(16, 16, 16, 16, 1, 4, 1, k=2).to(DEV).eval()
