@@ -295,13 +295,16 @@ def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, 
     raise ValueError(kind)
 
 
-def run_model(args, world, rank, dev, dist):
-    """--config c3 | c4: eval forward of the full models at BASELINE configs[2] / [3] in plain-bf16 products (the dtype those configs name)."""
+MODEL_TOL = {"bf16": 5e-2, "bf16x3": 1e-4, "f16f6": 1e-4, "fp32": 1e-4}     # normalised max error of the model logits vs the fp32 oracle, per arithmetic mode
+
+
+def model_setup(config, B, rank, dev):
+    """Model, synthetic batch and oracle hook of BASELINE configs[2] (c3: MC CTI, Visual7W shapes) / configs[3] (c4: FFOE BAN + CTI teacher).
+    Returns dict(fwd, flops, workload, out_shape, oracle): fwd() -> logits tensor(s); oracle(n) -> list of (name, gpu rows, oracle rows) over the
+    first n rows (oracle/cti_models.py, numpy fp32 -- a checker, after the timed region)."""
     import types
     import cti_amd
-    prec = args.precision if args.precision_given else "bf16"
-    cti_amd.set_precision(prec)
-    B, ntoken = args.batch, 20000
+    ntoken = 20000
     torch.manual_seed(SEED)
 
     def ds(num_ans):
@@ -318,7 +321,10 @@ def run_model(args, world, rank, dev, dist):
         t[torch.arange(L)[None, :] >= n[:, None]] = ntoken
         return t.to(dev)
 
-    if args.config == "c3":
+    def state(m):
+        return {k: t_.detach().cpu().numpy() for k, t_ in m.state_dict().items()}
+
+    if config == "c3":
         # Visual7W: 64 images x 4 candidate answers = 256 rows, every image repeated for its candidates (src/MC/train.py:75-79)
         rep = 4
         vi = torch.randn(B // rep, 36, 2048, generator=g).abs()
@@ -332,35 +338,47 @@ def run_model(args, world, rank, dev, dist):
         m = cti_amd.build_mc_cti(margs(2), ds(2)).to(dev).eval()
         m.v_replication = rep
         fwd = lambda: m(v, boxes, q, a)[0]                                           # noqa: E731
-        flops = model_flops("cti", B, 36, 12, 6, 2, n_ans=2)
-        workload = "BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B
-        out_shape = (B, 2)
-    else:
-        v = torch.randn(B, 36, 2048, generator=g).abs()
-        nv = torch.randint(10, 37, (B,), generator=g)
-        v[torch.arange(36)[None, :] >= nv[:, None]] = 0
-        v = v.to(dev)
-        q, a = tokens(14), tokens(3)
-        boxes = torch.rand(B, 36, 6, generator=g).to(dev)
-        ban = cti_amd.build_ban(margs(8), ds(3129)).to(dev).eval()
-        cti = cti_amd.build_cti(margs(2), ds(3129)).to(dev).eval()
 
-        def fwd():
-            return ban(v, boxes, q, None)[0], cti(v, q, a)
-        flops = model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2)
-        workload = ("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
-                    ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes" % B)
-        out_shape = (B, 3129)
+        def oracle(n, out):
+            from oracle import cti_models as OM
+            ref = OM.mc_tan_forward(v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
+            return [("mc_cti logits", out[:n].cpu().numpy(), ref)]
+        return dict(fwd=fwd, oracle=oracle, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2),
+                    workload="BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B)
+    v = torch.randn(B, 36, 2048, generator=g).abs()
+    nv = torch.randint(10, 37, (B,), generator=g)
+    v[torch.arange(36)[None, :] >= nv[:, None]] = 0
+    v = v.to(dev)
+    q, a = tokens(14), tokens(3)
+    boxes = torch.rand(B, 36, 6, generator=g).to(dev)
+    ban = cti_amd.build_ban(margs(8), ds(3129)).to(dev).eval()
+    cti = cti_amd.build_cti(margs(2), ds(3129)).to(dev).eval()
 
+    def fwd():
+        return ban(v, boxes, q, None)[0], cti(v, q, a)
+
+    def oracle(n, out):
+        from oracle import cti_models as OM
+        vn, qn, an = v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy()
+        return [("ban logits", out[0][:n].cpu().numpy(), OM.ffoe_ban_forward(vn, qn, state(ban), 8)[0]),
+                ("cti logits", out[1][:n].cpu().numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
+    return dict(fwd=fwd, oracle=oracle, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129),
+                workload=("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
+                          ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes" % B))
+
+
+def model_measure(setup, steps, warmup, world, dist, dev, graphed, prec):
+    """Times setup['fwd'] (hipGraph replay unless graphed is False) and checks the forward that was TIMED (the replayed graph's static output)
+    against the oracle on its first 4 rows.  Returns (elapsed, parity record)."""
+    from oracle.cti_oracle import norm_max_err
     holder = {}
 
     def step():
-        holder["out"] = fwd()
+        holder["out"] = setup["fwd"]()
 
     # The forward is ~190 launches for 1.3-3.2 ms of GPU work: issued eagerly it times the box's CPU as much as the GPU (74 k and 81 k samples/s
     # for c4 on two boxes).  It contains no collective, allocates nothing and never synchronises, so it is captured into a hipGraph once and
     # replayed (tools/graph_model.py checks replay == eager); --no-graph keeps the eager launches.
-    graphed = not args.no_graph
     with torch.no_grad():
         if graphed:
             for _ in range(3):
@@ -373,12 +391,30 @@ def run_model(args, world, rank, dev, dist):
                 with torch.cuda.graph(gr, stream=side):
                     step()
             torch.cuda.current_stream().wait_stream(side)
-            el = measure(gr.replay, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+            el = measure(gr.replay, steps, warmup, world, torch.cuda.synchronize, dist, dev)
         else:
-            el = measure(step, args.steps, args.warmup, world, torch.cuda.synchronize, dist, dev)
+            el = measure(step, steps, warmup, world, torch.cuda.synchronize, dist, dev)
     out = holder["out"]
     out0 = out[0] if isinstance(out, tuple) else out
-    assert tuple(out0.shape) == out_shape and bool(torch.isfinite(out0).all())
+    assert tuple(out0.shape) == setup["out_shape"] and bool(torch.isfinite(out0).all())
+    parity = {"rows": 4, "tol": MODEL_TOL[prec], "vs": "oracle/cti_models.py (numpy fp32) on the first 4 rows of the timed forward's output"}
+    for name, got, ref in setup["oracle"](4, out):
+        parity[name] = float(norm_max_err(got, ref))
+        if not parity[name] < MODEL_TOL[prec]:
+            raise SystemExit("bench.py: %s of the timed %s forward are %.3g from the oracle (tolerance %.3g) -- no number printed" % (name, prec, parity[name], MODEL_TOL[prec]))
+    return el, parity
+
+
+def run_model(args, world, rank, dev, dist):
+    """--config c3 | c4: eval forward of the full models at BASELINE configs[2] / [3] in plain-bf16 products (the dtype those configs name)."""
+    import cti_amd
+    prec = args.precision if args.precision_given else "bf16"
+    cti_amd.set_precision(prec)
+    B = args.batch
+    setup = model_setup(args.config, B, rank, dev)
+    graphed = not args.no_graph
+    el, parity = model_measure(setup, args.steps, args.warmup, world, dist, dev, graphed, prec)
+    flops, workload = setup["flops"], setup["workload"]
     if dist.is_initialized():
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
@@ -393,7 +429,71 @@ def run_model(args, world, rank, dev, dist):
                        "gflop_per_batch": round(flops / 1e9, 3), "launch": "hipGraph replay of the captured forward" if graphed else "eager"},
             "roofline": {"bound": "mfma", "kernel": "whole forward (launch sequence; dominant kernels are the projection GEMMs)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                         "note": "algorithmic flops of SURVEY.md 8(d) summed over the module calls / wall time of the forward"}}), flush=True)
+                         "note": "algorithmic flops of SURVEY.md 8(d) summed over the module calls / wall time of the forward"},
+            "parity_of_timed_forward": parity}), flush=True)
+
+
+def model_subrecord(config, dev):
+    """The c3 / c4 full-model forward as a sub-record of the default line: bf16 (the dtype configs[2] / [3] name), hipGraph replay, ~0.3 s."""
+    import cti_amd
+    old = cti_amd.get_precision()
+    cti_amd.set_precision("bf16")
+    try:
+        setup = model_setup(config, 256, 0, dev)
+        steps = 200 if config == "c3" else 100
+        el, parity = model_measure(setup, steps, 10, 1, None, dev, True, "bf16")
+    finally:
+        cti_amd.set_precision(old)
+    ach = setup["flops"] * steps / el / 1e12
+    return {"workload": setup["workload"], "value": 256 * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "dtype": DTYPE_NAME["bf16"], "launch": "hipGraph replay of the captured forward", "gflop_per_batch": round(setup["flops"] / 1e9, 3),
+            "achieved_tflops": ach, "frac_of_bf16_peak": ach / PEAK_TFLOPS["bf16"], "parity_of_timed_forward": parity}
+
+
+def aside_kernels(c, dev):
+    """The a-side kernels of the f16f6 step, launched stand-alone at the configs[1] shapes through their own C-ABI entry points and timed with
+    HIP events on the launch stream: inside cti_tcnet_forward they run back to back on the main stream (only the mode-3 product has events of
+    its own).  -> list of roofline_kernels records."""
+    import cti_amd
+    ops, L = cti_amd.ops, cti_amd.pkg._lib
+    lib = L.lib()
+    rows, K1, h, A = c["B"] * c["A"], c["a_dim"], c["h_mm"], c["A"]
+    st = ops._stream()
+
+    def t(fn, n=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    g = torch.Generator(device="cpu").manual_seed(SEED + 7)
+    x = torch.randn(rows, K1, generator=g).to(dev)
+    w1 = (torch.randn(h, K1, generator=g) * 0.05).to(dev)
+    w2 = (torch.randn(h, h, generator=g) * 0.05).to(dev)
+    b1 = torch.randn(h, generator=g).to(dev) * 0.1
+    nbx = lib.cti_f16f6_planes_bytes(rows, K1, 0)
+    px = torch.empty(nbx, device=dev, dtype=torch.uint8)
+    t_q = t(lambda: L.check(lib.cti_quantize_f16f6(x.data_ptr(), K1, rows, K1, 0, px.data_ptr(), nbx, st), "cti_quantize_f16f6"))
+    pw1, pw2 = ops.quantize_f16f6(w1), ops.quantize_f16f6(w2)
+    nby = lib.cti_f16f6_planes_bytes(rows, h, 0)
+    y1 = torch.zeros(nby, device=dev, dtype=torch.uint8)
+    t_t = t(lambda: L.check(lib.cti_gemm_nt_f16f6_planes(pw1.data_ptr(), h, px.data_ptr(), rows, y1.data_ptr(), nby, 0, h, rows, K1, b1.data_ptr(), 1, st), "tucker"))
+    nbz = lib.cti_f16f6_planes_bytes(rows, h, A)
+    y2 = torch.zeros(nbz, device=dev, dtype=torch.uint8)
+    t_r = t(lambda: L.check(lib.cti_gemm_nt_f16f6_planes(pw2.data_ptr(), h, y1.data_ptr(), rows, y2.data_ptr(), nbz, A, h, rows, h, b1.data_ptr(), 1, st), "rank"))
+    q_bytes = rows * K1 * 4 + rows * ((K1 + 31) // 32) * 90
+    peak = PEAK_TFLOPS["f16f6"]
+    recs = [{"kernel": "quantize_f16f6_kernel (`a` fp32 -> f16f6 planes)", "ms": t_q, "bound": "hbm", "achieved": q_bytes / t_q / 1e6, "unit": "GB/s",
+             "frac": q_bytes / t_q / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": q_bytes}]
+    for name, ms, K in (("gemm_f16f6_kernel<EPI_PLANES_T> a-side Tucker projection (512 x %d x %d)" % (rows, K1), t_t, K1),
+                        ("gemm_f16f6_kernel<EPI_PLANES_T> a-side rank nets (512 x %d x 512)" % rows, t_r, h)):
+        fl = 2.0 * rows * h * K
+        recs.append({"kernel": name, "ms": ms, "bound": "mfma", "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / peak, "flops": fl})
+    return recs
 
 
 def run_forward(args, world, rank, dev, dist):
@@ -421,7 +521,8 @@ def run_forward(args, world, rank, dev, dist):
     if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_fp32_exact:
         # the strict-fp32 arithmetic (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) on the driver's clock, a few steps
         gpu_first = out[:4].cpu().numpy()
-        del out, res_holder["out"]
+        out = None
+        del res_holder["out"]
         cti_amd.set_precision("fp32")
         with torch.no_grad():
             el32 = measure(step, 4, 1, 1, torch.cuda.synchronize, None, dev)
@@ -471,7 +572,7 @@ def run_forward(args, world, rank, dev, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: TCNet.forward fp32, B=%d/GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, "
+            "config": {"workload": "BASELINE configs[1]: TCNet.forward (fp32 in / fp32 out; arithmetic: see dtype), B=%d/GPU, V=36x2048, Q=14x1024, A=3129x300, rank=32, "
                                    "h_mm=512, glimpse=2" % c["B"], "global_batch": world * c["B"], "precision": args.precision,
                        "parallelism": "replicas x%d (batch-sharded, no data-path collective)" % world,
                        "gflop_per_sample": round(fl["total"] / 1e9, 4)},
@@ -486,10 +587,26 @@ def run_forward(args, world, rank, dev, dist):
             "whole_step_tflops": fl["total"] * c["B"] * args.steps / el / 1e12,
             "kernel_ms": kern,
         }
+        rk = [{"kernel": "gemm_f16f6_kernel<EPI_INTERLEAVE2> mode-3 product + rank sum" if args.precision == "f16f6" else "mode-3 product + rank sum: " + variant,
+               "ms": core_ms, "bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "frac": achieved / peak, "flops": core_flops}]
+        if args.precision == "f16f6" and world == 1 and not args.no_subrecords:
+            out = None
+            res_holder.pop("out", None)
+            torch.cuda.empty_cache()
+            rk += aside_kernels(c, dev)
+        step_ms = el / args.steps * 1e3
+        for r in rk:
+            r["share_of_step"] = r["ms"] / step_ms
+        res["roofline_kernels"] = {"note": "every kernel family >= 5 % of the step: mode-3 from the library's hipEvents inside the timed steps; the "
+                                           "a-side kernels re-launched stand-alone at the same shapes (HIP events on the launch stream)", "kernels": rk}
         if fp32_exact is not None:
             res["fp32_exact"] = fp32_exact
         if bf16x3 is not None:
             res["bf16x3"] = bf16x3
+        if world == 1 and not args.no_subrecords and args.batch == C2["B"]:
+            # BASELINE configs[2] / [3] on the same clock: full-model forwards, bf16, hipGraph replay, each checked against the oracle
+            torch.cuda.empty_cache()
+            res["configs"] = {"c3": model_subrecord("c3", dev), "c4": model_subrecord("c4", dev)}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(c, state, (v, q, a), gpu_first, args.cpu_budget)
@@ -525,6 +642,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="--mode train: eager launches even on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the 4-step exact-fp32 sub-record of the default line")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip the c3 / c4 model sub-records and the stand-alone a-side kernel timings of the default line")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous + timing path only (gloo on CPU, no GPU work)")
     args = ap.parse_args()

@@ -127,19 +127,20 @@ struct F6GemmArgs {
 constexpr int GUARD_WORDS = 64, GUARD_W_STATUS = 0, GUARD_W_DONE = 1, GUARD_W_SEG = 4, GUARD_MAX_SEG = 12;
 struct GuardSeg {
     const void* p;                             // kind 0: an S plane ([Kb][rows_allocS][2 B]); kind 1: fp32 values
-    int kind, Kb;
-    int64_t rows_allocS, nb, rdiv, rstride;    // kind 0: nb batches of rdiv real rows starting at multiples of rstride
+    int kind, Kb, slot;                        // slot: which word of the guard block collects this tensor's maximum
+    int64_t rows_allocS, nb, rdiv, rstride, rows_total;   // kind 0: nb batches of rdiv real rows (rows_total in all) starting at multiples of rstride
     int64_t n;                                 // kind 1: element count
 };
-struct GuardArgs { GuardSeg seg[GUARD_MAX_SEG]; int nseg; unsigned* words; };
-inline GuardSeg guard_seg_planes(const F6Planes& P, int64_t rows) {
+// One scan launch: its segments; `final`: the last workgroup evaluates slots [0, n_slots) (bit k of f32_slots: slot k is a non-finite flag)
+struct GuardArgs { GuardSeg seg[GUARD_MAX_SEG]; int nseg; unsigned* words; int final, n_slots; unsigned f32_slots; };
+inline GuardSeg guard_seg_planes(const F6Planes& P, int64_t rows, int slot) {
     GuardSeg s{};
-    s.p = P.S; s.kind = 0; s.Kb = P.Kb; s.rows_allocS = P.rows_allocS;
-    if (P.rdiv > 0) { s.nb = (rows + P.rdiv - 1) / P.rdiv; s.rdiv = P.rdiv; s.rstride = P.rstride; }
-    else            { s.nb = 1; s.rdiv = rows; s.rstride = 0; }
+    s.p = P.S; s.kind = 0; s.Kb = P.Kb; s.rows_allocS = P.rows_allocS; s.slot = slot;
+    if (P.rdiv > 0) { s.nb = (rows + P.rdiv - 1) / P.rdiv; s.rdiv = P.rdiv; s.rstride = P.rstride; s.rows_total = s.nb * P.rdiv; }
+    else            { s.rdiv = s.rstride = 4096; s.nb = (rows + 4095) / 4096; s.rows_total = rows; }     // unbatched rows: virtual batches, so that many workgroups share a K block
     return s;
 }
-inline GuardSeg guard_seg_f32(const float* x, int64_t n) { GuardSeg s{}; s.p = x; s.kind = 1; s.n = n; return s; }
+inline GuardSeg guard_seg_f32(const float* x, int64_t n, int slot) { GuardSeg s{}; s.p = x; s.kind = 1; s.n = n; s.slot = slot; return s; }
 int guard_reset(unsigned* words, hipStream_t st);
 int guard_scan(const GuardArgs& g, hipStream_t st);
 int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st);

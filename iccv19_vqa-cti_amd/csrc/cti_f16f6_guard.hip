@@ -8,8 +8,9 @@
 // rows that feed the direct-encoding M build:
 //
 //   guard_reset  (first kernel of the call)        zeroes the guard block at the head of the workspace
-//   guard_scan   (before the mode-3 product)       per tensor: max eh byte over its REAL rows (padding rows between batches hold stale bytes);
-//                                                   the last workgroup to finish evaluates the status word
+//   guard_scan   (x2: behind the M build on the auxiliary stream for what chain B and the encoder of `a` produced; before the mode-3 product
+//                 for a~ and A^)                   per tensor: max eh byte over its REAL rows (padding rows between batches hold stale bytes);
+//                                                   the last workgroup of the FINAL scan evaluates the status word
 //   guard_poison (after the mode-3 product)        status != 0: the output is overwritten with NaN -- never a finite, plausible, wrong number
 //
 // status bits: 1 = a block at or beyond the f16 range (|x| > 61440, incl. inf / NaN in an encoded tensor), 2 = a tensor that is not all zero
@@ -36,27 +37,34 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
 }
 
 __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
-    const unsigned tid = blockIdx.x * 256u + threadIdx.x, nthr = gridDim.x * 256u;
     const int lane = threadIdx.x & 63;
     for (int s = 0; s < g.nseg; ++s) {
         const GuardSeg sg = g.seg[s];
         unsigned mx = 0u;
         if (sg.kind == 0) {
-            // S plane: [Kb][rows_allocS][2 B]; real rows = nb batches of rdiv rows starting at multiples of rstride (a multiple of 8).  One item
-            // = four consecutive rows of one (K block, batch): an aligned 8-B load; rows beyond the batch are skipped.
-            const unsigned rows4 = (unsigned)((sg.rdiv + 3) >> 2), per_kb = (unsigned)sg.nb * rows4, items = (unsigned)sg.Kb * per_kb;
-            for (unsigned i = tid; i < items; i += nthr) {
-                const unsigned kb = i / per_kb, rem = i - kb * per_kb, b = rem / rows4, r4 = rem - b * rows4;
-                const int64_t prow = (int64_t)b * sg.rstride + (int64_t)r4 * 4;
-                const uint2 w = *reinterpret_cast<const uint2*>(static_cast<const uint8_t*>(sg.p) + ((int64_t)kb * sg.rows_allocS + prow) * 2);
-                const int left = (int)sg.rdiv - (int)r4 * 4;                                   // real rows in this item (>= 1)
-                mx = max(mx, w.x & 0xffu);
-                if (left > 1) mx = max(mx, (w.x >> 16) & 0xffu);
-                if (left > 2) mx = max(mx, w.y & 0xffu);
-                if (left > 3) mx = max(mx, (w.y >> 16) & 0xffu);
+            // S plane: [Kb][rows_allocS][2 B]; real rows = nb batches of rdiv rows (the last one may be shorter: rows_total) starting at multiples
+            // of rstride (a multiple of 8).  A workgroup takes whole (K block, batch) pairs -- one scalar division per pair -- and its threads
+            // sweep the pair's rows eight at a time with aligned 16-B loads; rows beyond the batch are skipped.
+            const unsigned pairs = (unsigned)sg.Kb * (unsigned)sg.nb;
+            for (unsigned pr = blockIdx.x; pr < pairs; pr += gridDim.x) {
+                const unsigned kb = pr / (unsigned)sg.nb, b = pr - kb * (unsigned)sg.nb;
+                const int64_t left_total = sg.rows_total - (int64_t)b * sg.rdiv;
+                const int rows = (int)(left_total < sg.rdiv ? left_total : sg.rdiv);
+                const uint8_t* base = static_cast<const uint8_t*>(sg.p) + ((int64_t)kb * sg.rows_allocS + (int64_t)b * sg.rstride) * 2;
+                for (int r8 = threadIdx.x; r8 * 8 < rows; r8 += 256) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(base + (int64_t)r8 * 16);
+                    const int left = rows - r8 * 8;                                            // real rows in this item (>= 1)
+                    const unsigned d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (left > 2 * u) mx = max(mx, d[u] & 0xffu);
+                        if (left > 2 * u + 1) mx = max(mx, (d[u] >> 16) & 0xffu);
+                    }
+                }
             }
         } else {
             // fp32 rows: any inf / NaN (exponent field all ones)
+            const unsigned tid = blockIdx.x * 256u + threadIdx.x, nthr = gridDim.x * 256u;
             const float* x = static_cast<const float*>(sg.p);
             const int64_t n4 = sg.n >> 2;
             for (int64_t i = tid; i < n4; i += nthr) {
@@ -68,8 +76,9 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
                 if ((__builtin_bit_cast(unsigned, x[i]) & 0x7f800000u) == 0x7f800000u) mx = 1u;
         }
         mx = wave_max_u32(mx);
-        if (lane == 0 && mx) atomicMax(&g.words[GUARD_W_SEG + s], mx);
+        if (lane == 0 && mx) atomicMax(&g.words[GUARD_W_SEG + sg.slot], mx);
     }
+    if (!g.final) return;                      // (the early scan: the final one is stream-ordered behind it)
     // last workgroup out: evaluate.  (Device-scope atomics execute at the memory side on gfx950: every workgroup's maxima are visible to the
     // atomic reads below once its own fence + counter increment have been performed.)
     __shared__ bool last;
@@ -79,12 +88,13 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
     __syncthreads();
     if (!last || threadIdx.x != 0) return;
     unsigned status = 0u;
-    for (int s = 0; s < g.nseg; ++s) {
-        const unsigned m = atomicOr(&g.words[GUARD_W_SEG + s], 0u);
-        if (g.seg[s].kind == 0) {
+    for (int k = 0; k < g.n_slots; ++k) {
+        const unsigned m = atomicOr(&g.words[GUARD_W_SEG + k], 0u);
+        if ((g.f32_slots >> k) & 1u) { if (m) status |= CTI_GUARD_NONFINITE; }
+        else {
             if (m >= (unsigned)GUARD_SAT_BYTE) status |= CTI_GUARD_SATURATED;
             if (m > 1u && m < (unsigned)GUARD_KNEE_BYTE) status |= CTI_GUARD_UNDERFLOW;
-        } else if (m) status |= CTI_GUARD_NONFINITE;
+        }
     }
     atomicExch(&g.words[GUARD_W_STATUS], status);
 }
@@ -106,8 +116,9 @@ int guard_scan(const GuardArgs& g, hipStream_t st) {
     if (g.nseg <= 0 || g.nseg > GUARD_MAX_SEG) return fail(CTI_E_SHAPE, "guard_scan: %d segments", g.nseg);
     for (int s = 0; s < g.nseg; ++s) {
         const GuardSeg& sg = g.seg[s];
-        if (sg.kind == 0 && ((sg.rstride & 7) || (sg.rows_allocS & 7) || sg.rdiv <= 0 || sg.nb <= 0 ||
-                             (int64_t)sg.Kb * sg.nb * ((sg.rdiv + 3) >> 2) >= (1ll << 32) || (reinterpret_cast<uintptr_t>(sg.p) & 7)))
+        if (sg.slot < 0 || sg.slot >= GUARD_MAX_SEG) return fail(CTI_E_SHAPE, "guard_scan: segment %d has slot %d", s, sg.slot);
+        if (sg.kind == 0 && ((sg.rstride & 7) || (sg.rows_allocS & 7) || sg.rdiv <= 0 || sg.nb <= 0 || sg.rdiv >= (1ll << 31) ||
+                             (int64_t)sg.Kb * sg.nb >= (1ll << 32) || (reinterpret_cast<uintptr_t>(sg.p) & 15)))
             return fail(CTI_E_SHAPE, "guard_scan: segment %d (Kb=%d nb=%lld rdiv=%lld rstride=%lld)", s, sg.Kb, (long long)sg.nb, (long long)sg.rdiv, (long long)sg.rstride);
         if (sg.kind == 1 && (reinterpret_cast<uintptr_t>(sg.p) & 15)) return fail(CTI_E_ALIGN, "guard_scan: fp32 segment %d is not 16-B aligned", s);
     }

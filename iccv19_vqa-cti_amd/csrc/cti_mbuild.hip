@@ -230,14 +230,21 @@ int launch(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsig
 
 // returns CTI_E_UNSUPPORTED (without setting an error message the caller must surface) when the shape is outside the
 // fast path, so that the caller can take the generic kernel of cti_paralind.hip.
+static size_t mbuild_fast_lds(int V, int Q, int hr, int G) {
+    return sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)hr * ((Q + 1) | 1));
+}
+// the fast kernel's shape test by sizes only (cti_tcnet.hip plans its workspace with it)
+bool mbuild_fast_fits(int B, int V, int Q, int R, int hr, int G) {
+    (void)R;
+    if (hr != 4 && hr != 8 && hr != 16) return false;
+    if (B > 65535 || mbuild_fast_lds(V, Q, hr, G) > 160 * 1024) return false;
+    // per-thread column / row / prefetch budgets of the fast kernel
+    return !(hr * hr * G > 1024 || (int64_t)V * G * ((Q + 1) / 2) > 2048 || hr * hr * hr * G / 4 > 4096 || V * hr > 1024 || Q * hr > 1024);
+}
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm, hipStream_t st) {
-    if (hr != 4 && hr != 8 && hr != 16) return CTI_E_UNSUPPORTED;
-    if (B > 65535) return CTI_E_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)hr * hr * hr * G + (size_t)V * G * hr * hr + (size_t)(V + 8) * hr + (size_t)hr * ((Q + 1) | 1));
-    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
-    if (hr * hr * G > 1024 || (int64_t)V * G * ((Q + 1) / 2) > 2048 || hr * hr * hr * G / 4 > 4096 || V * hr > 1024 || Q * hr > 1024)
-        return CTI_E_UNSUPPORTED;                           // per-thread column / row / prefetch budgets of the fast kernel
+    if (!mbuild_fast_fits(B, V, Q, R, hr, G)) return CTI_E_UNSUPPORTED;
+    const size_t lds = mbuild_fast_lds(V, Q, hr, G);
     const bool planes = Mh != nullptr;
 #define CTI_MB(H) (planes ? launch<H, true>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st) \
                           : launch<H, false>(Vr, Qr, Teff, Mf, Mh, Ml, B, V, Q, R, G, ldm, lds, st))
@@ -657,17 +664,21 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
 
 }  // namespace
 
+bool mbuild_mfma_fits(int B, int V, int Q, int R, int hr, int G) {
+#ifdef CTI_NO_MBUILD_MFMA
+    return false;
+#endif
+    return hr == 16 && G == 2 && V >= 1 && V <= 64 && Q >= 1 && Q <= 16 && (R & 1) == 0 && B <= 65535 &&
+           sizeof(float) * ((size_t)V * G * 16 * MB_XP + 16 * 16 * MB_SP) <= 160 * 1024;
+}
+
 // Tt: the core pre-transposed to [r][c][i] (cti_transpose_f32 of T_eff[r] (i x c) for every r).  CTI_E_UNSUPPORTED = take mbuild_fast.
 int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st) {
-#ifdef CTI_NO_MBUILD_MFMA
-    return CTI_E_UNSUPPORTED;
-#endif
-    if (hr != 16 || G != 2 || V > 64 || Q > 16 || (R & 1) || B > 65535 || !Tt || !((Mh && Ml) || Mf)) return CTI_E_UNSUPPORTED;
+    if (!mbuild_mfma_fits(B, V, Q, R, hr, G) || !Tt || !((Mh && Ml) || Mf)) return CTI_E_UNSUPPORTED;
     if (Mf && ((reinterpret_cast<uintptr_t>(Mf) & 15) || (pitchM & 3))) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
     const size_t lds = sizeof(float) * ((size_t)V * G * 16 * MB_XP + 16 * 16 * MB_SP);
-    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);

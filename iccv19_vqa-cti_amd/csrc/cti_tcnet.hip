@@ -16,6 +16,8 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
+bool mbuild_mfma_fits(int B, int V, int Q, int R, int hr, int G);
+bool mbuild_fast_fits(int B, int V, int Q, int R, int hr, int G);
 bool mbuild_core_small_fits(int B, int V, int Q, int A, int R, int hr, int G);
 }
 using namespace cti;
@@ -62,6 +64,12 @@ static bool small_a(const Dims& d) { return mbuild_core_small_fits(d.B, d.V, d.Q
 // f16f6 mode: the M build encodes the mode-3 product's planes itself (mbuild_mfma_f6's own shape test, by sizes only -- the workspace then
 // holds no fp32 M); other shapes build fp32 rows and run the encoding pass.
 static bool direct_m(const Dims& d) { return mbuild_mfma_f6_fits(d.B, d.V, d.Q, d.R, d.h / d.R, d.G); }
+// bf16 planes modes: neither plane-writing M build takes the shape (their LDS budgets end at ~56 objects for hr = 16; other hr / odd rank counts
+// never fit): the generic kernel builds fp32 rows that a split pass turns into planes -- in `out` when it is large enough (A >= h), else in a scratch block
+static bool m_needs_scratch(const Dims& d) {
+    const int hr = d.h / d.R;
+    return !mbuild_mfma_fits(d.B, d.V, d.Q, d.R, hr, d.G) && !mbuild_fast_fits(d.B, d.V, d.Q, d.R, hr, d.G) && d.A < d.h;
+}
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
@@ -75,6 +83,7 @@ struct Plan {
     // f16f6 mode: the mode-3 product runs on f16 + fp6 planes (cti_f16f6.h) written by the rank GEMM's epilogue (A^) and an encoding pass (M);
     // every other GEMM stays on bf16x3
     F6Planes f_Arp, f_Mp; float* Mf32;
+    float* Mscr;                               // bf16 planes modes, m_needs_scratch(): fp32 M rows of the generic M build
     // ... and so do the a-side rank nets (A >= 7): the Tucker GEMM's epilogue encodes a~ (f_At), the rank nets run as one transposed f16f6 product
     // whose register epilogue encodes A^ (gemm_nt_f16f6 epi 6) against the rank weights' block f_wra (weight-norm scale folded in; prepared)
     F6Planes f_At, f_wra;
@@ -140,6 +149,7 @@ Plan carve(const Dims& d, int prec, void* ws) {
         } else if (!f6) {
             p.Arp = take_planes(w, rows[2], d.h);
             p.Mp = take_planes(w, mrows, d.h);
+            if (m_needs_scratch(d)) p.Mscr = static_cast<float*>(w.take(sizeof(float) * mrows * d.h));
         } else {
             const int64_t mpb = (int64_t)d.V * d.Q * d.G;
             p.f_Arp = f6_carve(w.take(f6_planes_bytes(rows[2], d.h, d.A)), rows[2], d.h, d.A);
@@ -418,13 +428,28 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, p.Mp.hi, p.Mp.lo, nullptr, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) rc = mbuild_fast(p.Vr, p.Qr, p.Teff, nullptr, p.Mp.hi, p.Mp.lo, B, V, Q, R, hr, G, p.Mp.rows_alloc * 16, sb);
     if (rc == CTI_E_UNSUPPORTED) {
-        // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h)
-        if (A < h) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: h/rank=%d is outside the fast M build and A < h", hr));
-        rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, out, B, V, Q, R, hr, hr, hr, G, sb); if (rc) return finish(rc);
-        rc = split_planes(out, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, sb);
+        // generic M build writes fp32 (B,V,Q,G,h): borrow `out` as scratch when it is large enough (B*V*Q*A*G >= B*V*Q*G*h), else the plan
+        // carved a scratch block (m_needs_scratch)
+        float* mscr = p.Mscr ? p.Mscr : out;
+        if (!p.Mscr && A < h) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: the plan carved no M scratch for a shape its plane M builds refuse (V=%d Q=%d h/rank=%d A=%d)", V, Q, hr, A));
+        rc = cti_paralind_mbuild_fwd(p.Vr, p.Qr, p.Teff, mscr, B, V, Q, R, hr, hr, hr, G, sb); if (rc) return finish(rc);
+        rc = split_planes(mscr, h, (int64_t)B * mrows_per_b, h, p.Mp.hi, p.Mp.lo, p.Mp.rows_alloc, sb);
     }
     }
     if (rc) return finish(rc);
+    if (f6) {
+        // Range guard, first scan (cti_f16f6_guard.hip), on chain B's stream: the scale bytes of M and of the a-side weights + a non-finite sweep of the fp32
+        // rows behind the M build.  Starved of CUs by the persistent a-side GEMMs, it fills their tails like the rest of chain B.
+        GuardArgs gb{};
+        gb.words = p.guard;
+        gb.seg[gb.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
+        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
+        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
+        rc = guard_scan(gb, sb); if (rc) return finish(rc);
+    }
     if (aux_stream) (void)hipEventRecord(ev_join, sb);
     // chain A on the main stream
     rc = side(2, st); if (rc) return finish(rc);
@@ -434,20 +459,14 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
         c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
         if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }     // the Tri softmax's partial pass, from the accumulators
-        // Range guard: everything the f16f6 kernels read is encoded by now.  The scan (scale bytes of the six encoded operands + a non-finite
-        // sweep of the fp32 rows behind the M build: ~75 MB at configs[1]) leaves the status word BEFORE ev_core_begin, so a host that waits
-        // for that event learns the verdict while the mode-3 product is still running; the NaN fill behind the product needs no host at all.
+        // Range guard, second (final) scan: `a`, a~ and A^ are encoded by now (67 MB of scale bytes at configs[1]); everything else was scanned on the
+        // auxiliary stream behind the M build.  It leaves the status word BEFORE ev_core_begin, so a host that waits for that event learns the
+        // verdict while the mode-3 product is still running; the NaN fill behind the product needs no host at all.
         GuardArgs ga{};
-        ga.words = p.guard;
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2]);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2]);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2]);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h);
-        ga.seg[ga.nseg++] = guard_seg_f32(p.Vr, rows[0] * h);
-        ga.seg[ga.nseg++] = guard_seg_f32(p.Qr, rows[1] * h);
-        ga.seg[ga.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G);
+        ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         rc = guard_scan(ga, st); if (rc) return finish(rc);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);

@@ -70,18 +70,22 @@ def test_inputs_inside_the_domain_do_not_trip_the_guard():
     print("f16f6 guard, clean inputs: err %.3g, no trip" % e)
 
 
-@pytest.mark.parametrize("scale,bit", [(1e3, cti_amd.pkg._lib.GUARD_SATURATED), (1e-4, cti_amd.pkg._lib.GUARD_UNDERFLOW)])
-def test_scaled_inputs_take_the_explicit_bf16x3_fallback(scale, bit):
-    """x10^3: M ~ V^ Q^ grows with the square (beyond f16's 65504); x10^-4: M sinks below the f16 subnormal knee.  Either way the guard must
-    trip and the re-run must be fp32-grade."""
+@pytest.mark.parametrize("scale,bit", [(1e3, cti_amd.pkg._lib.GUARD_SATURATED), (1e-4, None), (1e-7, cti_amd.pkg._lib.GUARD_UNDERFLOW)])
+def test_scaled_inputs_are_fp32_grade_or_take_the_explicit_bf16x3_fallback(scale, bit):
+    """x10^3: M ~ V^ Q^ grows with the square, beyond f16's 65504 -- the guard must trip.  x10^-4: the layers' biases keep the intermediates in
+    range and `a` itself (|x| ~ 1e-4, above the 2^-12 knee of its largest blocks) still encodes to 2^-15 of its block maxima: either verdict
+    is fine as long as the numbers are right.  x10^-7: `a` lies entirely in f16's subnormal range -- the guard must trip.  In every case the
+    caller gets fp32-grade numbers."""
     params, v, q, a = _case(A=3129)
     v, q, a = (v * np.float32(scale)), (q * np.float32(scale)), (a * np.float32(scale))
     out, calls, trips, status = _run(params, v, q, a)
-    assert calls == 1 and trips == 1 and (status & bit), (calls, trips, status)
+    assert calls == 1
+    if bit is not None:
+        assert trips == 1 and (status & bit), (calls, trips, status)
     ref = O.tcnet_forward(v, q, a, params, "TriAtt.", dtype=np.float64)
     e = _err(out, ref)
-    assert np.isfinite(out).all() and e < TOL, e
-    print("f16f6 guard, inputs x%g: status %d -> bf16x3 re-run, err %.3g" % (scale, status, e))
+    assert np.isfinite(out).all() and e < TOL, (e, trips, status)
+    print("f16f6 guard, inputs x%g: trips %d status %d, err %.3g" % (scale, trips, status, e))
 
 
 def test_one_large_outlier_per_block():
