@@ -34,6 +34,10 @@ inline int launch_status(const char* what) {
 
 constexpr int WAVE = 64;
 
+// ReLU as torch defines it: NaN stays NaN (fmaxf / v_max_f32 return the other operand, and a NaN in the inputs would come out of every
+// layer as a clean zero -- the reference's relu propagates it, src/fc.py:24)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);

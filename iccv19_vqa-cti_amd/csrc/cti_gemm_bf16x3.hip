@@ -398,7 +398,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 for (int e = 0; e < 16; ++e) {
                     const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     float x = acc[i][j][e] * sc + bi;
-                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.relu) x = relu_nan(x);
                     stg[row * 36 + (lane & 31)] = real ? x : 0.f;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave writes and reads its patch: in-order LDS, no barrier
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     x[u] = x[u] * sc[u] + bi[u];
-                    if (p.relu) x[u] = fmaxf(x[u], 0.f);
+                    if (p.relu) x[u] = relu_nan(x[u]);
                     if (nb + u >= p.N) x[u] = 0.f;
                 }
                 if (EPI == EPI_PLANES) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float x = acc[i][j][e] * sc + bi;
-                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.relu) x = relu_nan(x);
                     C[(int64_t)(m / p.gdiv) * p.ldc_m + (m % p.gdiv) + (int64_t)n * p.ldc_n] = x;
                 }
             }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float* __restr
         const int n = n0 + u;
         if (n < N) {
             float x = a[u] * (scale ? scale[n / scale_div] : 1.f) + (bias ? bias[n] : 0.f);
-            if (relu) x = fmaxf(x, 0.f);
+            if (relu) x = relu_nan(x);
             C[(int64_t)m * ldc_m + n] = x;
         }
     }

@@ -85,23 +85,28 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // 256 x 192 tile, 8 waves.  One ring slot = one 32-deep K block of both operands:
 //   A_H 256 rows x 64 B | B_H 192 x 64 B | A_FL 256 x 24 B | B_FL 192 x 24 B | A_S 256 x 2 B | B_S 192 x 2 B (+ 640 B the last piece over-writes)
 // = exactly 40 pieces of 1 KiB (one LDS-DMA wave-instruction each), five per wave; four slots fill the CU's 160 KiB.
-template <int WM_, int WN_, int TM_, int TN_>
+template <int WM_, int WN_, int TM_, int TN_, int NST_ = 4>
 struct GeoF6T {
-    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NST = 4;
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NST = NST_;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64, NW = WM * WN;
     static constexpr int PAH = BM / 16, PBH = BN / 16, PAF = BM * 24 / 1024, PBF = BN * 24 / 1024;      // whole pieces; B_FL leaves a 512-B tail
     static constexpr int OFF_AH = 0, OFF_BH = OFF_AH + BM * 64, OFF_AFL = OFF_BH + BN * 64, OFF_BFL = OFF_AFL + BM * 24;
-    static constexpr int OFF_AS = OFF_BFL + BN * 24, OFF_BS = OFF_AS + BM * 2;
+    static constexpr int OFF_AS = OFF_BFL + BN * 24, OFF_BS = OFF_AS + 512;                            // (the A scales' half piece always moves 512 B = 256 rows)
     static constexpr int SLOT = OFF_BS + 1024;
-    static constexpr int NPIECE = PAH + PBH + PAF + PBF + 2;
-    static constexpr int CNT = NPIECE / NW;                        // pieces per wave and slot
+    static constexpr int NREAL = PAH + PBH + PAF + PBF + 2;          // pieces a slot needs
+    static constexpr int CNT = (NREAL + NW - 1) / NW;                // pieces per wave and slot
+    static constexpr int NPIECE = CNT * NW;                          // issued: the NPIECE - NREAL extra ones repeat the first pieces (same bytes, same place)
     static constexpr int LDS = NST * SLOT;
-    static_assert(BM * 24 % 1024 == 0 && BN * 24 % 1024 == 512 && BM * 2 == 512, "the B_FL tail and the A scales share one piece");
+    static constexpr int MINW = 160 * 1024 / LDS >= 2 ? 2 * NW / 4 : NW / 4;     // waves per SIMD the launch bounds promise (two co-resident workgroups when the LDS allows)
+    static_assert(BM * 24 % 1024 == 0 && BN * 24 % 1024 == 512 && BM * 2 <= 512, "the B_FL tail and the A scales share one piece");
     static_assert(OFF_AS == OFF_BFL + PBF * 1024 + 512, "the shared piece is contiguous in LDS");
-    static_assert(NPIECE % NW == 0, "every wave issues the same number of pieces");
-    static_assert(LDS <= 160 * 1024, "ring exceeds the CU's LDS");
+    static_assert(NST >= 2 && LDS <= 160 * 1024, "ring exceeds the CU's LDS");
 };
 using GeoF6 = GeoF6T<4, 2, 2, 3>;                    // 8 waves of 64 x 96, two per SIMD
+// Round 3 experiment (d): 128 x 192 tiles, FOUR waves of 64 x 96 (the same wave tile, so the same fragment reads / conversions / MFMAs per wave
+// and K block), a 2-slot ring of 31 KiB -- TWO independent workgroups per CU, each with its own barriers: one workgroup's epilogue (and every
+// other phase) overlaps the other's K loop instead of idling the matrix pipe.  Price: 43 % more DMA bytes per flop and one block in flight.
+using GeoF6Half = GeoF6T<2, 2, 2, 3, 2>;
 
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -284,7 +289,7 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
                     const int m = cm0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (m < p.M && !((CTI_F6_ABL & 8) && sc != 12345.f)) {
                         float x = acc[i][j][e] * sc + bi;
-                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (p.relu) x = relu_nan(x);
                         C[(int64_t)(m / p.gdiv) * p.ldc_m + (m % p.gdiv) + (int64_t)n * p.ldc_n] = x;
                     }
                 }
@@ -293,7 +298,7 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
 }
 
 template <int EPI, class G>
-__global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
+__global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
     constexpr int WN = G::WN, TM = G::TM, TN = G::TN, NST = G::NST, BM = G::BM, BN = G::BN, NW = G::NW, SLOT = G::SLOT, CNT = G::CNT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -312,17 +317,19 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
     // 64-bit source pointer (H pieces: rows (lane >> 2) of the piece, 16-B chunk (lane & 3) ^ ((row >> 2) & 3); the others 16 B per lane) that
     // walks the K blocks of the tile being issued: one VALU add per piece and block, no scalar address arithmetic in the loop.
     const char* vp[CNT]; int64_t kstride[CNT]; int ldsoff[CNT];
-    const bool shared_piece_wave = (G::NPIECE - 2) % NW == wid;
+    const bool shared_piece_wave = (G::NREAL - 2) % NW == wid;
+    constexpr int U_SHARED = (G::NREAL - 2) / NW;                   // which of that wave's pieces is the shared one
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
         int g = wid + u * NW;
+        if (g >= G::NREAL) g -= G::NREAL;                          // padding pieces repeat the slot's first ones
         if (g < G::PAH)                   { kstride[u] = p.pA * 64; ldsoff[u] = G::OFF_AH + g * 1024; }
         else if ((g -= G::PAH) < G::PBH)  { kstride[u] = p.pB * 64; ldsoff[u] = G::OFF_BH + g * 1024; }
         else if ((g -= G::PBH) < G::PAF)  { kstride[u] = p.pA * 24; ldsoff[u] = G::OFF_AFL + g * 1024; }
         else if ((g -= G::PAF) <= G::PBF) { kstride[u] = p.pB * 24; ldsoff[u] = G::OFF_BFL + g * 1024; }   // g == PBF: the tail
         else                              { kstride[u] = p.pBS * 2; ldsoff[u] = G::OFF_BS; }
     }
-    const int64_t vks_last = (shared_piece_wave && h) ? p.pAS * 2 : kstride[CNT - 1];       // per lane: the shared piece's halves walk different planes
+    const int64_t vks_shared = (shared_piece_wave && h) ? p.pAS * 2 : kstride[U_SHARED];    // per lane: the shared piece's halves walk different planes
     int iss_tile = blockIdx.x, iss_kb = 0, issued = 0;
     auto issue_tile_setup = [&]() {
         // The plane pointers and batch strides are needed once per tile: they are re-read from the kernel-argument segment here (scalar loads
@@ -338,13 +345,14 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
             int g = w + u * NW;
+            if (g >= G::NREAL) g -= G::NREAL;
             if (g < G::PAH)                   vp[u] = q->AH + (ra + g * 16) * 64 + hoff;
             else if ((g -= G::PAH) < G::PBH)  vp[u] = q->BH + (rb + g * 16) * 64 + hoff;
             else if ((g -= G::PBH) < G::PAF)  vp[u] = q->AFL + ra * 24 + g * 1024 + loff;
             else if ((g -= G::PAF) <= G::PBF) vp[u] = q->BFL + rb * 24 + g * 1024 + loff;
             else                              vp[u] = q->BS + rb * 2 + loff;
         }
-        if (shared_piece_wave && h) vp[CNT - 1] = q->AS + ra * 2 - 512 + loff;      // upper 32 lanes: the A scales, 16 B per lane from lane 32 on
+        if (shared_piece_wave && h) vp[U_SHARED] = q->AS + ra * 2 - 512 + loff;     // upper 32 lanes: the A scales, 16 B per lane from lane 32 on
     };
     auto issue_next = [&](int pos) {                                // the stream's next K block into ring slot `pos`
         if (issued >= nblk || (CTI_F6_ABL & 1)) return;
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
             dma16(vp[u], slot + ldsoff[u]);
-            vp[u] += u == CNT - 1 ? vks_last : kstride[u];
+            vp[u] += u == U_SHARED ? vks_shared : kstride[u];
         }
         ++issued;
         if (++iss_kb == nkb) {
@@ -541,15 +549,18 @@ __global__ __launch_bounds__(G::NTHR) void gemm_f16f6_kernel(F6P p) {
 #ifndef CTI_F6_OVERSUB_DEFAULT
 #define CTI_F6_OVERSUB_DEFAULT 1
 #endif
-template <int EPI>
-int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
-    using G = GeoF6;
+// CTI_F6_GEO=half selects the two-workgroups-per-CU geometry (GeoF6Half) for the plain mode-3 product and the transposed a-side products
+// (experiment (d) of round 3; the softmax-partials variant keeps the layout of its partials and stays on GeoF6).
+static int f6_geo() { static const int g = [] { const char* e = getenv("CTI_F6_GEO"); return (e && e[0] == 'h') ? 1 : 0; }(); return g; }
+
+template <int EPI, class G>
+int launch_f6g(const F6P& p0, long long nb, int ncols, hipStream_t st) {
     auto kern = gemm_f16f6_kernel<EPI, G>;
     static thread_local int attr_dev = -1;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (attr_dev != dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) return fail((int)e, "gemm_nt_f16f6: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_dev = dev;
     }
@@ -562,12 +573,19 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
     // Workgroups per CU.  One = fully persistent: every workgroup walks total / n_cu tiles, assigned statically -- a CU that starts late because a
     // kernel of the other stream sat on it (the M build: one workgroup per CU, all of its LDS) finishes late, and the stream-ordered GEMM behind
     // this one waits for it.  With a few workgroups per CU the hardware dispatcher balances that: a delayed CU simply takes fewer of them; the
-    // price is one ring refill per workgroup.  CTI_F6_OVERSUB overrides (experiments).
+    // price is one ring refill per workgroup.  CTI_F6_OVERSUB overrides (experiments).  Geometries whose ring leaves room for two workgroups
+    // per CU launch two per CU: they are co-resident, not queued.
     static const int oversub = [] { const char* e = getenv("CTI_F6_OVERSUB"); const int v = e ? atoi(e) : CTI_F6_OVERSUB_DEFAULT; return v < 1 ? 1 : v; }();
-    long long grid = (long long)n_cu * oversub;
+    long long grid = (long long)n_cu * oversub * (160 * 1024 / G::LDS >= 2 ? 2 : 1);
     if (grid > total) grid = total;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NTHR), G::LDS, st, p);
     return launch_status("gemm_nt_f16f6");
+}
+
+template <int EPI>
+int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
+    if ((EPI == F6_EPI_INTERLEAVE2 || EPI == F6_EPI_PLANES_T) && f6_geo() == 1) return launch_f6g<EPI == F6_EPI_INTERLEAVE2 ? F6_EPI_INTERLEAVE2 : F6_EPI_PLANES_T, GeoF6Half>(p0, nb, ncols, st);
+    return launch_f6g<EPI, GeoF6>(p0, nb, ncols, st);
 }
 
 }  // namespace

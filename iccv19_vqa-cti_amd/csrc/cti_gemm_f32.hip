@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_f32_kernel(GemmP p) {
                 const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     float x = acc[i][j][e] * sc + bi;
-                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.relu) x = relu_nan(x);
                     C[(int64_t)m * p.ldc_m + (int64_t)n * p.ldc_n] = x;
                 }
             }

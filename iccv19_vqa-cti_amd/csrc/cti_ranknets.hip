@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void rn_fwd_kernel(const float* __restrict__ x
                 const int64_t row = tile0 + 4 * kq + i;
                 if (row < rows) {
                     float v = fmaf(acc[i], sc, bb);
-                    if (relu) v = fmaxf(v, 0.f);
+                    if (relu) v = relu_nan(v);
                     y[row * ldy + r * hr + l15] = v;
                 }
             }

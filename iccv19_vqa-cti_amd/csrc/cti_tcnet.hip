@@ -344,9 +344,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
     // an auxiliary stream from the caller chain B runs beside chain A's split pass: fork/join with two events, no host sync.
     hipStream_t sb = aux_stream ? as_stream(aux_stream) : st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_at = nullptr;          // ev_at: the a side's Tucker product has encoded a~ (range guard, f16f6 mode)
     if (aux_stream) {
-        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+            (p.guard && hipEventCreateWithFlags(&ev_at, hipEventDisableTiming) != hipSuccess))
             return fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed");
         (void)hipEventRecord(ev_fork, st);                  // scales, T_eff (and the mask) precede both chains
         (void)hipStreamWaitEvent(sb, ev_fork, 0);
@@ -354,6 +355,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     auto finish = [&](int code) {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_at) (void)hipEventDestroy(ev_at);
         return code;
     };
     const int Kh = planes_kp(h);
@@ -376,6 +378,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
             F6GemmArgs t{};                                  // a~^T = W_t a^T, then A^^T = W_r a~^T: rows = features, columns = the B * A answer tokens
             t.A = p.f_wta; t.B = p.f_Ain; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_At; t.bias = tucker_b[2]; t.relu = relu;
             r_ = gemm_nt_f16f6(t, ss); if (r_) return r_;
+            if (ev_at) (void)hipEventRecord(ev_at, ss);
             t.A = p.f_wra; t.B = p.f_At; t.out = &p.f_Arp; t.bias = rank_b[2];
             return gemm_nt_f16f6(t, ss);
         }
@@ -437,35 +440,47 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     }
     }
     if (rc) return finish(rc);
-    if (f6) {
-        // Range guard, first scan (cti_f16f6_guard.hip), on chain B's stream: the scale bytes of M and of the a-side weights + a non-finite sweep of the fp32
-        // rows behind the M build.  Starved of CUs by the persistent a-side GEMMs, it fills their tails like the rest of chain B.
+    // Range guard (cti_f16f6_guard.hip), first scan: the scale bytes of M and of the a-side weights + a non-finite sweep of the fp32 rows behind the
+    // M build.  With an auxiliary stream it is issued further down, behind the a side's Tucker product (so that it also covers `a` and a~), and
+    // runs beside the rank nets' product: starved of CUs by the persistent GEMM, it fills its tails like the rest of chain B.
+    auto early_scan = [&](bool with_a) -> int {
         GuardArgs gb{};
         gb.words = p.guard;
         gb.seg[gb.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
         gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
         gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        if (with_a) {
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        }
         gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
         gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
         gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
-        rc = guard_scan(gb, sb); if (rc) return finish(rc);
-    }
-    if (aux_stream) (void)hipEventRecord(ev_join, sb);
+        return guard_scan(gb, sb);
+    };
+    if (f6 && !aux_stream) { rc = early_scan(false); if (rc) return finish(rc); }
+    if (aux_stream && !f6) (void)hipEventRecord(ev_join, sb);
     // chain A on the main stream
     rc = side(2, st); if (rc) return finish(rc);
-    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
+    if (f6 && aux_stream) {
+        (void)hipStreamWaitEvent(sb, ev_at, 0);               // `a` and a~ are encoded: chain B ends with the early scan
+        rc = early_scan(true); if (rc) return finish(rc);
+    }
+    if (aux_stream) { if (f6) (void)hipEventRecord(ev_join, sb); (void)hipStreamWaitEvent(st, ev_join, 0); }
     if (f6) {
         F6GemmArgs c{};                                      // mode 3 + rank sum on the f16 + fp6 planes
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
         c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
         if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }     // the Tri softmax's partial pass, from the accumulators
-        // Range guard, second (final) scan: `a`, a~ and A^ are encoded by now (67 MB of scale bytes at configs[1]); everything else was scanned on the
-        // auxiliary stream behind the M build.  It leaves the status word BEFORE ev_core_begin, so a host that waits for that event learns the
-        // verdict while the mode-3 product is still running; the NaN fill behind the product needs no host at all.
+        // Range guard, final scan: A^ is encoded by now (26 MB of scale bytes at configs[1]; without an auxiliary stream `a` and a~ as well).  It
+        // leaves the status word BEFORE ev_core_begin, so a host that waits for that event learns the verdict while the mode-3 product is
+        // still running; the NaN fill behind the product needs no host at all.
         GuardArgs ga{};
         ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        if (!aux_stream) {
+            ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
+            ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        }
         ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         rc = guard_scan(ga, st); if (rc) return finish(rc);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
