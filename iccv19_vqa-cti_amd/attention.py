@@ -43,6 +43,11 @@ class TriAttention(nn.Module):
         self.TriAtt = TCNet(v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, dropout=dropout, k=k)
 
     def forward(self, v, q, a):
+        t = self.TriAtt
+        if self.glimpse >= 2 and t._fusable(v, q, a):
+            # eval: logits, mask and softmax in ONE library call (cti_triattention_forward)
+            tucker, rank = t._fused_args()
+            return ops.triattention_forward(v.float(), q.float(), a.float(), tucker, rank, t.T_g.detach(), relu=(t._act == 'ReLU'), prepared=t._prep)
         logits, mask, partials = self.TriAtt(v, q, a, _want_mask=True, _want_sm_partials=True)
         if logits.dim() != 5:
             # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises

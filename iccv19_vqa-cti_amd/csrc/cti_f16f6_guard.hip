@@ -29,18 +29,20 @@ constexpr int GUARD_KNEE_BYTE = 113;           // f6_scale_byte(2^-12)
 
 __global__ __launch_bounds__(64) void guard_reset_kernel(unsigned* words) { words[threadIdx.x] = 0u; }
 
-// one wave-wide maximum of small non-negative integers
-__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = max(x, (unsigned)__shfl_xor((int)x, o, 64));
-    return x;
+// What a tensor's scale bytes say, as bits (a slot of the guard block is the OR over the tensor): 1 = a block that is not all zero, 2 = a
+// block at or above the 2^-12 knee, 4 = a block at or beyond the f16 range.  fp32 segments: 1 = a non-finite value.
+constexpr unsigned GB_NONZERO = 1u, GB_HEALTHY = 2u, GB_SAT = 4u;
+__device__ __forceinline__ unsigned guard_bits(unsigned byte) {
+    return (byte > 1u ? GB_NONZERO : 0u) | (byte >= (unsigned)GUARD_KNEE_BYTE ? GB_HEALTHY : 0u) | (byte >= (unsigned)GUARD_SAT_BYTE ? GB_SAT : 0u);
 }
 
 __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned wg_bits[GUARD_MAX_SEG];
+    if (threadIdx.x < GUARD_MAX_SEG) wg_bits[threadIdx.x] = 0u;
+    __syncthreads();
     for (int s = 0; s < g.nseg; ++s) {
         const GuardSeg sg = g.seg[s];
-        unsigned mx = 0u;
+        unsigned bits = 0u;
         if (sg.kind == 0) {
             // S plane: [Kb][rows_allocS][2 B]; real rows = nb batches of rdiv rows (the last one may be shorter: rows_total) starting at multiples
             // of rstride (a multiple of 8).  A workgroup takes whole (K block, batch) pairs -- one scalar division per pair -- and its threads
@@ -57,8 +59,8 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
                     const unsigned d[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (left > 2 * u) mx = max(mx, d[u] & 0xffu);
-                        if (left > 2 * u + 1) mx = max(mx, (d[u] >> 16) & 0xffu);
+                        if (left > 2 * u) bits |= guard_bits(d[u] & 0xffu);
+                        if (left > 2 * u + 1) bits |= guard_bits((d[u] >> 16) & 0xffu);
                     }
                 }
             }
@@ -70,16 +72,25 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
             for (int64_t i = tid; i < n4; i += nthr) {
                 const uint4 w = reinterpret_cast<const uint4*>(x)[i];
                 const unsigned e = 0x7f800000u;
-                if ((w.x & e) == e || (w.y & e) == e || (w.z & e) == e || (w.w & e) == e) mx = 1u;
+                if ((w.x & e) == e || (w.y & e) == e || (w.z & e) == e || (w.w & e) == e) bits = 1u;
             }
             for (int64_t i = (n4 << 2) + tid; i < sg.n; i += nthr)
-                if ((__builtin_bit_cast(unsigned, x[i]) & 0x7f800000u) == 0x7f800000u) mx = 1u;
+                if ((__builtin_bit_cast(unsigned, x[i]) & 0x7f800000u) == 0x7f800000u) bits = 1u;
         }
-        mx = wave_max_u32(mx);
-        if (lane == 0 && mx) atomicMax(&g.words[GUARD_W_SEG + sg.slot], mx);
+        if (bits) atomicOr(&wg_bits[sg.slot], bits);           // LDS: cheap
+    }
+    __syncthreads();
+    // One global atomic per workgroup and slot AT MOST, and only for bits the word does not show yet: thousands of atomics on one address
+    // serialise at the memory side (the first version's per-wave atomicMax cost 0.1 ms).  A stale read only costs a redundant atomicOr.
+    if (threadIdx.x < GUARD_MAX_SEG) {
+        const unsigned mine = wg_bits[threadIdx.x];
+        if (mine) {
+            const unsigned seen = __atomic_load_n(&g.words[GUARD_W_SEG + threadIdx.x], __ATOMIC_RELAXED);
+            if (mine & ~seen) atomicOr(&g.words[GUARD_W_SEG + threadIdx.x], mine & ~seen);
+        }
     }
     if (!g.final) return;                      // (the early scan: the final one is stream-ordered behind it)
-    // last workgroup out: evaluate.  (Device-scope atomics execute at the memory side on gfx950: every workgroup's maxima are visible to the
+    // last workgroup out: evaluate.  (Device-scope atomics execute at the memory side on gfx950: every workgroup's bits are visible to the
     // atomic reads below once its own fence + counter increment have been performed.)
     __shared__ bool last;
     __threadfence();
@@ -92,8 +103,8 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
         const unsigned m = atomicOr(&g.words[GUARD_W_SEG + k], 0u);
         if ((g.f32_slots >> k) & 1u) { if (m) status |= CTI_GUARD_NONFINITE; }
         else {
-            if (m >= (unsigned)GUARD_SAT_BYTE) status |= CTI_GUARD_SATURATED;
-            if (m > 1u && m < (unsigned)GUARD_KNEE_BYTE) status |= CTI_GUARD_UNDERFLOW;
+            if (m & GB_SAT) status |= CTI_GUARD_SATURATED;
+            if ((m & GB_NONZERO) && !(m & GB_HEALTHY)) status |= CTI_GUARD_UNDERFLOW;
         }
     }
     atomicExch(&g.words[GUARD_W_STATUS], status);

@@ -554,7 +554,8 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
 template <int AT, int VT>
 __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                                  const float* __restrict__ Tt, const float* __restrict__ Ar,
-                                                                 float* __restrict__ out, int V, int Q, int A, int R) {
+                                                                 float* __restrict__ out, int V, int Q, int A, int R,
+                                                                 const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p) {
     constexpr int HR = 16, G = 2, INNER = HR * HR * G;
     extern __shared__ __attribute__((aligned(16))) float X2[];  // [V][G][HR(k)][MB_XP], then Ar[b]: [A][K]
     const int b = blockIdx.x;
@@ -648,16 +649,77 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
 #undef CTI_MC_LOAD
     // the two k-halves of a lane pair (lanes l and l + 32) meet; the lower half writes out[b, v, q, a, 0:2]
 #pragma unroll
-    for (int t = 0; t < VT; ++t) {
-        const int v = wid + 16 * t;
+    for (int t = 0; t < VT; ++t)
 #pragma unroll
         for (int a = 0; a < AT; ++a)
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[t][a][g] += __shfl_xor(acc[t][a][g], 32);
-        if (v < V && qok && kg == 0) {
-            float* o = out + (((int64_t)b * V + v) * Q + l31) * A * G;
+    if (sm_p == nullptr) {
 #pragma unroll
-            for (int a = 0; a < AT; ++a) if (a < A) { o[a * G] = acc[t][a][0]; o[a * G + 1] = acc[t][a][1]; }
+        for (int t = 0; t < VT; ++t) {
+            const int v = wid + 16 * t;
+            if (v < V && qok && kg == 0) {
+                float* o = out + (((int64_t)b * V + v) * Q + l31) * A * G;
+#pragma unroll
+                for (int a = 0; a < AT; ++a) if (a < A) { o[a * G] = acc[t][a][0]; o[a * G + 1] = acc[t][a][1]; }
+            }
+        }
+        return;
+    }
+    // TriAttention's masked softmax (reference src/attention.py:55-58) in the same kernel: the workgroup holds ALL of the sample's V*Q*A*G
+    // logits in registers, so the per-glimpse maximum and sum are two workgroup reductions and `logits` (-inf on the all-zero rows of v) and
+    // `p` are written once -- no second and third pass over the logits, no extra launches.  An all-masked sample keeps the reference's NaN row.
+    constexpr float L2E = 1.4426950408889634f;
+    const float ninf = -__builtin_huge_valf();
+    __syncthreads();                                            // every wave is done with X2 / ArS: the reductions reuse the LDS
+    float* red = X2;                                            // [16 waves][2]
+    bool rowok[VT];
+    float mx[G] = {ninf, ninf};
+#pragma unroll
+    for (int t = 0; t < VT; ++t) {
+        const int v = wid + 16 * t;
+        rowok[t] = v < V && sm_mask[(int64_t)b * V + (v < V ? v : 0)] == 0;       // (wave-uniform)
+        if (rowok[t] && qok) {
+#pragma unroll
+            for (int a = 0; a < AT; ++a) if (a < A) { mx[0] = fmaxf(mx[0], acc[t][a][0]); mx[1] = fmaxf(mx[1], acc[t][a][1]); }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float w = wave_max(mx[g]); if (lane == 0) red[wid * 2 + g] = w; }
+    __syncthreads();
+    float gm[G] = {ninf, ninf};
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { gm[0] = fmaxf(gm[0], red[w * 2]); gm[1] = fmaxf(gm[1], red[w * 2 + 1]); }
+    __syncthreads();
+    float e[VT][AT][G];
+    float sum[G] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < VT; ++t)
+#pragma unroll
+        for (int a = 0; a < AT; ++a)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                // exp(x - m) = exp2(x log2e - m log2e); masked rows contribute exp(-inf) = 0; m = -inf (every row masked) gives NaN like the reference
+                e[t][a][g] = rowok[t] ? __builtin_amdgcn_exp2f(fmaf(acc[t][a][g], L2E, -gm[g] * L2E)) : (gm[g] == ninf ? __builtin_nanf("") : 0.f);
+                if (qok && kg == 0 && a < A && wid + 16 * t < V) sum[g] += e[t][a][g];
+            }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float w = wave_sum(sum[g]); if (lane == 0) red[wid * 2 + g] = w; }
+    __syncthreads();
+    float tot[G] = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { tot[0] += red[w * 2]; tot[1] += red[w * 2 + 1]; }
+    const float inv[G] = {1.f / tot[0], 1.f / tot[1]};
+#pragma unroll
+    for (int t = 0; t < VT; ++t) {
+        const int v = wid + 16 * t;
+        if (v < V && qok && kg == 0) {
+            const int64_t off = (((int64_t)b * V + v) * Q + l31) * A * G;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) if (a < A) {
+                out[off + a * G] = rowok[t] ? acc[t][a][0] : ninf; out[off + a * G + 1] = rowok[t] ? acc[t][a][1] : ninf;
+                sm_p[off + a * G] = e[t][a][0] * inv[0]; sm_p[off + a * G + 1] = e[t][a][1] * inv[1];
+            }
         }
     }
 }
@@ -733,9 +795,10 @@ int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Pl
 }
 
 // Modes 1 + 2 + 3 for few answer tokens, out (B,V,Q,A,G) fp32.  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2, V <= 64, Q <= 16, A <= 6:
-// the caller takes the M build + GEMM pair.
+// the caller takes the M build + GEMM pair.  sm_p != NULL (with sm_mask = the zero-row mask of v): TriAttention's masked softmax in the same
+// kernel -- `out` gets -inf on masked rows, sm_p the attention map.
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st) {
+                      hipStream_t st, const uint8_t* sm_mask, float* sm_p) {
 #ifdef CTI_NO_MBUILD_CORE_SMALL
     return CTI_E_UNSUPPORTED;
 #endif
@@ -748,7 +811,7 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
         auto kern = mbuild_core_small_kernel<AT, VTv>;                                                                                      \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
         if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                       \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R);                                            \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R, sm_mask, sm_p);                             \
     }
     if (A <= 3) { if (VT <= 3) CTI_MC_LAUNCH(3, 3) else CTI_MC_LAUNCH(3, 4) }
     else        { if (VT <= 3) CTI_MC_LAUNCH(6, 3) else CTI_MC_LAUNCH(6, 4) }

@@ -12,7 +12,7 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
                 int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st);
+                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
@@ -260,7 +260,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part);
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused = nullptr);
 
 extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
@@ -291,7 +291,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part) {
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -411,7 +411,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         rc = side(2, st); if (rc) return finish(rc);
         if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
-        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st);
+        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused);   // p_fused: + the masked softmax
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         return finish(rc);
     }
@@ -498,4 +498,48 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     rc = gemm_nt_planes(c, st);
     if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
     return finish(rc);
+}
+
+
+// ---- TriAttention.forward (reference src/attention.py:49-59) as ONE call: logits = TCNet.forward, -inf on the all-zero rows of v, softmax over
+// the flattened (v, q, a) axis per glimpse.  Few answer tokens (the FFOE / MC models): the fused modes-1+2+3 kernel holds a sample's logits in
+// registers and writes `logits` and `p` itself -- no softmax launches at all.  f16f6 mode with glimpse 2: the mode-3 product leaves the softmax's
+// partial pass, one normalise pass follows.  Otherwise: the two-pass masked softmax.
+static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t cti_triattention_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec) {
+    const size_t t = cti_tcnet_forward_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
+    if (t == 0) return 0;
+    return a256(t) + a256(cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, prec)) + a256(cti_softmax_tri_workspace_bytes(B, V, (int64_t)Q * A, G));
+}
+
+extern "C" int cti_triattention_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                                        const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                                        const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                                        uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                        int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                        void* ev_core_end, void* aux_stream, void* stream) {
+    CTI_REQUIRE_PTR(p_out); CTI_REQUIRE_PTR(zero_mask); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(G >= 2, CTI_E_UNSUPPORTED, "cti_triattention_forward: glimpse must be >= 2 (the reference's mask expand fails for 1, src/attention.py:55)");
+    const size_t need = cti_triattention_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
+    CTI_REQUIRE(need != 0, CTI_E_SHAPE, "cti_triattention_forward: B=%d V=%d Q=%d A=%d h=%d R=%d G=%d", B, V, Q, A, h, R, G);
+    CTI_REQUIRE(workspace_bytes >= need, CTI_E_WORKSPACE, "cti_triattention_forward: workspace %zu < %zu", workspace_bytes, need);
+    const size_t wt = cti_tcnet_forward_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
+    const size_t pb = cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, prec);
+    const size_t sb = cti_softmax_tri_workspace_bytes(B, V, (int64_t)Q * A, G);
+    char* w = static_cast<char*>(workspace);
+    float* part = reinterpret_cast<float*>(w + a256(wt));
+    void* sws = w + a256(wt) + a256(pb);
+    Dims d{B, V, Q, A, v_dim, q_dim, a_dim, h, R, G};
+    int rc = check_dims(d); if (rc) return rc;
+    const bool planes_mode = prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || (prec == CTI_PREC_F16F6 && h % 32 == 0);
+    if (planes_mode && small_a(d))                             // logits + p out of the fused kernel's registers
+        return tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
+                                  G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, nullptr, p_out);
+    const bool partials = pb != 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && ((int64_t)V * Q * A) % 2 == 0;
+    rc = tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
+                            G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, partials ? part : nullptr);
+    if (rc) return rc;
+    if (partials) return cti_masked_softmax_tri_from_partials_fwd(logits, zero_mask, part, pb, p_out, B, V, (int64_t)Q * A, G, sws, sb, stream);
+    return cti_masked_softmax_tri_fwd(logits, zero_mask, p_out, B, V, (int64_t)Q * A, G, sws, sb, stream);
 }

@@ -6,12 +6,17 @@ import torch
 from . import _lib as L
 
 _PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16, "f16f6": L.PREC_F16F6}
-_default_prec = "bf16x3"     # fp32-grade (1e-5 vs float64 truth at the BASELINE shapes) at 3/16 of the exact-fp32 MFMA cost
+# Default: 'f16f6' = the mode bench.py's headline line runs.  Outside the fused TCNet.forward / TriAttention.forward with more than 6 answer
+# tokens it IS bf16x3 (fp32-grade, 1e-5 vs float64 truth at the BASELINE shapes, 3/16 of the exact-fp32 MFMA cost); inside, the a side and the
+# mode-3 product run on f16 + block-scaled fp6 planes (3e-5) under the range guard below, which re-runs a call as bf16x3 when an operand leaves
+# the format's domain -- so the default never trades range or NaN semantics for speed.
+_default_prec = "f16f6"
 
 
 def set_precision(name):
-    """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade), 'f16f6' (fused TCNet.forward on f16 + block-scaled fp6 products,
-    fp32-grade; everything else as bf16x3) or 'bf16'."""
+    """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade), 'f16f6' (the default: fused TCNet.forward on f16 + block-scaled fp6
+    products, fp32-grade INSIDE the format's domain -- magnitudes in f16's normal range, 6e-5 ... 65504, finite -- and guarded outside it: the
+    call is re-run as bf16x3, see set_range_check; everything else as bf16x3) or 'bf16'."""
     global _default_prec
     if name not in _PREC:
         raise ValueError("precision must be one of %s" % sorted(_PREC))
@@ -425,12 +430,12 @@ def tcnet_prepare(tucker, rank, T_g, prec=None):
     return block, pr
 
 
-def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False):
+def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False, _tri=False):
     """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
     the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  prepared: the (block, precision) pair of tcnet_prepare for
     these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)] [, partials]: with want_sm_partials (needs want_mask) the third
     value is the Tri softmax's partial pass left by the mode-3 GEMM (masked_softmax_tri_from_partials_), or None where the library has no
-    fused form for this precision / glimpse."""
+    fused form for this precision / glimpse.  _tri (triattention_forward): cti_triattention_forward instead -- returns (p, logits)."""
     for t, n in ((v, "v"), (q, "q"), (a, "a"), (T_g, "T_g")):
         _req(t, n)
     v, q, a = v.contiguous(), q.contiguous(), a.contiguous()
@@ -450,10 +455,14 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     twv, tg, tb, rwv, rg, rb, keep = _weight_arrays(tucker, rank)
     Tg = T_g.contiguous()
     out = torch.empty((B, V, Q, A, G), device=v.device, dtype=torch.float32)
+    if _tri:
+        want_mask, want_sm_partials = True, False
     mask = torch.empty((B, V), device=v.device, dtype=torch.uint8) if want_mask else None
     if want_sm_partials and not want_mask:
         raise ValueError("want_sm_partials needs want_mask")
     if out.numel() == 0:                                   # empty batch (or a zero-length axis): nothing to launch
+        if _tri:
+            return torch.empty_like(out), out
         return ((out, mask, None) if want_sm_partials else (out, mask)) if want_mask else out
     pr = _prec(prec, fused=True)
     if pr == L.PREC_F16F6 and h % 32:
@@ -469,8 +478,8 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     if wait_guard and _range_log["skip"] > 0:
         # this process keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
         _range_log["skip"] -= 1
-        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials)
-    wsb = lib.cti_tcnet_forward_workspace_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr)
+        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri)
+    wsb = (lib.cti_triattention_workspace_bytes if _tri else lib.cti_tcnet_forward_workspace_bytes)(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
     ev0 = ev1 = None
     if _prof is not None:                       # hipEvents around the mode-3 GEMM, recorded by the library on the launch stream
@@ -478,20 +487,26 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         _prof.setdefault("paralind_core", []).append(_LibEventPair(ev0, ev1))
     elif wait_guard:
         ev0, ev1, _ = _guard_resources(v.device)
-    part = None
+    part = p_att = None
     if want_sm_partials:
         pb = lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, pr)
         if pb and out.data_ptr() % 16 == 0 and (V * Q * A) % 2 == 0:
             part = torch.empty(pb, device=v.device, dtype=torch.uint8)
-    with _timed("tcnet_forward"):
-        if part is not None:
+    act = L.ACT_RELU if relu else L.ACT_NONE
+    with _timed("triattention_forward" if _tri else "tcnet_forward"):
+        if _tri:
+            p_att = torch.empty_like(out)
+            L.check(lib.cti_triattention_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+                                                 p_att.data_ptr(), mask.data_ptr(), B, V, Q, A, vd, qd, ad, h, R, G, act, pr, prep_ptr, ws.data_ptr(), wsb,
+                                                 ev0, ev1, _aux_stream(v.device), _stream()), "cti_triattention_forward")
+        elif part is not None:
             L.check(lib.cti_tcnet_forward_sm(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
-                                             _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                             _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, act, pr,
                                              prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream(), part.data_ptr(), pb),
                     "cti_tcnet_forward_sm")
         else:
             L.check(lib.cti_tcnet_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
-                                          _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, L.ACT_RELU if relu else L.ACT_NONE, pr,
+                                          _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, act, pr,
                                           prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
     if guarded:
         _range_log["calls"] += 1
@@ -511,11 +526,19 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
                 import warnings
                 warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the bf16x3 mode; see ops.f16f6_range_status()"
                               % (status.value, ", ".join(n for b, n in ((1, "saturation / non-finite"), (2, "underflow"), (4, "non-finite V^/Q^/T")) if status.value & b)))
-            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials)
+            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri)
         _range_log["consecutive"] = 0
+    if _tri:
+        return p_att, out
     if want_sm_partials:
         return out, mask, part
     return (out, mask) if want_mask else out
+
+
+def triattention_forward(v, q, a, tucker, rank, T_g, relu=True, prec=None, prepared=None):
+    """TriAttention.forward (reference src/attention.py:49-59) in ONE C-ABI call (cti_triattention_forward): returns (p, logits), both
+    (B,V,Q,A,G), logits with -inf on the all-zero rows of v.  Arguments as tcnet_forward."""
+    return tcnet_forward(v, q, a, tucker, rank, T_g, relu, True, prec, prepared, False, True)
 
 
 def masked_softmax_tri_from_partials_(logits, mask, partials):

@@ -188,6 +188,20 @@ int cti_tcnet_prepare(const float* const* tucker_wv, const float* const* tucker_
                       void* stream);
 size_t cti_tcnet_prepared_bytes(int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
 
+/* TriAttention.forward (reference src/attention.py:49-59) as ONE call: logits = TCNet.forward(v, q, a); rows v with every element == 0 get
+ * -inf (zero_mask, required, receives the mask); p[b,:,:,:,g] = softmax over the flattened (v, q, a) axis.  Arguments as cti_tcnet_forward plus
+ * p_out (B,V,Q,A,G).  Few answer tokens (A <= 6 with h/R = 16, glimpse 2: the FFOE / MC models): the fused modes-1+2+3 kernel holds a sample's
+ * logits in registers and writes `logits` and `p_out` itself -- no softmax launch at all; CTI_PREC_F16F6 with glimpse 2: the mode-3 product
+ * leaves the softmax's partial pass and ONE normalise pass follows; otherwise the two-pass masked softmax runs behind the product.
+ * workspace: cti_triattention_workspace_bytes(...) (its head is cti_tcnet_forward's workspace, range-guard block included). */
+size_t cti_triattention_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
+int cti_triattention_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                             const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                             const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                             uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                             int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                             void* ev_core_end, void* aux_stream, void* stream);
+
 /* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
 
 /* Tri: logits (B, V, QA, G) contiguous, G innermost.  In place: rows v with mask[b,v] != 0 are filled with -inf
