@@ -540,7 +540,7 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
 // channel -- 13.6 flop per HBM byte, near the fp32 VALU ridge -- so the instruction count decides.  A thread owns TWO channels and
 // first forms P[q,a] = qt[q,d] * at[a,d] (Q*A float2 registers); every v is then ONE dot product of the compacted attention row
 // w[v, 0:QA] (LDS, broadcast ds_read_b128) with P: QA packed FMAs per v and channel pair, no padding of A, no per-q re-association.
-template <int QA, int NG>
+template <int QA, int NG, int AC>
 __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                                   const float* __restrict__ at, const float* __restrict__ w,
                                                                   int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
@@ -552,39 +552,35 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
     const bool live = d < D;
     const int dd = live ? d : 0;
     constexpr int NT = 128 * NG;
+    // Round 3: the kernel ran as a CHAIN of exposed global-load latencies -- the attention slice, then the q / a rows, then four groups of
+    // nine v rows, each waited for before the next was issued, with two waves per SIMD to hide them (the whole grid is one round of 1 024
+    // two-wave workgroups).  Now every independent load is in flight before the first wait: the first v group and the q / a rows are
+    // issued ahead of the attention slice's compaction, and v group c + 1 is loaded under group c's arithmetic.
+    const float* vb = vt + (int64_t)b * V * D + dd;
+    const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
+    float2 vr[VC], vn[VC];
+#pragma unroll
+    for (int u = 0; u < VC; ++u) vr[u] = v_lo + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v_lo + u) * D) : make_float2(0.f, 0.f);
+    constexpr int QC = QA / AC;                                      // Q and A are compile-time here (A == AC, Q == QC: the launcher checks)
+    float2 ar[AC], qr[QC];
+#pragma unroll
+    for (int a = 0; a < AC; ++a) ar[a] = *reinterpret_cast<const float2*>(at + ((int64_t)b * AC + a) * D + dd);
+#pragma unroll
+    for (int q = 0; q < QC; ++q) qr[q] = *reinterpret_cast<const float2*>(qt + ((int64_t)b * QC + q) * D + dd);
     const float* wb = w + (int64_t)b * w_sb;
     for (int i = tt; i < V * QAP; i += NT) {
-        const int qa = i % QAP, v = i / QAP, q = qa / A, a = qa - q * A;
+        const int qa = i % QAP, v = i / QAP, q = qa / AC, a = qa - q * AC;      // (compile-time divisors)
         sm[i] = qa < QA ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
     }
     float2 P[QAP];
-    {
-        float2 ar[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) ar[a] = a < A ? *reinterpret_cast<const float2*>(at + ((int64_t)b * A + a) * D + dd) : make_float2(0.f, 0.f);
-        int q = 0, a = 0;
-#pragma unroll
-        for (int i = 0; i < QAP; ++i) {
-            if (i < QA) {
-                const float2 qv = *reinterpret_cast<const float2*>(qt + ((int64_t)b * Q + q) * D + dd);
-                float2 av = ar[0];
-#pragma unroll
-                for (int u = 1; u < 8; ++u) if (u == a) av = ar[u];
-                P[i] = make_float2(qv.x * av.x, qv.y * av.y);
-                if (++a == A) { a = 0; ++q; }
-            } else {
-                P[i] = make_float2(0.f, 0.f);
-            }
-        }
-    }
+    for (int i = 0; i < QAP; ++i)
+        P[i] = i < QA ? make_float2(qr[i / AC].x * ar[i % AC].x, qr[i / AC].y * ar[i % AC].y) : make_float2(0.f, 0.f);
     __syncthreads();
-    const float* vb = vt + (int64_t)b * V * D + dd;
     float2 acc = make_float2(0.f, 0.f);
-    const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
     for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
-        float2 vr[VC];
 #pragma unroll
-        for (int u = 0; u < VC; ++u) vr[u] = v0 + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + u) * D) : make_float2(0.f, 0.f);
+        for (int u = 0; u < VC; ++u) vn[u] = v0 + VC + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + VC + u) * D) : make_float2(0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -603,6 +599,8 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
                 acc.y = fmaf(s0.y + s1.y, vr[u].y, acc.y);
             }
         }
+#pragma unroll
+        for (int u = 0; u < VC; ++u) vr[u] = vn[u];
     }
     if (NG > 1) {
         __syncthreads();
@@ -765,9 +763,12 @@ typedef float lf32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ h,
                                                             const float* __restrict__ h_scale, const float* __restrict__ h_bias,
-                                                            float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic) {
+                                                            float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][2][64][40];      // [buffer][hi | lo][row v][32 k + 8 pad]
     const int b = blockIdx.x, ks = blockIdx.y;
+    // blockIdx.z: which group of NTW column tiles this workgroup owns.  The kernel is latency-bound per 32-deep slice (one slice of loads in flight
+    // per workgroup), so more, thinner workgroups per CU -- each re-reading the small vt slice from L2 -- hide it: round 3, 98 -> measured below.
+    const int ct0 = blockIdx.z * NTW;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int N = G * Q;
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
     const float* hp[2]; const float* qp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int c = (wid + 4 * j) * 16 + l15;
-        cok[j] = (wid + 4 * j) < NT && c < N;
+        const int c = (ct0 + wid + 4 * j) * 16 + l15;
+        cok[j] = (wid + 4 * j) < NTW && (ct0 + wid + 4 * j) < NT && c < N;
         cg[j] = cok[j] ? c / Q : 0; cq[j] = cok[j] ? c - cg[j] * Q : 0;
         hp[j] = h + (int64_t)cg[j] * D + kq * 8;
         qp[j] = qt + ((int64_t)b * Q + cq[j]) * D + kq * 8;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         lbf16x8 bh[2], bl[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            if (wid + 4 * j < NT)                                    // uniform
+            if (wid + 4 * j < NTW && ct0 + wid + 4 * j < NT)        // uniform
                 split8(make_float4(rh0[j].x * rq0[j].x, rh0[j].y * rq0[j].y, rh0[j].z * rq0[j].z, rh0[j].w * rq0[j].w),
                        make_float4(rh1[j].x * rq1[j].x, rh1[j].y * rq1[j].y, rh1[j].z * rq1[j].z, rh1[j].w * rq1[j].w), bh[j], bl[j]);
         float4 n0 = z4, n1 = z4;
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
                 const lbf16x8 al = *reinterpret_cast<const lbf16x8*>(&As[buf][1][m * 16 + l15][kq * 8]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (wid + 4 * j < NT) {
+                    if (wid + 4 * j < NTW && ct0 + wid + 4 * j < NT) {
                         acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j][m], 0, 0, 0);
                         acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j][m], 0, 0, 0);
                         acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j][m], 0, 0, 0);
@@ -1297,11 +1298,11 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
         const dim3 grid((D / 2 + 127) / 128, B);
         size_t lds_t = sizeof(float) * (size_t)V * ((QA + 3) & ~3);
         if (lds_t < sizeof(float2) * 128 * (NGT - 1)) lds_t = sizeof(float2) * 128 * (NGT - 1);
-#define CTI_TT(QAv) hipLaunchKernelGGL((tri_pool_table_kernel<QAv, NGT>), grid, dim3(128 * NGT), lds_t, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
-        if (lds_t <= 64 * 1024) {
+#define CTI_TT(QAv, Av) hipLaunchKernelGGL((tri_pool_table_kernel<QAv, NGT, Av>), grid, dim3(128 * NGT), lds_t, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
+        if (lds_t <= 64 * 1024 && A == 3) {
             // measured at B = 256, D = 1024 (rocprofv3): QA = 42: 27.1 us (stream form 31.6); QA = 72: 53 us (stream form 46.5, kept there)
-            if (QA == 42) { CTI_TT(42); return launch_status("cti_tri_pool_fwd"); }
-            if (QA == 36) { CTI_TT(36); return launch_status("cti_tri_pool_fwd"); }
+            if (QA == 42) { CTI_TT(42, 3); return launch_status("cti_tri_pool_fwd"); }
+            if (QA == 36) { CTI_TT(36, 3); return launch_status("cti_tri_pool_fwd"); }
         }
 #undef CTI_TT
     }
@@ -1388,8 +1389,15 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
         const int KS = D >= 1024 ? 2 : 1;
         const int dper = ((D / 32 + KS - 1) / KS) * 32;
         if (KS > 1) { int rcz = zero_fill(logits, (int64_t)B * G * V * Q, as_stream(stream)); if (rcz) return rcz; }
-        hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
-                           (G * Q + 15) / 16, dper, KS > 1 ? 1 : 0);
+        // column tiles per workgroup: four (one per wave) once that still gives every CU several workgroups' worth of loads in flight
+        const int NT = (G * Q + 15) / 16;
+#ifndef CTI_BL_NTW
+#define CTI_BL_NTW 4
+#endif
+        static const int ntw_max = [] { const char* e = getenv("CTI_BL_NTW"); const int v = e ? atoi(e) : CTI_BL_NTW; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // (A/B knob; 8 = the round-2 form)
+        const int NTW = NT > ntw_max ? ntw_max : NT, NZ = (NT + NTW - 1) / NTW;
+        hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
+                           NT, dper, KS > 1 ? 1 : 0, NTW);
         return launch_status("cti_bi_logits_mfma_fwd");
     }
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;
