@@ -88,6 +88,8 @@ SIGNATURES = {
     "cti_swish_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "cti_seq_sum": (_int, [_vp, _vp, _int, _int, _int, C.c_float, _vp]),
     "cti_seq_bcast_add": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "cti_linear_residual_workspace_bytes": (_sz, [_int] * 4),
+    "cti_linear_residual_pb": (_int, [_vp, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp, C.c_float, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_bce_logits_rows_fwd": (_int, [_vp, _vp, _vp, _int, _int, _vp]),
     "cti_bce_logits_bwd": (_int, [_vp, _vp, _vp, C.c_float, _vp, _i64, C.c_float, _vp]),
     "cti_kd_rows_fwd": (_int, [_vp, _vp, _vp, _int, _int, C.c_float, _vp]),

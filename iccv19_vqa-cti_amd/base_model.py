@@ -20,17 +20,35 @@ from . import ops
 from .attention import BiAttention, TriAttention
 from .bc import BCNet
 from .classifier import SimpleClassifier
-from .fc import FCNet, HoistedProjection
+from .fc import FCNet, HoistedProjection, WNLinear
 from .language_model import QuestionEmbedding, WordEmbedding
 from .tc import TCNet, _needs_grad
 
 
-def _residual(prj, b_emb, seq):
-    """prj(b_emb.unsqueeze(1)) + seq  (src/FFOE/base_model.py:61,131-132): (B,H) through the FCNet, broadcast over the sequence."""
+def _residual(prj, b_emb, seq, acc=None, beta=0.0):
+    """prj(b_emb.unsqueeze(1)) + seq  (src/FFOE/base_model.py:61,131-132): (B,H) through the FCNet, broadcast over the sequence.
+    acc (inference only, a (B,H) buffer): also acc = beta * acc + new_seq.sum(1) -- the sequence sums the classifier input is built from
+    (:66,134) ride in the same pass.  Inference with a single weight-normalised Linear (the reference's q_prj / a_prj): split + GEMM + ONE
+    fused reduce / broadcast-add / sum kernel (cti_linear_residual_pb)."""
+    lin = _single_linear(prj)
+    if lin is not None and not prj.training and not _needs_grad(b_emb, seq, *prj.parameters()):
+        out = ops.linear_residual(b_emb, lin.planes(), lin.scale(), lin.out_features, lin.bias, seq, acc=acc, beta=beta)
+        if out is not None:
+            return out
     y = prj(b_emb)                                                           # (B, H)
     if _needs_grad(y, seq):
+        assert acc is None
         return AG.SeqBcastAddFn.apply(seq, y)
-    return ops.seq_bcast_add(seq, y)
+    out = ops.seq_bcast_add(seq, y)
+    if acc is not None:
+        ops.seq_sum(out, out=acc, beta=beta)
+    return out
+
+
+def _single_linear(prj):
+    """The WNLinear of an FCNet([in, out], '', p) -- one weight-normalised Linear, no activation -- or None."""
+    mods = [m for m in prj.main if not isinstance(m, nn.Dropout)]
+    return mods[0] if len(mods) == 1 and isinstance(mods[0], WNLinear) else None
 
 
 def _joint(q_emb, ans_emb):
@@ -71,9 +89,15 @@ class BanModel(nn.Module):
         att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
         vp = self._v_hoist.maybe(v)
         total = None
+        fused_sum = not torch.is_grad_enabled()
+        if fused_sum:                                                        # inference: the per-glimpse sums accumulate inside the residual pass
+            total = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32)
         for g in range(self.glimpse):
             w_g = att[:, g, :, :]
             b_emb = self.b_net[g].forward_with_weights(v, q_emb, w_g) if vp is None else self.b_net[g]._pool_projected(vp[g], q_emb, w_g)
+            if fused_sum:
+                q_emb = _residual(self.q_prj[g], b_emb, q_emb, acc=total, beta=1.0 if g > 0 else 0.0)
+                continue
             q_emb = _residual(self.q_prj[g], b_emb, q_emb)
             # torch.stack(q_emb_list, 1).sum(1) then .sum(1): accumulate the per-glimpse sequence sums
             if _needs_grad(q_emb):
@@ -116,13 +140,16 @@ class _TriModel(nn.Module):
                 vp = [x.repeat_interleave(rep, 0) for x in vp]              # one (B,V,N) copy per glimpse: far cheaper than the projection
         else:
             vp = self._v_hoist.maybe(v)
+        fused_sum = not torch.is_grad_enabled()
+        joint = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32) if fused_sum and self.glimpse > 0 else None
         for g in range(self.glimpse):
             w_g = att[:, :, :, :, g]
             b_emb = (self.t_net[g].forward_with_weights(v, q_emb, ans_emb, w_g) if vp is None
                      else self.t_net[g]._pool_projected(vp[g], q_emb, ans_emb, w_g))
-            q_emb = _residual(self.q_prj[g], b_emb, q_emb)
-            ans_emb = _residual(self.a_prj[g], b_emb, ans_emb)
-        return self.classifier(_joint(q_emb, ans_emb)), att
+            last = joint is not None and g == self.glimpse - 1                # q_emb.sum(1) + ans_emb.sum(1) of :134 rides in the last residual passes
+            q_emb = _residual(self.q_prj[g], b_emb, q_emb, acc=joint if last else None, beta=0.0)
+            ans_emb = _residual(self.a_prj[g], b_emb, ans_emb, acc=joint if last else None, beta=1.0)
+        return self.classifier(joint if joint is not None else _joint(q_emb, ans_emb)), att
 
 
 class CTIModel(_TriModel):

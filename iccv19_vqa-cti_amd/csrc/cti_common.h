@@ -115,6 +115,7 @@ struct PlaneGemmArgs {
     // that write fp32 partials [ksplit][M][N] into `partial`; a reduce kernel sums them and applies scale / bias / act.
     // Only for nb1 == nb2 == 1 and epi 0; pick ksplit with plan_ksplit().
     int ksplit; float* partial;
+    int partials_only;                         // ksplit > 1: leave the fp32 partials [ksplit][M][N] to the caller (no reduce kernel, C / scale / bias unused)
     int64_t kc2;                               // set by the split-K path itself: batch b2 starts kc2 * b2 K-chunks into both operands
 };
 int plan_ksplit(int M, int N, int Kp, long long nb);       // 1 = do not split

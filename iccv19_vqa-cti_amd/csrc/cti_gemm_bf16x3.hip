@@ -721,6 +721,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
         b.scale = nullptr; b.bias = nullptr; b.relu = 0;
         b.kc2 = a.Kp / a.ksplit / 16;
         int rc = gemm_nt_planes(b, st); if (rc) return rc;
+        if (a.partials_only) return CTI_OK;                   // the caller's own kernel reduces them (cti_linear_residual_pb)
         const int64_t items = (int64_t)a.M * ((a.N + 3) / 4);
         hipLaunchKernelGGL(ksplit_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a.partial, a.ksplit, a.M, a.N, a.C,
                            a.ldc_m, a.scale, a.scale_div > 0 ? a.scale_div : 1, a.bias, a.relu);

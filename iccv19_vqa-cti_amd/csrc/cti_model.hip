@@ -96,6 +96,44 @@ __global__ void seq_bcast_add_kernel(const float* __restrict__ x, const float* _
     out[idx] = (x ? x[idx] : 0.f) + y[b * H + h];
 }
 
+// The residual projection of the model forwards in one pass behind the GEMM (reference src/FFOE/base_model.py:61,131-132,134):
+//   y[b, n]      = scale[n / div] * sum_s part[s][b][n] + bias[n]           (split-K partials of x @ W^T; S = 1: the plain product)
+//   out[b, l, n] = seq[b, l, n] + y[b, n]                                  (q_prj(b_emb.unsqueeze(1)) + q_emb)
+//   acc[b, n]    = beta * acc[b, n] + sum_l out[b, l, n]                   (optional: the q_emb.sum(1) the classifier input is built from)
+// One float4 of a (b, n) column per thread: the S partials and the L sequence rows are coalesced across the workgroup.  Replaces the
+// split-K reduce kernel + the broadcast-add kernel + the sequence-sum kernel of a glimpse (three launches, two extra passes over seq).
+__global__ __launch_bounds__(256) void linear_residual_kernel(const float* __restrict__ part, int S, const float* __restrict__ scale, int scale_div,
+                                                               const float* __restrict__ bias, const float* __restrict__ seq, float* __restrict__ out,
+                                                               float* __restrict__ acc, float beta, int B, int L, int N) {
+    const int n4 = N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * n4) return;
+    const int b = (int)(idx / n4), n0 = (int)(idx % n4) * 4;
+    const int64_t BN = (int64_t)B * N;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float4 x = *reinterpret_cast<const float4*>(part + s * BN + (int64_t)b * N + n0);
+        y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+    }
+    const float4 bi = bias ? *reinterpret_cast<const float4*>(bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    y.x = y.x * (scale ? scale[n0 / scale_div] : 1.f) + bi.x;             y.y = y.y * (scale ? scale[(n0 + 1) / scale_div] : 1.f) + bi.y;
+    y.z = y.z * (scale ? scale[(n0 + 2) / scale_div] : 1.f) + bi.z;       y.w = y.w * (scale ? scale[(n0 + 3) / scale_div] : 1.f) + bi.w;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* sp = seq + ((int64_t)b * L) * N + n0;
+    float* op = out + ((int64_t)b * L) * N + n0;
+    for (int l = 0; l < L; ++l) {
+        float4 v = *reinterpret_cast<const float4*>(sp + (int64_t)l * N);
+        v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
+        *reinterpret_cast<float4*>(op + (int64_t)l * N) = v;
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    if (acc) {
+        float4* ap = reinterpret_cast<float4*>(acc + (int64_t)b * N + n0);
+        if (beta != 0.f) { const float4 o = *ap; sum.x += beta * o.x; sum.y += beta * o.y; sum.z += beta * o.z; sum.w += beta * o.w; }
+        *ap = sum;
+    }
+}
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -227,6 +265,44 @@ int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, voi
     hipLaunchKernelGGL(seq_sum_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), x, out, B, L, H, beta);
     return launch_status("cti_seq_sum");
 }
+size_t cti_linear_residual_workspace_bytes(int B, int N, int K, int prec) {
+    if (B <= 0 || N <= 0 || K <= 0 || (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16)) return 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int S = plan_ksplit(B, N, planes_kp(K), 1);
+    return al(planes_bytes((int64_t)B + PLANE_SLACK_ROWS, K)) + al(sizeof(float) * (size_t)(S > 1 ? S : 1) * (size_t)B * (size_t)N);
+}
+int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, const float* scale, int scale_div, const float* bias, const float* seq,
+                           float* out, float* acc, float beta, int B, int L, int N, int K, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(W_planes); CTI_REQUIRE_PTR(seq); CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(B > 0 && L > 0 && N > 0 && K > 0 && ldx >= K, CTI_E_SHAPE, "cti_linear_residual_pb: B=%d L=%d N=%d K=%d ldx=%lld", B, L, N, K, (long long)ldx);
+    CTI_REQUIRE(N % 4 == 0 && ((reinterpret_cast<uintptr_t>(seq) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(acc) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                CTI_E_ALIGN, "cti_linear_residual_pb: N %% 4 == 0 and 16-B aligned seq / out / acc / bias are required (N=%d)", N);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_linear_residual_pb: prec=%d (resident planes exist in the bf16 modes only)", prec);
+    CTI_REQUIRE(scale == nullptr || scale_div > 0, CTI_E_SHAPE, "cti_linear_residual_pb: scale_div=%d", scale_div);
+    const size_t need = cti_linear_residual_workspace_bytes(B, N, K, prec);
+    CTI_REQUIRE(workspace_bytes >= need, CTI_E_WORKSPACE, "cti_linear_residual_pb: workspace %zu < %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    const int Kp = planes_kp(K);
+    const int64_t ra = (int64_t)B + PLANE_SLACK_ROWS, rb = (int64_t)N + PLANE_SLACK_ROWS;
+    unsigned short* ah = static_cast<unsigned short*>(workspace);
+    unsigned short* al_ = ah + (size_t)ra * Kp;
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255));
+    const unsigned short* bh = static_cast<const unsigned short*>(W_planes);
+    const unsigned short* bl = bh + (size_t)rb * Kp;
+    int rc = split_planes(x, ldx, B, K, ah, al_, ra, st); if (rc) return rc;
+    PlaneGemmArgs g{};
+    g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
+    g.M = B; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
+    const int S = plan_ksplit(B, N, Kp, 1);
+    if (S > 1) { g.ksplit = S; g.partial = part; g.partials_only = 1; }
+    else       { g.C = part; g.ldc_m = N; g.ldc_n = 1; }
+    rc = gemm_nt_planes(g, st); if (rc) return rc;
+    const int64_t items = (int64_t)B * (N / 4);
+    hipLaunchKernelGGL(linear_residual_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, part, S > 1 ? S : 1, scale, scale ? scale_div : 1, bias, seq, out,
+                       acc, beta, B, L, N);
+    return launch_status("cti_linear_residual_pb");
+}
+
 int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream) {
     CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B >= 0 && L >= 0 && H > 0, CTI_E_SHAPE, "cti_seq_bcast_add: B=%d L=%d H=%d", B, L, H);

@@ -4,6 +4,7 @@ CPU or eager-PyTorch path in this package."""
 import torch
 
 from . import _lib as L
+from . import _lib as L_      # (functions that use L as a local size keep the module reachable)
 
 _PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16, "f16f6": L.PREC_F16F6}
 # Default: 'f16f6' = the mode bench.py's headline line runs.  Outside the fused TCNet.forward / TriAttention.forward with more than 6 answer
@@ -1245,6 +1246,27 @@ def seq_bcast_add(x, y, Lq=None):
         x = x.contiguous()
     out = torch.empty((B, Lq, H), device=y.device, dtype=torch.float32)
     L.check(L.lib().cti_seq_bcast_add(_ptr(x), y.contiguous().data_ptr(), out.data_ptr(), B, Lq, H, _stream()), "cti_seq_bcast_add")
+    return out
+
+
+def linear_residual(x, w_planes, scale, scale_div, bias, seq, acc=None, beta=0.0, prec=None):
+    """out[b,l,:] = seq[b,l,:] + (scale * (x @ W^T) + bias)[b,:]; acc[b,:] = beta * acc[b,:] + sum_l out[b,l,:] when acc is given.  x (B,K),
+    W as split_operand(weight_v) planes of an (N,K) weight, seq (B,L,N).  Returns out, or None when the fused form does not apply (exact-fp32
+    mode, N % 4 != 0): the caller then takes wn_linear + seq_bcast_add (+ seq_sum)."""
+    _req(x, "x"); _req(seq, "seq")
+    pr = _prec(prec)
+    B, L, N = seq.shape
+    K = x.shape[-1]
+    if pr == L_.PREC_F32 or w_planes is None or N % 4 or x.shape[0] != B or B == 0 or L == 0:
+        return None
+    x2, ldx = _rows2d(x)
+    seq = seq.contiguous()
+    out = torch.empty_like(seq)
+    lib = L_.lib()
+    wsb = lib.cti_linear_residual_workspace_bytes(B, N, K, pr)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    L_.check(lib.cti_linear_residual_pb(x2.data_ptr(), ldx, w_planes.data_ptr(), _ptr(scale), int(scale_div), _ptr(bias), seq.data_ptr(), out.data_ptr(),
+                                        _ptr(acc), float(beta), B, L, N, K, pr, ws.data_ptr(), wsb, _stream()), "cti_linear_residual_pb")
     return out
 
 

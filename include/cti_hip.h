@@ -481,6 +481,14 @@ int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* s
 int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, void* stream);
 /* out[b,l,h] = x[b,l,h] + y[b,h]  (x NULL = 0)         (q_prj(b_emb.unsqueeze(1)) + q_emb, src/FFOE/base_model.py:61,131-132) */
 int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream);
+/* The residual projection of a glimpse as ONE call (src/FFOE/base_model.py:61,131-132 `q_prj(b_emb.unsqueeze(1)) + q_emb`, and the sequence sums
+ * of :66,134): y = scale * (x @ W^T) + bias with x (B, K) fp32 and W given as resident planes (cti_split_operand of the (N x K) weight_v);
+ * out[b,l,:] = seq[b,l,:] + y[b,:]; acc (nullable) [b,:] = beta * acc[b,:] + sum_l out[b,l,:].  Three launches (split of x, split-K GEMM,
+ * one fused reduce + broadcast-add + sum pass) instead of five.  N % 4 == 0; bf16 modes only (the planes); workspace:
+ * cti_linear_residual_workspace_bytes(B, N, K, prec). */
+size_t cti_linear_residual_workspace_bytes(int B, int N, int K, int prec);
+int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, const float* scale, int scale_div, const float* bias, const float* seq,
+                           float* out, float* acc, float beta, int B, int L, int N, int K, int prec, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nn.BCEWithLogitsLoss(reduction='sum') per row (src/FFOE/train.py:28-33, divided by the batch size at src/FFOE/trainer.py:189-190):
  * row_loss[r] = sum_c max(x,0) - x*t + log(1 + exp(-|x|)); reduce the rows with cti_sum_batches.
