@@ -112,9 +112,9 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-#ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fp6 conversion, 8 no epilogue stores, 64 no lane swaps
-#define CTI_F6_ABL 0
-#endif
+#ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fp6 conversion, 8 no epilogue stores, 64 no lane swaps,
+#define CTI_F6_ABL 0        // 256 the A operand's LDS fragment reads only in a tile's first K block, 512 no conversion of the A fragments, 1024 no DMA of the A
+#endif                      // operand's pieces  (256 | 512 | 1024 = "the A operand is free": the ceiling of any scheme that takes it out of the LDS path)
 
 typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
@@ -317,12 +317,14 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
     // 64-bit source pointer (H pieces: rows (lane >> 2) of the piece, 16-B chunk (lane & 3) ^ ((row >> 2) & 3); the others 16 B per lane) that
     // walks the K blocks of the tile being issued: one VALU add per piece and block, no scalar address arithmetic in the loop.
     const char* vp[CNT]; int64_t kstride[CNT]; int ldsoff[CNT];
+    bool piece_is_a[CNT];                                           // (ablation 1024 only)
     const bool shared_piece_wave = (G::NREAL - 2) % NW == wid;
     constexpr int U_SHARED = (G::NREAL - 2) / NW;                   // which of that wave's pieces is the shared one
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
         int g = wid + u * NW;
         if (g >= G::NREAL) g -= G::NREAL;                          // padding pieces repeat the slot's first ones
+        piece_is_a[u] = g < G::PAH || (g >= G::PAH + G::PBH && g < G::PAH + G::PBH + G::PAF);
         if (g < G::PAH)                   { kstride[u] = p.pA * 64; ldsoff[u] = G::OFF_AH + g * 1024; }
         else if ((g -= G::PAH) < G::PBH)  { kstride[u] = p.pB * 64; ldsoff[u] = G::OFF_BH + g * 1024; }
         else if ((g -= G::PBH) < G::PAF)  { kstride[u] = p.pA * 24; ldsoff[u] = G::OFF_AFL + g * 1024; }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
         char* slot = smem + pos * SLOT;
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-            dma16(vp[u], slot + ldsoff[u]);
+            if (!((CTI_F6_ABL & 1024) && piece_is_a[u])) dma16(vp[u], slot + ldsoff[u]);
             vp[u] += u == U_SHARED ? vks_shared : kstride[u];
         }
         ++issued;
@@ -470,17 +472,30 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
 #else
 #define CTI_F6_SWAP(x, y) __builtin_amdgcn_permlane32_swap((unsigned)(x), (unsigned)(y), false, false)
 #endif
+#if CTI_F6_ABL & 256
+    f16x8 keep_a16[TM][2]; int keep_fa[TM][3], keep_spa[TM];
+#endif
+#define CTI_F6_A_READ_REAL(i)                                                                                                         \
+            a16[i][0] = *reinterpret_cast<const f16x8*>(s_a0 + i * 2048);                                                             \
+            a16[i][1] = *reinterpret_cast<const f16x8*>(s_a1 + i * 2048);                                                             \
+            { const u32x2 f01 = *reinterpret_cast<const u32x2*>(s_af + i * 768); fa[i][0] = f01.x; fa[i][1] = f01.y; }                  \
+            fa[i][2] = *reinterpret_cast<const int*>(s_af2 + i * 768);                                                                \
+            spa[i] = *reinterpret_cast<const int*>(s_as + i * 64);
+#if CTI_F6_ABL & 256
+#define CTI_F6_ABL_A_READ(i)                                                                                                          \
+            if (kb == 0) { CTI_F6_A_READ_REAL(i)                                                                                      \
+                keep_a16[i][0] = a16[i][0]; keep_a16[i][1] = a16[i][1]; keep_fa[i][0] = fa[i][0]; keep_fa[i][1] = fa[i][1]; keep_fa[i][2] = fa[i][2]; keep_spa[i] = spa[i]; } \
+            else { a16[i][0] = keep_a16[i][0]; a16[i][1] = keep_a16[i][1]; fa[i][0] = keep_fa[i][0]; fa[i][1] = keep_fa[i][1]; fa[i][2] = keep_fa[i][2]; spa[i] = keep_spa[i]; }
+#else
+#define CTI_F6_ABL_A_READ(i) CTI_F6_A_READ_REAL(i)
+#endif
 #define CTI_F6_READ_FRAGS(s)                                                                                                          \
     f16x8 a16[TM][2], b16[TN][2]; i32x8 a6[TM], b6[TN]; int sa[TM], sb[TN]; int fa[TM][3], fb[TN][3], spa[TM], spb[TN];               \
     {                                                                                                                                 \
         const char *s_a0 = (s) + aH0, *s_a1 = (s) + aH1, *s_b0 = (s) + bH0, *s_b1 = (s) + bH1, *s_af = (s) + aF, *s_bf = (s) + bF, *s_as = (s) + aS, *s_bs = (s) + bS; \
         const char *s_af2 = (s) + aF2, *s_bf2 = (s) + bF2;                                                                            \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {         /* every LDS read of the block first: one latency, not five */        \
-            a16[i][0] = *reinterpret_cast<const f16x8*>(s_a0 + i * 2048);                                                             \
-            a16[i][1] = *reinterpret_cast<const f16x8*>(s_a1 + i * 2048);                                                             \
-            { const u32x2 f01 = *reinterpret_cast<const u32x2*>(s_af + i * 768); fa[i][0] = f01.x; fa[i][1] = f01.y; }                  \
-            fa[i][2] = *reinterpret_cast<const int*>(s_af2 + i * 768);                                                                \
-            spa[i] = *reinterpret_cast<const int*>(s_as + i * 64);                                                                    \
+            CTI_F6_ABL_A_READ(i)                                                                                                      \
         }                                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                              \
             b16[j][0] = *reinterpret_cast<const f16x8*>(s_b0 + j * 2048);                                                             \
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
     }                                                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                           /* (the scheduler would otherwise pair each read with its conversion) */ \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                                  \
-        const u32x6 own = f6_codes_of_f16(a16[i][0], a16[i][1], spa[i] >> shS);                                                       \
+        const u32x6 own = (CTI_F6_ABL & 512) ? u32x6{(unsigned)fa[i][0], (unsigned)fa[i][1], (unsigned)fa[i][2], 0u, 0u, 0u} : f6_codes_of_f16(a16[i][0], a16[i][1], spa[i] >> shS); \
         const auto w0 = CTI_F6_SWAP(own[0], fa[i][0]);                                                                                \
         const auto w1 = CTI_F6_SWAP(own[1], fa[i][1]);                                                                                \
         const auto w2 = CTI_F6_SWAP(own[2], fa[i][2]);                                                                                \
@@ -536,6 +551,8 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
         }
     }
 #undef CTI_F6_READ_FRAGS
+#undef CTI_F6_ABL_A_READ
+#undef CTI_F6_A_READ_REAL
 #undef CTI_F6_SWAP
 #undef CTI_F6_MFMAS
 #if CTI_F6_ABL & 128
