@@ -34,7 +34,8 @@ SIGNATURES = {
     "cti_tcnet_forward_sm": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz]),
     "cti_tcnet_softmax_partials_bytes": (_sz, [_int] * 7),
     "cti_triattention_workspace_bytes": (_sz, [_int] * 11),
-    "cti_triattention_forward": (_int, [_vp] * 13 + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "cti_triattention_forward": (_int, [_vp] * 13 + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i64, _int]),
+    "cti_triattention_hoist_ok": (_int, [_int] * 8),
     "cti_tcnet_forward_guard_bytes": (_sz, [_int] * 11),
     "cti_guard_read": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "cti_masked_softmax_tri_from_partials_fwd": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),

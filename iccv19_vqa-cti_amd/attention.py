@@ -42,12 +42,15 @@ class TriAttention(nn.Module):
         self.glimpse = glimpse
         self.TriAtt = TCNet(v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, dropout=dropout, k=k)
 
-    def forward(self, v, q, a):
+    def forward(self, v, q, a, _v_tucked=None, _v_rep=1):
+        """_v_tucked / _v_rep (the model forwards' private arguments): relu(TriAtt.v_tucker(v)) already computed in the batched projection
+        of the glimpses' pooling networks, one block per image when the batch repeats every image _v_rep times."""
         t = self.TriAtt
         if self.glimpse >= 2 and t._fusable(v, q, a):
             # eval: logits, mask and softmax in ONE library call (cti_triattention_forward)
             tucker, rank = t._fused_args()
-            return ops.triattention_forward(v.float(), q.float(), a.float(), tucker, rank, t.T_g.detach(), relu=(t._act == 'ReLU'), prepared=t._prep)
+            return ops.triattention_forward(v.float(), q.float(), a.float(), tucker, rank, t.T_g.detach(), relu=(t._act == 'ReLU'), prepared=t._prep,
+                                            v_tucked=_v_tucked if t._act == 'ReLU' else None, v_rep=_v_rep)
         logits, mask, partials = self.TriAtt(v, q, a, _want_mask=True, _want_sm_partials=True)
         if logits.dim() != 5:
             # glimpse == 1: TCNet.forward squeezed G away and the reference's mask expand (attention.py:55) raises

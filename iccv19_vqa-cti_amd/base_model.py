@@ -126,20 +126,27 @@ class _TriModel(nn.Module):
         else:
             q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
             ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
-        att, logits = t_att(v, q_emb, ans_emb)                              # b x v x q x a x g
         if not hasattr(self, "_v_hoist"):
-            object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net]))
-        # N1: the glimpses' v projections as one batched GEMM.  `v_replication` = r > 1 (set by the caller; the MC pipeline feeds every image
-        # once per candidate answer, src/MC/train.py:75-79, so rows b*r .. b*r+r-1 of v are identical): the projections run once per image
+            # N1: the v projections of the glimpses' pooling networks AND of the attention (512 wide, zero-padded to their 1 024) as one batched GEMM:
+            # `v` is read and split into operand planes once
+            object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net], padded=[t_att.TriAtt.v_tucker]))
+        # `v_replication` = r > 1 (set by the caller; the MC pipeline feeds every image once per candidate answer, src/MC/train.py:75-79, so
+        # rows b*r .. b*r+r-1 of v are identical): the projections -- and the attention's whole v side -- run once per image
         rep = int(getattr(self, "v_replication", 1))
         if rep > 1 and v.shape[0] % rep == 0:
             if _os.environ.get("CTI_CHECK_REPLICATION", "0") == "1":
                 assert torch.equal(v.view(v.shape[0] // rep, rep, *v.shape[1:])[:, :1].expand(-1, rep, -1, -1).reshape(v.shape), v), "v_replication does not hold"
             vp = self._v_hoist.maybe(v[::rep])
-            if vp is not None:
+        else:
+            rep = 1
+            vp = self._v_hoist.maybe(v)
+        if vp is not None:
+            pad = self._v_hoist.last_padded
+            att, logits = t_att(v, q_emb, ans_emb, _v_tucked=pad[0] if pad else None, _v_rep=rep)        # b x v x q x a x g
+            if rep > 1:
                 vp = [x.repeat_interleave(rep, 0) for x in vp]              # one (B,V,N) copy per glimpse: far cheaper than the projection
         else:
-            vp = self._v_hoist.maybe(v)
+            att, logits = t_att(v, q_emb, ans_emb)
         fused_sum = not torch.is_grad_enabled()
         joint = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32) if fused_sum and self.glimpse > 0 else None
         for g in range(self.glimpse):

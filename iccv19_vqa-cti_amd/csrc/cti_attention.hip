@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
                                                             float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][2][64][40];      // [buffer][hi | lo][row v][32 k + 8 pad]
     const int b = blockIdx.x, ks = blockIdx.y;
-    // blockIdx.z: which group of NTW column tiles this workgroup owns.  The kernel is latency-bound per 32-deep slice (one slice of loads in flight
-    // per workgroup), so more, thinner workgroups per CU -- each re-reading the small vt slice from L2 -- hide it: round 3, 98 -> measured below.
+    // blockIdx.z: which group of NTW column tiles this workgroup owns (round-3 experiment: thinner workgroups to put more loads in flight -- measured
+    // SLOWER, see the launcher: the default keeps all tiles in one workgroup).
     const int ct0 = blockIdx.z * NTW;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -1392,8 +1392,8 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
         // column tiles per workgroup: four (one per wave) once that still gives every CU several workgroups' worth of loads in flight
         const int NT = (G * Q + 15) / 16;
 #ifndef CTI_BL_NTW
-#define CTI_BL_NTW 4
-#endif
+#define CTI_BL_NTW 8        // column tiles per workgroup.  8 = all of them (one workgroup per sample and K half).  Measured at B = 256, G = 8, D = 3072
+#endif                      // (profiles/r03_hbm_kernels.jsonl): 8 -> 96 us, 4 -> 135, 2 -> 174, 1 -> 262: every extra workgroup re-splits the vt slice, and that VALU work is the bound
         static const int ntw_max = [] { const char* e = getenv("CTI_BL_NTW"); const int v = e ? atoi(e) : CTI_BL_NTW; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // (A/B knob; 8 = the round-2 form)
         const int NTW = NT > ntw_max ? ntw_max : NT, NZ = (NT + NTW - 1) / NTW;
         hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,

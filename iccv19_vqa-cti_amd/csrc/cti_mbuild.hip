@@ -555,7 +555,7 @@ template <int AT, int VT>
 __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                                  const float* __restrict__ Tt, const float* __restrict__ Ar,
                                                                  float* __restrict__ out, int V, int Q, int A, int R,
-                                                                 const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p) {
+                                                                 const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p, int v_rep) {
     constexpr int HR = 16, G = 2, INNER = HR * HR * G;
     extern __shared__ __attribute__((aligned(16))) float X2[];  // [V][G][HR(k)][MB_XP], then Ar[b]: [A][K]
     const int b = blockIdx.x;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
     float* ArS = X2 + (size_t)V * G * HR * MB_XP;
     for (int i = threadIdx.x; i < A * K; i += 1024) ArS[i] = Ar[(int64_t)b * A * K + i];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* vb = Vr + (int64_t)b * V * K + kg * 8;
+    const float* vb = Vr + (int64_t)(b / v_rep) * V * K + kg * 8;        // v_rep > 1: rows b*v_rep .. +v_rep-1 share one image (V^ holds one block per image)
     const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
     const int v0 = l31, v1 = 32 + l31;
     const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
@@ -798,7 +798,7 @@ int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Pl
 // the caller takes the M build + GEMM pair.  sm_p != NULL (with sm_mask = the zero-row mask of v): TriAttention's masked softmax in the same
 // kernel -- `out` gets -inf on masked rows, sm_p the attention map.
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask, float* sm_p) {
+                      hipStream_t st, const uint8_t* sm_mask, float* sm_p, int v_rep) {
 #ifdef CTI_NO_MBUILD_CORE_SMALL
     return CTI_E_UNSUPPORTED;
 #endif
@@ -811,7 +811,7 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
         auto kern = mbuild_core_small_kernel<AT, VTv>;                                                                                      \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
         if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                       \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R, sm_mask, sm_p);                             \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R, sm_mask, sm_p, v_rep > 0 ? v_rep : 1);      \
     }
     if (A <= 3) { if (VT <= 3) CTI_MC_LAUNCH(3, 3) else CTI_MC_LAUNCH(3, 4) }
     else        { if (VT <= 3) CTI_MC_LAUNCH(6, 3) else CTI_MC_LAUNCH(6, 4) }

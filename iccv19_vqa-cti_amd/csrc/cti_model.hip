@@ -294,8 +294,8 @@ int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, co
     g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
     g.M = B; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
     const int S = plan_ksplit(B, N, Kp, 1);
+    g.C = part; g.ldc_m = N; g.ldc_n = 1;                        // S == 1: the plain product lands where the partials would
     if (S > 1) { g.ksplit = S; g.partial = part; g.partials_only = 1; }
-    else       { g.C = part; g.ldc_m = N; g.ldc_n = 1; }
     rc = gemm_nt_planes(g, st); if (rc) return rc;
     const int64_t items = (int64_t)B * (N / 4);
     hipLaunchKernelGGL(linear_residual_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, part, S > 1 ? S : 1, scale, scale ? scale_div : 1, bias, seq, out,

@@ -12,7 +12,7 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
                 int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr);
+                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
@@ -260,7 +260,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused = nullptr);
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused = nullptr,
+                              const float* v_tucked = nullptr, int64_t ld_vt = 0, int v_rep = 1);
 
 extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
@@ -291,7 +292,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               const float* const* rank_g, const float* const* rank_b, const float* T_g, float* out,
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused) {
+                              void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused,
+                              const float* v_tucked, int64_t ld_vt, int v_rep) {
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -338,6 +340,9 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
 
     const bool f6 = prec == CTI_PREC_F16F6;
     const bool fused_core = small_a(d);                        // A <= 6: mbuild_core_small replaces M build + planes + mode-3 GEMM
+    CTI_REQUIRE(v_tucked == nullptr || (fused_core && v_rep >= 1 && B % v_rep == 0 && ld_vt >= h && h % 4 == 0 && (ld_vt & 3) == 0 &&
+                                        (reinterpret_cast<uintptr_t>(v_tucked) & 15) == 0),
+                CTI_E_UNSUPPORTED, "cti_triattention_forward: a hoisted v projection needs the few-answer path, B %% v_rep == 0 and 16-B aligned rows (A=%d v_rep=%d)", A, v_rep);
     CTI_REQUIRE(!(fused_core && sm_part), CTI_E_UNSUPPORTED, "cti_tcnet_forward_sm: no softmax partials on the few-answer path (A=%d)", A);
     const int terms = prec == CTI_PREC_BF16 ? 1 : 3;
     // Two independent chains feed the mode-3 GEMM: chain A (the a side: split, Tucker, rank nets -- 2.8 ms at config 2, opens with the
@@ -359,7 +364,27 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         return code;
     };
     const int Kh = planes_kp(h);
+    // v_tucked (cti_triattention_forward, few-answer path only): v's Tucker projection was computed by the caller -- hoisted into the batched GEMM of
+    // the glimpses' pooling networks and, with v_rep > 1, once per IMAGE instead of once per row (the MC pipeline repeats every image per candidate
+    // answer) -- as fp32 rows (B / v_rep * V, h) with row stride ld_vt; the rank nets then run on those rows (fp32 A operand split at
+    // fragment-read time) and V^ holds one block per image.
+    const bool hoisted_v = v_tucked != nullptr;
     auto side = [&](int s, hipStream_t ss) -> int {
+        if (s == 0 && hoisted_v) {
+            PlaneGemmArgs r{};
+            r.Bh = p.wr[0].hi; r.Bl = p.wr[0].lo;
+            if (terms == 3) { r.Af = v_tucked; r.ldaf = ld_vt; r.Kreal = h; r.rows_allocA = rows[0] / v_rep + PLANE_SLACK_ROWS; }   // (the fp32-A operand path exists for the 3-term mode)
+            else {
+                int r1 = split_planes(v_tucked, ld_vt, rows[0] / v_rep, h, p.tp[0].hi, p.tp[0].lo, p.tp[0].rows_alloc, ss); if (r1) return r1;
+                r.Ah = p.tp[0].hi; r.Al = p.tp[0].lo; r.rows_allocA = p.tp[0].rows_alloc;
+            }
+            r.rows_allocB = p.wr[0].rows_alloc; r.nb1 = 1; r.nb2 = 1;
+            r.M = (int)(rows[0] / v_rep); r.N = h; r.Kp = planes_kp(h); r.terms = terms;
+            r.scale = p.scale_r[0]; r.scale_div = hr; r.bias = rank_b[0]; r.relu = relu;
+            r.epi = 0; r.C = p.Vr; r.ldc_m = h; r.ldc_n = 1;
+            if (!prepared) { int r0 = split_planes(rank_wv[0], h, h, h, p.wr[0].hi, p.wr[0].lo, p.wr[0].rows_alloc, ss); if (r0) return r0; }
+            return gemm_nt_planes(r, ss);
+        }
         const bool f6_side = s == 2 && f6 && !fused_core;       // a side of the f16f6 mode: encode a -> transposed f16f6 Tucker product -> planes -> transposed f16f6 rank product -> planes
         const bool af32 = !f6_side && af32_side(prec, in[s]);
         if (af32 && (reinterpret_cast<uintptr_t>(x[s]) & 15)) return fail(CTI_E_ALIGN, "cti_tcnet_forward: input %d must be 16-B aligned (its rows are DMA'd as fp32)", s);
@@ -411,7 +436,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         rc = side(2, st); if (rc) return finish(rc);
         if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
-        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused);   // p_fused: + the masked softmax
+        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1);   // p_fused: + the masked softmax
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         return finish(rc);
     }
@@ -507,6 +532,14 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
 // partial pass, one normalise pass follows.  Otherwise: the two-pass masked softmax.
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+/* 1 when cti_triattention_forward accepts v_tucker_out for this shape / mode (the fused few-answer path), else 0 */
+extern "C" int cti_triattention_hoist_ok(int B, int V, int Q, int A, int h, int R, int G, int prec) {
+    if (B <= 0 || V <= 0 || Q <= 0 || A <= 0 || h <= 0 || R <= 0 || G <= 0 || h % R || h % 4) return 0;
+    if (!(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || (prec == CTI_PREC_F16F6 && h % 32 == 0))) return 0;
+    Dims d{B, V, Q, A, 1, 1, 1, h, R, G};
+    return small_a(d) ? 1 : 0;
+}
+
 extern "C" size_t cti_triattention_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec) {
     const size_t t = cti_tcnet_forward_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
     if (t == 0) return 0;
@@ -518,7 +551,7 @@ extern "C" int cti_triattention_forward(const float* v, const float* q, const fl
                                         const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
                                         uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                         int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                                        void* ev_core_end, void* aux_stream, void* stream) {
+                                        void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep) {
     CTI_REQUIRE_PTR(p_out); CTI_REQUIRE_PTR(zero_mask); CTI_REQUIRE_PTR(workspace);
     CTI_REQUIRE(G >= 2, CTI_E_UNSUPPORTED, "cti_triattention_forward: glimpse must be >= 2 (the reference's mask expand fails for 1, src/attention.py:55)");
     const size_t need = cti_triattention_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
@@ -535,7 +568,8 @@ extern "C" int cti_triattention_forward(const float* v, const float* q, const fl
     const bool planes_mode = prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || (prec == CTI_PREC_F16F6 && h % 32 == 0);
     if (planes_mode && small_a(d))                             // logits + p out of the fused kernel's registers
         return tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
-                                  G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, nullptr, p_out);
+                                  G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, nullptr, p_out, v_tucker_out, ld_vt, v_rep > 0 ? v_rep : 1);
+    CTI_REQUIRE(v_tucker_out == nullptr, CTI_E_UNSUPPORTED, "cti_triattention_forward: a hoisted v projection is taken on the few-answer path only (cti_triattention_hoist_ok)");
     const bool partials = pb != 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && ((int64_t)V * Q * A) % 2 == 0;
     rc = tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
                             G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, partials ? part : nullptr);

@@ -125,24 +125,34 @@ class HoistedProjection:
     `maybe(...)` returns None whenever the fusion does not apply and the caller takes the per-network path.
     The concatenated weights are cached until a parameter changes (`_version` / `data_ptr`)."""
 
-    def __init__(self, nets):
+    def __init__(self, nets, padded=()):
+        """padded: further networks of the same form and input width whose output is NARROWER than the common one (TriAttention's v_tucker, 512
+        wide, beside the pooling networks' 1024): they join the batched GEMM with zero rows up to the common width -- after `maybe` their
+        outputs are in `last_padded` (full width: the caller reads the first out_features columns, row stride = the common width; empty when
+        such a network does not have the batched form)."""
         self.nets = list(nets)
+        self.padded = list(padded)
+        self.last_padded = []
         self._key = None
 
+    @staticmethod
+    def _layer_of(n):
+        mods = [m for m in n.main if not isinstance(m, nn.Dropout)]
+        return mods[0] if len(mods) == 2 and isinstance(mods[0], WNLinear) and isinstance(mods[1], nn.ReLU) else None
+
     def _layers(self):
-        out = []
-        for n in self.nets:
-            mods = [m for m in n.main if not isinstance(m, nn.Dropout)]
-            if len(mods) != 2 or not isinstance(mods[0], WNLinear) or not isinstance(mods[1], nn.ReLU):
-                return None
-            out.append(mods[0])
-        if len({(l.in_features, l.out_features) for l in out}) != 1:
+        main = [self._layer_of(n) for n in self.nets]
+        if any(l is None for l in main) or len({(l.in_features, l.out_features) for l in main}) != 1:
             return None
-        return out
+        extra = [self._layer_of(n) for n in self.padded]
+        if any(l is None or l.in_features != main[0].in_features or l.out_features > main[0].out_features or n.training for l, n in zip(extra, self.padded)):
+            extra = []                                   # a narrower network of another form (e.g. act='Tanh'): the main ones still batch
+        return main + extra
 
     def maybe(self, x):
         """x (..., in) -> list of (..., out) tensors, one per network, or None."""
-        if len(self.nets) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets for p in n.parameters())):
+        self.last_padded = []
+        if len(self.nets) + len(self.padded) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets + self.padded for p in n.parameters())):
             return None
         if any(n.training for n in self.nets):
             return None
@@ -152,8 +162,12 @@ class HoistedProjection:
         key = (ops._param_epoch[0], ops.get_precision()) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
         if key != self._key:
             with torch.no_grad():
-                self._w = torch.cat([l.weight_v.detach() for l in layers], 0).contiguous()
-                self._b = torch.cat([l.bias.detach() for l in layers], 0).contiguous()
+                od = layers[0].out_features
+
+                def rows(t, l):                       # a narrower layer: zero rows up to the common width
+                    return t if l.out_features == od else torch.cat([t, t.new_zeros((od - l.out_features,) + tuple(t.shape[1:]))], 0)
+                self._w = torch.cat([rows(l.weight_v.detach(), l) for l in layers], 0).contiguous()
+                self._b = torch.cat([rows(l.bias.detach(), l) for l in layers], 0).contiguous()
                 self._s = torch.cat([l.scale().view(1) for l in layers], 0).contiguous()
                 self._wp = ops.split_operand(self._w)
             self._key = key
@@ -161,4 +175,6 @@ class HoistedProjection:
         x2 = x.reshape(-1, x.shape[-1])
         y = ops.gemm_nt(x2, self._w, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, scale=self._s, scale_div=out_dim, scale_bs=1,
                         bias=self._b, bias_bs=out_dim, relu=True, B_planes=self._wp)
-        return [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
+        outs = [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
+        self.last_padded = outs[len(self.nets):]      # the narrower networks' outputs (full width; the first out_features columns count), possibly none
+        return outs[:len(self.nets)]

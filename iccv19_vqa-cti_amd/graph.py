@@ -31,20 +31,27 @@ class GraphedTrainStep:
         self.static_tgt = example_target.clone()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_update = torch.cuda.CUDAGraph() if self.split else None
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        # The warm-up steps run on ONE side stream, the capture on ANOTHER: with a process group the warm-up issues eager RCCL all-reduces whose
+        # completion events live on the stream they ran on, and the process group's watchdog thread may still poll such an event after the
+        # capture has begun -- HIP refuses a query of an event whose stream is capturing (hipErrorCapturedEvent) and the watchdog takes the
+        # process down.  A stream that never captures keeps those events queryable.
+        w = torch.cuda.Stream()
+        w.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(w):
             for _ in range(warmup):
                 self._step()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
             ops.invalidate_caches()                      # the captured step must contain the per-step refresh of every derived cache
             if not self.split:
                 with torch.cuda.graph(self.graph, stream=s):
                     self.static_loss = self._step()
             else:
-                with torch.cuda.graph(self.graph, stream=s):
+                # (thread-local capture mode: the process group's watchdog thread keeps making HIP calls of its own while this thread captures)
+                with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
                     self.static_loss = self._forward_backward()
-                with torch.cuda.graph(self.graph_update, stream=s):
+                with torch.cuda.graph(self.graph_update, stream=s, capture_error_mode="thread_local"):
                     self.opt.apply_update()
         torch.cuda.current_stream().wait_stream(s)
 

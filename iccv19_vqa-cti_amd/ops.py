@@ -431,7 +431,7 @@ def tcnet_prepare(tucker, rank, T_g, prec=None):
     return block, pr
 
 
-def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False, _tri=False):
+def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False, _tri=False, _v_tucked=None, _v_rep=1):
     """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
     the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  prepared: the (block, precision) pair of tcnet_prepare for
     these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)] [, partials]: with want_sm_partials (needs want_mask) the third
@@ -479,7 +479,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     if wait_guard and _range_log["skip"] > 0:
         # this process keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
         _range_log["skip"] -= 1
-        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri)
+        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
     wsb = (lib.cti_triattention_workspace_bytes if _tri else lib.cti_tcnet_forward_workspace_bytes)(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
     ev0 = ev1 = None
@@ -497,9 +497,16 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     with _timed("triattention_forward" if _tri else "tcnet_forward"):
         if _tri:
             p_att = torch.empty_like(out)
+            vt_ptr, vt_ld, vt_rep = 0, 0, 1
+            if _v_tucked is not None and lib.cti_triattention_hoist_ok(B, V, Q, A, h, R, G, pr) and B % int(_v_rep) == 0:
+                # relu(v_tucker(v)) from the caller's batched projection (one block per image when _v_rep > 1): rows (B / rep * V, >= h), 16-B aligned
+                vt2 = _v_tucked.reshape(-1, _v_tucked.shape[-1])
+                if (vt2.stride(1) == 1 and vt2.shape[0] == (B // int(_v_rep)) * V and vt2.shape[1] >= h and vt2.stride(0) % 4 == 0
+                        and vt2.data_ptr() % 16 == 0 and vt2.dtype == torch.float32):
+                    vt_ptr, vt_ld, vt_rep = vt2.data_ptr(), vt2.stride(0), int(_v_rep)
             L.check(lib.cti_triattention_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                                  p_att.data_ptr(), mask.data_ptr(), B, V, Q, A, vd, qd, ad, h, R, G, act, pr, prep_ptr, ws.data_ptr(), wsb,
-                                                 ev0, ev1, _aux_stream(v.device), _stream()), "cti_triattention_forward")
+                                                 ev0, ev1, _aux_stream(v.device), _stream(), vt_ptr, vt_ld, vt_rep), "cti_triattention_forward")
         elif part is not None:
             L.check(lib.cti_tcnet_forward_sm(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                              _ptr(mask), B, V, Q, A, vd, qd, ad, h, R, G, act, pr,
@@ -527,7 +534,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
                 import warnings
                 warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the bf16x3 mode; see ops.f16f6_range_status()"
                               % (status.value, ", ".join(n for b, n in ((1, "saturation / non-finite"), (2, "underflow"), (4, "non-finite V^/Q^/T")) if status.value & b)))
-            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri)
+            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
         _range_log["consecutive"] = 0
     if _tri:
         return p_att, out
@@ -536,10 +543,11 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     return (out, mask) if want_mask else out
 
 
-def triattention_forward(v, q, a, tucker, rank, T_g, relu=True, prec=None, prepared=None):
+def triattention_forward(v, q, a, tucker, rank, T_g, relu=True, prec=None, prepared=None, v_tucked=None, v_rep=1):
     """TriAttention.forward (reference src/attention.py:49-59) in ONE C-ABI call (cti_triattention_forward): returns (p, logits), both
-    (B,V,Q,A,G), logits with -inf on the all-zero rows of v.  Arguments as tcnet_forward."""
-    return tcnet_forward(v, q, a, tucker, rank, T_g, relu, True, prec, prepared, False, True)
+    (B,V,Q,A,G), logits with -inf on the all-zero rows of v.  Arguments as tcnet_forward.  v_tucked (optional): relu(v_tucker(v)) from the
+    caller's batched projection, (B / v_rep, V, >= h) fp32 -- used where the library takes it (few answer tokens), ignored elsewhere."""
+    return tcnet_forward(v, q, a, tucker, rank, T_g, relu, True, prec, prepared, False, True, v_tucked, v_rep)
 
 
 def masked_softmax_tri_from_partials_(logits, mask, partials):

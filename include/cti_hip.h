@@ -193,14 +193,19 @@ size_t cti_tcnet_prepared_bytes(int v_dim, int q_dim, int a_dim, int h, int R, i
  * p_out (B,V,Q,A,G).  Few answer tokens (A <= 6 with h/R = 16, glimpse 2: the FFOE / MC models): the fused modes-1+2+3 kernel holds a sample's
  * logits in registers and writes `logits` and `p_out` itself -- no softmax launch at all; CTI_PREC_F16F6 with glimpse 2: the mode-3 product
  * leaves the softmax's partial pass and ONE normalise pass follows; otherwise the two-pass masked softmax runs behind the product.
- * workspace: cti_triattention_workspace_bytes(...) (its head is cti_tcnet_forward's workspace, range-guard block included). */
+ * workspace: cti_triattention_workspace_bytes(...) (its head is cti_tcnet_forward's workspace, range-guard block included).
+ * v_tucker_out (nullable; only where cti_triattention_hoist_ok(...) == 1): relu(v_tucker(v)) computed by the caller -- hoisted into the batched
+ * GEMM of the glimpses' pooling networks (one read of v for t_att and every t_net[g]) -- as fp32 rows (B / v_rep * V, h) with row
+ * stride ld_vt floats; v_rep > 1: batch rows b * v_rep .. b * v_rep + v_rep - 1 carry the SAME image (the MC pipeline repeats every image per
+ * candidate answer, src/MC/train.py:75-79) and the v side runs once per image.  `v` itself is still read for the zero-row mask. */
 size_t cti_triattention_workspace_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
 int cti_triattention_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                              const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                              const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
                              uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                              int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
-                             void* ev_core_end, void* aux_stream, void* stream);
+                             void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep);
+int cti_triattention_hoist_ok(int B, int V, int Q, int A, int h, int R, int G, int prec);
 
 /* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
 
