@@ -110,7 +110,7 @@ SIGNATURES = {
     "cti_softmax_tri_workspace_bytes": (_sz, [_int, _int, _i64, _int]),
     "cti_masked_softmax_bi_fwd": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "cti_tri_pool_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
-    "cti_tri_pool_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_tri_pool_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_bwd_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_row_sum": (_int, [_vp, _vp, _i64, _int, _vp]),
     "cti_pool_dw_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),

@@ -143,8 +143,6 @@ class _TriModel(nn.Module):
         if vp is not None:
             pad = self._v_hoist.last_padded
             att, logits = t_att(v, q_emb, ans_emb, _v_tucked=pad[0] if pad else None, _v_rep=rep)        # b x v x q x a x g
-            if rep > 1:
-                vp = [x.repeat_interleave(rep, 0) for x in vp]              # one (B,V,N) copy per glimpse: far cheaper than the projection
         else:
             att, logits = t_att(v, q_emb, ans_emb)
         fused_sum = not torch.is_grad_enabled()
@@ -152,7 +150,7 @@ class _TriModel(nn.Module):
         for g in range(self.glimpse):
             w_g = att[:, :, :, :, g]
             b_emb = (self.t_net[g].forward_with_weights(v, q_emb, ans_emb, w_g) if vp is None
-                     else self.t_net[g]._pool_projected(vp[g], q_emb, ans_emb, w_g))
+                     else self.t_net[g]._pool_projected(vp[g], q_emb, ans_emb, w_g, v_rep=rep))    # (one v block per image: the pool reads it in place)
             last = joint is not None and g == self.glimpse - 1                # q_emb.sum(1) + ans_emb.sum(1) of :134 rides in the last residual passes
             q_emb = _residual(self.q_prj[g], b_emb, q_emb, acc=joint if last else None, beta=0.0)
             ans_emb = _residual(self.a_prj[g], b_emb, ans_emb, acc=joint if last else None, beta=1.0)

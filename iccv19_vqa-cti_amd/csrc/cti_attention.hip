@@ -886,7 +886,7 @@ template <int A_, int KS>
 __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave) {
+                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep) {
     constexpr int QAP = KS * 16, MT = 2, WP = QAP + 4;             // W row pitch: +4 floats keeps b128 alignment and spreads the banks
     extern __shared__ __attribute__((aligned(16))) float sm[];     // Wc[64][WP]
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
         const int d_ = (tile_) * 32 + l31;                                                                       \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) qr_[q] = q < Q ? qt[((int64_t)b * Q + q) * D + d_] : 0.f; \
         _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = at[((int64_t)b * A_ + a) * D + d_];              \
-        const float* vb_ = vt + (int64_t)b * V * D + d_;                                                         \
+        const float* vb_ = vt + (int64_t)(b / v_rep) * V * D + d_;      /* v_rep > 1: one vt block per image, v_rep batch rows share it */ \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                         \
             const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;                                                       \
             v0_[e] = v < V ? vb_[(int64_t)v * D] : 0.f;                                                          \
@@ -1409,9 +1409,10 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
 }
 
 extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
+                                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    CTI_REQUIRE(v_rep >= 1 && B % v_rep == 0, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: v_rep=%d does not divide B=%d", v_rep, B);
     // measured at B = 256, D = 1024 (rocprofv3): A = 6: 35.4 us here vs 46.5 us in the streaming VALU form; A = 3: 29.1 us here vs 27.1 us in the
     // product-table VALU form -- so A = 3 stays there (CTI_TRI_MFMA_A3 builds it in for experiments)
 #ifndef CTI_TRI_MFMA_A3
@@ -1426,7 +1427,7 @@ extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const flo
     const int tpw = tiles >= 32 ? CTI_TPM_TPW : 1;
     const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
     const size_t lds = sizeof(float) * 64 * (size_t)(KS * 16 + 4);
-#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw)
+#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep)
     if (A == 3) { if (KS <= 2) CTI_TM(3, 2); else CTI_TM(3, 3); }
     else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
 #undef CTI_TM

@@ -596,11 +596,15 @@ def masked_softmax_bi_(logits, mask):
     return p
 
 
-def tri_pool(vt, qt, at, w):
-    """out[b,d] = sum_vqa vt[b,v,d] w[b,v,q,a] qt[b,q,d] at[b,a,d]; w may be any strided (B,V,Q,A) view."""
+def tri_pool(vt, qt, at, w, v_rep=1):
+    """out[b,d] = sum_vqa vt[b,v,d] w[b,v,q,a] qt[b,q,d] at[b,a,d]; w may be any strided (B,V,Q,A) view.  v_rep > 1: vt is (B / v_rep, V, D),
+    one block per image shared by v_rep consecutive batch rows (the kernel that takes it reads it in place; otherwise it is expanded here)."""
     for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
         _req(t, n)
-    B, V, D = vt.shape
+    v_rep = int(v_rep)
+    B, (V, D) = qt.shape[0], vt.shape[1:]
+    if vt.shape[0] * v_rep != B:
+        raise ValueError("vt has %d blocks for a batch of %d with v_rep=%d" % (vt.shape[0], B, v_rep))
     Q, A = qt.shape[1], at.shape[1]
     if tuple(w.shape) != (B, V, Q, A):
         raise ValueError("w must be (B,V,Q,A) = %s, got %s" % ((B, V, Q, A), tuple(w.shape)))
@@ -614,10 +618,12 @@ def tri_pool(vt, qt, at, w):
     lib = L.lib()
     if get_precision() != "fp32" and _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") != "1":      # fp32-grade MFMA form; exact-fp32 mode keeps the VALU kernels
         rc = lib.cti_tri_pool_mfma_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(), B, V, Q, A, D,
-                                       _stream())
+                                       v_rep, _stream())
         if rc != L.E_UNSUPPORTED:
             L.check(rc, "cti_tri_pool_mfma_fwd")
             return out
+    if v_rep > 1:
+        vt = vt.repeat_interleave(v_rep, 0)
     L.check(lib.cti_tri_pool_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
                                  B, V, Q, A, D, _stream()), "cti_tri_pool_fwd")
     return out

@@ -153,11 +153,12 @@ class TCNet(nn.Module):
     def forward_with_weights(self, v, q, a, w):
         return self._pool_projected(self.v_tucker(v), q, a, w)
 
-    def _pool_projected(self, v_, q, a, w):
-        """forward_with_weights given v_ = v_tucker(v), b x v x d (the model forwards compute it for all glimpses in one batched GEMM)."""
+    def _pool_projected(self, v_, q, a, w, v_rep=1):
+        """forward_with_weights given v_ = v_tucker(v), b x v x d (the model forwards compute it for all glimpses in one batched GEMM).
+        v_rep > 1 (inference): v_ holds one block per IMAGE, shared by v_rep consecutive batch rows."""
         q_ = self.q_tucker(q)
         a_ = self.a_tucker(a)
         w = w.float()
         if _needs_grad(v_, q_, a_, w):
-            return AG.TriPoolFn.apply(v_, q_, a_, w)
-        return ops.tri_pool(v_, q_, a_, w)
+            return AG.TriPoolFn.apply(v_.repeat_interleave(v_rep, 0) if v_rep > 1 else v_, q_, a_, w)
+        return ops.tri_pool(v_, q_, a_, w, v_rep=v_rep)

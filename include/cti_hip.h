@@ -230,9 +230,11 @@ int cti_masked_softmax_bi_fwd(float* logits, const uint8_t* mask, float* p, int 
 int cti_tri_pool_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
                      int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream);
 /* The same pool on the MFMA (fp32-grade 3-product bf16 mode) where that form is the faster one: A = 6 (the MC model's answer length),
- * Q <= 16, V <= 64, D % 32 == 0; returns CTI_E_UNSUPPORTED without a message otherwise (call cti_tri_pool_fwd then). */
+ * Q <= 16, V <= 64, D % 32 == 0; returns CTI_E_UNSUPPORTED without a message otherwise (call cti_tri_pool_fwd then).
+ * v_rep >= 1: vt holds ONE (V, D) block per image and batch rows b * v_rep .. b * v_rep + v_rep - 1 share it (the MC pipeline repeats
+ * every image per candidate answer, src/MC/train.py:75-79) -- vt is then (B / v_rep, V, D). */
 int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                          int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream);
+                          int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, void* stream);
 
 /* out[b,n] = sum_{t<k} sum_{v,q} vt[b,v,n*k+t] * w[b,v,q] * qt[b,q,n*k+t],  n < D/k.  w == NULL means w = 1
  * (that is BCNet.forward with h_out=None, src/bc.py:42-47: out is then (B,1,D) with k = 1). */
