@@ -10,6 +10,7 @@ python bench.py --precision bf16x3 --no-cpu-baseline > $E/bench_bf16x3.log 2>&1
 python bench.py --precision fp32 --no-cpu-baseline > $E/bench_fp32.log 2>&1
 python bench.py --precision bf16 --no-cpu-baseline --no-fp32-exact > $E/bench_bf16.log 2>&1
 python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.log | cut -c1-200
+CTI_BENCH_FORCE_DIST=1 python bench.py --mode train > $E/bench_train_rccl_world1.log 2>&1; tail -1 $E/bench_train_rccl_world1.log | cut -c1-200   # two graphs around an eager RCCL all-reduce
 python bench.py --config c3 > $E/bench_c3.log 2>&1; python bench.py --config c4 > $E/bench_c4.log 2>&1
 CTI_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-fp32-exact --steps 10 > $E/bench_rccl_world1.log 2>&1; tail -1 $E/bench_rccl_world1.log | cut -c1-120
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-exact > $E/rocprof_stats.log 2>&1
@@ -32,5 +33,6 @@ timeout 120 ./tools/mb/mb_f16f6 > $E/mb_f16f6.txt 2>&1
 timeout 120 ./tools/mb/mb_issue > $E/mb_issue.txt 2>&1
 timeout 300 python tools/f16f6_ksweep.py > $E/f16f6_ksweep.txt 2>/dev/null
 timeout 300 python tools/bench_f16f6_aside.py 2>/dev/null | grep '^{' > $E/aside_f16f6.jsonl
+bash tools/prof_models.sh > $E/prof_models.log 2>&1; cp gpurun_out/pc_c3/summary.txt $E/model_c3_kernel_stats.txt; cp gpurun_out/pc_c4/summary.txt $E/model_c4_kernel_stats.txt
 fi
 find $E -name "*.csv" | head -20; du -sh $E
