@@ -615,6 +615,85 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
     if (live && grp == 0) *reinterpret_cast<float2*>(out + (int64_t)b * D + d) = acc;
 }
 
+// Bi pool with k = 3 (BCNet(k=3).forward_with_weights, reference src/bc.py:73-77: the matmul pair over the 3*h channels, then AvgPool1d(3) * 3 = the
+// sum of each group of three).  A thread owns SIX consecutive channels = two output columns, so the pooling never crosses threads: three 8-B loads
+// per row, qt columns in registers, the attention slice compacted into LDS, v groups loaded one group ahead of their arithmetic (as in the tri pool's
+// table kernel).  Replaces the generic bi_pool_kernel at this shape: 193 us -> measured in profiles/r03_hbm_kernels.jsonl (B = 256, V = 36, Q = 14, D = 3072).
+template <int NG>
+__global__ __launch_bounds__(128 * NG, 2) void bi_pool_k3_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ w,
+                                                              int64_t w_sb, int64_t w_sv, int64_t w_sq, float* __restrict__ out, int V, int Q, int D) {
+    constexpr int QM = 16, VC = 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [V][QM]
+    const int b = blockIdx.y, tt = threadIdx.x, t = tt & 127, grp = tt >> 7;
+    const int d = (blockIdx.x * 128 + t) * 6;
+    const bool live = d < D;
+    const int dd = live ? d : 0;
+    constexpr int NT = 128 * NG;
+    const float* vb = vt + (int64_t)b * V * D + dd;
+    const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
+    const float2 z2 = make_float2(0.f, 0.f);
+    float2 vr[VC][3], vn[VC][3];
+#pragma unroll
+    for (int u = 0; u < VC; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vr[u][c] = v_lo + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v_lo + u) * D + 2 * c) : z2;
+    float2 qr[QM][3];
+#pragma unroll
+    for (int q = 0; q < QM; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qr[q][c] = q < Q ? *reinterpret_cast<const float2*>(qt + ((int64_t)b * Q + q) * D + dd + 2 * c) : z2;
+    if (w) {
+        const float* wb = w + (int64_t)b * w_sb;
+        for (int i = tt; i < V * QM; i += NT) { const int q = i % QM, v = i / QM; sm[i] = q < Q ? wb[v * w_sv + q * w_sq] : 0.f; }
+    } else {
+        for (int i = tt; i < V * QM; i += NT) sm[i] = (i % QM) < Q ? 1.f : 0.f;
+    }
+    __syncthreads();
+    float2 acc[3] = {z2, z2, z2};
+    for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
+#pragma unroll
+        for (int u = 0; u < VC; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vn[u][c] = v0 + VC + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + VC + u) * D + 2 * c) : z2;
+#pragma unroll
+        for (int u = 0; u < VC; ++u) {
+            const int v = v0 + u;
+            if (v < v_hi) {
+                const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * QM);
+                float2 sv[3] = {z2, z2, z2};
+#pragma unroll
+                for (int q4 = 0; q4 < QM / 4; ++q4) {
+                    const float4 ww = wr[q4];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        sv[c].x += ww.x * qr[q4 * 4][c].x + ww.y * qr[q4 * 4 + 1][c].x + ww.z * qr[q4 * 4 + 2][c].x + ww.w * qr[q4 * 4 + 3][c].x;
+                        sv[c].y += ww.x * qr[q4 * 4][c].y + ww.y * qr[q4 * 4 + 1][c].y + ww.z * qr[q4 * 4 + 2][c].y + ww.w * qr[q4 * 4 + 3][c].y;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { acc[c].x = fmaf(sv[c].x, vr[u][c].x, acc[c].x); acc[c].y = fmaf(sv[c].y, vr[u][c].y, acc[c].y); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VC; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vr[u][c] = vn[u][c];
+    }
+    // channels d .. d+5 = (acc[0].x, acc[0].y, acc[1].x | acc[1].y, acc[2].x, acc[2].y): the two pooled outputs
+    float2 o = make_float2(acc[0].x + acc[0].y + acc[1].x, acc[1].y + acc[2].x + acc[2].y);
+    if (NG > 1) {
+        __syncthreads();
+        float2* red = reinterpret_cast<float2*>(sm);
+        if (grp > 0) red[(grp - 1) * 128 + t] = o;
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < NG; ++g) { const float2 r = red[(g - 1) * 128 + t]; o.x += r.x; o.y += r.y; }
+        }
+    }
+    if (live && grp == 0) *reinterpret_cast<float2*>(out + (int64_t)b * (D / 3) + d / 3) = o;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // =====================================================================================================
@@ -1357,6 +1436,13 @@ extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w,
                            vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D)
         if (Q == 14) CTI_BP(14); else if (Q == 12) CTI_BP(12); else CTI_BP(0);
 #undef CTI_BP
+        return launch_status("cti_bi_pool_fwd");
+    }
+    if (k == 3 && Q <= 16 && D % 6 == 0 && (size_t)V * 16 * sizeof(float) <= 64 * 1024 && ((reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(out)) & 7) == 0) {
+        constexpr int NG3 = 2;
+        size_t lds3 = sizeof(float) * (size_t)V * 16;
+        if (lds3 < sizeof(float2) * 128 * (NG3 - 1)) lds3 = sizeof(float2) * 128 * (NG3 - 1);
+        hipLaunchKernelGGL((bi_pool_k3_kernel<NG3>), dim3((D / 6 + 127) / 128, B), dim3(128 * NG3), lds3, as_stream(stream), vt, qt, w, w_sb, w_sv, w_sq, out, V, Q, D);
         return launch_status("cti_bi_pool_fwd");
     }
     const size_t lds = sizeof(float) * 256 * (size_t)Q * k;

@@ -1,0 +1,181 @@
+"""Round-3 fusions on an MI355X against the float64 oracle / the unfused forms:
+  * cti_triattention_forward with the attention's v projection taken from the caller (`v_tucker_out`), once per image (`v_rep`);
+  * the MC / FFOE model forwards at h_mm / rank = 16 -- the shapes that reach the fused few-answer kernel (mask + softmax in its registers), the
+    padded batched v projection and the per-image tri pool (the reference fixtures g9_* have h_mm / rank = 4 and take the generic kernels);
+  * cti_linear_residual_pb (split-K reduce + broadcast-add + sequence sum in one pass), with and without a K split;
+  * the range guard without an auxiliary stream (both scans on the launch stream)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cti_amd
+from oracle import cti_models as OM
+from oracle import cti_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+ops = cti_amd.ops
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def sd(m):
+    return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+
+
+@pytest.fixture(params=["bf16x3", "f16f6"], autouse=True)
+def precision(request):
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(request.param)
+    yield request.param
+    cti_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("rep", [1, 2, 4])
+def test_triattention_takes_the_hoisted_v_projection(rep):
+    torch.manual_seed(5 + rep)
+    att = cti_amd.TriAttention(40, 32, 24, 64, 1, 4, 2, 1).to(DEV).eval()            # h / R = 16, glimpse 2: the fused few-answer path for A <= 6
+    rs = np.random.RandomState(rep)
+    Bu, V, Q, A = 3, 7, 5, 3
+    vu = np.abs(rs.standard_normal((Bu, V, 40))).astype(np.float32)
+    vu[1, 5:] = 0
+    v = np.repeat(vu, rep, axis=0)
+    q = np.tanh(rs.standard_normal((Bu * rep, Q, 32))).astype(np.float32)
+    a = np.tanh(rs.standard_normal((Bu * rep, A, 24))).astype(np.float32)
+    assert cti_amd.pkg._lib.lib().cti_triattention_hoist_ok(Bu * rep, V, Q, A, 64, 4, 2, 1) == 1
+    with torch.no_grad():
+        p0, l0 = att(T(v), T(q), T(a))
+        vt = att.TriAtt.v_tucker(T(vu))                                           # (Bu, V, 64): relu(v_tucker(v)), one block per image
+        wide = torch.zeros(Bu, V, 96, device=DEV); wide[..., :64] = vt; wide[..., 64:] = 7.0   # a wider row (the padded batch): columns beyond h are ignored
+        p1, l1 = att(T(v), T(q), T(a), _v_tucked=wide, _v_rep=rep)
+    p_ref, l_ref = O.tri_attention(v, q, a, sd(att), dtype=np.float64)
+    fin = np.isfinite(l_ref)
+    for p, l, what in ((p0, l0, "plain"), (p1, l1, "hoisted v, rep %d" % rep)):
+        assert np.array_equal(np.isfinite(l.cpu().numpy()), fin), what
+        assert O.norm_max_err(np.where(fin, l.cpu().numpy(), 0), np.where(fin, l_ref, 0)) < TOL, what
+        assert O.norm_max_err(p.cpu().numpy(), p_ref) < TOL, what
+    assert float((p1 - p0).abs().max()) <= 2e-6 * float(p0.abs().max())
+
+
+def _ds(ntoken, v_dim, num_ans):
+    return types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=ntoken), v_dim=v_dim, num_ans_candidates=num_ans)
+
+
+def _args(gamma):
+    return types.SimpleNamespace(op="c", num_hid=64, gamma=gamma, h_mm=64, rank=4, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+
+
+@pytest.mark.parametrize("rep", [1, 4])
+def test_mc_model_on_the_fused_few_answer_path(rep):
+    """MC TanModel with h_mm / rank = 16 (fused modes-1+2+3 kernel with mask + softmax inside, padded batched v projection, MFMA tri pool reading
+    one v block per image, fused residual projections) against the float64 oracle of src/MC/base_model.py:128-152."""
+    torch.manual_seed(31)
+    m = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
+    rs = np.random.RandomState(7)
+    Bu = 3
+    vu = np.abs(rs.standard_normal((Bu, 9, 48))).astype(np.float32)
+    vu[2, 6:] = 0
+    v = np.repeat(vu, 4, axis=0)
+    q = np.repeat(rs.randint(0, 50, size=(Bu, 7)), 4, axis=0)
+    a = rs.randint(0, 50, size=(Bu * 4, 6))
+    a[:, 4:] = 50                                                                 # padding tokens
+    m.v_replication = rep
+    with torch.no_grad():
+        out, att = m(T(v), None, T(q.astype(np.int64)), T(a.astype(np.int64)))
+    ref, att_ref = OM.mc_tan_forward(v, q, a, sd(m), 2, dtype=np.float64)
+    assert O.norm_max_err(att.cpu().numpy(), att_ref) < TOL
+    assert O.norm_max_err(out.cpu().numpy(), ref) < TOL
+
+
+def test_ffoe_models_on_the_fused_paths():
+    torch.manual_seed(32)
+    cti = cti_amd.build_cti(_args(2), _ds(50, 48, 11)).to(DEV).eval()
+    ban = cti_amd.build_ban(_args(4), _ds(50, 48, 11)).to(DEV).eval()
+    rs = np.random.RandomState(8)
+    v = np.abs(rs.standard_normal((5, 9, 48))).astype(np.float32)
+    v[0, 7:] = 0
+    q = rs.randint(0, 50, size=(5, 8)).astype(np.int64)
+    a = rs.randint(0, 50, size=(5, 3)).astype(np.int64)
+    with torch.no_grad():
+        lc = cti(T(v), T(q), T(a))
+        lb, attb = ban(T(v), None, T(q), None)
+    assert O.norm_max_err(lc.cpu().numpy(), OM.ffoe_cti_forward(v, q, a, sd(cti), 2, dtype=np.float64)) < TOL
+    rb, ab = OM.ffoe_ban_forward(v, q, sd(ban), 4, dtype=np.float64)
+    assert O.norm_max_err(attb.cpu().numpy(), ab) < 1.5e-4
+    assert O.norm_max_err(lb.cpu().numpy(), rb) < 1.5e-4
+
+
+@pytest.mark.parametrize("B,L,N,K", [(256, 14, 1024, 1024), (5, 3, 36, 40), (64, 12, 128, 96), (1, 1, 4, 8)])
+def test_linear_residual_reduces_adds_and_sums_in_one_pass(B, L, N, K):
+    """out = seq + (scale * x @ W^T + bias)[:, None, :]; acc = beta * acc + out.sum(1): with a K split (256 x 1024 x 1024) and without."""
+    rs = np.random.RandomState(B + N)
+    x = rs.standard_normal((B, K)).astype(np.float32)
+    w = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    seq = rs.standard_normal((B, L, N)).astype(np.float32)
+    acc0 = rs.standard_normal((B, N)).astype(np.float32)
+    scale = np.float32(1.7)
+    wp = ops.split_operand(T(w))
+    acc = T(acc0.copy())
+    out = ops.linear_residual(T(x), wp, T(np.array([scale], np.float32)), N, T(bias), T(seq), acc=acc, beta=0.5)
+    assert out is not None
+    y = scale * (x.astype(np.float64) @ w.astype(np.float64).T) + bias
+    ref = seq + y[:, None, :]
+    assert O.norm_max_err(out.cpu().numpy(), ref) < TOL
+    assert O.norm_max_err(acc.cpu().numpy(), 0.5 * acc0 + ref.sum(1)) < TOL
+    out2 = ops.linear_residual(T(x), wp, None, 1, None, T(seq))                 # no scale, no bias, no accumulator
+    assert O.norm_max_err(out2.cpu().numpy(), seq + (x.astype(np.float64) @ w.astype(np.float64).T)[:, None, :]) < TOL
+
+
+def test_linear_residual_declines_what_it_cannot_do():
+    x, seq = torch.randn(4, 8, device=DEV), torch.randn(4, 3, 6, device=DEV)     # N % 4 != 0
+    assert ops.linear_residual(x, ops.split_operand(torch.randn(6, 8, device=DEV)), None, 1, None, seq) is None
+
+
+def test_range_guard_without_an_auxiliary_stream(precision):
+    """CTI_NO_AUX_STREAM: both guard scans run on the launch stream; clean inputs pass, scaled inputs trip and the re-run is fp32-grade."""
+    if precision != "f16f6":
+        pytest.skip("the guard belongs to the f16f6 kernels")
+    import warnings
+    torch.manual_seed(9)
+    net = cti_amd.TCNet(48, 40, 24, 64, 1, 4, 2).to(DEV).eval()
+    rs = np.random.RandomState(3)
+    v = np.abs(rs.standard_normal((2, 9, 48))).astype(np.float32)
+    q = rs.standard_normal((2, 5, 40)).astype(np.float32)
+    a = rs.standard_normal((2, 40, 24)).astype(np.float32)
+    old = ops.use_aux_stream
+    ops.use_aux_stream = False
+    ops._range_log.update(consecutive=0, skip=0)
+    try:
+        before = ops.f16f6_range_status()
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o1 = net(T(v), T(q), T(a)).cpu().numpy()
+            mid = ops.f16f6_range_status()
+            o2 = net(T(v * 1000), T(q * 1000), T(a * 1000)).cpu().numpy()
+        after = ops.f16f6_range_status()
+    finally:
+        ops.use_aux_stream = old
+        ops._range_log.update(consecutive=0, skip=0)
+    assert mid["trips"] == before["trips"] and after["trips"] == mid["trips"] + 1
+    assert O.norm_max_err(o1, O.tcnet_forward(v, q, a, sd(net), dtype=np.float64)) < TOL
+    assert O.norm_max_err(o2, O.tcnet_forward(v * 1000, q * 1000, a * 1000, sd(net), dtype=np.float64)) < TOL
+
+
+@pytest.mark.parametrize("B,V,Q,D", [(256, 36, 14, 3072), (3, 5, 4, 36), (2, 64, 16, 96), (4, 7, 3, 30)])
+def test_bi_pool_k3_dedicated_kernel(B, V, Q, D):
+    """BCNet(k=3).forward_with_weights (src/bc.py:73-77): out[b, n] = sum_{t<3} sum_vq vt[b,v,3n+t] w[b,v,q] qt[b,q,3n+t], a strided attention slice."""
+    rs = np.random.RandomState(D + V)
+    vt = rs.standard_normal((B, V, D)).astype(np.float32)
+    qt = rs.standard_normal((B, Q, D)).astype(np.float32)
+    att = rs.random_sample((B, 3, V, Q)).astype(np.float32)
+    w = T(att)[:, 1]                                                              # (B, V, Q) view with a batch stride of 3 * V * Q
+    out = ops.bi_pool(T(vt), T(qt), w, 3)
+    ref = np.einsum("bvd,bvq,bqd->bd", vt.astype(np.float64), att[:, 1].astype(np.float64), qt.astype(np.float64)).reshape(B, D // 3, 3).sum(-1)
+    assert tuple(out.shape) == (B, D // 3)
+    assert O.norm_max_err(out.cpu().numpy(), ref) < 1e-5
