@@ -6,15 +6,15 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=gpurun_out/evidence; rm -rf $E; mkdir -p $E
 python -m pytest tests -m gpu -q > $E/pytest_gpu.log 2>&1; tail -2 $E/pytest_gpu.log
 python bench.py > $E/bench_f16f6.log 2>&1; tail -1 $E/bench_f16f6.log | cut -c1-200
-python bench.py --precision bf16x3 --no-cpu-baseline > $E/bench_bf16x3.log 2>&1
-python bench.py --precision fp32 --no-cpu-baseline > $E/bench_fp32.log 2>&1
-python bench.py --precision bf16 --no-cpu-baseline --no-fp32-exact > $E/bench_bf16.log 2>&1
+python bench.py --precision bf16x3 --no-cpu-baseline --no-subrecords > $E/bench_bf16x3.log 2>&1
+python bench.py --precision fp32 --no-cpu-baseline --no-subrecords > $E/bench_fp32.log 2>&1
+python bench.py --precision bf16 --no-cpu-baseline --no-fp32-exact --no-subrecords > $E/bench_bf16.log 2>&1
 python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.log | cut -c1-200
 CTI_BENCH_FORCE_DIST=1 python bench.py --mode train > $E/bench_train_rccl_world1.log 2>&1; tail -1 $E/bench_train_rccl_world1.log | cut -c1-200   # two graphs around an eager RCCL all-reduce
 python bench.py --config c3 > $E/bench_c3.log 2>&1; python bench.py --config c4 > $E/bench_c4.log 2>&1
-CTI_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-fp32-exact --steps 10 > $E/bench_rccl_world1.log 2>&1; tail -1 $E/bench_rccl_world1.log | cut -c1-120
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-exact > $E/rocprof_stats.log 2>&1
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-exact"
+CTI_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-fp32-exact --no-subrecords --steps 10 > $E/bench_rccl_world1.log 2>&1; tail -1 $E/bench_rccl_world1.log | cut -c1-120
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-exact --no-subrecords > $E/rocprof_stats.log 2>&1
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-exact --no-subrecords"
 # one small counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md counter budget); a group the
 # hardware cannot collect makes rocprofv3 abort and then hang, so every pass is bounded by `timeout`
 i=0
@@ -35,4 +35,7 @@ timeout 300 python tools/f16f6_ksweep.py > $E/f16f6_ksweep.txt 2>/dev/null
 timeout 300 python tools/bench_f16f6_aside.py 2>/dev/null | grep '^{' > $E/aside_f16f6.jsonl
 bash tools/prof_models.sh > $E/prof_models.log 2>&1; cp gpurun_out/pc_c3/summary.txt $E/model_c3_kernel_stats.txt; cp gpurun_out/pc_c4/summary.txt $E/model_c4_kernel_stats.txt
 fi
-find $E -name "*.csv" | head -20; du -sh $E
+# summaries on the box; the raw traces (100+ MB) stay there: gpurun merges at most 64 MiB back
+python tools/pmc_summary.py $E/pmc_summary.json $E $E/stats/fwd_kernel_stats.csv > $E/pmc_summary.log 2>&1
+find $E -name "*kernel_trace.csv" -delete; find $E -name "*counter_collection.csv" -delete; find gpurun_out/pc_c3 gpurun_out/pc_c4 -name "*kernel_trace.csv" -delete 2>/dev/null
+du -sh $E gpurun_out

@@ -2,13 +2,13 @@
 # Copy the summaries of gpurun_out/evidence (written by tools/collect_evidence.sh on the GPU box) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
-E=gpurun_out/evidence; R=${1:-r02}
+E=gpurun_out/evidence; R=${1:-r03}
 cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
 for f in f16f6 bf16x3 fp32 bf16 train train_rccl_world1 c3 c4 rccl_world1; do [ -s $E/bench_$f.log ] && tail -1 $E/bench_$f.log > profiles/${R}_bench_$f.json; done
 cp $E/stats/fwd_kernel_stats.csv profiles/${R}_rocprof_kernel_stats_f16f6.csv
 cat $E/model_fwd.jsonl $E/model_train.jsonl $E/model_fwd_bf16.jsonl > profiles/${R}_model_bench.jsonl 2>/dev/null || true
 for f in graph_train.jsonl hbm_kernels.jsonl mode3_f16f6_vs_bf16x3.json mb_f16f6.txt mb_issue.txt f16f6_ksweep.txt aside_f16f6.jsonl model_c3_kernel_stats.txt model_c4_kernel_stats.txt; do [ -s $E/$f ] && cp $E/$f profiles/${R}_$f; done
-python tools/pmc_summary.py profiles/${R}_pmc_summary.json $E profiles/${R}_rocprof_kernel_stats_f16f6.csv > /dev/null
+cp $E/pmc_summary.json profiles/${R}_pmc_summary.json
 python - "$R" <<'PY'
 import json, sys
 R = sys.argv[1]
