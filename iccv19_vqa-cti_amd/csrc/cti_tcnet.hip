@@ -369,6 +369,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // answer) -- as fp32 rows (B / v_rep * V, h) with row stride ld_vt; the rank nets then run on those rows (fp32 A operand split at
     // fragment-read time) and V^ holds one block per image.
     const bool hoisted_v = v_tucked != nullptr;
+    int a_phase = 0;                                           // f16f6 a side: 0 = all of it, 1 = up to the Tucker product (+ ev_at), 2 = the rank nets' product
     auto side = [&](int s, hipStream_t ss) -> int {
         if (s == 0 && hoisted_v) {
             PlaneGemmArgs r{};
@@ -390,10 +391,15 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (af32 && (reinterpret_cast<uintptr_t>(x[s]) & 15)) return fail(CTI_E_ALIGN, "cti_tcnet_forward: input %d must be 16-B aligned (its rows are DMA'd as fp32)", s);
         int r_;
         if (!af32 && !f6_side) { r_ = split_planes(x[s], in[s], rows[s], in[s], p.xin[s].hi, p.xin[s].lo, p.xin[s].rows_alloc, ss); if (r_) return r_; }
-        if (!prepared) {                                     // per-call weights: split beside this side's input (prepared: done once)
+        if (!prepared && !(f6_side && a_phase == 2)) {       // per-call weights: split beside this side's input (prepared: done once)
             r_ = split_planes(tucker_wv[s], in[s], h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, ss); if (r_) return r_;
             r_ = split_planes(rank_wv[s], h, h, h, p.wr[s].hi, p.wr[s].lo, p.wr[s].rows_alloc, ss); if (r_) return r_;
             if (s == 2 && f6) { r_ = quantize_rank_a(d, p, rank_wv[2], tucker_wv[2], ss); if (r_) return r_; }
+        }
+        if (f6_side && a_phase == 2) {
+            F6GemmArgs t{};
+            t.A = p.f_wra; t.B = p.f_At; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_Arp; t.bias = rank_b[2]; t.relu = relu;
+            return gemm_nt_f16f6(t, ss);
         }
         if (f6_side) {
             r_ = quantize_f16f6(x[2], in[2], rows[2], in[2], p.f_Ain, ss); if (r_) return r_;
@@ -404,6 +410,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
             t.A = p.f_wta; t.B = p.f_Ain; t.nb = 1; t.M = h; t.N = (int)rows[2]; t.epi = 6; t.out = &p.f_At; t.bias = tucker_b[2]; t.relu = relu;
             r_ = gemm_nt_f16f6(t, ss); if (r_) return r_;
             if (ev_at) (void)hipEventRecord(ev_at, ss);
+            if (a_phase == 1) return CTI_OK;
             t.A = p.f_wra; t.B = p.f_At; t.out = &p.f_Arp; t.bias = rank_b[2];
             return gemm_nt_f16f6(t, ss);
         }
@@ -440,6 +447,36 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         return finish(rc);
     }
+    // Range guard (cti_f16f6_guard.hip).  Three scans keep it off the critical path, which is chain B's END (the M build, starved of CUs by the
+    // persistent a-side GEMMs, finishes ~0.3 ms after them: profiles/r03 timeline):
+    //   early  (auxiliary stream, BEFORE the M build, behind the a side's Tucker product): the scale bytes of `a`, a~ and the a-side weights + a
+    //          non-finite sweep of V^ / Q^ / T_eff;
+    //   middle (main stream, right behind the rank nets' product, while the main stream would otherwise just wait for chain B): A^;
+    //   final  (main stream, behind the join): M's 8 MB of scale bytes, then the verdict -- ~10 us in front of the mode-3 product.
+    // Without an auxiliary stream everything is in stream order anyway: early = weights + fp32 sweeps, final = the four encoded tensors.
+    auto early_scan = [&](bool with_a) -> int {
+        GuardArgs gb{};
+        gb.words = p.guard;
+        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
+        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        if (with_a) {
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        }
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
+        gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
+        return guard_scan(gb, sb);
+    };
+    if (f6 && aux_stream) {
+        // host order matters: the main stream's first half (encode `a`, Tucker product, ev_at) is enqueued BEFORE chain B waits for ev_at
+        a_phase = 1;
+        rc = side(2, st); if (rc) return finish(rc);
+        (void)hipStreamWaitEvent(sb, ev_at, 0);
+        rc = early_scan(true); if (rc) return finish(rc);
+    } else if (f6) {
+        rc = early_scan(false); if (rc) return finish(rc);
+    }
     if (f6) {
         // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
         // start at multiples of 8 rows
@@ -465,48 +502,33 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     }
     }
     if (rc) return finish(rc);
-    // Range guard (cti_f16f6_guard.hip), first scan: the scale bytes of M and of the a-side weights + a non-finite sweep of the fp32 rows behind the
-    // M build.  With an auxiliary stream it is issued further down, behind the a side's Tucker product (so that it also covers `a` and a~), and
-    // runs beside the rank nets' product: starved of CUs by the persistent GEMM, it fills its tails like the rest of chain B.
-    auto early_scan = [&](bool with_a) -> int {
-        GuardArgs gb{};
-        gb.words = p.guard;
-        gb.seg[gb.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
-        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
-        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
-        if (with_a) {
-            gb.seg[gb.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
-            gb.seg[gb.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
-        }
-        gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
-        gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
-        gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
-        return guard_scan(gb, sb);
-    };
-    if (f6 && !aux_stream) { rc = early_scan(false); if (rc) return finish(rc); }
-    if (aux_stream && !f6) (void)hipEventRecord(ev_join, sb);
-    // chain A on the main stream
+    if (aux_stream) (void)hipEventRecord(ev_join, sb);
+    // chain A on the main stream (f16f6 with an auxiliary stream: its second half -- the first was enqueued above)
+    a_phase = (f6 && aux_stream) ? 2 : 0;
     rc = side(2, st); if (rc) return finish(rc);
-    if (f6 && aux_stream) {
-        (void)hipStreamWaitEvent(sb, ev_at, 0);               // `a` and a~ are encoded: chain B ends with the early scan
-        rc = early_scan(true); if (rc) return finish(rc);
+    if (f6 && aux_stream) {                                  // middle scan: A^, while the main stream would otherwise only wait for chain B
+        GuardArgs gm{};
+        gm.words = p.guard;
+        gm.seg[gm.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
+        rc = guard_scan(gm, st); if (rc) return finish(rc);
     }
-    if (aux_stream) { if (f6) (void)hipEventRecord(ev_join, sb); (void)hipStreamWaitEvent(st, ev_join, 0); }
+    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
     if (f6) {
         F6GemmArgs c{};                                      // mode 3 + rank sum on the f16 + fp6 planes
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
         c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
         if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }     // the Tri softmax's partial pass, from the accumulators
-        // Range guard, final scan: A^ is encoded by now (26 MB of scale bytes at configs[1]; without an auxiliary stream `a` and a~ as well).  It
-        // leaves the status word BEFORE ev_core_begin, so a host that waits for that event learns the verdict while the mode-3 product is
-        // still running; the NaN fill behind the product needs no host at all.
+        // Range guard, final scan: M (8 MB of scale bytes at configs[1]; without an auxiliary stream `a`, a~ and A^ as well), then the verdict.
+        // It leaves the status word BEFORE ev_core_begin, so a host that waits for that event learns it while the mode-3 product is still
+        // running; the NaN fill behind the product needs no host at all.
         GuardArgs ga{};
         ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
         if (!aux_stream) {
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+            ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         }
-        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         rc = guard_scan(ga, st); if (rc) return finish(rc);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
