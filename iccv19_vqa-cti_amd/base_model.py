@@ -31,6 +31,9 @@ def _residual(prj, b_emb, seq, acc=None, beta=0.0):
     (:66,134) ride in the same pass.  Inference with a single weight-normalised Linear (the reference's q_prj / a_prj): split + GEMM + ONE
     fused reduce / broadcast-add / sum kernel (cti_linear_residual_pb)."""
     lin = _single_linear(prj)
+    if lin is not None and (b_emb.shape[-1] != lin.in_features or seq.shape[-1] != lin.out_features):
+        raise ValueError("residual projection: b_emb has %d features and the sequence %d, the layer is %d -> %d"
+                         % (b_emb.shape[-1], seq.shape[-1], lin.in_features, lin.out_features))
     if lin is not None and not prj.training and not _needs_grad(b_emb, seq, *prj.parameters()):
         out = ops.linear_residual(b_emb, lin.planes(), lin.scale(), lin.out_features, lin.bias, seq, acc=acc, beta=beta)
         if out is not None:

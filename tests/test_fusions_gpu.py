@@ -67,7 +67,8 @@ def _ds(ntoken, v_dim, num_ans):
 
 
 def _args(gamma):
-    return types.SimpleNamespace(op="c", num_hid=64, gamma=gamma, h_mm=64, rank=4, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+    # h_mm * 2 = num_hid like the reference's 512 / 1024 (the pooled (B, h_mm * k) vector feeds q_prj: FCNet([num_hid, num_hid])); h_mm / rank = 16
+    return types.SimpleNamespace(op="c", num_hid=64, gamma=gamma, h_mm=32, rank=2, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
 
 
 @pytest.mark.parametrize("rep", [1, 4])
