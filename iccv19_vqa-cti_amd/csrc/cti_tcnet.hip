@@ -505,14 +505,21 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     if (aux_stream) (void)hipEventRecord(ev_join, sb);
     // chain A on the main stream (f16f6 with an auxiliary stream: its second half -- the first was enqueued above)
     a_phase = (f6 && aux_stream) ? 2 : 0;
+    // Where the main stream joins chain B (f16f6, auxiliary stream).  The M build cannot share a CU with the persistent a-side GEMMs (153 KB and
+    // 160 KB of LDS), so its 0.34 ms are exclusive wherever they fall: launched beside the rank nets' product it crawls in that product's tail and
+    // finishes ~0.3 ms AFTER it (timeline in profiles/r03_step_timeline.txt) with the mode-3 product waiting.  CTI_F6_JOIN=rank (experiment):
+    // join BEFORE the rank nets' product instead -- the M build then runs alone between the two a-side products.
+    static const bool join_before_rank = [] { const char* e = getenv("CTI_F6_JOIN"); return e && e[0] == 'r'; }();
+    const bool early_join = f6 && aux_stream && join_before_rank;
+    if (early_join) (void)hipStreamWaitEvent(st, ev_join, 0);
     rc = side(2, st); if (rc) return finish(rc);
-    if (f6 && aux_stream) {                                  // middle scan: A^, while the main stream would otherwise only wait for chain B
+    if (f6 && aux_stream && !early_join) {                   // middle scan: A^, while the main stream would otherwise only wait for chain B
         GuardArgs gm{};
         gm.words = p.guard;
         gm.seg[gm.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         rc = guard_scan(gm, st); if (rc) return finish(rc);
     }
-    if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
+    if (aux_stream && !early_join) (void)hipStreamWaitEvent(st, ev_join, 0);
     if (f6) {
         F6GemmArgs c{};                                      // mode 3 + rank sum on the f16 + fp6 planes
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
@@ -527,8 +534,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (!aux_stream) {
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
-            ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         }
+        if (!aux_stream || early_join) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
         rc = guard_scan(ga, st); if (rc) return finish(rc);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
