@@ -551,7 +551,32 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
 // (the sample's A x K block, staged in LDS once: A*K*4 <= 12 KiB) and keeps out[v, q, a, g] partial sums over the ranks in registers
 // (ceil(V/16) object rows per wave x A x G).  The two k-halves of a lane pair meet once at the end.  fp32 FMAs on fp32-grade M values.
 // =====================================================================================================
-template <int AT, int VT>
+typedef short mb_s16x4 __attribute__((ext_vector_type(4)));
+typedef float mb_f32x4 __attribute__((ext_vector_type(4)));
+// four fp32 values -> bf16 hi + bf16 lo (the residual), as the 16x16x16 MFMA's 4-element operands
+__device__ __forceinline__ void mb_split4(const float4 a, mb_s16x4& hi, mb_s16x4& lo) {
+    const float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = static_cast<__bf16>(x[e]);
+        hi[e] = __builtin_bit_cast(short, h);
+        lo[e] = __builtin_bit_cast(short, static_cast<__bf16>(x[e] - static_cast<float>(h)));
+    }
+}
+// fp32-grade product on the 16x16x16 MFMA: a * b ~= ah bh + ah bl + al bh
+__device__ __forceinline__ mb_f32x4 mb_mfma3(const mb_s16x4 ah, const mb_s16x4 al, const mb_s16x4 bh, const mb_s16x4 bl, mb_f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+}
+
+// Round 3: steps 2 AND 3 on the matrix cores, chained through registers.  The first form contracted the step-2 tile (32 x 32: rows (g, k), columns q)
+// with A^ on the VALU: V*Q*A*G*h FMAs per sample with only Q of a tile's 32 column lanes doing useful work -- 60 % of the kernel's issue slots.
+// Here step 2 runs per (v, g) on the 16x16x16 MFMA -- D1[k, q] = sum_j X[v, g, k, j] Q^[q, j]: rows k, columns q (12-14 of 16 useful) -- and
+// its accumulator layout (column = lane & 15, rows 4 (lane >> 4) .. + 3) IS the B-operand layout of the same instruction, so mode 3,
+// O[a, q] += sum_k A^[a, r, k] D1[k, q], takes D1 straight from the registers it was accumulated in (split to bf16 hi + lo: 12 VALU per tile):
+// no LDS round trip, no VALU contraction, 4 accumulator registers per (v, g) for any A <= 16, and no cross-lane sum at the end.
+template <int VT>
 __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                                  const float* __restrict__ Tt, const float* __restrict__ Ar,
                                                                  float* __restrict__ out, int V, int Q, int A, int R,
@@ -561,43 +586,38 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;  // 16 waves
     const int l31 = lane & 31, kg = lane >> 5;
+    const int l15 = lane & 15, l4 = lane >> 4;                  // 16x16x16 operand roles: row / column l15, 4-deep K slice l4
     const int K = R * HR;
     float* ArS = X2 + (size_t)V * G * HR * MB_XP;
     for (int i = threadIdx.x; i < A * K; i += 1024) ArS[i] = Ar[(int64_t)b * A * K + i];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* vb = Vr + (int64_t)(b / v_rep) * V * K + kg * 8;        // v_rep > 1: rows b*v_rep .. +v_rep-1 share one image (V^ holds one block per image)
-    const float* qb = Qr + (int64_t)b * Q * K + kg * 8;
+    const float* qb = Qr + ((int64_t)b * Q + (l15 < Q ? l15 : 0)) * K + l4 * 4;   // step 2's B operand: Q^[q = l15][r*16 + 4 l4 .. + 3]
     const int v0 = l31, v1 = 32 + l31;
-    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
+    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l15 < Q, aok = l15 < A;
     const int c1 = wid * 32 + l31;
     const int xk = l31 >> 1, xg = l31 & 1;
-    float acc[VT][AT][G];
+    mb_f32x4 acc[VT][G];                                        // O[a = 4 l4 + i, q = l15] of (v = wid + 16 t, g)
 #pragma unroll
     for (int t = 0; t < VT; ++t)
 #pragma unroll
-        for (int a = 0; a < AT; ++a) { acc[t][a][0] = 0.f; acc[t][a][1] = 0.f; }
-    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
-#define CTI_MC_LOAD(rr)                                                                                             \
-    {                                                                                                               \
-        const int o_ = (rr) * HR;                                                                                   \
-        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
-        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
-        if (qok)  { q0 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_); q1 = *reinterpret_cast<const float4*>(qb + (int64_t)l31 * K + o_ + 4); } \
-        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
-        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
-    }
-#ifndef CTI_MC_PREFETCH
-#define CTI_MC_PREFETCH 0        // 1: rank r + 1's fragments are loaded under rank r's arithmetic (32 more live registers: spills beside the accumulators)
-#endif
-    if (CTI_MC_PREFETCH) CTI_MC_LOAD(0)
+        for (int g = 0; g < G; ++g) acc[t][g] = mb_f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4;
     for (int r = 0; r < R; ++r) {
-        if (!CTI_MC_PREFETCH) CTI_MC_LOAD(r)
-        mb_bf16x8 ah0, al0, ah1, al1, th, tl, qh, ql;
+        {
+            const int o_ = r * HR;
+            if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); }
+            if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); }
+            if (qok)  q0 = *reinterpret_cast<const float4*>(qb + o_);
+            const float* tp_ = Tt + ((int64_t)r * INNER + c1) * HR + kg * 8;
+            t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);
+        }
+        mb_bf16x8 ah0, al0, ah1, al1, th, tl;
         mb_split8(a00, a01, ah0, al0);
         mb_split8(a10, a11, ah1, al1);
         mb_split8(t0, t1, th, tl);
-        mb_split8(q0, q1, qh, ql);
-        if (CTI_MC_PREFETCH && r + 1 < R) CTI_MC_LOAD(r + 1)
+        mb_s16x4 qh, ql;
+        mb_split4(q0, qh, ql);
         mb_f32x16 x0, x1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
@@ -612,56 +632,39 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
         __syncthreads();                                        // step-2 readers of the previous rank are done with X2 (and Ar[b] is staged)
         mb_store_x(X2, x0, x1, V, kg, xg, xk, wid, lane);
         __syncthreads();
-        // the Ar entries this lane half meets in rank r: k = 4 kg + {0-3} and 8 + 4 kg + {0-3} (register e of the step-2 tile is row rho = (e & 3) + 8 (e >> 2)
-        // + 4 kg = g * 16 + k: registers 0-7 are g = 0, 8-15 are g = 1, each (k = 4 kg .. +3, 8 + 4 kg .. +3))
-        const float* arp = ArS + r * HR + 4 * kg;                  // (read per use: two broadcast 16-B LDS reads; held in registers they push the kernel over its 128)
-        const int sg = l31 >> 4, sk = l31 & 15;
+        // mode 3's A operand of this rank: A^[a = l15][r*16 + 4 l4 .. + 3] (zero rows beyond A), shared by every (v, g) tile of the wave
+        mb_s16x4 arh, arl;
+        mb_split4(aok ? *reinterpret_cast<const float4*>(ArS + l15 * K + r * HR + l4 * 4) : z4, arh, arl);
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             const int v = wid + 16 * t;
             if (v < V) {                                        // (wave-uniform)
-                const float* xr = X2 + ((v * G + sg) * HR + sk) * MB_XP + kg * 8;
-                mb_bf16x8 xh, xl;
-                mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
-                mb_f32x16 m;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) m[e] = 0.f;
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, qh, m, 0, 0, 0);
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ql, m, 0, 0, 0);
-                m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, qh, m, 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < AT; ++a) {
-                    const float* ap = arp + (a < A ? a : 0) * K;
-                    const float4 lo = *reinterpret_cast<const float4*>(ap), hi = *reinterpret_cast<const float4*>(ap + 8);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        float sacc = acc[t][a][g];
-                        sacc = fmaf(m[8 * g + 0], lo.x, sacc); sacc = fmaf(m[8 * g + 1], lo.y, sacc);
-                        sacc = fmaf(m[8 * g + 2], lo.z, sacc); sacc = fmaf(m[8 * g + 3], lo.w, sacc);
-                        sacc = fmaf(m[8 * g + 4], hi.x, sacc); sacc = fmaf(m[8 * g + 5], hi.y, sacc);
-                        sacc = fmaf(m[8 * g + 6], hi.z, sacc); sacc = fmaf(m[8 * g + 7], hi.w, sacc);
-                        acc[t][a][g] = sacc;
-                    }
+                for (int g = 0; g < G; ++g) {
+                    // step 2: A operand X[v, g, k = l15, j = 4 l4 .. + 3] from LDS (16-B reads, pitch 20 floats), B operand Q^ from registers
+                    mb_s16x4 xh, xl;
+                    mb_split4(*reinterpret_cast<const float4*>(X2 + ((v * G + g) * HR + l15) * MB_XP + l4 * 4), xh, xl);
+                    const mb_f32x4 d1 = mb_mfma3(xh, xl, qh, ql, mb_f32x4{0.f, 0.f, 0.f, 0.f});        // D1[k = 4 l4 + i, q = l15]
+                    // mode 3: D1 is already in B-operand position (k = 4 l4 + i of column q = l15)
+                    mb_s16x4 dh, dl;
+                    mb_split4(make_float4(d1[0], d1[1], d1[2], d1[3]), dh, dl);
+                    acc[t][g] = mb_mfma3(arh, arl, dh, dl, acc[t][g]);                                 // O[a = 4 l4 + i, q = l15]
                 }
             }
         }
     }
-#undef CTI_MC_LOAD
-    // the two k-halves of a lane pair (lanes l and l + 32) meet; the lower half writes out[b, v, q, a, 0:2]
-#pragma unroll
-    for (int t = 0; t < VT; ++t)
-#pragma unroll
-        for (int a = 0; a < AT; ++a)
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc[t][a][g] += __shfl_xor(acc[t][a][g], 32);
+    // lane (l15 = q, l4): out[b, v, q, a = 4 l4 + i, g] for i < 4
     if (sm_p == nullptr) {
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             const int v = wid + 16 * t;
-            if (v < V && qok && kg == 0) {
-                float* o = out + (((int64_t)b * V + v) * Q + l31) * A * G;
+            if (v < V && qok) {
+                float* o = out + (((int64_t)b * V + v) * Q + l15) * A * G;
 #pragma unroll
-                for (int a = 0; a < AT; ++a) if (a < A) { o[a * G] = acc[t][a][0]; o[a * G + 1] = acc[t][a][1]; }
+                for (int i = 0; i < 4; ++i) {
+                    const int a = 4 * l4 + i;
+                    if (a < A) { o[a * G] = acc[t][0][i]; o[a * G + 1] = acc[t][1][i]; }
+                }
             }
         }
         return;
@@ -673,15 +676,17 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
     const float ninf = -__builtin_huge_valf();
     __syncthreads();                                            // every wave is done with X2 / ArS: the reductions reuse the LDS
     float* red = X2;                                            // [16 waves][2]
-    bool rowok[VT];
+    bool rowok[VT], live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) live[i] = qok && 4 * l4 + i < A;
     float mx[G] = {ninf, ninf};
 #pragma unroll
     for (int t = 0; t < VT; ++t) {
         const int v = wid + 16 * t;
         rowok[t] = v < V && sm_mask[(int64_t)b * V + (v < V ? v : 0)] == 0;       // (wave-uniform)
-        if (rowok[t] && qok) {
+        if (rowok[t]) {
 #pragma unroll
-            for (int a = 0; a < AT; ++a) if (a < A) { mx[0] = fmaxf(mx[0], acc[t][a][0]); mx[1] = fmaxf(mx[1], acc[t][a][1]); }
+            for (int i = 0; i < 4; ++i) if (live[i]) { mx[0] = fmaxf(mx[0], acc[t][0][i]); mx[1] = fmaxf(mx[1], acc[t][1][i]); }
         }
     }
 #pragma unroll
@@ -691,17 +696,17 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
 #pragma unroll
     for (int w = 0; w < 16; ++w) { gm[0] = fmaxf(gm[0], red[w * 2]); gm[1] = fmaxf(gm[1], red[w * 2 + 1]); }
     __syncthreads();
-    float e[VT][AT][G];
+    float e[VT][G][4];
     float sum[G] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < VT; ++t)
 #pragma unroll
-        for (int a = 0; a < AT; ++a)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+            for (int i = 0; i < 4; ++i) {
                 // exp(x - m) = exp2(x log2e - m log2e); masked rows contribute exp(-inf) = 0; m = -inf (every row masked) gives NaN like the reference
-                e[t][a][g] = rowok[t] ? __builtin_amdgcn_exp2f(fmaf(acc[t][a][g], L2E, -gm[g] * L2E)) : (gm[g] == ninf ? __builtin_nanf("") : 0.f);
-                if (qok && kg == 0 && a < A && wid + 16 * t < V) sum[g] += e[t][a][g];
+                e[t][g][i] = rowok[t] ? __builtin_amdgcn_exp2f(fmaf(acc[t][g][i], L2E, -gm[g] * L2E)) : (gm[g] == ninf ? __builtin_nanf("") : 0.f);
+                if (live[i] && wid + 16 * t < V) sum[g] += e[t][g][i];
             }
 #pragma unroll
     for (int g = 0; g < G; ++g) { const float w = wave_sum(sum[g]); if (lane == 0) red[wid * 2 + g] = w; }
@@ -713,12 +718,15 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < VT; ++t) {
         const int v = wid + 16 * t;
-        if (v < V && qok && kg == 0) {
-            const int64_t off = (((int64_t)b * V + v) * Q + l31) * A * G;
+        if (v < V && qok) {
+            const int64_t off = (((int64_t)b * V + v) * Q + l15) * A * G;
 #pragma unroll
-            for (int a = 0; a < AT; ++a) if (a < A) {
-                out[off + a * G] = rowok[t] ? acc[t][a][0] : ninf; out[off + a * G + 1] = rowok[t] ? acc[t][a][1] : ninf;
-                sm_p[off + a * G] = e[t][a][0] * inv[0]; sm_p[off + a * G + 1] = e[t][a][1] * inv[1];
+            for (int i = 0; i < 4; ++i) {
+                const int a = 4 * l4 + i;
+                if (a < A) {
+                    out[off + a * G] = rowok[t] ? acc[t][0][i] : ninf; out[off + a * G + 1] = rowok[t] ? acc[t][1][i] : ninf;
+                    sm_p[off + a * G] = e[t][0][i] * inv[0]; sm_p[off + a * G + 1] = e[t][1][i] * inv[1];
+                }
             }
         }
     }
@@ -806,15 +814,14 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt) | reinterpret_cast<uintptr_t>(Ar)) & 15) return CTI_E_UNSUPPORTED;
     const size_t lds = mbuild_core_small_lds(V, A, R, hr, G);
     const int VT = (V + 15) / 16;
-#define CTI_MC_LAUNCH(AT, VTv)                                                                                                              \
+#define CTI_MC_LAUNCH(VTv)                                                                                                                  \
     {                                                                                                                                       \
-        auto kern = mbuild_core_small_kernel<AT, VTv>;                                                                                      \
+        auto kern = mbuild_core_small_kernel<VTv>;                                                                                          \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
         if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                       \
         hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R, sm_mask, sm_p, v_rep > 0 ? v_rep : 1);      \
     }
-    if (A <= 3) { if (VT <= 3) CTI_MC_LAUNCH(3, 3) else CTI_MC_LAUNCH(3, 4) }
-    else        { if (VT <= 3) CTI_MC_LAUNCH(6, 3) else CTI_MC_LAUNCH(6, 4) }
+    if (VT <= 3) CTI_MC_LAUNCH(3) else CTI_MC_LAUNCH(4)
 #undef CTI_MC_LAUNCH
     return launch_status("mbuild_core_small");
 }
