@@ -603,21 +603,29 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[t][g] = mb_f32x4{0.f, 0.f, 0.f, 0.f};
     float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4;
+#define CTI_MC_LOAD(rr)                                                                                             \
+    {                                                                                                               \
+        const int o_ = (rr) * HR;                                                                                   \
+        if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); } \
+        if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); } \
+        if (qok)  q0 = *reinterpret_cast<const float4*>(qb + o_);                                                   \
+        const float* tp_ = Tt + ((int64_t)(rr) * INNER + c1) * HR + kg * 8;                                         \
+        t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);                 \
+    }
+#ifndef CTI_MC_PREFETCH
+#define CTI_MC_PREFETCH 1        // rank r + 1's fragments are loaded under rank r's arithmetic, into the fp32 registers rank r's splits have just freed
+#endif
+    constexpr bool PF = CTI_MC_PREFETCH && VT <= 3;            // (four object rows per wave, V > 48: the prefetch registers would spill)
+    if (PF) CTI_MC_LOAD(0)
     for (int r = 0; r < R; ++r) {
-        {
-            const int o_ = r * HR;
-            if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_); a01 = *reinterpret_cast<const float4*>(vb + (int64_t)v0 * K + o_ + 4); }
-            if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_); a11 = *reinterpret_cast<const float4*>(vb + (int64_t)v1 * K + o_ + 4); }
-            if (qok)  q0 = *reinterpret_cast<const float4*>(qb + o_);
-            const float* tp_ = Tt + ((int64_t)r * INNER + c1) * HR + kg * 8;
-            t0 = *reinterpret_cast<const float4*>(tp_); t1 = *reinterpret_cast<const float4*>(tp_ + 4);
-        }
+        if (!PF) CTI_MC_LOAD(r)
         mb_bf16x8 ah0, al0, ah1, al1, th, tl;
         mb_split8(a00, a01, ah0, al0);
         mb_split8(a10, a11, ah1, al1);
         mb_split8(t0, t1, th, tl);
         mb_s16x4 qh, ql;
         mb_split4(q0, qh, ql);
+        if (PF && r + 1 < R) CTI_MC_LOAD(r + 1)
         mb_f32x16 x0, x1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
@@ -653,6 +661,7 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
             }
         }
     }
+#undef CTI_MC_LOAD
     // lane (l15 = q, l4): out[b, v, q, a = 4 l4 + i, g] for i < 4
     if (sm_p == nullptr) {
 #pragma unroll
