@@ -563,11 +563,30 @@ __device__ __forceinline__ void mb_split4(const float4 a, mb_s16x4& hi, mb_s16x4
         lo[e] = __builtin_bit_cast(short, static_cast<__bf16>(x[e] - static_cast<float>(h)));
     }
 }
-// fp32-grade product on the 16x16x16 MFMA: a * b ~= ah bh + ah bl + al bh
+// fp32-grade product on the 16x16x16 MFMA: a * b ~= ah bh + ah bl + al bh  (TERMS == 1: the plain-bf16 mode, hi x hi only)
+template <int TERMS>
 __device__ __forceinline__ mb_f32x4 mb_mfma3(const mb_s16x4 ah, const mb_s16x4 al, const mb_s16x4 bh, const mb_s16x4 bl, mb_f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+    if (TERMS == 3) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+    }
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+}
+template <int TERMS>
+__device__ __forceinline__ void mb_split4t(const float4 a, mb_s16x4& hi, mb_s16x4& lo) {
+    if (TERMS == 3) { mb_split4(a, hi, lo); return; }
+    const float x[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hi[e] = __builtin_bit_cast(short, static_cast<__bf16>(x[e]));
+    lo = hi;                                                    // (unused)
+}
+template <int TERMS>
+__device__ __forceinline__ void mb_split8t(const float4 a, const float4 b, mb_bf16x8& hi, mb_bf16x8& lo) {
+    if (TERMS == 3) { mb_split8(a, b, hi, lo); return; }
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = static_cast<__bf16>(x[e]);
+    lo = hi;
 }
 
 // Round 3: steps 2 AND 3 on the matrix cores, chained through registers.  The first form contracted the step-2 tile (32 x 32: rows (g, k), columns q)
@@ -576,7 +595,7 @@ __device__ __forceinline__ mb_f32x4 mb_mfma3(const mb_s16x4 ah, const mb_s16x4 a
 // its accumulator layout (column = lane & 15, rows 4 (lane >> 4) .. + 3) IS the B-operand layout of the same instruction, so mode 3,
 // O[a, q] += sum_k A^[a, r, k] D1[k, q], takes D1 straight from the registers it was accumulated in (split to bf16 hi + lo: 12 VALU per tile):
 // no LDS round trip, no VALU contraction, 4 accumulator registers per (v, g) for any A <= 16, and no cross-lane sum at the end.
-template <int VT>
+template <int VT, int TERMS>
 __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                                  const float* __restrict__ Tt, const float* __restrict__ Ar,
                                                                  float* __restrict__ out, int V, int Q, int A, int R,
@@ -620,21 +639,25 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
     for (int r = 0; r < R; ++r) {
         if (!PF) CTI_MC_LOAD(r)
         mb_bf16x8 ah0, al0, ah1, al1, th, tl;
-        mb_split8(a00, a01, ah0, al0);
-        mb_split8(a10, a11, ah1, al1);
-        mb_split8(t0, t1, th, tl);
+        mb_split8t<TERMS>(a00, a01, ah0, al0);
+        mb_split8t<TERMS>(a10, a11, ah1, al1);
+        mb_split8t<TERMS>(t0, t1, th, tl);
         mb_s16x4 qh, ql;
-        mb_split4(q0, qh, ql);
+        mb_split4t<TERMS>(q0, qh, ql);
         if (PF && r + 1 < R) CTI_MC_LOAD(r + 1)
         mb_f32x16 x0, x1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
-        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
-        x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
+        if (TERMS == 3) {
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
+        }
         x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, th, x0, 0, 0, 0);
         if (V > 32) {
-            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
+            if (TERMS == 3) {
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
+            }
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
         }
         __syncthreads();                                        // step-2 readers of the previous rank are done with X2 (and Ar[b] is staged)
@@ -642,7 +665,7 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
         __syncthreads();
         // mode 3's A operand of this rank: A^[a = l15][r*16 + 4 l4 .. + 3] (zero rows beyond A), shared by every (v, g) tile of the wave
         mb_s16x4 arh, arl;
-        mb_split4(aok ? *reinterpret_cast<const float4*>(ArS + l15 * K + r * HR + l4 * 4) : z4, arh, arl);
+        mb_split4t<TERMS>(aok ? *reinterpret_cast<const float4*>(ArS + l15 * K + r * HR + l4 * 4) : z4, arh, arl);
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             const int v = wid + 16 * t;
@@ -651,12 +674,12 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
                 for (int g = 0; g < G; ++g) {
                     // step 2: A operand X[v, g, k = l15, j = 4 l4 .. + 3] from LDS (16-B reads, pitch 20 floats), B operand Q^ from registers
                     mb_s16x4 xh, xl;
-                    mb_split4(*reinterpret_cast<const float4*>(X2 + ((v * G + g) * HR + l15) * MB_XP + l4 * 4), xh, xl);
-                    const mb_f32x4 d1 = mb_mfma3(xh, xl, qh, ql, mb_f32x4{0.f, 0.f, 0.f, 0.f});        // D1[k = 4 l4 + i, q = l15]
+                    mb_split4t<TERMS>(*reinterpret_cast<const float4*>(X2 + ((v * G + g) * HR + l15) * MB_XP + l4 * 4), xh, xl);
+                    const mb_f32x4 d1 = mb_mfma3<TERMS>(xh, xl, qh, ql, mb_f32x4{0.f, 0.f, 0.f, 0.f});        // D1[k = 4 l4 + i, q = l15]
                     // mode 3: D1 is already in B-operand position (k = 4 l4 + i of column q = l15)
                     mb_s16x4 dh, dl;
-                    mb_split4(make_float4(d1[0], d1[1], d1[2], d1[3]), dh, dl);
-                    acc[t][g] = mb_mfma3(arh, arl, dh, dl, acc[t][g]);                                 // O[a = 4 l4 + i, q = l15]
+                    mb_split4t<TERMS>(make_float4(d1[0], d1[1], d1[2], d1[3]), dh, dl);
+                    acc[t][g] = mb_mfma3<TERMS>(arh, arl, dh, dl, acc[t][g]);                                 // O[a = 4 l4 + i, q = l15]
                 }
             }
         }
@@ -815,7 +838,7 @@ int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Pl
 // the caller takes the M build + GEMM pair.  sm_p != NULL (with sm_mask = the zero-row mask of v): TriAttention's masked softmax in the same
 // kernel -- `out` gets -inf on masked rows, sm_p the attention map.
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask, float* sm_p, int v_rep) {
+                      hipStream_t st, const uint8_t* sm_mask, float* sm_p, int v_rep, int terms) {
 #ifdef CTI_NO_MBUILD_CORE_SMALL
     return CTI_E_UNSUPPORTED;
 #endif
@@ -823,14 +846,16 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt) | reinterpret_cast<uintptr_t>(Ar)) & 15) return CTI_E_UNSUPPORTED;
     const size_t lds = mbuild_core_small_lds(V, A, R, hr, G);
     const int VT = (V + 15) / 16;
-#define CTI_MC_LAUNCH(VTv)                                                                                                                  \
+#define CTI_MC_LAUNCH(VTv, TRM)                                                                                                             \
     {                                                                                                                                       \
-        auto kern = mbuild_core_small_kernel<VTv>;                                                                                          \
+        auto kern = mbuild_core_small_kernel<VTv, TRM>;                                                                                     \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
         if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                       \
         hipLaunchKernelGGL(kern, dim3(B), dim3(1024), lds, st, Vr, Qr, Tt, Ar, out, V, Q, A, R, sm_mask, sm_p, v_rep > 0 ? v_rep : 1);      \
     }
-    if (VT <= 3) CTI_MC_LAUNCH(3) else CTI_MC_LAUNCH(4)
+    // terms = 1: the plain-bf16 mode (CTI_PREC_BF16: one product per pair, no lo parts -- the hi / lo splits are this kernel's VALU bound)
+    if (terms == 1) { if (VT <= 3) CTI_MC_LAUNCH(3, 1) else CTI_MC_LAUNCH(4, 1) }
+    else            { if (VT <= 3) CTI_MC_LAUNCH(3, 3) else CTI_MC_LAUNCH(4, 3) }
 #undef CTI_MC_LAUNCH
     return launch_status("mbuild_core_small");
 }

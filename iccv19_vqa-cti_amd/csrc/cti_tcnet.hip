@@ -12,7 +12,7 @@ int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned shor
                 int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1);
+                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1, int terms = 3);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
@@ -443,7 +443,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         rc = side(2, st); if (rc) return finish(rc);
         if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
-        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1);   // p_fused: + the masked softmax
+        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1, terms);   // p_fused: + the masked softmax
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         return finish(rc);
     }
