@@ -8,8 +8,9 @@ python3 - $c <<'PY' | tee gpurun_out/pc_$c/summary.txt
 import csv,glob,sys
 f=glob.glob('gpurun_out/pc_%s/**/*kernel_stats.csv'%sys.argv[1],recursive=True)[0]
 rows=list(csv.reader(open(f)))[1:]
-tot=sum(float(r[2]) for r in rows)
-print("total kernel ms over run", tot/1e6, "per forward (35 forwards + 3 warm-ups of the capture path)", tot/1e6/35)
+setup=sum(float(r[2]) for r in rows if 'copyBuffer' in r[0])     # the model's .to(device): host-to-device staging copies during set-up, not the forward
+tot=sum(float(r[2]) for r in rows)-setup
+print("total kernel ms over run (without the set-up copies, %.2f ms)" % (setup/1e6), tot/1e6, "per forward (35 forwards + 3 warm-ups of the capture path)", tot/1e6/35)
 for r in rows[:40]:
     print(r[0][:110].ljust(112), r[1], "tot %.2f ms avg %.1f us %s%%"%(float(r[2])/1e6, float(r[3])/1e3, r[4]))
 PY
