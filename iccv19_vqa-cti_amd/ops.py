@@ -118,6 +118,7 @@ class tuning:
 
 
 _aux = {}
+_AUX_PRIORITY = int(_os.environ.get("CTI_AUX_PRIORITY", "0"))      # -1 = the auxiliary chain's workgroups are dispatched ahead of the caller's stream (A/B knob)
 use_aux_stream = _os.environ.get("CTI_NO_AUX_STREAM", "0") != "1"
 
 
@@ -135,7 +136,7 @@ def aux_stream_object(device):
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _aux:
-        _aux[key] = torch.cuda.Stream(device=device)
+        _aux[key] = torch.cuda.Stream(device=device, priority=_AUX_PRIORITY)
     return _aux[key]
 
 
