@@ -540,6 +540,10 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
 // channel -- 13.6 flop per HBM byte, near the fp32 VALU ridge -- so the instruction count decides.  A thread owns TWO channels and
 // first forms P[q,a] = qt[q,d] * at[a,d] (Q*A float2 registers); every v is then ONE dot product of the compacted attention row
 // w[v, 0:QA] (LDS, broadcast ds_read_b128) with P: QA packed FMAs per v and channel pair, no padding of A, no per-q re-association.
+#ifndef CTI_TP_ABL
+#define CTI_TP_ABL 0            // timing-only ablations (wrong results): 1 one packed-FMA group per object instead of QA/4, 2 no LDS reads of the attention row,
+#endif                          // 4 only the first v group is loaded, 8 no attention-slice compaction.  Measured (profiles/r03_tri_pool_ablation.txt): 24.9 us; 1: 14.0;
+                                // 2: 21.9; 4: 22.9; 8: 20.0; all: 10.2 -- a one-round kernel whose phases add up on a 10-us floor, not one saturated resource
 template <int QA, int NG, int AC>
 __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                                   const float* __restrict__ at, const float* __restrict__ w,
@@ -568,9 +572,11 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < QC; ++q) qr[q] = *reinterpret_cast<const float2*>(qt + ((int64_t)b * QC + q) * D + dd);
     const float* wb = w + (int64_t)b * w_sb;
+    if (!(CTI_TP_ABL & 8)) {
     for (int i = tt; i < V * QAP; i += NT) {
         const int qa = i % QAP, v = i / QAP, q = qa / AC, a = qa - q * AC;      // (compile-time divisors)
         sm[i] = qa < QA ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+    }
     }
     float2 P[QAP];
 #pragma unroll
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
     float2 acc = make_float2(0.f, 0.f);
     for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
 #pragma unroll
-        for (int u = 0; u < VC; ++u) vn[u] = v0 + VC + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + VC + u) * D) : make_float2(0.f, 0.f);
+        for (int u = 0; u < VC; ++u) vn[u] = (v0 + VC + u < v_hi && !(CTI_TP_ABL & 4)) ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + VC + u) * D) : make_float2(0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -588,8 +594,8 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
                 const float4* wr = reinterpret_cast<const float4*>(sm + (size_t)v * QAP);
                 float2 s0 = make_float2(0.f, 0.f), s1 = s0;
 #pragma unroll
-                for (int i4 = 0; i4 < QAP / 4; ++i4) {
-                    const float4 ww = wr[i4];
+                for (int i4 = 0; i4 < ((CTI_TP_ABL & 1) ? 1 : QAP / 4); ++i4) {
+                    const float4 ww = (CTI_TP_ABL & 2) ? make_float4(vr[u].x, vr[u].y, vr[u].x, vr[u].y) : wr[i4];
                     s0.x = fmaf(ww.x, P[i4 * 4].x, s0.x);     s0.y = fmaf(ww.x, P[i4 * 4].y, s0.y);
                     s1.x = fmaf(ww.y, P[i4 * 4 + 1].x, s1.x); s1.y = fmaf(ww.y, P[i4 * 4 + 1].y, s1.y);
                     s0.x = fmaf(ww.z, P[i4 * 4 + 2].x, s0.x); s0.y = fmaf(ww.z, P[i4 * 4 + 2].y, s0.y);
@@ -597,6 +603,7 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
                 }
                 acc.x = fmaf(s0.x + s1.x, vr[u].x, acc.x);
                 acc.y = fmaf(s0.y + s1.y, vr[u].y, acc.y);
+
             }
         }
 #pragma unroll
