@@ -360,6 +360,211 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_staged_kernel(const float* __
 }
 
 // =====================================================================================================================
+// M build backward on the matrix cores (round 3; hr = 16, G = 2, V <= 48, Q <= 16: every model configuration).  The staged kernel above is fp32 VALU
+// work -- 0.90 ms of the 5.6-ms training step at B = 256.  All five contractions of a rank are small GEMMs whose 16-wide axes fit the 16x16x16 bf16 MFMA
+// (operands split into bf16 hi + lo in registers, three products per pair: fp32-grade, like the forward's M build):
+//   1  X[v, c]  = sum_i Vr[v, i] T[i, c]                  3 v tiles x 32 c tiles (c = (g, j) x k), one K step
+//   2  dQr[q, j] += sum_k dM[(v, q, g), k] X[v, g, j, k]   per (v, g): A = the dM rows of the pair, B = the X tile            } one pass, wave-local: the lane
+//   3  dX[v, g, j, k] = sum_q dM[(v, q, g), k] Qr[q, j]    per (v, g): A = the same dM rows transposed, B = Qr; OVERWRITES X } that read X[..] writes dX[..] there
+//   4  dVr[v, i] = sum_c dX[v, c] T[i, c]                  3 v tiles, K = 512 in 32 steps over 15 waves, partials summed through LDS
+//   5  dT[i, c]  = sum_v Vr[v, i] dX[v, c]                 32 c tiles, K = V in 3 steps; written straight to the per-sample partial
+// LDS: one region time-shared by T[r] (rows 516 floats apart, (g, j, k) order: de-interleaved from the (j, k, g) order of T_eff on the way in) and the
+// rank's dM slice (rows 20 floats apart), as in the staged kernel; X / dX as [v][516] with the four 16-B chunks of a 16-float (g, j) row XOR-swizzled by
+// (j >> 2) & 3 so that the 16 lanes of an operand read (stride 64 B) and the accumulator stores hit distinct banks.  T[r + 1] and the next dM slice are
+// prefetched into registers (8 + 16 per thread) under the arithmetic of rank r.
+typedef short bw_s16x4 __attribute__((ext_vector_type(4)));
+typedef float bw_f32x4 __attribute__((ext_vector_type(4)));
+template <int TERMS>
+__device__ __forceinline__ void bw_split4(const bw_f32x4 x, bw_s16x4& hi, bw_s16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = static_cast<__bf16>(x[e]);
+        hi[e] = __builtin_bit_cast(short, h);
+        lo[e] = TERMS == 3 ? __builtin_bit_cast(short, static_cast<__bf16>(x[e] - static_cast<float>(h))) : (short)0;
+    }
+}
+template <int TERMS>
+__device__ __forceinline__ bw_f32x4 bw_mfma(const bw_s16x4 ah, const bw_s16x4 al, const bw_s16x4 bh, const bw_s16x4 bl, bw_f32x4 c) {
+    if (TERMS == 3) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+}
+constexpr int MBM_PV = 516;          // row pitch (floats) of Xs[v] and of T[i] in LDS: 4 * 516 = 16 (mod 64) banks between the four row groups of a lane quartet
+constexpr int MBM_HP = 20;           // row pitch of the dM slice
+constexpr int MBM_T_FLOATS = 16 * MBM_PV, MBM_SCR_Q = 16 * 256, MBM_SCR_V = 15 * 256;
+
+template <int TERMS>
+__global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __restrict__ dM, const float* __restrict__ Vr, const float* __restrict__ Qr,
+                                                               const float* __restrict__ Teff, float* __restrict__ dVr, float* __restrict__ dQr,
+                                                               float* __restrict__ dTpart, int V, int Q, int R, int rpb, int region_floats) {
+    constexpr int HR = 16, G = 2, inner = HR * HR * G, PV = MBM_PV, HP = MBM_HP;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* R1 = sm;                              // T[r] ([16][PV]) + reduction scratch, or the dM slice ([V*Q*G][HP])
+    float* Xs = R1 + region_floats;              // [V][PV]: X, later dX; a (g, j) row of 16 k values at (g*16 + j)*16, chunks swizzled
+    float* Vs = Xs + (size_t)V * PV;             // [48][16], rows >= V zero
+    float* Qs = Vs + 48 * HR;                    // [16][16], rows >= Q zero
+    float* scrQ = R1 + MBM_T_FLOATS;             // [16 waves][16 q][16 j]   partial dQr tiles
+    float* scrV = scrQ + MBM_SCR_Q;              // [15 waves][16 v][16 i]   partial dVr tiles
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int b = blockIdx.y;
+    const int K = R * HR;
+    const int rowsM = V * Q * G;
+    const float* vb = Vr + (int64_t)b * V * K;
+    const float* qb = Qr + (int64_t)b * Q * K;
+    const float* dmb = dM + (int64_t)b * rowsM * K;
+    const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
+    const bw_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // prefetch registers: T[r] = 2 048 16-B pieces (2 per thread), the dM slice = rowsM * 4 pieces (<= 4 per thread: rowsM <= 1 024); piece f = t + 1024 u is
+    // floats part*4 .. +3 of row f >> 2 (addresses recomputed where they are used: index arrays would cost 12 registers of the 128)
+    const int nD4 = rowsM * 4;
+    bw_f32x4 tp[2] = {z4, z4}, dp[4] = {z4, z4, z4, z4};
+    auto pf_T = [&](int rr) {
+        const bw_f32x4* Tr = reinterpret_cast<const bw_f32x4*>(Teff + (int64_t)rr * HR * inner);
+        tp[0] = Tr[t]; tp[1] = Tr[t + 1024];
+    };
+    auto pf_D = [&](int rr) {
+        const float* s_ = dmb + rr * HR;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int f = t + u * 1024; if (f < nD4) dp[u] = *reinterpret_cast<const bw_f32x4*>(s_ + (f >> 2) * K + (f & 3) * 4); }
+    };
+    auto put_T = [&]() {                         // piece f: i = f / 128, c0 = (f % 128) * 4 = (jk0, g0) (jk0, g1) (jk0 + 1, g0) (jk0 + 1, g1) -> [i][g * 256 + jk]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = t + u * 1024, i = f >> 7, jk0 = (f & 127) * 2;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 g0 = {tp[u][0], tp[u][2]}, g1 = {tp[u][1], tp[u][3]};
+            *reinterpret_cast<f32x2*>(R1 + i * PV + jk0) = g0;
+            *reinterpret_cast<f32x2*>(R1 + i * PV + 256 + jk0) = g1;
+        }
+    };
+    pf_T(r_lo);
+    pf_D(r_lo);
+    for (int r = r_lo; r < r_hi; ++r) {
+        __syncthreads();                                                        // previous rank: phase 5 / the reductions are done with T, Vs, Qs, scratch
+        put_T();
+        if (t < 48 * HR) { const int v = t >> 4, i = t & 15; Vs[t] = v < V ? vb[(int64_t)v * K + r * HR + i] : 0.f; }
+        else { const int e = t - 48 * HR, q = e >> 4, j = e & 15; Qs[e] = q < Q ? qb[(int64_t)q * K + r * HR + j] : 0.f; }
+        __syncthreads();
+        // ---- 1: X = Vr T.  Wave w: c tiles 2w, 2w + 1 against the three v tiles
+        {
+            bw_s16x4 ah[3], al[3];
+#pragma unroll
+            for (int vt = 0; vt < 3; ++vt) bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Vs + (vt * 16 + l15) * HR + 4 * l4), ah[vt], al[vt]);
+#pragma unroll 1
+            for (int n = 0; n < 2; ++n) {
+                const int ct = 2 * wid + n;
+                bw_f32x4 tb;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) tb[ii] = R1[(4 * l4 + ii) * PV + ct * 16 + l15];
+                bw_s16x4 bh, bl;
+                bw_split4<TERMS>(tb, bh, bl);
+                const int sw = ct * 16 + ((((l15 >> 2) ^ ((ct >> 2) & 3)) << 2) | (l15 & 3));     // (j >> 2) & 3 == (ct >> 2) & 3
+#pragma unroll
+                for (int vt = 0; vt < 3; ++vt) {
+                    const bw_f32x4 x = bw_mfma<TERMS>(ah[vt], al[vt], bh, bl, z4);      // rows v = 16 vt + 4 l4 + ii, column k = l15 of tile ct
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) { const int v = vt * 16 + 4 * l4 + ii; if (v < V) Xs[v * PV + sw] = x[ii]; }
+                }
+            }
+        }
+        __syncthreads();                                                        // T readers done: the region becomes the dM slice
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int f = t + u * 1024; if (f < nD4) *reinterpret_cast<bw_f32x4*>(R1 + (f >> 2) * HP + (f & 3) * 4) = dp[u]; }
+        __syncthreads();
+        // ---- 2 + 3: per (v, g) pair, wave-local.  dQr tile (rows q, columns j) accumulates over the wave's pairs; dX overwrites X in place
+        bw_f32x4 accQ = z4;
+        {
+            bw_f32x4 qv;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) qv[ii] = Qs[(4 * l4 + ii) * HR + l15];       // B of phase 3: column j = l15, K = q (rows >= Q are zero)
+            bw_s16x4 qh, ql;
+            bw_split4<TERMS>(qv, qh, ql);
+            const int qrow = min(l15, Q - 1);                                        // rows q >= Q of the dQr tile are never stored
+            for (int p = wid; p < V * G; p += 16) {
+                const int v = p >> 1, g = p & 1;
+                float* xt = Xs + v * PV + (g * 16 + l15) * 16 + ((l4 ^ ((l15 >> 2) & 3)) << 2);     // X[v, g, j = l15, k = 4 l4 ..]: read here, dX written here
+                bw_s16x4 a2h, a2l, b2h, b2l, a3h, a3l;
+                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + ((v * Q + qrow) * G + g) * HP + 4 * l4), a2h, a2l);
+                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(xt), b2h, b2l);
+                accQ = bw_mfma<TERMS>(a2h, a2l, b2h, b2l, accQ);
+                bw_f32x4 a3;                                                           // A of phase 3: row k = l15, K = q = 4 l4 + ii (clamped: Qr's zero rows cancel it)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) a3[ii] = R1[((v * Q + min(4 * l4 + ii, Q - 1)) * G + g) * HP + l15];
+                bw_split4<TERMS>(a3, a3h, a3l);
+                const bw_f32x4 d3 = bw_mfma<TERMS>(a3h, a3l, qh, ql, z4);           // rows k = 4 l4 + ii, column j = l15: this lane's four k are ONE 16-B chunk of row (g, j)
+                *reinterpret_cast<bw_f32x4*>(xt) = d3;
+            }
+        }
+        __syncthreads();                                                        // slice readers done: the region becomes T again (+ scratch behind it)
+        put_T();
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) scrQ[wid * 256 + (4 * l4 + ii) * 16 + l15] = accQ[ii];
+        __syncthreads();
+        if (r + 1 < r_hi) { pf_T(r + 1); pf_D(r + 1); }                         // the next rank's T and dM slice fly under phases 4 + 5 (issued here, not earlier: 24 registers)
+        // ---- 4: dVr = dX T^T.  Waves 0..14: v tile w / 5, K steps (w % 5), + 5, ... of the 32
+        if (wid < 15) {
+            const int vt = wid / 5;
+            const int vrow = min(vt * 16 + l15, V - 1);
+            bw_f32x4 accV = z4;
+            for (int ks = wid - vt * 5; ks < 32; ks += 5) {
+                bw_s16x4 a4h, a4l, b4h, b4l;
+                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Xs + vrow * PV + ks * 16 + ((l4 ^ ((ks >> 2) & 3)) << 2)), a4h, a4l);
+                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + l15 * PV + ks * 16 + 4 * l4), b4h, b4l);
+                accV = bw_mfma<TERMS>(a4h, a4l, b4h, b4l, accV);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) scrV[wid * 256 + (4 * l4 + ii) * 16 + l15] = accV[ii];
+        }
+        // ---- 5: dT = Vr^T dX.  Wave w: c tiles 2w, 2w + 1; K = v in three steps
+        {
+            bw_s16x4 a5h[3], a5l[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                bw_f32x4 av;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) av[ii] = Vs[(s3 * 16 + 4 * l4 + ii) * HR + l15];      // row i = l15, K = v (rows >= V are zero)
+                bw_split4<TERMS>(av, a5h[s3], a5l[s3]);
+            }
+            float* o = dTpart + ((int64_t)b * R + r) * HR * inner;
+#pragma unroll 1
+            for (int n = 0; n < 2; ++n) {
+                const int ct = 2 * wid + n, g = ct >> 4, j = ct & 15;
+                const int sw = ct * 16 + ((((l15 >> 2) ^ ((ct >> 2) & 3)) << 2) | (l15 & 3));
+                bw_f32x4 accT = z4;
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    bw_f32x4 xv;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) xv[ii] = Xs[min(s3 * 16 + 4 * l4 + ii, V - 1) * PV + sw];
+                    bw_s16x4 b5h, b5l;
+                    bw_split4<TERMS>(xv, b5h, b5l);
+                    accT = bw_mfma<TERMS>(a5h[s3], a5l[s3], b5h, b5l, accT);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) o[(4 * l4 + ii) * inner + (j * 16 + l15) * G + g] = accT[ii];     // rows i, column (j, k = l15, g) in T_eff's order
+            }
+        }
+        __syncthreads();
+        // ---- the partial tiles of phases 2 and 4
+        if (t < 256) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s_ += scrQ[w * 256 + t];
+            const int q = t >> 4, j = t & 15;
+            if (q < Q) dQr[((int64_t)b * Q + q) * K + r * HR + j] = s_;
+        } else {
+            const int e = t - 256, vt = e >> 8, idx = e & 255, v = vt * 16 + (idx >> 4), i = idx & 15;
+            float s_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) s_ += scrV[(vt * 5 + w) * 256 + idx];
+            if (v < V) dVr[((int64_t)b * V + v) * K + r * HR + i] = s_;
+        }
+    }
+}
+
+// =====================================================================================================================
 // softmax backward: dl = p * (dp - sum p*dp) over the softmax axis.
 // =====================================================================================================================
 constexpr int GMAXB = 8;
@@ -695,6 +900,8 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
     if (lane == 0) out[row] = s;
 }
 
+inline bool aligned16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <class K>
 int set_lds(K kern, size_t bytes, const char* what) {
     if (bytes <= 64 * 1024) return CTI_OK;
@@ -899,6 +1106,35 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
     if (hr == 4) { CTI_MBB(4) } else if (hr == 8) { CTI_MBB(8) } else { CTI_MBB(16) }
 #undef CTI_MBB
     return launch_status("cti_paralind_mbuild_bwd");
+}
+
+// The same gradients on the matrix cores (mbuild_bwd_mfma_kernel: bf16 hi / lo split products, fp32-grade; prec = CTI_PREC_BF16: one product per pair).
+// CTI_E_UNSUPPORTED (nothing launched, no message) outside hr = 16, G = 2, V <= 48, Q <= 16, V*Q*G <= 1 024 or its LDS budget, and in the exact-fp32 mode:
+// the caller takes cti_paralind_mbuild_bwd.
+extern "C" int cti_paralind_mbuild_bwd_mfma(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
+                                            float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, int prec, void* stream) {
+    CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(dVr); CTI_REQUIRE_PTR(dQr); CTI_REQUIRE_PTR(dTeff_partial);
+    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && R > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd_mfma: B=%d V=%d Q=%d R=%d G=%d", B, V, Q, R, G);
+    if (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16) return CTI_E_UNSUPPORTED;
+    if (hr != 16 || G != 2 || V > 48 || Q > 16 || V * Q * G > 1024) return CTI_E_UNSUPPORTED;
+    if (!aligned16b(dM) || !aligned16b(Teff)) return CTI_E_UNSUPPORTED;
+    const int rowsM = V * Q * G;
+    const int scratch = MBM_T_FLOATS + MBM_SCR_Q + MBM_SCR_V;
+    const int region = rowsM * MBM_HP > scratch ? rowsM * MBM_HP : scratch;
+    const size_t lds = sizeof(float) * ((size_t)region + (size_t)V * MBM_PV + 48 * 16 + 16 * 16);
+    if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
+    int groups = (256 + B - 1) / B; if (groups > R) groups = R;
+    const int rpb = (R + groups - 1) / groups;
+    const dim3 grid((R + rpb - 1) / rpb, B);
+    int rc;
+    if (prec == CTI_PREC_BF16X3) {
+        rc = set_lds(mbuild_bwd_mfma_kernel<3>, lds, "cti_paralind_mbuild_bwd_mfma"); if (rc) return rc;
+        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<3>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, rpb, region);
+    } else {
+        rc = set_lds(mbuild_bwd_mfma_kernel<1>, lds, "cti_paralind_mbuild_bwd_mfma"); if (rc) return rc;
+        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<1>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, rpb, region);
+    }
+    return launch_status("cti_paralind_mbuild_bwd_mfma");
 }
 
 // ---- M-build backward for ANY cubic core size (the reference takes any --rank / --h_mm, src/FFOE/main.py:61-64): plain fp32 VALU kernels,

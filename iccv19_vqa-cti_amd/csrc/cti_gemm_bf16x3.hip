@@ -570,11 +570,15 @@ using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
 // plain-bf16 products (one MFMA per product): slots hold the hi planes only (16 KiB per 16-deep slice of the 256 x 256 tile).  Measured at the
 // configs[1] mode-3 shape (tools/tune_gemm.py run 5 2): 4 slots / 1 per barrier 1.52 ms, 6 / 2 1.54 ms, deeper rings slower -- the kernel is
 // not ring-latency-bound; its DMA (0.5 ms), MFMA (0.7 ms) and store (0.4 ms) phases add up instead of overlapping, as in the 3-term form.
+// Round 3, at the shapes this geometry actually runs in the models (the hoisted v projections of configs[2] / [3]: 9 216 x 2 048 against n x 1 024 rows,
+// tools/bench_gemm_pb.py, split of x included): 4 / 1: 205.6 / 202.5 / 615.9 us (n = 3 as one 3 072-row weight, n = 3, n = 11); 8 / 2: 200.9 / 195.8 / 597.1;
+// 6 / 2: 201.6 / 197.3 / 594.5; 9 / 3: 196.5 / 195.7 / 582.8 (730 TFLOP/s = 0.29 of the bf16 peak); 8 / 1: 209.9 / 203.9 / 620.5; 6 / 1 with the fragment
+// reads of the next slice behind the MFMAs (CTI_PIPE): 227.5 / 221.3 / 678.9.  Three slices per barrier it is: fewer barriers per MFMA at K = 2 048.
 #ifndef CTI_BIG1_NST
-#define CTI_BIG1_NST 4
+#define CTI_BIG1_NST 9
 #endif
 #ifndef CTI_BIG1_SPB
-#define CTI_BIG1_SPB 1
+#define CTI_BIG1_SPB 3
 #endif
 using GeoBig1 = Geo<4, 2, 2, 4, CTI_LW, CTI_BIG1_NST, CTI_BIG1_SPB, 1>;
 using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;

@@ -1000,7 +1000,7 @@ def ranknets_drop_dx(dzs, wv, mask, R, p):
     return dx
 
 
-def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
+def paralind_mbuild_bwd(dM, Vr, Qr, Teff, prec=None):
     """-> dVr, dQr, dTeff (summed over the batch)."""
     R, I, J, K, G = Teff.shape
     B, V, _ = Vr.shape
@@ -1011,8 +1011,14 @@ def paralind_mbuild_bwd(dM, Vr, Qr, Teff):
     dVr, dQr = torch.empty_like(Vr), torch.empty_like(Qr)
     part = torch.empty((B,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
     lib = L.lib()
-    rc = lib.cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
-                                     part.data_ptr(), B, V, Q, R, I, G, _stream())
+    rc = L.E_UNSUPPORTED
+    pr = _prec(prec)
+    if pr != L.PREC_F32 and B > 0 and _os.environ.get("CTI_NO_MBUILD_BWD_MFMA", "0") != "1":      # matrix-core form (fp32-grade split products); exact-fp32 mode keeps the VALU kernels
+        rc = lib.cti_paralind_mbuild_bwd_mfma(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
+                                              part.data_ptr(), B, V, Q, R, I, G, L.PREC_BF16 if pr == L.PREC_BF16 else L.PREC_BF16X3, _stream())
+    if rc == L.E_UNSUPPORTED:
+        rc = lib.cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
+                                         part.data_ptr(), B, V, Q, R, I, G, _stream())
     if rc == L.E_UNSUPPORTED:                                  # h/rank outside {4, 8, 16} (or beyond the staged kernels' budgets): the generic VALU form
         wsb = lib.cti_paralind_mbuild_bwd_generic_workspace_bytes(B, V, R, I, G)
         ws = torch.empty(wsb, device=Vr.device, dtype=torch.uint8)

@@ -464,6 +464,14 @@ int cti_gru_backward(const float* dout, const float* w_hh, const float* save, fl
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec);
 
+/* cti_paralind_mbuild_bwd on the matrix cores (round 3; reference: the autograd of src/Tensor.py:9-14 through src/tc.py:48-50): the five contractions of
+ * a rank as 16x16x16 bf16 MFMA products with operands split into bf16 hi + lo in registers (prec = CTI_PREC_BF16X3: three products per pair, fp32-grade;
+ * CTI_PREC_BF16: one).  Same arguments, outputs and partial layout as cti_paralind_mbuild_bwd.  Returns CTI_E_UNSUPPORTED -- nothing launched, no message --
+ * outside hr = 16, G = 2, V <= 48, Q <= 16, V*Q*G <= 1024 or its LDS budget, for prec = CTI_PREC_F32, or for dM / Teff that are not 16-B aligned: the caller
+ * then takes cti_paralind_mbuild_bwd (exact fp32). */
+int cti_paralind_mbuild_bwd_mfma(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
+                                 float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, int prec, void* stream);
+
 /* M-build backward for any cubic core size h/rank (plain fp32 VALU kernels through the forward's intermediates; cti_paralind_mbuild_bwd is the
  * fast form for h/rank in {4, 8, 16} and returns CTI_E_UNSUPPORTED otherwise).  Same outputs: dVr, dQr, per-sample dT_eff partials (B, R,hr,hr,hr,G). */
 int cti_paralind_mbuild_bwd_generic(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr, float* dTeff_partial,

@@ -216,3 +216,33 @@ def test_mbuild_backward_for_any_core_size(hr, R, G):
     # and the forward of the same shapes (generic kernel) for completeness
     Mf = ops.paralind_mbuild(Vr.to(DEV), Qr.to(DEV), T_.to(DEV))
     assert float((Mf.cpu().double() - M.detach()).abs().max() / M.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,V,Q,R", [(3, 36, 14, 32), (2, 36, 12, 4), (2, 1, 1, 2), (2, 48, 10, 2), (1, 17, 16, 3), (2, 37, 14, 2)])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_mbuild_backward_on_the_matrix_cores(B, V, Q, R, prec):
+    """cti_paralind_mbuild_bwd_mfma (hr = 16, G = 2: the models' cores) against float64 autograd of the closed form, at the model shapes (V = 36, Q = 14 / 12),
+    at one object / one token, at the tile limits (V = 48, Q = 16) and at a ragged V; and against the exact-fp32 VALU kernel it replaces."""
+    ops = cti_amd.ops
+    hr, G = 16, 2
+    g = torch.Generator().manual_seed(V * 100 + Q + R)
+    Vr = torch.randn(B, V, R * hr, generator=g); Qr = torch.randn(B, Q, R * hr, generator=g)
+    T_ = torch.randn(R, hr, hr, hr, G, generator=g); dM = torch.randn(B, V, Q, G, R * hr, generator=g)
+    old = ops.get_precision()
+    try:
+        ops.set_precision(prec)
+        dVr, dQr, dT = ops.paralind_mbuild_bwd(dM.to(DEV), Vr.to(DEV), Qr.to(DEV), T_.to(DEV))
+        ops.set_precision("fp32")
+        eVr, eQr, eT = ops.paralind_mbuild_bwd(dM.to(DEV), Vr.to(DEV), Qr.to(DEV), T_.to(DEV))
+    finally:
+        ops.set_precision(old)
+    v64, q64, t64 = (x.double().requires_grad_(True) for x in (Vr, Qr, T_))
+    M = torch.einsum("rijkg,bvri,bqrj->bvqgrk", t64, v64.view(B, V, R, hr), q64.view(B, Q, R, hr)).reshape(B, V, Q, G, R * hr)
+    (M * dM.double()).sum().backward()
+    tol = 2e-5 if prec == "bf16x3" else 2e-2
+    for got, exact, ref, n_ in ((dVr, eVr, v64.grad, "dVr"), (dQr, eQr, q64.grad, "dQr"), (dT, eT, t64.grad, "dT")):
+        assert torch.isfinite(got).all(), n_
+        e = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e < tol, (n_, e)
+        e2 = float((exact.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e2 < 1e-5, (n_, "exact", e2)
