@@ -52,6 +52,7 @@ SIGNATURES = {
     "cti_wn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _sz, _vp]),
     "cti_wn_bwd_workspace_bytes": (_sz, [_int, _i64]),
     "cti_paralind_mbuild_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_paralind_mbuild_bwd_mfma_partials": (_int, [_int, _int]),
     "cti_paralind_mbuild_bwd_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_bwd_generic": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_paralind_mbuild_bwd_generic_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),

@@ -395,10 +395,41 @@ constexpr int MBM_PV = 516;          // row pitch (floats) of Xs[v] and of T[i] 
 constexpr int MBM_HP = 20;           // row pitch of the dM slice
 constexpr int MBM_T_FLOATS = 16 * MBM_PV, MBM_SCR_Q = 16 * 256, MBM_SCR_V = 15 * 256;
 
+// Operands that are read more than once live in LDS PRE-SPLIT: one dword per element = bf16 hi | bf16 lo << 16 (the same 4 B as the fp32 value).  A consumer
+// turns four dwords into the MFMA's hi and lo operands with four v_perm_b32 instead of ~20 VALU per split -- the splits, not the MFMAs, were the kernel's bound
+// (T is split once per workgroup, the dM slice once per sample instead of twice, dX once instead of twice, Vr once instead of twice).
+template <int TERMS>
+__device__ __forceinline__ float bw_pack(float x) {
+    const __bf16 h = static_cast<__bf16>(x);
+    const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h);
+    if (TERMS != 3) return __builtin_bit_cast(float, hb);
+    const unsigned lb = (unsigned)__builtin_bit_cast(unsigned short, static_cast<__bf16>(x - static_cast<float>(h)));
+    return __builtin_bit_cast(float, hb | (lb << 16));
+}
+template <int TERMS>
+__device__ __forceinline__ bw_f32x4 bw_pack4(const bw_f32x4 x) {
+    const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    const bw_f32x4 o = {bw_pack<TERMS>(x0), bw_pack<TERMS>(x1), bw_pack<TERMS>(x2), bw_pack<TERMS>(x3)};
+    return o;
+}
+template <int TERMS>
+__device__ __forceinline__ void bw_unpack4(const bw_f32x4 p, bw_s16x4& hi, bw_s16x4& lo) {
+    // (through scalar copies: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 whatever the index -- hipcc 7.2, found the hard way)
+    const float f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3];
+    const unsigned u0 = __builtin_bit_cast(unsigned, f0), u1 = __builtin_bit_cast(unsigned, f1), u2 = __builtin_bit_cast(unsigned, f2), u3 = __builtin_bit_cast(unsigned, f3);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 h = {__builtin_amdgcn_perm(u1, u0, 0x05040100u), __builtin_amdgcn_perm(u3, u2, 0x05040100u)};
+    hi = __builtin_bit_cast(bw_s16x4, h);
+    if (TERMS == 3) {
+        const u32x2 l = {__builtin_amdgcn_perm(u1, u0, 0x07060302u), __builtin_amdgcn_perm(u3, u2, 0x07060302u)};
+        lo = __builtin_bit_cast(bw_s16x4, l);
+    } else lo = hi;
+}
+
 template <int TERMS>
 __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __restrict__ dM, const float* __restrict__ Vr, const float* __restrict__ Qr,
                                                                const float* __restrict__ Teff, float* __restrict__ dVr, float* __restrict__ dQr,
-                                                               float* __restrict__ dTpart, int V, int Q, int R, int rpb, int region_floats) {
+                                                               float* __restrict__ dTpart, int B, int V, int Q, int R, int bpc, int region_floats) {
     constexpr int HR = 16, G = 2, inner = HR * HR * G, PV = MBM_PV, HP = MBM_HP;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* R1 = sm;                              // T[r] ([16][PV]) + reduction scratch, or the dM slice ([V*Q*G][HP])
@@ -408,26 +439,28 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
     float* scrQ = R1 + MBM_T_FLOATS;             // [16 waves][16 q][16 j]   partial dQr tiles
     float* scrV = scrQ + MBM_SCR_Q;              // [15 waves][16 v][16 i]   partial dVr tiles
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int b = blockIdx.y;
+    // workgroup = (rank r, chunk of bpc samples): T[r] is loaded ONCE (8 registers per thread, re-put into the time-shared region twice per sample) and the
+    // dT tiles accumulate over the chunk in registers -- one partial per (chunk, rank) instead of one per (sample, rank): 8 MB instead of 268 MB at B = 256
+    const int r = blockIdx.x;
+    const int b_lo = blockIdx.y * bpc, b_hi = min(B, b_lo + bpc);
     const int K = R * HR;
     const int rowsM = V * Q * G;
-    const float* vb = Vr + (int64_t)b * V * K;
-    const float* qb = Qr + (int64_t)b * Q * K;
-    const float* dmb = dM + (int64_t)b * rowsM * K;
-    const int r_lo = blockIdx.x * rpb, r_hi = min(R, r_lo + rpb);
     const bw_f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     // prefetch registers: T[r] = 2 048 16-B pieces (2 per thread), the dM slice = rowsM * 4 pieces (<= 4 per thread: rowsM <= 1 024); piece f = t + 1024 u is
     // floats part*4 .. +3 of row f >> 2 (addresses recomputed where they are used: index arrays would cost 12 registers of the 128)
     const int nD4 = rowsM * 4;
     bw_f32x4 tp[2] = {z4, z4}, dp[4] = {z4, z4, z4, z4};
-    auto pf_T = [&](int rr) {
-        const bw_f32x4* Tr = reinterpret_cast<const bw_f32x4*>(Teff + (int64_t)rr * HR * inner);
-        tp[0] = Tr[t]; tp[1] = Tr[t + 1024];
-    };
-    auto pf_D = [&](int rr) {
-        const float* s_ = dmb + rr * HR;
+    {
+        const bw_f32x4* Tr = reinterpret_cast<const bw_f32x4*>(Teff + (int64_t)r * HR * inner);
+        tp[0] = bw_pack4<TERMS>(Tr[(unsigned)t]); tp[1] = bw_pack4<TERMS>(Tr[(unsigned)t + 1024u]);       // split ONCE per workgroup
+    }
+    auto pf_D = [&](int bb) {
+        const float* s_ = dM + (int64_t)bb * rowsM * K + r * HR;
+        int tz = t;
+        asm volatile("" : "+v"(tz));            // lane offsets recomputed per call: hoisted out of the rank loop they spill, and a scratch reload waits for vmcnt(0),
+                                                // i.e. serialises the four prefetch loads it sits between
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int f = t + u * 1024; if (f < nD4) dp[u] = *reinterpret_cast<const bw_f32x4*>(s_ + (f >> 2) * K + (f & 3) * 4); }
+        for (int u = 0; u < 4; ++u) { const int f = tz + u * 1024; const unsigned off = (unsigned)((f >> 2) * K + (f & 3) * 4); if (f < nD4) dp[u] = *reinterpret_cast<const bw_f32x4*>(s_ + off); }
     };
     auto put_T = [&]() {                         // piece f: i = f / 128, c0 = (f % 128) * 4 = (jk0, g0) (jk0, g1) (jk0 + 1, g0) (jk0 + 1, g1) -> [i][g * 256 + jk]
 #pragma unroll
@@ -439,19 +472,37 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
             *reinterpret_cast<f32x2*>(R1 + i * PV + 256 + jk0) = g1;
         }
     };
-    pf_T(r_lo);
-    pf_D(r_lo);
-    for (int r = r_lo; r < r_hi; ++r) {
-        __syncthreads();                                                        // previous rank: phase 5 / the reductions are done with T, Vs, Qs, scratch
+    // this thread's element of the sample's Vr / Qr slice (rows beyond V / Q: zero), loaded one sample ahead like the dM slice: read at the top of the
+    // iteration it cost an exposed global-load latency per sample
+    float vq_pf = 0.f;
+    auto pf_VQ = [&](int bb) {
+        int tz = t;
+        asm volatile("" : "+v"(tz));
+        vq_pf = 0.f;
+        if (tz < 48 * HR) { const int v = tz >> 4, i = tz & 15; if (v < V) vq_pf = (Vr + (int64_t)bb * V * K + r * HR)[(unsigned)(v * K + i)]; }
+        else { const int e = tz - 48 * HR, q = e >> 4, j = e & 15; if (q < Q) vq_pf = (Qr + (int64_t)bb * Q * K + r * HR)[(unsigned)(q * K + j)]; }
+    };
+    pf_D(b_lo);
+    pf_VQ(b_lo);
+    bw_f32x4 accT[2] = {z4, z4};
+    for (int b = b_lo; b < b_hi; ++b) {
+        // the lane coordinates are re-derived from an opaque copy in every iteration: as loop invariants the ~25 LDS / global lane offsets of the five phases
+        // are all hoisted, and what does not fit the 128 registers is spilled (a reload waits for vmcnt(0): it stalls on the prefetch in flight)
+        int ln_ = lane;
+        asm volatile("" : "+v"(ln_));
+        const int l15 = ln_ & 15, l4 = ln_ >> 4;
+        __syncthreads();                                                        // previous sample: phase 5 / the reductions are done with T, Vs, Qs, scratch
         put_T();
-        if (t < 48 * HR) { const int v = t >> 4, i = t & 15; Vs[t] = v < V ? vb[(int64_t)v * K + r * HR + i] : 0.f; }
-        else { const int e = t - 48 * HR, q = e >> 4, j = e & 15; Qs[e] = q < Q ? qb[(int64_t)q * K + r * HR + j] : 0.f; }
+        // (wave-uniform 64-bit bases + 32-bit lane offsets everywhere: per-lane 64-bit addresses hoisted out of the rank loop were what spilled, and a
+        // scratch reload waits for vmcnt(0) -- i.e. for the prefetches in flight)
+        Vs[t] = bw_pack<TERMS>(vq_pf);                                           // [48][16] then [16][16]: Qs = Vs + 768 (the element was loaded one sample ahead)
         __syncthreads();
+        if (b + 1 < b_hi) pf_VQ(b + 1);
         // ---- 1: X = Vr T.  Wave w: c tiles 2w, 2w + 1 against the three v tiles
         {
             bw_s16x4 ah[3], al[3];
 #pragma unroll
-            for (int vt = 0; vt < 3; ++vt) bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Vs + (vt * 16 + l15) * HR + 4 * l4), ah[vt], al[vt]);
+            for (int vt = 0; vt < 3; ++vt) bw_unpack4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Vs + (vt * 16 + l15) * HR + 4 * l4), ah[vt], al[vt]);
 #pragma unroll 1
             for (int n = 0; n < 2; ++n) {
                 const int ct = 2 * wid + n;
@@ -459,7 +510,7 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) tb[ii] = R1[(4 * l4 + ii) * PV + ct * 16 + l15];
                 bw_s16x4 bh, bl;
-                bw_split4<TERMS>(tb, bh, bl);
+                bw_unpack4<TERMS>(tb, bh, bl);
                 const int sw = ct * 16 + ((((l15 >> 2) ^ ((ct >> 2) & 3)) << 2) | (l15 & 3));     // (j >> 2) & 3 == (ct >> 2) & 3
 #pragma unroll
                 for (int vt = 0; vt < 3; ++vt) {
@@ -471,7 +522,7 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
         }
         __syncthreads();                                                        // T readers done: the region becomes the dM slice
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int f = t + u * 1024; if (f < nD4) *reinterpret_cast<bw_f32x4*>(R1 + (f >> 2) * HP + (f & 3) * 4) = dp[u]; }
+        for (int u = 0; u < 4; ++u) { const int f = t + u * 1024; if (f < nD4) *reinterpret_cast<bw_f32x4*>(R1 + (f >> 2) * HP + (f & 3) * 4) = bw_pack4<TERMS>(dp[u]); }
         __syncthreads();
         // ---- 2 + 3: per (v, g) pair, wave-local.  dQr tile (rows q, columns j) accumulates over the wave's pairs; dX overwrites X in place
         bw_f32x4 accQ = z4;
@@ -480,21 +531,21 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) qv[ii] = Qs[(4 * l4 + ii) * HR + l15];       // B of phase 3: column j = l15, K = q (rows >= Q are zero)
             bw_s16x4 qh, ql;
-            bw_split4<TERMS>(qv, qh, ql);
+            bw_unpack4<TERMS>(qv, qh, ql);
             const int qrow = min(l15, Q - 1);                                        // rows q >= Q of the dQr tile are never stored
             for (int p = wid; p < V * G; p += 16) {
                 const int v = p >> 1, g = p & 1;
                 float* xt = Xs + v * PV + (g * 16 + l15) * 16 + ((l4 ^ ((l15 >> 2) & 3)) << 2);     // X[v, g, j = l15, k = 4 l4 ..]: read here, dX written here
                 bw_s16x4 a2h, a2l, b2h, b2l, a3h, a3l;
-                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + ((v * Q + qrow) * G + g) * HP + 4 * l4), a2h, a2l);
+                bw_unpack4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + ((v * Q + qrow) * G + g) * HP + 4 * l4), a2h, a2l);
                 bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(xt), b2h, b2l);
                 accQ = bw_mfma<TERMS>(a2h, a2l, b2h, b2l, accQ);
                 bw_f32x4 a3;                                                           // A of phase 3: row k = l15, K = q = 4 l4 + ii (clamped: Qr's zero rows cancel it)
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) a3[ii] = R1[((v * Q + min(4 * l4 + ii, Q - 1)) * G + g) * HP + l15];
-                bw_split4<TERMS>(a3, a3h, a3l);
+                bw_unpack4<TERMS>(a3, a3h, a3l);
                 const bw_f32x4 d3 = bw_mfma<TERMS>(a3h, a3l, qh, ql, z4);           // rows k = 4 l4 + ii, column j = l15: this lane's four k are ONE 16-B chunk of row (g, j)
-                *reinterpret_cast<bw_f32x4*>(xt) = d3;
+                *reinterpret_cast<bw_f32x4*>(xt) = bw_pack4<TERMS>(d3);              // dX is stored pre-split: phases 4 and 5 both read it
             }
         }
         __syncthreads();                                                        // slice readers done: the region becomes T again (+ scratch behind it)
@@ -502,7 +553,7 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) scrQ[wid * 256 + (4 * l4 + ii) * 16 + l15] = accQ[ii];
         __syncthreads();
-        if (r + 1 < r_hi) { pf_T(r + 1); pf_D(r + 1); }                         // the next rank's T and dM slice fly under phases 4 + 5 (issued here, not earlier: 24 registers)
+        if (b + 1 < b_hi) pf_D(b + 1);                                          // the next sample's dM slice flies under phases 4 + 5 (issued here, not earlier: 16 registers)
         // ---- 4: dVr = dX T^T.  Waves 0..14: v tile w / 5, K steps (w % 5), + 5, ... of the 32
         if (wid < 15) {
             const int vt = wid / 5;
@@ -510,8 +561,8 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
             bw_f32x4 accV = z4;
             for (int ks = wid - vt * 5; ks < 32; ks += 5) {
                 bw_s16x4 a4h, a4l, b4h, b4l;
-                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Xs + vrow * PV + ks * 16 + ((l4 ^ ((ks >> 2) & 3)) << 2)), a4h, a4l);
-                bw_split4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + l15 * PV + ks * 16 + 4 * l4), b4h, b4l);
+                bw_unpack4<TERMS>(*reinterpret_cast<const bw_f32x4*>(Xs + vrow * PV + ks * 16 + ((l4 ^ ((ks >> 2) & 3)) << 2)), a4h, a4l);
+                bw_unpack4<TERMS>(*reinterpret_cast<const bw_f32x4*>(R1 + l15 * PV + ks * 16 + 4 * l4), b4h, b4l);
                 accV = bw_mfma<TERMS>(a4h, a4l, b4h, b4l, accV);
             }
 #pragma unroll
@@ -525,42 +576,47 @@ __global__ __launch_bounds__(1024) void mbuild_bwd_mfma_kernel(const float* __re
                 bw_f32x4 av;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) av[ii] = Vs[(s3 * 16 + 4 * l4 + ii) * HR + l15];      // row i = l15, K = v (rows >= V are zero)
-                bw_split4<TERMS>(av, a5h[s3], a5l[s3]);
+                bw_unpack4<TERMS>(av, a5h[s3], a5l[s3]);
             }
-            float* o = dTpart + ((int64_t)b * R + r) * HR * inner;
-#pragma unroll 1
+#pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int ct = 2 * wid + n, g = ct >> 4, j = ct & 15;
+                const int ct = 2 * wid + n;
                 const int sw = ct * 16 + ((((l15 >> 2) ^ ((ct >> 2) & 3)) << 2) | (l15 & 3));
-                bw_f32x4 accT = z4;
 #pragma unroll
                 for (int s3 = 0; s3 < 3; ++s3) {
                     bw_f32x4 xv;
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) xv[ii] = Xs[min(s3 * 16 + 4 * l4 + ii, V - 1) * PV + sw];
                     bw_s16x4 b5h, b5l;
-                    bw_split4<TERMS>(xv, b5h, b5l);
-                    accT = bw_mfma<TERMS>(a5h[s3], a5l[s3], b5h, b5l, accT);
+                    bw_unpack4<TERMS>(xv, b5h, b5l);
+                    accT[n] = bw_mfma<TERMS>(a5h[s3], a5l[s3], b5h, b5l, accT[n]);          // accumulates over the chunk's samples
                 }
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) o[(4 * l4 + ii) * inner + (j * 16 + l15) * G + g] = accT[ii];     // rows i, column (j, k = l15, g) in T_eff's order
             }
         }
         __syncthreads();
         // ---- the partial tiles of phases 2 and 4
+        int tq = t;
+        asm volatile("" : "+v"(tq));                                            // (as in pf_D: keeps the store addresses out of the loop-invariant set)
         if (t < 256) {
             float s_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) s_ += scrQ[w * 256 + t];
-            const int q = t >> 4, j = t & 15;
-            if (q < Q) dQr[((int64_t)b * Q + q) * K + r * HR + j] = s_;
+            const int q = tq >> 4, j = tq & 15;
+            if (q < Q) (dQr + (int64_t)b * Q * K + r * HR)[(unsigned)(q * K + j)] = s_;
         } else {
-            const int e = t - 256, vt = e >> 8, idx = e & 255, v = vt * 16 + (idx >> 4), i = idx & 15;
+            const int e = tq - 256, vt = e >> 8, idx = e & 255, v = vt * 16 + (idx >> 4), i = idx & 15;
             float s_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 5; ++w) s_ += scrV[(vt * 5 + w) * 256 + idx];
-            if (v < V) dVr[((int64_t)b * V + v) * K + r * HR + i] = s_;
+            if (v < V) (dVr + (int64_t)b * V * K + r * HR)[(unsigned)(v * K + i)] = s_;
         }
+    }
+    float* o = dTpart + ((int64_t)blockIdx.y * R + r) * HR * inner;             // this chunk's partial of dT_eff[r]: rows i, column (j, k = l15, g) in T_eff's order
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ct = 2 * wid + n, g = ct >> 4, j = ct & 15;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) o[(unsigned)((4 * l4 + ii) * inner + (j * 16 + l15) * G + g)] = accT[n][ii];
     }
 }
 
@@ -1108,13 +1164,21 @@ extern "C" int cti_paralind_mbuild_bwd(const float* dM, const float* Vr, const f
     return launch_status("cti_paralind_mbuild_bwd");
 }
 
+// Partials of dT_eff that cti_paralind_mbuild_bwd_mfma writes: one per chunk of samples (about 256 workgroups = R ranks x chunks), each chunk's sum formed in registers
+extern "C" int cti_paralind_mbuild_bwd_mfma_partials(int B, int R) {
+    if (B <= 0 || R <= 0) return 0;
+    int nc = 256 / R; if (nc < 1) nc = 1; if (nc > B) nc = B;
+    const int bpc = (B + nc - 1) / nc;
+    return (B + bpc - 1) / bpc;
+}
+
 // The same gradients on the matrix cores (mbuild_bwd_mfma_kernel: bf16 hi / lo split products, fp32-grade; prec = CTI_PREC_BF16: one product per pair).
 // CTI_E_UNSUPPORTED (nothing launched, no message) outside hr = 16, G = 2, V <= 48, Q <= 16, V*Q*G <= 1 024 or its LDS budget, and in the exact-fp32 mode:
 // the caller takes cti_paralind_mbuild_bwd.
 extern "C" int cti_paralind_mbuild_bwd_mfma(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
                                             float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, int prec, void* stream) {
     CTI_REQUIRE_PTR(dM); CTI_REQUIRE_PTR(Vr); CTI_REQUIRE_PTR(Qr); CTI_REQUIRE_PTR(Teff); CTI_REQUIRE_PTR(dVr); CTI_REQUIRE_PTR(dQr); CTI_REQUIRE_PTR(dTeff_partial);
-    CTI_REQUIRE(B > 0 && B <= 65535 && V > 0 && Q > 0 && R > 0 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd_mfma: B=%d V=%d Q=%d R=%d G=%d", B, V, Q, R, G);
+    CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && R > 0 && R <= 65535 && G > 0, CTI_E_SHAPE, "cti_paralind_mbuild_bwd_mfma: B=%d V=%d Q=%d R=%d G=%d", B, V, Q, R, G);
     if (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16) return CTI_E_UNSUPPORTED;
     if (hr != 16 || G != 2 || V > 48 || Q > 16 || V * Q * G > 1024) return CTI_E_UNSUPPORTED;
     if (!aligned16b(dM) || !aligned16b(Teff)) return CTI_E_UNSUPPORTED;
@@ -1123,16 +1187,16 @@ extern "C" int cti_paralind_mbuild_bwd_mfma(const float* dM, const float* Vr, co
     const int region = rowsM * MBM_HP > scratch ? rowsM * MBM_HP : scratch;
     const size_t lds = sizeof(float) * ((size_t)region + (size_t)V * MBM_PV + 48 * 16 + 16 * 16);
     if (lds > 160 * 1024) return CTI_E_UNSUPPORTED;
-    int groups = (256 + B - 1) / B; if (groups > R) groups = R;
-    const int rpb = (R + groups - 1) / groups;
-    const dim3 grid((R + rpb - 1) / rpb, B);
+    const int nparts = cti_paralind_mbuild_bwd_mfma_partials(B, R);
+    const int bpc = (B + nparts - 1) / nparts;
+    const dim3 grid(R, nparts);
     int rc;
     if (prec == CTI_PREC_BF16X3) {
         rc = set_lds(mbuild_bwd_mfma_kernel<3>, lds, "cti_paralind_mbuild_bwd_mfma"); if (rc) return rc;
-        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<3>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, rpb, region);
+        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<3>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, B, V, Q, R, bpc, region);
     } else {
         rc = set_lds(mbuild_bwd_mfma_kernel<1>, lds, "cti_paralind_mbuild_bwd_mfma"); if (rc) return rc;
-        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<1>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, V, Q, R, rpb, region);
+        hipLaunchKernelGGL(mbuild_bwd_mfma_kernel<1>, grid, dim3(1024), lds, as_stream(stream), dM, Vr, Qr, Teff, dVr, dQr, dTeff_partial, B, V, Q, R, bpc, region);
     }
     return launch_status("cti_paralind_mbuild_bwd_mfma");
 }

@@ -1009,14 +1009,18 @@ def paralind_mbuild_bwd(dM, Vr, Qr, Teff, prec=None):
         raise L.CtiError("M-build backward is built for cubic cores (hv = hq = ha)")
     dM, Vr, Qr, Teff = dM.contiguous(), Vr.contiguous(), Qr.contiguous(), Teff.contiguous()
     dVr, dQr = torch.empty_like(Vr), torch.empty_like(Qr)
-    part = torch.empty((B,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
     lib = L.lib()
     rc = L.E_UNSUPPORTED
     pr = _prec(prec)
+    nparts = B
     if pr != L.PREC_F32 and B > 0 and _os.environ.get("CTI_NO_MBUILD_BWD_MFMA", "0") != "1":      # matrix-core form (fp32-grade split products); exact-fp32 mode keeps the VALU kernels
+        nparts = lib.cti_paralind_mbuild_bwd_mfma_partials(B, R)                                   # one partial of dT_eff per chunk of samples
+        part = torch.empty((nparts,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
         rc = lib.cti_paralind_mbuild_bwd_mfma(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
                                               part.data_ptr(), B, V, Q, R, I, G, L.PREC_BF16 if pr == L.PREC_BF16 else L.PREC_BF16X3, _stream())
     if rc == L.E_UNSUPPORTED:
+        nparts = B
+        part = torch.empty((B,) + tuple(Teff.shape), device=Vr.device, dtype=torch.float32)
         rc = lib.cti_paralind_mbuild_bwd(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
                                          part.data_ptr(), B, V, Q, R, I, G, _stream())
     if rc == L.E_UNSUPPORTED:                                  # h/rank outside {4, 8, 16} (or beyond the staged kernels' budgets): the generic VALU form
@@ -1025,7 +1029,7 @@ def paralind_mbuild_bwd(dM, Vr, Qr, Teff, prec=None):
         rc = lib.cti_paralind_mbuild_bwd_generic(dM.data_ptr(), Vr.data_ptr(), Qr.data_ptr(), Teff.data_ptr(), dVr.data_ptr(), dQr.data_ptr(),
                                                  part.data_ptr(), B, V, Q, R, I, G, ws.data_ptr(), wsb, _stream())
     L.check(rc, "cti_paralind_mbuild_bwd")
-    dT = sum_batches(part, B, Teff.numel()).view(Teff.shape)
+    dT = sum_batches(part, nparts, Teff.numel()).view(Teff.shape)
     return dVr, dQr, dT
 
 

@@ -466,9 +466,11 @@ size_t cti_gru_backward_workspace_bytes(int B, int T, int H, int prec);
 
 /* cti_paralind_mbuild_bwd on the matrix cores (round 3; reference: the autograd of src/Tensor.py:9-14 through src/tc.py:48-50): the five contractions of
  * a rank as 16x16x16 bf16 MFMA products with operands split into bf16 hi + lo in registers (prec = CTI_PREC_BF16X3: three products per pair, fp32-grade;
- * CTI_PREC_BF16: one).  Same arguments, outputs and partial layout as cti_paralind_mbuild_bwd.  Returns CTI_E_UNSUPPORTED -- nothing launched, no message --
+ * CTI_PREC_BF16: one).  Same arguments and outputs as cti_paralind_mbuild_bwd, except that dTeff_partial holds cti_paralind_mbuild_bwd_mfma_partials(B, R) partials
+ * instead of B (a workgroup owns a rank and a chunk of samples and sums its chunk's dT_eff in registers).  Returns CTI_E_UNSUPPORTED -- nothing launched, no message --
  * outside hr = 16, G = 2, V <= 48, Q <= 16, V*Q*G <= 1024 or its LDS budget, for prec = CTI_PREC_F32, or for dM / Teff that are not 16-B aligned: the caller
  * then takes cti_paralind_mbuild_bwd (exact fp32). */
+int cti_paralind_mbuild_bwd_mfma_partials(int B, int R);   /* n: dTeff_partial is (n, R, hr, hr, hr, G) here -- one partial per chunk of samples, summed in registers */
 int cti_paralind_mbuild_bwd_mfma(const float* dM, const float* Vr, const float* Qr, const float* Teff, float* dVr, float* dQr,
                                  float* dTeff_partial, int B, int V, int Q, int R, int hr, int G, int prec, void* stream);
 
