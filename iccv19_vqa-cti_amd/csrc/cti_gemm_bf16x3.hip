@@ -146,6 +146,7 @@ struct Geo {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, LW = LW_, NST = NST_, SPB = SPB_;
     static constexpr int PL = PL_;                                     // planes per operand held in a slot: 2 (hi + lo) or 1 (plain bf16: hi only)
     static_assert(NST_ % SPB_ == 0 && NST_ > SPB_, "ring = whole groups of SPB slots, at least one group in flight");
+    static_assert(32 % (16 * SPB_) == 0, "a barrier group (SPB slices of 16) must divide the planes' K padding (KPAD = 32): the K loop runs Kp / (16 SPB) groups");
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NCONS = WM * WN * 64, NTHR = NCONS + LW * 64;
     static constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
@@ -572,13 +573,14 @@ using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
 // not ring-latency-bound; its DMA (0.5 ms), MFMA (0.7 ms) and store (0.4 ms) phases add up instead of overlapping, as in the 3-term form.
 // Round 3, at the shapes this geometry actually runs in the models (the hoisted v projections of configs[2] / [3]: 9 216 x 2 048 against n x 1 024 rows,
 // tools/bench_gemm_pb.py, split of x included): 4 / 1: 205.6 / 202.5 / 615.9 us (n = 3 as one 3 072-row weight, n = 3, n = 11); 8 / 2: 200.9 / 195.8 / 597.1;
-// 6 / 2: 201.6 / 197.3 / 594.5; 9 / 3: 196.5 / 195.7 / 582.8 (730 TFLOP/s = 0.29 of the bf16 peak); 8 / 1: 209.9 / 203.9 / 620.5; 6 / 1 with the fragment
-// reads of the next slice behind the MFMAs (CTI_PIPE): 227.5 / 221.3 / 678.9.  Three slices per barrier it is: fewer barriers per MFMA at K = 2 048.
+// 6 / 2: 201.6 / 197.3 / 594.5 (715 TFLOP/s = 0.29 of the bf16 peak); 8 / 1: 209.9 / 203.9 / 620.5; 6 / 1 with the fragment reads of the next slice behind the
+// MFMAs (CTI_PIPE): 227.5 / 221.3 / 678.9.  Two slices per barrier it is.  (9 / 3 "measured" 582.8 -- by dropping the K tail: planes are padded to 32 in K,
+// a barrier group must divide that; the static_assert in Geo now says so.)
 #ifndef CTI_BIG1_NST
-#define CTI_BIG1_NST 9
+#define CTI_BIG1_NST 6
 #endif
 #ifndef CTI_BIG1_SPB
-#define CTI_BIG1_SPB 3
+#define CTI_BIG1_SPB 2
 #endif
 using GeoBig1 = Geo<4, 2, 2, 4, CTI_LW, CTI_BIG1_NST, CTI_BIG1_SPB, 1>;
 using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;
