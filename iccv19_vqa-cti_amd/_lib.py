@@ -119,6 +119,7 @@ SIGNATURES = {
     "cti_bi_pool_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_biattention_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
 }
 
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3

@@ -27,6 +27,11 @@ class BiAttention(nn.Module):
         return p, logits
 
     def forward_all(self, v, q, v_mask=True):
+        if not torch.is_grad_enabled() and not self.logits.training:
+            # eval: logits, mask and softmax in ONE launch of the logits kernel (cti_biattention_fwd)
+            fused = self.logits._attention(v, q, ops.zero_row_mask(v) if v_mask else None)
+            if fused is not None:
+                return fused
         logits = self.logits(v, q)                                  # b x g x v x q
         mask = ops.zero_row_mask(v) if v_mask else None
         if _needs_grad(logits):

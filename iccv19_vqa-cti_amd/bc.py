@@ -68,6 +68,24 @@ class BCNet(nn.Module):
             return self._logits(v_, q_, self.h_mat_v, self.h_mat_g, self.h_bias)
         return self._logits(v_, q_, self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias)
 
+    def _attention(self, v, q, mask):
+        """BiAttention.forward_all on this network, eval / no-grad only: (p, logits) with the mask and the softmax applied in the logits kernel's own launch
+        (ops.biattention_forward), or None when the caller must take forward() + the separate softmax (training, autograd, the pooled form)."""
+        if self.h_out is None or self.training:
+            return None
+        if self.h_out <= self.c:
+            h, h_g, h_bias = (self.h_mat, None, self.h_bias) if 'h_mat' in self._parameters else (self.h_mat_v, self.h_mat_g, self.h_bias)
+        else:
+            h, h_g, h_bias = self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias
+        if _needs_grad(v, q, h, h_g, h_bias) or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return None
+        v_ = self.v_net(v)
+        q_ = self.q_net(q)
+        G, D = (h.shape[-3] if h.dim() == 4 else h.shape[0]), h.shape[-1]
+        h2 = h.reshape(G, D)
+        scale = ops.wn_scale(h2.reshape(1, -1), h_g.reshape(1)) if h_g is not None else None
+        return ops.biattention_forward(v_, q_, h2, scale, h_bias, mask)
+
     def forward_with_weights(self, v, q, w):
         return self._pool_projected(self.v_net(v), q, w)
 

@@ -849,7 +849,8 @@ typedef float lf32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ h,
                                                             const float* __restrict__ h_scale, const float* __restrict__ h_bias,
-                                                            float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW) {
+                                                            float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW,
+                                                            const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p, int* __restrict__ sm_cnt, int sm_parts) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][2][64][40];      // [buffer][hi | lo][row v][32 k + 8 pad]
     const int b = blockIdx.x, ks = blockIdx.y;
     // blockIdx.z: which group of NTW column tiles this workgroup owns (round-3 experiment: thinner workgroups to put more loads in flight -- measured
@@ -957,6 +958,52 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
                     }
                 }
         }
+    }
+    // ---- BiAttention's mask + softmax in the same launch (round 3; reference src/attention.py:35-39).  A sample's G*V*Q logits (4 032 at the FFOE
+    // shape) are complete once the sm_parts workgroups that add into them have passed this point: the LAST of them (a per-sample counter that it
+    // resets for the next call) reads them back from the L2, fills the masked rows with -inf and writes p -- a wave per glimpse, V*Q values over
+    // its lanes.  Replaces a 10-us launch over 8 MB.
+    if (sm_p == nullptr) return;
+    __shared__ int sm_last;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) {
+        sm_last = 1;
+        if (sm_parts > 1) {
+            sm_last = atomicAdd(sm_cnt + b, 1) == sm_parts - 1;
+            if (sm_last) atomicExch(sm_cnt + b, 0);
+        }
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    __threadfence();
+    const int n = V * Q;
+    const float ninf = -__builtin_huge_valf();
+    for (int g = wid; g < G; g += 4) {
+        float* lg = logits + ((int64_t)b * G + g) * n;
+        float* pg = sm_p + ((int64_t)b * G + g) * n;
+        float x[16];                                                     // n <= 64 * 16 (V <= 64, Q <= 16: the launcher checks)
+        float mx = ninf;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i;
+            x[i] = ninf;
+            if (e < n) {
+                const float val = __hip_atomic_load(lg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written by atomics / another workgroup: from the L2
+                const bool masked = sm_mask != nullptr && sm_mask[(int64_t)b * V + e / Q] != 0;
+                x[i] = masked ? ninf : val;
+                if (masked) lg[e] = ninf;
+            }
+            mx = fmaxf(mx, x[i]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = lane + 64 * i; if (e < n) { x[i] = __expf(x[i] - mx); sum += x[i]; } }     // all masked: -inf - -inf = NaN, like the reference
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = lane + 64 * i; if (e < n) pg[e] = x[i] * inv; }
     }
 }
 
@@ -1469,8 +1516,27 @@ extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* 
     return launch_status("cti_bi_logits_fwd");
 }
 
+static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt);
+
 extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                                       float* logits, int B, int G, int V, int Q, int D, void* stream) {
+    return bi_logits_mfma_impl(vt, qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, nullptr, nullptr, nullptr);
+}
+
+// BiAttention.forward_all's logits + mask + softmax in ONE launch (reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the bilinear
+// logits as cti_bi_logits_mfma_fwd, then the last workgroup of a sample fills the rows of `mask` (B, V; NULL = none) with -inf in `logits` and writes
+// p = softmax over (V, Q) per glimpse.  `counters`: B ints that are ZERO at entry and zero again at exit (the caller allocates and zeroes them once).
+// CTI_E_UNSUPPORTED (nothing launched) outside V <= 64, Q <= 16, G*Q <= 128, D % 32 == 0, 16-B aligned operands: the caller takes the separate calls.
+extern "C" int cti_biattention_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias, const uint8_t* mask,
+                                   float* logits, float* p, int* counters, int B, int G, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(p); CTI_REQUIRE_PTR(counters);
+    if (Q > 16) return CTI_E_UNSUPPORTED;
+    return bi_logits_mfma_impl(vt, qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, mask, p, counters);
+}
+
+static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
     CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_mfma_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
     if (D % 16 != 0 || !aligned16(vt) || !aligned16(qt) || !aligned16(h))
@@ -1478,7 +1544,9 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
 #ifndef CTI_BL_LDS
 #define CTI_BL_LDS 1
 #endif
-    if (CTI_BL_LDS && V <= 64 && G * Q <= 128 && D % 32 == 0) {     // left operand split once per workgroup (see bi_logits_lds_kernel)
+    const bool lds_form = CTI_BL_LDS && V <= 64 && G * Q <= 128 && D % 32 == 0;
+    if (sm_p && !lds_form) return CTI_E_UNSUPPORTED;                 // the fused mask + softmax lives in the LDS form only
+    if (lds_form) {                                                  // left operand split once per workgroup (see bi_logits_lds_kernel)
         const int KS = D >= 1024 ? 2 : 1;
         const int dper = ((D / 32 + KS - 1) / KS) * 32;
         if (KS > 1) { int rcz = zero_fill(logits, (int64_t)B * G * V * Q, as_stream(stream)); if (rcz) return rcz; }
@@ -1490,7 +1558,7 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
         static const int ntw_max = [] { const char* e = getenv("CTI_BL_NTW"); const int v = e ? atoi(e) : CTI_BL_NTW; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // (A/B knob; 8 = the round-2 form)
         const int NTW = NT > ntw_max ? ntw_max : NT, NZ = (NT + NTW - 1) / NTW;
         hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
-                           NT, dper, KS > 1 ? 1 : 0, NTW);
+                           NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
         return launch_status("cti_bi_logits_mfma_fwd");
     }
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;

@@ -676,6 +676,38 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     return out
 
 
+_bi_counters = {}
+
+
+def biattention_forward(vt, qt, h, h_scale, h_bias, mask):
+    """(p, logits) of BiAttention.forward_all from the projections: bilinear logits, -inf on the rows of `mask` ((B, V) uint8 or None) and the softmax over (V, Q)
+    per glimpse, in ONE launch (cti_biattention_fwd).  Shapes outside that kernel: the separate calls."""
+    _req(vt, "vt"); _req(qt, "qt"); _req(h, "h")
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    G = h.shape[0]
+    if B * G * V * Q > 0 and get_precision() != "fp32" and _os.environ.get("CTI_NO_BIATT_FUSED", "0") != "1":
+        vt, qt, h = vt.contiguous(), qt.contiguous(), h.contiguous()
+        hb = h_bias.contiguous().view(-1) if h_bias is not None else None
+        if mask is not None:
+            _req(mask, "mask", torch.uint8)
+            mask = mask.contiguous()
+        dev = vt.device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        cnt = _bi_counters.get(key)
+        if cnt is None or cnt.numel() < B:
+            cnt = _bi_counters[key] = torch.zeros(max(B, 4096), device=dev, dtype=torch.int32)      # zero at entry, zeroed again by the kernel's last arrivers
+        logits = torch.empty((B, G, V, Q), device=dev, dtype=torch.float32)
+        p = torch.empty_like(logits)
+        rc = L.lib().cti_biattention_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), _ptr(mask), logits.data_ptr(), p.data_ptr(),
+                                         cnt.data_ptr(), B, G, V, Q, D, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_biattention_fwd")
+            return p, logits
+    logits = bi_logits(vt, qt, h, h_scale, h_bias)
+    return masked_softmax_bi_(logits, mask), logits
+
+
 # ---- backward-pass primitives ---------------------------------------------------------------------------------------
 def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None, sC1=0, scale=None, scale_div=1, bias=None, relu=False,
             prec=None, scale_bs=0, bias_bs=0, B_planes=None):

@@ -253,6 +253,14 @@ int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const fl
 int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                            float* logits, int B, int G, int V, int Q, int D, void* stream);
 
+/* BiAttention.forward_all's logits + mask + softmax in ONE launch (round 3; reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the
+ * bilinear logits as cti_bi_logits_mfma_fwd, then the last workgroup to add into a sample's logits fills the rows of `mask` ((B, V) bytes, 1 = all-zero object
+ * row; NULL = no mask) with -inf in `logits` and writes p = softmax over (V, Q) per glimpse (an all-masked sample gives the reference's NaN row).
+ * `counters`: B ints, ZERO at entry and zero again at exit -- allocate and zero them once.  Returns CTI_E_UNSUPPORTED (nothing launched, no message) outside
+ * V <= 64, Q <= 16, G*Q <= 128, D % 32 == 0 and 16-B aligned operands: the caller then takes cti_bi_logits_(mfma_)fwd + cti_masked_softmax_bi_fwd. */
+int cti_biattention_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias, const uint8_t* mask,
+                        float* logits, float* p, int* counters, int B, int G, int V, int Q, int D, void* stream);
+
 /* ---- backward-pass primitives ----------------------------------------------------------------------------------------
  * The gradient contractions of every layer are NT GEMMs of transposed operands; these entry points are what the
  * autograd Functions of the host code (iccv19_vqa-cti_amd/autograd.py) are made of.  The reference has no explicit

@@ -180,3 +180,40 @@ def test_bi_pool_k3_dedicated_kernel(B, V, Q, D):
     ref = np.einsum("bvd,bvq,bqd->bd", vt.astype(np.float64), att[:, 1].astype(np.float64), qt.astype(np.float64)).reshape(B, D // 3, 3).sum(-1)
     assert tuple(out.shape) == (B, D // 3)
     assert O.norm_max_err(out.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,G,V,Q,D", [(5, 8, 36, 14, 3072), (3, 2, 36, 12, 1024), (2, 1, 1, 1, 32), (2, 8, 64, 16, 96), (4, 3, 17, 5, 992)])
+def test_biattention_mask_and_softmax_inside_the_logits_launch(B, G, V, Q, D):
+    """cti_biattention_fwd (logits + -inf fill + softmax in the logits kernel's launch; src/attention.py:29-40) against the separate kernels it replaces:
+    both K-split forms (D >= 1024: two workgroups add into a sample's logits, the last one runs the softmax), a fully masked sample (the reference's NaN row),
+    no mask, ragged shapes; twice in a row (the per-sample counters must come back to zero)."""
+    import os
+    ops = cti_amd.ops
+    g = torch.Generator().manual_seed(B * 31 + D)
+    vt = torch.randn(B, V, D, generator=g).to(DEV); qt = torch.randn(B, Q, D, generator=g).to(DEV)
+    h = (torch.randn(G, D, generator=g) / 8).to(DEV); hb = torch.randn(G, generator=g).to(DEV); hs = torch.tensor([0.7], device=DEV)
+    mask = (torch.rand(B, V, generator=g) < 0.3).to(torch.uint8)
+    mask[0] = 1                                                           # sample 0: every object row masked
+    if B > 1:
+        mask[1] = 0
+    mask = mask.to(DEV)
+    old = ops.get_precision()
+    try:
+        ops.set_precision("bf16x3")
+        for m in (mask, None):
+            os.environ["CTI_NO_BIATT_FUSED"] = "1"
+            p_ref, l_ref = ops.biattention_forward(vt, qt, h, hs, hb, m)
+            os.environ["CTI_NO_BIATT_FUSED"] = "0"
+            for _ in range(2):
+                p, l = ops.biattention_forward(vt, qt, h, hs, hb, m)
+                assert torch.equal(torch.isneginf(l), torch.isneginf(l_ref))
+                assert torch.equal(torch.isnan(p), torch.isnan(p_ref))
+                fin = ~torch.isneginf(l_ref)
+                assert float((l[fin] - l_ref[fin]).abs().max()) <= 2e-5 * float(l_ref[fin].abs().max())
+                ok = ~torch.isnan(p_ref)
+                assert float((p[ok] - p_ref[ok]).abs().max()) < 2e-6
+                if m is not None:
+                    assert bool(torch.isnan(p[0]).all())                  # the fully masked sample
+    finally:
+        os.environ.pop("CTI_NO_BIATT_FUSED", None)
+        ops.set_precision(old)
