@@ -106,6 +106,8 @@ SIGNATURES = {
     "cti_paralind_core_planes_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "cti_paralind_core_bwd_planes": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_ranknets_drop_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _int, _vp]),
+    "cti_ranknets_drop_fwd_mfma_workspace_bytes": (_sz, [_int, _int, _int]),
+    "cti_ranknets_drop_fwd_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _int, _int, _vp, _sz, _vp]),
     "cti_ranknets_drop_dw": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _vp]),
     "cti_ranknets_drop_dx": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, C.c_float, _vp]),
     "cti_masked_softmax_tri_fwd": (_int, [_vp, _vp, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),

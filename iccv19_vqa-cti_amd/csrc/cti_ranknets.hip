@@ -79,6 +79,126 @@ __global__ __launch_bounds__(256) void rn_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// ---- forward on the bf16 matrix cores (round 3; h = 512, hr = 16: the models' widths; every mode but exact fp32) ------------------------------------
+// The fp32-MFMA forward above is bound by its own issue rate (16x16x4 f32: 1/16 of the bf16 rate -- 35 us of MFMA time alone for the visual branch, 186 us
+// measured).  Here the products are bf16 hi / lo split products on the 16x16x16 MFMA (three per pair: fp32-grade, as everywhere else):
+//   * the wave's x fragments are split ONCE into MFMA-ready hi / lo operands (2 + 2 registers per 16-deep K step: the same 128 registers the fp32 form
+//     spends on raw x) and masked per rank with two v_perm_b32 + four v_and_b32 per step (mask bytes x 255 -> byte masks -> 16-bit lane masks);
+//   * W_r arrives PRE-SPLIT (bf16 hi and lo planes written by rn_w_split_kernel into the caller's workspace, 1 MB) through LDS-DMA into a double-buffered
+//     [plane][16 rows][1 056 B] image shared by the workgroup's four row tiles: 4x less L2 traffic than per-wave global fragments (590 MB per launch
+//     otherwise), rows 264 dwords apart so that the 8-B fragment reads of 16 rows x 4 K quarters take the minimum two LDS passes.
+typedef short rn_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned rn_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int RNM_PITCH = 1056;                                      // bytes between W rows in LDS (h = 512 bf16 + 32)
+constexpr int RNM_BUF = 2 * 16 * RNM_PITCH;                          // one rank: hi plane + lo plane
+
+__global__ __launch_bounds__(256) void rn_w_split_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wh, unsigned short* __restrict__ Wl, int64_t n, int h) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 w = ld4(W + i);
+    const float v[4] = {w.x, w.y, w.z, w.w};
+    unsigned short hb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = static_cast<__bf16>(v[e]);
+        hb[e] = __builtin_bit_cast(unsigned short, hh);
+        lb[e] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v[e] - static_cast<float>(hh)));
+    }
+    // K order of the planes: inside every 64-deep group the 4-element pieces are stored (i', kq)-major instead of (kq, i')-major -- piece (kq, i') = elements
+    // 16 kq + 4 i' .. + 3 of the group goes to position 16 i' + 4 kq -- so that MFMA step s = 4 j + i' finds the four K quarters' pieces side by side (the
+    // conflict-free LDS read) while lane quarter kq multiplies x[64 j + 16 kq + 4 i' ..]: its FOUR steps' mask bytes are then one contiguous 16-B load
+    const int64_t row = i / h;
+    const int k0 = (int)(i - row * h), grp = k0 >> 6, rem = k0 & 63, kq = rem >> 4, ip = (rem & 15) >> 2;
+    const int64_t o = row * h + grp * 64 + ip * 16 + kq * 4;
+    *reinterpret_cast<uint2*>(Wh + o) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+    *reinterpret_cast<uint2*>(Wl + o) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void rn_fwd_mfma_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, const unsigned short* __restrict__ Wh,
+                                                          const unsigned short* __restrict__ Wl, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int64_t rows, int R, float inv_keep, int relu, int r_per) {
+    constexpr int h = 512, hr = 16, NS = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][hi | lo][16 rows][RNM_PITCH]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wid) * 16;
+    const int64_t m = tile0 + l15;                                   // the row this lane feeds as the A operand
+    const bool mok = m < rows;                                       // (no early exit: every wave takes part in the DMA and the barriers)
+    const int64_t mc = mok ? m : rows - 1;
+    rn_u32x2 xh[NS], xl[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float4 v4 = ld4(x + mc * h + (s >> 2) * 64 + 16 * kq + 4 * (s & 3));       // step s = 4 j + i': this lane's K quartet is 64 j + 16 kq + 4 i' ..
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        unsigned hb[4], lb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 hh = static_cast<__bf16>(v[e]);
+            hb[e] = __builtin_bit_cast(unsigned short, hh);
+            lb[e] = TERMS == 3 ? (unsigned)__builtin_bit_cast(unsigned short, static_cast<__bf16>(v[e] - static_cast<float>(hh))) : 0u;
+        }
+        xh[s] = rn_u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+        xl[s] = rn_u32x2{lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+    }
+    const int r_lo = blockIdx.y * r_per, r_hi = min(R, r_lo + r_per);
+    // W_r: 32 pieces of 1 KiB (plane, row), eight per wave, one LDS-DMA instruction each (64 lanes x 16 B = one 512-element row of a plane)
+    auto dma_w = [&](int r, int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = wid * 8 + u, plane = id >> 4, row = id & 15;
+            if (TERMS == 1 && plane) continue;
+            const unsigned short* src = (plane ? Wl : Wh) + ((int64_t)r * hr + row) * h + lane * 8;
+            char* dst = smem + buf * RNM_BUF + (plane * 16 + row) * RNM_PITCH;              // wave-uniform; the hardware adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    dma_w(r_lo, 0);
+    const int ldy = R * hr;
+    for (int r = r_lo; r < r_hi; ++r) {
+        const int buf = (r - r_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of W_r have landed
+        __syncthreads();                                                 // everyone's have; and everyone is done with the other buffer
+        if (r + 1 < r_hi) dma_w(r + 1, buf ^ 1);
+        const uint8_t* mp = mask + ((int64_t)r * rows + mc) * h + 16 * kq;
+        const char* wb = smem + buf * RNM_BUF + l15 * RNM_PITCH + kq * 8;
+        rf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        uint4 mq[NS / 4];
+#pragma unroll
+        for (int j = 0; j < NS / 4; ++j) mq[j] = *reinterpret_cast<const uint4*>(mp + j * 64);       // the mask bytes of four steps per 16-B load
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned mq4[4] = {mq[s >> 2].x, mq[s >> 2].y, mq[s >> 2].z, mq[s >> 2].w};
+            const unsigned mk = mq4[s & 3];                                                  // four mask bytes (0 / 1) of this lane's k quartet
+            const unsigned t = mk * 255u;                                                    // 0x00 / 0xFF per byte
+            const unsigned m01 = __builtin_amdgcn_perm(t, t, 0x01010000u), m23 = __builtin_amdgcn_perm(t, t, 0x03030202u);
+            const rn_u32x2 ahu = {xh[s][0] & m01, xh[s][1] & m23};
+            const rn_s16x4 ah = __builtin_bit_cast(rn_s16x4, ahu);
+            const rn_s16x4 bh = *reinterpret_cast<const rn_s16x4*>(wb + s * 32);
+            if (TERMS == 3) {
+                const rn_u32x2 alu = {xl[s][0] & m01, xl[s][1] & m23};
+                const rn_s16x4 al = __builtin_bit_cast(rn_s16x4, alu);
+                const rn_s16x4 bl = *reinterpret_cast<const rn_s16x4*>(wb + 16 * RNM_PITCH + s * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc, 0, 0, 0);
+        }
+        {                                                                // C/D: column = lane & 15 (n), rows 4 * (lane >> 4) + i
+            const float sc = scale[r] * inv_keep, bb = bias ? bias[r * hr + l15] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = tile0 + 4 * kq + i;
+                if (row < rows) {
+                    float v = fmaf(acc[i], sc, bb);
+                    if (relu) v = relu_nan(v);
+                    y[row * ldy + r * hr + l15] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradient: one workgroup per (64 input columns, rank); its 16 waves split the rows and meet in LDS in a fixed order ---------
 __global__ __launch_bounds__(1024) void rn_dw_kernel(const float* __restrict__ dzs, const float* __restrict__ x, const uint8_t* __restrict__ mask,
                                                      float* __restrict__ G, int64_t rows, int h, int R, int hr, float inv_keep, int64_t rows_per_wave) {
@@ -229,6 +349,53 @@ extern "C" int cti_ranknets_drop_fwd(const float* x, const uint8_t* mask, const 
     if (h <= 64) CTI_RNF(4); else if (h <= 128) CTI_RNF(8); else if (h <= 256) CTI_RNF(16); else CTI_RNF(32);
 #undef CTI_RNF
     return launch_status("cti_ranknets_drop_fwd");
+}
+
+// The same forward on the bf16 matrix cores (rn_fwd_mfma_kernel): h = 512, hr = 16, prec = CTI_PREC_BF16X3 (three split products per pair) or CTI_PREC_BF16 (one).
+// workspace: cti_ranknets_drop_fwd_mfma_workspace_bytes(h, R, hr) bytes for the bf16 hi / lo planes of W.  CTI_E_UNSUPPORTED (nothing launched, no message)
+// for other widths, the exact-fp32 mode or unaligned operands: the caller takes cti_ranknets_drop_fwd.
+extern "C" size_t cti_ranknets_drop_fwd_mfma_workspace_bytes(int h, int R, int hr) {
+    if (h <= 0 || R <= 0 || hr <= 0) return 0;
+    return 2 * sizeof(unsigned short) * (size_t)R * hr * h + 256;
+}
+
+extern "C" int cti_ranknets_drop_fwd_mfma(const float* x, const uint8_t* mask, const float* W, const float* scale, const float* bias, float* y,
+                                          int64_t rows, int h, int R, int hr, float p, int relu, int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(mask); CTI_REQUIRE_PTR(W); CTI_REQUIRE_PTR(scale); CTI_REQUIRE_PTR(y);
+    CTI_REQUIRE(rows > 0 && h > 0 && R > 0 && hr > 0 && p >= 0.f && p < 1.f, CTI_E_SHAPE, "cti_ranknets_drop_fwd_mfma: rows=%lld h=%d R=%d hr=%d p=%f",
+                (long long)rows, h, R, hr, p);
+    if (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16) return CTI_E_UNSUPPORTED;
+    if (h != 512 || hr != 16 || R > 65535 || (rows + 63) / 64 > 0x7fffffffLL || !aligned16(x) || !aligned16(W) || (reinterpret_cast<uintptr_t>(mask) & 15))
+        return CTI_E_UNSUPPORTED;
+    CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(workspace_bytes >= cti_ranknets_drop_fwd_mfma_workspace_bytes(h, R, hr) && aligned16(workspace), CTI_E_WORKSPACE,
+                "cti_ranknets_drop_fwd_mfma: workspace too small or not 16-B aligned");
+    const int64_t nW = (int64_t)R * hr * h;
+    unsigned short* Wh = static_cast<unsigned short*>(workspace);
+    unsigned short* Wl = Wh + nW;
+    hipLaunchKernelGGL(rn_w_split_kernel, dim3((unsigned)((nW / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), W, Wh, Wl, nW, h);
+    int rc = launch_status("cti_ranknets_drop_fwd_mfma/split"); if (rc) return rc;
+    const int64_t wgs = (rows + 63) / 64;
+    int rs = 1;                                                      // split the ranks until every CU has two workgroups (67 KB of LDS each)
+    while (rs < R && wgs * rs < 512) rs *= 2;
+    const int r_per = (R + rs - 1) / rs;
+    const dim3 grid((unsigned)wgs, (unsigned)((R + r_per - 1) / r_per));
+    const float inv_keep = 1.f / (1.f - p);
+    const size_t lds = 2 * (size_t)RNM_BUF;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rn_fwd_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(rn_fwd_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "cti_ranknets_drop_fwd_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
+    if (prec == CTI_PREC_BF16X3)
+        hipLaunchKernelGGL(rn_fwd_mfma_kernel<3>, grid, dim3(256), lds, as_stream(stream), x, mask, Wh, Wl, scale, bias, y, rows, R, inv_keep, relu, r_per);
+    else
+        hipLaunchKernelGGL(rn_fwd_mfma_kernel<1>, grid, dim3(256), lds, as_stream(stream), x, mask, Wh, Wl, scale, bias, y, rows, R, inv_keep, relu, r_per);
+    return launch_status("cti_ranknets_drop_fwd_mfma");
 }
 
 extern "C" int cti_ranknets_drop_dw(const float* dzs, const float* x, const uint8_t* mask, float* G, int64_t rows, int h, int R, int hr, float p,

@@ -1005,6 +1005,17 @@ def ranknets_drop_fwd(x2, mask, wv, scale, bias, R, p, relu):
     rows, h = x2.shape
     hr = wv.shape[0] // R
     y = torch.empty((rows, R * hr), device=x2.device, dtype=torch.float32)
+    pr = _prec(None)
+    if pr != L.PREC_F32 and rows > 0 and _os.environ.get("CTI_NO_RANKNETS_MFMA", "0") != "1":       # bf16 split products on the matrix cores (h = 512, hr = 16)
+        lib = L.lib()
+        wsb = lib.cti_ranknets_drop_fwd_mfma_workspace_bytes(h, R, hr)
+        ws = torch.empty(wsb, device=x2.device, dtype=torch.uint8)
+        rc = lib.cti_ranknets_drop_fwd_mfma(_req(x2, "x").data_ptr(), mask.data_ptr(), _req(wv, "W").data_ptr(), _req(scale, "scale").data_ptr(), _ptr(bias),
+                                            y.data_ptr(), rows, h, R, hr, float(p), 1 if relu else 0, L.PREC_BF16 if pr == L.PREC_BF16 else L.PREC_BF16X3,
+                                            ws.data_ptr(), wsb, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_ranknets_drop_fwd_mfma")
+            return y
     rc = L.lib().cti_ranknets_drop_fwd(_req(x2, "x").data_ptr(), mask.data_ptr(), _req(wv, "W").data_ptr(), _req(scale, "scale").data_ptr(),
                                        _ptr(bias), y.data_ptr(), rows, h, R, hr, float(p), 1 if relu else 0, _stream())
     if rc == L.E_UNSUPPORTED:

@@ -376,6 +376,15 @@ int cti_paralind_core_bwd_planes(const float* dout, const void* Mh, const void* 
  * (fwd: h <= 512) or unaligned operands return CTI_E_UNSUPPORTED without a message: the caller takes cti_dropout(period) + cti_gemm_nt. */
 int cti_ranknets_drop_fwd(const float* x, const uint8_t* mask, const float* W, const float* scale, const float* bias, float* y, int64_t rows,
                           int h, int R, int hr, float p, int relu, void* stream);
+
+/* cti_ranknets_drop_fwd on the bf16 matrix cores (round 3): the products as bf16 hi / lo split products on the 16x16x16 MFMA (prec = CTI_PREC_BF16X3: three per
+ * pair, fp32-grade; CTI_PREC_BF16: one), x split once per wave and masked per rank in registers, W pre-split into `workspace`
+ * (cti_ranknets_drop_fwd_mfma_workspace_bytes(h, R, hr) bytes, 16-B aligned) and shared by a workgroup's row tiles through LDS.  Same arguments and result as
+ * cti_ranknets_drop_fwd.  Returns CTI_E_UNSUPPORTED (nothing launched, no message) unless h = 512 and hr = 16 (the reference's --h_mm 512 --rank 32,
+ * src/FFOE/main.py:61-64), for prec = CTI_PREC_F32 and for unaligned operands: the caller then takes cti_ranknets_drop_fwd. */
+size_t cti_ranknets_drop_fwd_mfma_workspace_bytes(int h, int R, int hr);
+int cti_ranknets_drop_fwd_mfma(const float* x, const uint8_t* mask, const float* W, const float* scale, const float* bias, float* y,
+                               int64_t rows, int h, int R, int hr, float p, int relu, int prec, void* workspace, size_t workspace_bytes, void* stream);
 int cti_ranknets_drop_dw(const float* dzs, const float* x, const uint8_t* mask, float* G, int64_t rows, int h, int R, int hr, float p,
                          void* stream);
 int cti_ranknets_drop_dx(const float* dzs, const float* W, const uint8_t* mask, float* dx, int64_t rows, int h, int R, int hr, float p,

@@ -246,3 +246,32 @@ def test_mbuild_backward_on_the_matrix_cores(B, V, Q, R, prec):
         assert e < tol, (n_, e)
         e2 = float((exact.cpu().double() - ref).abs().max() / ref.abs().max())
         assert e2 < 1e-5, (n_, "exact", e2)
+
+
+@pytest.mark.parametrize("R,rows", [(2, 1), (5, 130), (32, 77), (3, 64), (32, 300)])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_rank_net_forward_on_the_matrix_cores(R, rows, prec):
+    """cti_ranknets_drop_fwd_mfma (h = 512, hr = 16: the models' widths) against float64 with the mask applied by hand and against the fp32-MFMA kernel it
+    replaces: one row, row counts around the 64-row workgroup, one rank group and several (R = 32 splits over workgroups), with and without ReLU."""
+    ops = cti_amd.pkg.ops
+    hr, h, p = 16, 512, 0.3
+    g = torch.Generator().manual_seed(R * 1000 + rows)
+    x = torch.randn(rows, h, generator=g); W = torch.randn(R * hr, h, generator=g) / 4
+    scale = torch.rand(R, generator=g) + 0.5; bias = torch.randn(R * hr, generator=g)
+    mask = ops.dropout_mask((R, rows, h), p, torch.device(DEV))
+    Xd = x.double()[None] * (mask.cpu().double() / (1 - p))
+    old = ops.get_precision()
+    try:
+        for relu in (True, False):
+            ops.set_precision(prec)
+            y = ops.ranknets_drop_fwd(x.to(DEV), mask, W.to(DEV), scale.to(DEV), bias.to(DEV), R, p, relu)
+            ops.set_precision("fp32")
+            y32 = ops.ranknets_drop_fwd(x.to(DEV), mask, W.to(DEV), scale.to(DEV), bias.to(DEV), R, p, relu)
+            ref = torch.cat([scale[r].double() * (Xd[r] @ W[r * hr:(r + 1) * hr].double().t()) + bias[r * hr:(r + 1) * hr].double() for r in range(R)], 1)
+            if relu:
+                ref = torch.relu(ref)
+            den = float(ref.abs().max())
+            assert float((y32.cpu().double() - ref).abs().max()) / den < 2e-6
+            assert float((y.cpu().double() - ref).abs().max()) / den < (2e-5 if prec == "bf16x3" else 2e-2), (prec, relu)
+    finally:
+        ops.set_precision(old)
