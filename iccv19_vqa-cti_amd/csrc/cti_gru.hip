@@ -95,10 +95,20 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 // (~19 us) + a partial-summing gate kernel (~5 us).
 typedef float g_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int GF_NST = 4, GF_SLOT = 16384;                         // slot: A [plane][chunk][64 rows][32 B] = 8 KiB, B likewise (48 of 64 rows used)
+#ifndef CTI_GF_KPB
+#define CTI_GF_KPB 1
+#endif
+constexpr int GF_KPB = CTI_GF_KPB;                                   // 32-deep K sub-steps per barrier of the fused step kernel (ring: GF_NST slots of GF_KPB sub-slots)
+#ifndef CTI_GF_NST
+#define CTI_GF_NST 4
+#endif
+constexpr int GF_NST = CTI_GF_NST, GF_SLOT = 16384;                         // slot: A [plane][chunk][64 rows][32 B] = 8 KiB, B likewise (48 of 64 rows used)
 template <int N> __device__ __forceinline__ void gf_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TERMS>
+// KPB (round 3 experiment): 32-deep K sub-steps per barrier (a slot holds KPB sub-slots of the same layout).  Measured on the MC model forward (16 GRU steps
+// on its critical path; alternating runs on one box): KPB 1 / 2 / 4 (2-slot ring) / 2 (3-slot ring) = 0.913-0.923 / 0.923-0.927 / 0.927-0.932 / 0.922-0.924 ms:
+// the step kernel (11.7 us at B = 256, H = 1 024) is not bound by its 32 barrier rounds; default stays 1.
+template <int TERMS, int KPB>
 __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
                                                              const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl, int64_t pitchW,
                                                              int nsteps, const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ b_hh,
@@ -126,17 +136,21 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
         ldso[u] = opnd * 8192 + plane * 4096 + chunk * 2048 + half * 1024;
     }
     const int64_t kstepH = 2 * pitchH, kstepW = 2 * pitchW;       // elements per 32-deep K step
-    auto issue = [&](int pos, int ks) {
+    constexpr int SLOT = KPB * GF_SLOT;
+    auto issue = [&](int pos, int kg) {                            // kg: group of KPB sub-steps
+#pragma unroll
+        for (int sub = 0; sub < KPB; ++sub)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = wid * 4 + u;
             if (NPL == 1 && ((q >> 2) & 1)) continue;              // plain bf16: the lo planes are not staged
-            const unsigned short* s_ = src[u] + (int64_t)ks * ((q >> 3) ? kstepW : kstepH);
+            const unsigned short* s_ = src[u] + (int64_t)(kg * KPB + sub) * ((q >> 3) ? kstepW : kstepH);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
-                                             (__attribute__((address_space(3))) void*)(gsm + pos * GF_SLOT + ldso[u]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(gsm + pos * SLOT + sub * GF_SLOT + ldso[u]), 16, 0, 0);
         }
     };
-    constexpr int PER = 4;                                         // DMA instructions per wave and slot (plain bf16: waves 0 and 2 issue 4, waves 1 and 3 -- the lo planes -- none)
+    constexpr int PER = 4 * KPB;                                   // DMA instructions per wave and slot (plain bf16: waves 0 and 2 issue them, waves 1 and 3 -- the lo planes -- none)
+    nsteps /= KPB;                                                 // barrier groups (the launcher checks divisibility)
     g_f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -151,7 +165,9 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
         if (rem >= GF_NST - 2) gf_wait<(GF_NST - 2) * PER>(); else if (rem == 1) gf_wait<PER>(); else gf_wait<0>();
         __builtin_amdgcn_s_barrier();
         if (ks + GF_NST - 1 < nsteps) issue(pos == 0 ? GF_NST - 1 : pos - 1, ks + GF_NST - 1);
-        const char* s = gsm + pos * GF_SLOT;
+#pragma unroll
+        for (int sub = 0; sub < KPB; ++sub) {
+        const char* s = gsm + pos * SLOT + sub * GF_SLOT;
         const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(s + fa);
         g_bf16x8 al = ah;
         if (TERMS == 3) al = *reinterpret_cast<const g_bf16x8*>(s + fa + 4096);
@@ -165,6 +181,7 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[g], 0, 0, 0);
             }
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[g], 0, 0, 0);
+        }
         }
         pos = pos == GF_NST - 1 ? 0 : pos + 1;
     }
@@ -309,8 +326,10 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (attr_dev != dev) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3, GF_KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_KPB * GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, GF_KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_KPB * GF_NST * GF_SLOT);
             if (e != hipSuccess) return fail((int)e, "cti_gru_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_dev = dev;
         }
@@ -319,11 +338,14 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         const int cur = t & 1, prev = cur ^ 1;
         if (fused && t) {
             const dim3 grid((H + 15) / 16, (B + 63) / 64);
-#define CTI_GF(TR) hipLaunchKernelGGL(gru_step_fused_kernel<TR>, grid, dim3(256), GF_NST * GF_SLOT, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, \
+#define CTI_GF(TR) CTI_GF2(TR, 1)
+#define CTI_GF2(TR, KP) hipLaunchKernelGGL((gru_step_fused_kernel<TR, KP>), grid, dim3(256), KP * GF_NST * GF_SLOT, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, \
                                       gi + (size_t)t * H3, (int64_t)T * H3, b_hh, h_tm + (size_t)(t - 1) * B * H, out + (size_t)t * H, (int64_t)T * H,                     \
                                       h_tm + (size_t)t * B * H, save ? save + (size_t)t * B * 5 * H : nullptr, hp_[cur], hl_[cur], rh * 16, B, H)
-            if (terms == 3) CTI_GF(3); else CTI_GF(1);
+            if ((KpH / 32) % GF_KPB == 0 && KpH / 32 >= 2 * GF_KPB) { if (terms == 3) CTI_GF2(3, GF_KPB); else CTI_GF2(1, GF_KPB); }
+            else { if (terms == 3) CTI_GF(3); else CTI_GF(1); }
 #undef CTI_GF
+#undef CTI_GF2
             rc = launch_status("cti_gru_forward/fused step"); if (rc) return rc;
             continue;
         }

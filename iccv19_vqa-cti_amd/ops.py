@@ -693,7 +693,7 @@ def biattention_forward(vt, qt, h, h_scale, h_bias, mask):
             _req(mask, "mask", torch.uint8)
             mask = mask.contiguous()
         dev = vt.device
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())       # per stream: two streams must not share counters
         cnt = _bi_counters.get(key)
         if cnt is None or cnt.numel() < B:
             cnt = _bi_counters[key] = torch.zeros(max(B, 4096), device=dev, dtype=torch.int32)      # zero at entry, zeroed again by the kernel's last arrivers
