@@ -989,7 +989,8 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
             const int e = lane + 64 * i;
             x[i] = ninf;
             if (e < n) {
-                const float val = __hip_atomic_load(lg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written by atomics / another workgroup: from the L2
+                const float val = lg[e];       // plain loads behind the acquire fence above (it invalidates this CU's L1): sixteen in flight at once -- as agent-scope atomic loads they were
+                                               // issued one L2 round trip at a time, 37 us of tail
                 const bool masked = sm_mask != nullptr && sm_mask[(int64_t)b * V + e / Q] != 0;
                 x[i] = masked ? ninf : val;
                 if (masked) lg[e] = ninf;

@@ -686,7 +686,10 @@ def biattention_forward(vt, qt, h, h_scale, h_bias, mask):
     B, V, D = vt.shape
     Q = qt.shape[1]
     G = h.shape[0]
-    if B * G * V * Q > 0 and get_precision() != "fp32" and _os.environ.get("CTI_NO_BIATT_FUSED", "0") != "1":
+    # OFF by default: measured SLOWER than the two launches it replaces (tools/bench_pools.py, B = 256, G = 8, D = 3 072: 145 against 108 us) -- the release
+    # fence in front of the per-sample counter makes every workgroup wait for its 4 000 atomic adds to be acknowledged by the L2, which a kernel boundary
+    # overlaps with the next launch.  CTI_BIATT_FUSED=1 enables it (tests do).
+    if B * G * V * Q > 0 and get_precision() != "fp32" and _os.environ.get("CTI_BIATT_FUSED", "0") == "1":
         vt, qt, h = vt.contiguous(), qt.contiguous(), h.contiguous()
         hb = h_bias.contiguous().view(-1) if h_bias is not None else None
         if mask is not None:

@@ -275,3 +275,30 @@ def test_rank_net_forward_on_the_matrix_cores(R, rows, prec):
             assert float((y.cpu().double() - ref).abs().max()) / den < (2e-5 if prec == "bf16x3" else 2e-2), (prec, relu)
     finally:
         ops.set_precision(old)
+
+
+def test_matrix_core_backward_kernels_at_the_full_training_shapes():
+    """Whole-launch coverage at the shapes of the data-parallel step (BASELINE configs[4]: 256 rows per GPU): the MFMA M-build backward (every (rank, chunk)
+    workgroup: 32 x 8) and the MFMA rank-net forward (every 64-row workgroup and rank group of the visual branch, 9 216 rows) against the exact-fp32 kernels they
+    replace -- all outputs, <= 2e-5 of the largest value."""
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(77)
+    B, V, Q, R, hr, G = 256, 36, 14, 32, 16, 2
+    Vr = torch.randn(B, V, R * hr, generator=g).to(DEV); Qr = torch.randn(B, Q, R * hr, generator=g).to(DEV)
+    T_ = torch.randn(R, hr, hr, hr, G, generator=g).to(DEV); dM = torch.randn(B, V, Q, G, R * hr, generator=g).to(DEV)
+    rows, h, p = B * V, 512, 0.3
+    x = torch.randn(rows, h, generator=g).to(DEV); W = (torch.randn(R * hr, h, generator=g) / 4).to(DEV)
+    scale = (torch.rand(R, generator=g) + 0.5).to(DEV); bias = torch.randn(R * hr, generator=g).to(DEV)
+    mask = ops.dropout_mask((R, rows, h), p, torch.device(DEV))
+    old = ops.get_precision()
+    try:
+        ops.set_precision("bf16x3")
+        got = ops.paralind_mbuild_bwd(dM, Vr, Qr, T_) + (ops.ranknets_drop_fwd(x, mask, W, scale, bias, R, p, True),)
+        ops.set_precision("fp32")
+        ref = ops.paralind_mbuild_bwd(dM, Vr, Qr, T_) + (ops.ranknets_drop_fwd(x, mask, W, scale, bias, R, p, True),)
+    finally:
+        ops.set_precision(old)
+    for a, b_, n_ in zip(got, ref, ("dVr", "dQr", "dT", "rank nets y")):
+        assert torch.isfinite(a).all(), n_
+        e = float((a - b_).abs().max() / b_.abs().max())
+        assert e < 2e-5, (n_, e)

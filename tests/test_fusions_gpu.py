@@ -201,9 +201,9 @@ def test_biattention_mask_and_softmax_inside_the_logits_launch(B, G, V, Q, D):
     try:
         ops.set_precision("bf16x3")
         for m in (mask, None):
-            os.environ["CTI_NO_BIATT_FUSED"] = "1"
+            os.environ["CTI_BIATT_FUSED"] = "0"
             p_ref, l_ref = ops.biattention_forward(vt, qt, h, hs, hb, m)
-            os.environ["CTI_NO_BIATT_FUSED"] = "0"
+            os.environ["CTI_BIATT_FUSED"] = "1"
             for _ in range(2):
                 p, l = ops.biattention_forward(vt, qt, h, hs, hb, m)
                 assert torch.equal(torch.isneginf(l), torch.isneginf(l_ref))
@@ -215,5 +215,5 @@ def test_biattention_mask_and_softmax_inside_the_logits_launch(B, G, V, Q, D):
                 if m is not None:
                     assert bool(torch.isnan(p[0]).all())                  # the fully masked sample
     finally:
-        os.environ.pop("CTI_NO_BIATT_FUSED", None)
+        os.environ.pop("CTI_BIATT_FUSED", None)
         ops.set_precision(old)

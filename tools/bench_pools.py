@@ -61,6 +61,14 @@ def main(reps=20):
     mask = ops.zero_row_mask(v)
     lg = torch.randn(B, 8, V, Q, device=DEV)
     report("masked_softmax_bi G=8", timeit(lambda: ops.masked_softmax_bi_(lg.clone(), mask), reps), 2 * f * B * 8 * V * Q, note="includes a clone of the logits")
+    # round 3: mask + softmax in the logits kernel's last workgroup per sample (cti_biattention_fwd) -- built, parity-green, measured SLOWER than two launches; off by default
+    import os
+    os.environ["CTI_BIATT_FUSED"] = "0"
+    t_sep = timeit(lambda: ops.biattention_forward(vt3, qt3, h, hs, hb, mask), reps)
+    os.environ["CTI_BIATT_FUSED"] = "1"
+    t_fus = timeit(lambda: ops.biattention_forward(vt3, qt3, h, hs, hb, mask), reps)
+    os.environ.pop("CTI_BIATT_FUSED")
+    report("BiAttention logits + mask + softmax, ONE launch (G=8)", t_fus, f * (B * (V * D3 + Q * D3 + 2 * 8 * V * Q) + 8 * D3), Q=Q, D=D3, G=8, separate_launches_us=round(t_sep, 2))
     for (Q, A, tag) in ((14, 3, "C4"), (14, 3129, "C2")):
         Bc = B if A < 100 else 64
         lg = torch.randn(Bc, V, Q, A, 2, device=DEV)
