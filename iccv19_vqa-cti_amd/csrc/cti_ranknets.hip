@@ -21,7 +21,10 @@ typedef float rf32x4 __attribute__((ext_vector_type(4)));
 // Every load below is UNCONDITIONAL from a clamped (always valid) address; out-of-range lanes are zeroed by a select on the value, or
 // left as garbage where the result is never stored (a predicated load costs an exec-mask region and a wait of its own per instruction).
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ uchar4 ldm4(const uint8_t* p) { return *reinterpret_cast<const uchar4*>(p); }
+#ifndef CTI_RN_ABL
+#define CTI_RN_ABL 0            // timing-only ablation (wrong results): 1 = no mask loads (every kernel takes an all-ones mask)
+#endif
+__device__ __forceinline__ uchar4 ldm4(const uint8_t* p) { if (CTI_RN_ABL & 1) return make_uchar4(1, 1, 1, 1); return *reinterpret_cast<const uchar4*>(p); }
 __device__ __forceinline__ float4 ld4p(const float* p, bool ok) { return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ uchar4 ldm4p(const uint8_t* p, bool ok) { return ok ? *reinterpret_cast<const uchar4*>(p) : make_uchar4(0, 0, 0, 0); }
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void rn_fwd_mfma_kernel(const float* __restric
         rf32x4 acc = {0.f, 0.f, 0.f, 0.f};
         uint4 mq[NS / 4];
 #pragma unroll
-        for (int j = 0; j < NS / 4; ++j) mq[j] = *reinterpret_cast<const uint4*>(mp + j * 64);       // the mask bytes of four steps per 16-B load
+        for (int j = 0; j < NS / 4; ++j) mq[j] = (CTI_RN_ABL & 1) ? make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u) : *reinterpret_cast<const uint4*>(mp + j * 64);       // the mask bytes of four steps per 16-B load
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const unsigned mq4[4] = {mq[s >> 2].x, mq[s >> 2].y, mq[s >> 2].z, mq[s >> 2].w};
@@ -376,8 +379,9 @@ extern "C" int cti_ranknets_drop_fwd_mfma(const float* x, const uint8_t* mask, c
     hipLaunchKernelGGL(rn_w_split_kernel, dim3((unsigned)((nW / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), W, Wh, Wl, nW, h);
     int rc = launch_status("cti_ranknets_drop_fwd_mfma/split"); if (rc) return rc;
     const int64_t wgs = (rows + 63) / 64;
-    int rs = 1;                                                      // split the ranks until every CU has two workgroups (67 KB of LDS each)
-    while (rs < R && wgs * rs < 512) rs *= 2;
+    int rs = 1;                                                      // split the ranks over workgroups while they all stay co-resident (two per CU: 67 KB of LDS each)
+    static const long long rn_wgs = [] { const char* e = getenv("CTI_RN_MFMA_WGS"); return e ? atoll(e) : 512LL; }();      // A/B knob
+    while (rs < R && wgs * rs * 2 <= rn_wgs) rs *= 2;
     const int r_per = (R + rs - 1) / rs;
     const dim3 grid((unsigned)wgs, (unsigned)((R + r_per - 1) / r_per));
     const float inv_keep = 1.f / (1.f - p);
