@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
     };
     constexpr int PER = 4 * KPB;                                   // DMA instructions per wave and slot (plain bf16: waves 0 and 2 issue them, waves 1 and 3 -- the lo planes -- none)
     nsteps /= KPB;                                                 // barrier groups (the launcher checks divisibility)
+#ifndef CTI_GF_ABL
+#define CTI_GF_ABL 0            // timing-only ablations (wrong results): 1 = no K loop (launch + epilogue only), 2 = K loop over a quarter of K
+#endif
+    if (CTI_GF_ABL & 1) nsteps = 0;
+    if (CTI_GF_ABL & 2) nsteps /= 4;
     g_f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
