@@ -63,6 +63,11 @@ __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __rest
     if (row < rows) f6_encode_row32_lds(st + lane * 36, p, f6_prow(p, row), kb);
 }
 
+// (Round 3, measured and removed: a row-walking form -- one wave keeps its 64 rows and walks all their K blocks, block kb + 1 loaded into registers under the
+// encoding of block kb, so that the two pieces of a straddled cache line are read by the same CU (the counters show 1.35x the algorithmic read bytes at an L2 hit
+// rate of 63 % for the form above) -- 0.446 against 0.388 ms on the configs[1] `a`, 4.75 against 4.69 ms per step: Kb times fewer, longer-lived waves at three
+// per SIMD keep fewer bytes in flight than the many short ones.)
+
 // ---- GEMM --------------------------------------------------------------------------------------------------------------
 struct F6P {
     const char* AH; const char* AFL; const char* AS;
