@@ -151,7 +151,11 @@ struct Geo {
     static constexpr int NCONS = WM * WN * 64, NTHR = NCONS + LW * 64;
     static constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
     static constexpr int STAGE = PL * (A_PLANE + B_PLANE);             // [A_hi | A_lo | B_hi | B_lo]  (PL = 1: [A_hi | B_hi])
-    static constexpr int LDS = NST * STAGE;
+    // the staged epilogues park (TM*32) x 64 floats per consumer wave in the idle ring: a hi-only ring (PL = 1) of few slots is SMALLER than that -- the launch
+    // must ask for the larger of the two (out-of-range LDS writes are dropped and reads return 0: with 4 or 6 slots of 16 KiB the last waves' rows of every
+    // 256 x 256 tile came out as bias only in the plain-bf16 mode; found in round 3 by checking every row of a 9 216-row product)
+    static constexpr int EPI_STAGE = WM * WN * TM * 32 * 64 * 4;
+    static constexpr int LDS = NST * STAGE > EPI_STAGE ? NST * STAGE : EPI_STAGE;
 };
 
 // LDS-DMA of this wave's share of one operand's slice pair (hi plane rows, then lo plane rows: 2*ROWS/32 pieces of 1 KiB =
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     if (EPI == EPI_F16F6) {
         // Per 32-column MFMA tile the wave parks its (TM*32) x 32 block in a private LDS patch ([row][36 floats]: conflict-free 16-B row reads),
         // scale / bias / ReLU applied on the way in; then every lane encodes ONE (row, 32-block) item straight into the f16f6 planes.
-        static_assert(TM * 32 == 64, "one (row, block) item per lane");
+        static_assert(EPI != EPI_F16F6 || TM * 32 == 64, "one (row, block) item per lane");
         float* stg = reinterpret_cast<float*>(smem) + wid * (64 * 36);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -582,7 +586,13 @@ using GeoBig = Geo<4, 2, 2, 4, CTI_LW, 4, CTI_BIG_SPB>;
 #ifndef CTI_BIG1_SPB
 #define CTI_BIG1_SPB 2
 #endif
-using GeoBig1 = Geo<4, 2, 2, 4, CTI_LW, CTI_BIG1_NST, CTI_BIG1_SPB, 1>;
+#ifndef CTI_BIG1_WM            // wave grid and wave tile of the plain-bf16 256 x 256 geometry (experiment knobs: 2,2,4,4 = four waves of 128 x 128, one per SIMD)
+#define CTI_BIG1_WM 4
+#define CTI_BIG1_WN 2
+#define CTI_BIG1_TM 2
+#define CTI_BIG1_TN 4
+#endif
+using GeoBig1 = Geo<CTI_BIG1_WM, CTI_BIG1_WN, CTI_BIG1_TM, CTI_BIG1_TN, CTI_LW, CTI_BIG1_NST, CTI_BIG1_SPB, 1>;
 using GeoMid = Geo<4, 2, 2, 2, CTI_LW, 6, 2>;
 using GeoSmall = Geo<2, 2, 2, 2, (CTI_LW > 2 ? 2 : CTI_LW), 6, 2>;
 

@@ -302,3 +302,25 @@ def test_matrix_core_backward_kernels_at_the_full_training_shapes():
         assert torch.isfinite(a).all(), n_
         e = float((a - b_).abs().max() / b_.abs().max())
         assert e < 2e-5, (n_, e)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 8e-3), ("bf16x3", 2e-5)])
+@pytest.mark.parametrize("M,n,N,K", [(9216, 3, 1024, 2048), (2304, 1, 3072, 2048), (777, 2, 1024, 512)])
+def test_projection_gemm_every_row_at_model_shapes(prec, tol, M, n, N, K):
+    """The hoisted projection GEMMs (cti_gemm_nt_pb: 256 x 256 tiles at these sizes) with EVERY output row checked against float64, per 64-row block of the
+    tile: the plain-bf16 form of that geometry once launched with less LDS than its staged epilogue uses (the last waves' rows of each tile came out as bias
+    only) and nothing looked at those rows -- the model-level checks compare the first samples."""
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(M + n)
+    a = torch.randn(M, K, generator=g).to(DEV); w = (torch.randn(n * N, K, generator=g) / 8).to(DEV); b = torch.randn(n * N, generator=g).to(DEV)
+    old = ops.get_precision()
+    try:
+        ops.set_precision(prec)
+        wp = ops.split_operand(w)
+        y = ops.gemm_nt(a, w, nb1=n, rA1=0, rB1=N, M=M, N=N, bias=b, bias_bs=N, relu=True, B_planes=wp)
+    finally:
+        ops.set_precision(old)
+    ref = torch.relu((a.double() @ w.double().t() + b.double()).view(M, n, N).permute(1, 0, 2))
+    err = (y.double().view(n, M, N) - ref).abs().amax(-1) / ref.abs().max()                  # (n, M)
+    worst = float(err.max())
+    assert worst < tol, (prec, worst, int(err.argmax() % M))

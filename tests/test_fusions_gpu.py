@@ -217,3 +217,29 @@ def test_biattention_mask_and_softmax_inside_the_logits_launch(B, G, V, Q, D):
     finally:
         os.environ.pop("CTI_BIATT_FUSED", None)
         ops.set_precision(old)
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+def test_full_batch_model_forward_agrees_across_precisions_on_every_row(config):
+    """BASELINE configs[2] / [3] at their full batch (256 rows): the plain-bf16 forward (what bench.py times) against the bf16x3 forward on EVERY row -- the
+    oracle check of the bench line looks at the first four samples only, which is how a tile-geometry bug that zeroed the last rows of every 256-row GEMM tile
+    went unseen."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    old = cti_amd.get_precision()
+    try:
+        outs = {}
+        for prec in ("bf16", "bf16x3"):
+            cti_amd.set_precision(prec)
+            torch.manual_seed(5)
+            s = bench.model_setup(config, 256, 0, torch.device(DEV))
+            with torch.no_grad():
+                o = s["fwd"]()
+            outs[prec] = [t.float() for t in (o if isinstance(o, (tuple, list)) else (o,))]
+        for a, b in zip(outs["bf16"], outs["bf16x3"]):
+            assert a.shape == b.shape and torch.isfinite(a).all()
+            per_row = (a - b).abs().flatten(1).amax(1) / b.abs().max()
+            assert float(per_row.max()) < 3e-2, (config, float(per_row.max()), int(per_row.argmax()))
+    finally:
+        cti_amd.set_precision(old)
