@@ -324,3 +324,69 @@ def test_projection_gemm_every_row_at_model_shapes(prec, tol, M, n, N, K):
     err = (y.double().view(n, M, N) - ref).abs().amax(-1) / ref.abs().max()                  # (n, M)
     worst = float(err.max())
     assert worst < tol, (prec, worst, int(err.argmax() % M))
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("bf16x3", 2e-5), ("fp32", 5e-6)])
+@pytest.mark.parametrize("rows,K,N,n_mats", [(9216, 2048, 512, 1), (9216, 512, 512, 32), (3072, 1024, 3072, 1)])
+def test_linear_layer_forward_and_backward_every_entry_at_training_shapes(prec, tol, rows, K, N, n_mats):
+    """WNLinearFn WITHOUT an activation (a ReLU kink would turn 1e-6 forward differences into single-entry gradient flips) at the row counts of the training step:
+    y, dx (cti_gemm_nn), dV (cti_gemm_tn: split-K over the rows), dg and db -- every entry against float64 autograd.  These row counts select the 256-row tiles
+    and the split-K planners that the small fixtures never reach."""
+    AG = cti_amd.pkg.autograd
+    g = torch.Generator().manual_seed(rows + N + n_mats)
+    x = torch.randn(rows, K, generator=g).to(DEV); V = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    gg = (torch.rand(n_mats, generator=g) + 0.5).to(DEV); b = (torch.randn(N, generator=g) * 0.1).to(DEV); dy = torch.randn(rows, N, generator=g).to(DEV)
+    x6, V6, g6, b6 = (t.double().requires_grad_(True) for t in (x, V, gg, b))
+    sc = (g6 / V6.view(n_mats, -1).norm(dim=1)).repeat_interleave(N // n_mats)
+    y6 = x6 @ V6.t() * sc + b6
+    (y6 * dy.double()).sum().backward()
+    old = cti_amd.get_precision()
+    try:
+        cti_amd.set_precision(prec)
+        xs, Vs, gs, bs = (t.clone().requires_grad_(True) for t in (x, V, gg, b))
+        y = AG.WNLinearFn.apply(xs, Vs, gs, bs, False, n_mats)
+        (y * dy).sum().backward()
+    finally:
+        cti_amd.set_precision(old)
+    for got, ref, n_ in ((y, y6.detach(), "y"), (xs.grad, x6.grad, "dx"), (Vs.grad, V6.grad, "dV"), (gs.grad, g6.grad, "dg"), (bs.grad, b6.grad, "db")):
+        e = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert e < (10 * tol if n_ == "dg" else tol), (n_, e)               # dg = <G, V> / g: a scalar left over from a million cancelling terms
+
+
+def test_pools_and_bilinear_logits_every_sample_at_full_batch():
+    """The sum-pools and the bilinear logits at the FFOE / MC shapes with all 256 samples against float64 einsums on the device: these kernels are the same in every
+    precision mode (fp32 VALU / their own MFMA forms), so the cross-precision model tests cannot see them, and the oracle checks of the bench line cover four samples."""
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(9)
+    B, V, D = 256, 36, 1024
+    for (Q, A) in ((14, 3), (12, 6)):
+        vt = torch.randn(B, V, D, generator=g).to(DEV); qt = torch.randn(B, Q, D, generator=g).to(DEV); at = torch.randn(B, A, D, generator=g).to(DEV)
+        att = torch.softmax(torch.randn(B, V * Q * A, 2, generator=g), 1).view(B, V, Q, A, 2).to(DEV)
+        for gl in (0, 1):
+            w = att[..., gl]
+            out = ops.tri_pool(vt, qt, at, w)
+            ref = torch.einsum("bvd,bqd,bad,bvqa->bd", vt.double(), qt.double(), at.double(), w.double())
+            e = ((out.double() - ref).abs().amax(1) / ref.abs().max())
+            assert float(e.max()) < 2e-5, ("tri_pool", Q, A, gl, float(e.max()), int(e.argmax()))
+    Q, D3, G = 14, 3072, 8
+    vt = torch.randn(B, V, D3, generator=g).to(DEV); qt = torch.randn(B, Q, D3, generator=g).to(DEV)
+    w = torch.softmax(torch.randn(B, G, V * Q, generator=g), 2).view(B, G, V, Q).to(DEV)
+    out = ops.bi_pool(vt, qt, w[:, 3], 3)
+    ref = torch.einsum("bvd,bqd,bvq->bd", vt.double(), qt.double(), w[:, 3].double()).view(B, D3 // 3, 3).sum(2)
+    e = ((out.double() - ref).abs().amax(1) / ref.abs().max())
+    assert float(e.max()) < 2e-5, ("bi_pool k=3", float(e.max()), int(e.argmax()))
+    out = ops.bi_pool(vt[..., :1024].contiguous(), qt[..., :1024].contiguous(), w[:, 5], 1)
+    ref = torch.einsum("bvd,bqd,bvq->bd", vt[..., :1024].double(), qt[..., :1024].double(), w[:, 5].double())
+    e = ((out.double() - ref).abs().amax(1) / ref.abs().max())
+    assert float(e.max()) < 2e-5, ("bi_pool k=1", float(e.max()), int(e.argmax()))
+    h = (torch.randn(G, D3, generator=g) / 8).to(DEV); hb = torch.randn(G, generator=g).to(DEV); hs = torch.tensor([0.7], device=DEV)
+    old = cti_amd.get_precision()
+    try:
+        for prec, tol in (("bf16x3", 2e-5), ("fp32", 5e-6)):
+            cti_amd.set_precision(prec)
+            lg = ops.bi_logits(vt, qt, h, hs, hb)
+            ref = 0.7 * torch.einsum("bvd,gd,bqd->bgvq", vt.double(), h.double(), qt.double()) + hb.double()[None, :, None, None]
+            e = ((lg.double() - ref).abs().flatten(1).amax(1) / ref.abs().max())
+            assert float(e.max()) < tol, ("bi_logits", prec, float(e.max()), int(e.argmax()))
+    finally:
+        cti_amd.set_precision(old)
