@@ -343,7 +343,7 @@ def model_setup(config, B, rank, dev):
             from oracle import cti_models as OM
             ref = OM.mc_tan_forward(v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
             return [("mc_cti logits", out[:n].cpu().numpy(), ref)]
-        return dict(fwd=fwd, oracle=oracle, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2),
+        return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2),
                     workload="BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B)
     v = torch.randn(B, 36, 2048, generator=g).abs()
     nv = torch.randint(10, 37, (B,), generator=g)
@@ -362,7 +362,7 @@ def model_setup(config, B, rank, dev):
         vn, qn, an = v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy()
         return [("ban logits", out[0][:n].cpu().numpy(), OM.ffoe_ban_forward(vn, qn, state(ban), 8)[0]),
                 ("cti logits", out[1][:n].cpu().numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
-    return dict(fwd=fwd, oracle=oracle, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129),
+    return dict(fwd=fwd, oracle=oracle, models={"ban": ban, "cti": cti}, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129),
                 workload=("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
                           ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes" % B))
 

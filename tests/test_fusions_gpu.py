@@ -294,3 +294,47 @@ def test_full_batch_gradients_agree_across_precisions():
     flatx = torch.cat([grads["bf16x3"][n].double().flatten() for n in grads["fp32"]])
     tot = float((flatx - flat32).norm() / flat32.norm())
     assert tot < 2e-3, tot                                                     # all 30 M gradient entries together
+
+
+def test_full_batch_model_gradients_agree_across_precisions():
+    """BAN (8 glimpses) and the CTI model of BASELINE configs[3] at B = 256, gradients enabled (eval(): no dropout noise): every parameter gradient -- word embedding,
+    GRU, BiAttention / TriAttention, pooling networks, classifier -- in the bf16x3 mode against the exact-fp32 mode (L2 metrics, see the fusion-block test).  These
+    are the shapes at which the weight-gradient GEMMs plan for 256 x 256 tiles and split K over the 9 216 rows."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    old = cti_amd.get_precision()
+    try:
+        grads = {}
+        for prec in ("bf16x3", "fp32"):
+            cti_amd.set_precision(prec)
+            torch.manual_seed(5)
+            s = bench.model_setup("c4", 256, 0, torch.device(DEV))
+            outs = s["fwd"]()
+            loss = sum((o.float() * torch.linspace(-1, 1, o.shape[-1], device=o.device)).sum() for o in outs) / 256
+            loss.backward()
+            grads[prec] = {}
+            for mname, m in s["models"].items():
+                for n, p in m.named_parameters():
+                    if p.grad is not None:
+                        grads[prec][mname + "." + n] = p.grad.detach().clone()
+            assert len(grads[prec]) > 40
+    finally:
+        cti_amd.set_precision(old)
+    flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
+    flatx = torch.cat([grads["bf16x3"][n].double().flatten() for n in grads["fp32"]])
+    gnorm = float(flat32.norm())
+    worst = ("", 0.0)
+    for n, g32 in grads["fp32"].items():
+        gx = grads["bf16x3"][n]
+        assert torch.isfinite(gx).all(), n
+        den = float(g32.double().norm())
+        if den < 1e-5 * gnorm:              # e.g. the attention logits' bias: its gradient is the sum of a softmax backward, zero up to rounding in either mode
+            assert float(gx.double().norm()) < 1e-4 * gnorm, n
+            continue
+        e = float((gx.double() - g32.double()).norm()) / den
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < 5e-2, worst
+    tot = float((flatx - flat32).norm() / gnorm)
+    assert tot < 2e-3, tot
