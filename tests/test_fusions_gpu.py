@@ -265,7 +265,7 @@ def test_full_batch_gradients_agree_across_precisions():
     old = cti_amd.get_precision()
     grads = {}
     try:
-        for prec in ("bf16x3", "fp32"):
+        for prec in ("bf16x3", "bf16", "fp32"):
             cti_amd.set_precision(prec)
             torch.manual_seed(3)
             model = bench.CTIFusionBlock(cti_amd).to(DEV).eval()
@@ -278,22 +278,25 @@ def test_full_batch_gradients_agree_across_precisions():
     # Metric: relative L2 error per tensor.  The two modes' forward values differ by ~1e-6, so a handful of the 4.7 M pre-activations per layer that sit within
     # that distance of zero take the other side of the ReLU kink; each flip moves single gradient entries by O(1) of their size (measured: 2e-2 of a tensor's
     # largest entry, on WNLinearFn alone against float64 autograd), which a max-norm would report as a mismatch and an L2 norm weighs as what it is.
-    worst = ("", 0.0)
-    for n, g32 in grads["fp32"].items():
-        gx = grads["bf16x3"][n]
-        assert torch.isfinite(gx).all(), n
-        den = float(g32.double().norm())
-        if den == 0.0:
-            assert float(gx.abs().max()) == 0.0, n
-            continue
-        e = float((gx.double() - g32.double()).norm()) / den
-        if e > worst[1]:
-            worst = (n, e)
-    assert worst[1] < 5e-2, worst                                              # a tile of zeros / a dropped K tail shows up as 0.1-1 here
-    flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
-    flatx = torch.cat([grads["bf16x3"][n].double().flatten() for n in grads["fp32"]])
-    tot = float((flatx - flat32).norm() / flat32.norm())
-    assert tot < 2e-3, tot                                                     # all 30 M gradient entries together
+    for mode, t_tensor, t_total in (("bf16x3", 5e-2, 2e-3), ("bf16", 0.3, 5e-2)):
+        worst = ("", 0.0)
+        for n, g32 in grads["fp32"].items():
+            gx = grads[mode][n]
+            assert torch.isfinite(gx).all(), n
+            den = float(g32.double().norm())
+            if den == 0.0:
+                assert float(gx.abs().max()) == 0.0, n
+                continue
+            e = float((gx.double() - g32.double()).norm()) / den
+            if mode == "bf16" and g32.numel() == 1:
+                continue                    # weight_g: <G, V> / g, a scalar left over from a million cancelling terms -- meaningless at 8 mantissa bits
+            if e > worst[1]:
+                worst = (n, e)
+        assert worst[1] < t_tensor, (mode, worst)                                  # a tile of zeros / a dropped K tail shows up as 0.1-1 here (bf16x3), 0.5+ (bf16)
+        flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
+        flatx = torch.cat([grads[mode][n].double().flatten() for n in grads["fp32"]])
+        tot = float((flatx - flat32).norm() / flat32.norm())
+        assert tot < t_total, (mode, tot)                                          # all 30 M gradient entries together
 
 
 def test_full_batch_model_gradients_agree_across_precisions():
