@@ -146,7 +146,9 @@ struct Geo {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, LW = LW_, NST = NST_, SPB = SPB_;
     static constexpr int PL = PL_;                                     // planes per operand held in a slot: 2 (hi + lo) or 1 (plain bf16: hi only)
     static_assert(NST_ % SPB_ == 0 && NST_ > SPB_, "ring = whole groups of SPB slots, at least one group in flight");
+#ifndef CTI_ALLOW_SPB4          // experiment: four slices per barrier (needs Kp % 64 == 0: NOT checked at run time -- measurement builds only)
     static_assert(32 % (16 * SPB_) == 0, "a barrier group (SPB slices of 16) must divide the planes' K padding (KPAD = 32): the K loop runs Kp / (16 SPB) groups");
+#endif
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NCONS = WM * WN * 64, NTHR = NCONS + LW * 64;
     static constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     // PIPE (SPB == 1, NG >= 4): fragments of slice g+1 are read from LDS at the END of step g (behind slice g's MFMAs), so
     // every step opens with MFMAs instead of an exposed LDS round trip.  For that slot g+1 must already be visible after
     // barrier g: the issuing waves retire one group more per step (NG-3 instead of NG-2 groups stay in flight).
-    constexpr bool PIPE = (CTI_PIPE != 0) && SPB == 1 && NG >= 4;
+    constexpr bool PIPE2 = (CTI_PIPE == 2) && TERMS == 1 && !AF32 && SPB == 1 && NG >= 4 && LW == 0 && TM * TN >= TM + TN;
+    constexpr bool PIPE = ((CTI_PIPE == 1) || PIPE2) && SPB == 1 && NG >= 4;
     bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
     auto load_frags = [&](const char* s) {
         const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
@@ -362,6 +365,41 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
             }
             mfma_frags();
         }
+    } else if (PIPE2) {
+        // Round-3 experiment (CTI_PIPE=2, plain bf16): TWO fragment sets, the LDS reads of slice g + 1 interleaved one-for-one with the MFMAs of slice g by
+        // sched_group_barrier -- the software-pipelined stream the vendor GEMMs are written in, as far as the compiler can be told to emit it.
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto ldf = [&](const char* s, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+            const char* sAh = s + (wm * TM * 32) * ROW_BYTES;
+            const char* sBh = s + G::PL * A_PLANE + (wn * TN * 32) * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = frag(sAh, i * 32 + r, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = frag(sBh, j * 32 + r, h);
+        };
+        auto body = [&](int g, bf16x8 (&ca)[TM], bf16x8 (&cb)[TN], bf16x8 (&na)[TM], bf16x8 (&nb)[TN]) {
+            const int pos = g % NG;
+            if (g > 0) {
+                sync_g(g);
+                if (g + NG - 1 < ngr) issue_group(pos == 0 ? NG - 1 : pos - 1, g + NG - 1);
+            }
+            if (g + 1 < ngr) ldf(smem + (pos == NG - 1 ? 0 : pos + 1) * SLOT, na, nb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < TM + TN; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        };
+        sync_g(0);
+        if (NG - 1 < ngr) issue_group(NG - 1, NG - 1);
+        ldf(smem, fa[0], fb[0]);
+        for (int g = 0; g < ngr; g += 2) {
+            body(g, fa[0], fb[0], fa[1], fb[1]);
+            if (g + 1 < ngr) body(g + 1, fa[1], fb[1], fa[0], fb[0]);
+        }
+        __syncthreads();
     } else {
     int pos = 0;
     for (int g = 0; g < ngr; ++g) {
