@@ -341,3 +341,44 @@ def test_full_batch_model_gradients_agree_across_precisions():
     assert worst[1] < 5e-2, worst
     tot = float((flatx - flat32).norm() / gnorm)
     assert tot < 2e-3, tot
+
+
+@pytest.mark.parametrize("config", ["c3", "c4"])
+@pytest.mark.parametrize("prec", ["bf16", "f16f6"])
+def test_full_batch_graph_replay_equals_eager_on_every_row(config, prec):
+    """What bench.py times for configs[2] / [3] is a hipGraph REPLAY of the forward (two streams inside: GRUs, the fused TriAttention's auxiliary chain): the replayed
+    output must equal the eager one on all 256 rows, twice in a row (buffers re-used across replays, counters, guard words)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    old = cti_amd.get_precision()
+    try:
+        cti_amd.set_precision(prec)
+        torch.manual_seed(5)
+        s = bench.model_setup(config, 256, 0, torch.device(DEV))
+        holder = {}
+
+        def step():
+            holder["out"] = s["fwd"]()
+        with torch.no_grad():
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            eager = [t.clone() for t in (holder["out"] if isinstance(holder["out"], (tuple, list)) else (holder["out"],))]
+            gr = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gr, stream=side):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            static = holder["out"] if isinstance(holder["out"], (tuple, list)) else (holder["out"],)
+            for _ in range(2):
+                for t in static:
+                    t.fill_(float("nan"))
+                gr.replay()
+                torch.cuda.synchronize()
+                for a, b in zip(static, eager):
+                    assert torch.equal(a, b), (config, prec, float((a - b).abs().max()))
+    finally:
+        cti_amd.set_precision(old)
