@@ -402,6 +402,22 @@ def model_measure(setup, steps, warmup, world, dist, dev, graphed, prec):
         parity[name] = float(norm_max_err(got, ref))
         if not parity[name] < MODEL_TOL[prec]:
             raise SystemExit("bench.py: %s of the timed %s forward are %.3g from the oracle (tolerance %.3g) -- no number printed" % (name, prec, parity[name], MODEL_TOL[prec]))
+    # ... and EVERY row of the timed forward against the library's own fp32-grade (bf16x3) forward of the same model and batch, on the device: the oracle
+    # leg covers four samples, and a geometry bug that zeroed the last rows of every 256-row GEMM tile once sat outside them
+    if prec != "bf16x3":
+        import cti_amd
+        timed = [t.clone() for t in (out if isinstance(out, (tuple, list)) else (out,))]
+        cti_amd.set_precision("bf16x3")
+        try:
+            with torch.no_grad():
+                ref_out = setup["fwd"]()
+        finally:
+            cti_amd.set_precision(prec)
+        ref_out = ref_out if isinstance(ref_out, (tuple, list)) else (ref_out,)
+        worst = max(float(((a.float() - b.float()).abs().flatten(1).amax(1) / b.float().abs().max()).max()) for a, b in zip(timed, ref_out))
+        parity["every_row_vs_bf16x3_forward"] = worst
+        if not worst < MODEL_TOL[prec]:
+            raise SystemExit("bench.py: a row of the timed %s forward is %.3g from the bf16x3 forward (tolerance %.3g) -- no number printed" % (prec, worst, MODEL_TOL[prec]))
     return el, parity
 
 
