@@ -161,14 +161,14 @@ __global__ __launch_bounds__(256) void rn_fwd_mfma_kernel(const float* __restric
     for (int r = r_lo; r < r_hi; ++r) {
         const int buf = (r - r_lo) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of W_r have landed
-        __syncthreads();                                                 // everyone's have; and everyone is done with the other buffer
-        if (r + 1 < r_hi) dma_w(r + 1, buf ^ 1);
+        __builtin_amdgcn_s_barrier();                                    // everyone's have; and everyone is done with the other buffer (raw: __syncthreads() is a fence too)
         const uint8_t* mp = mask + ((int64_t)r * rows + mc) * h + 16 * kq;
         const char* wb = smem + buf * RNM_BUF + l15 * RNM_PITCH + kq * 8;
         rf32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        uint4 mq[NS / 4];
+        uint4 mq[NS / 4];                                                // requested before the next rank's pieces are issued
 #pragma unroll
         for (int j = 0; j < NS / 4; ++j) mq[j] = (CTI_RN_ABL & 1) ? make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u) : *reinterpret_cast<const uint4*>(mp + j * 64);       // the mask bytes of four steps per 16-B load
+        if (r + 1 < r_hi) dma_w(r + 1, buf ^ 1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const unsigned mq4[4] = {mq[s >> 2].x, mq[s >> 2].y, mq[s >> 2].z, mq[s >> 2].w};
@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256) void rn_fwd_mfma_kernel(const float* __restric
             const unsigned m01 = __builtin_amdgcn_perm(t, t, 0x01010000u), m23 = __builtin_amdgcn_perm(t, t, 0x03030202u);
             const rn_u32x2 ahu = {xh[s][0] & m01, xh[s][1] & m23};
             const rn_s16x4 ah = __builtin_bit_cast(rn_s16x4, ahu);
-            const rn_s16x4 bh = *reinterpret_cast<const rn_s16x4*>(wb + s * 32);
+            const rn_s16x4 bh = __builtin_bit_cast(rn_s16x4, *reinterpret_cast<const rn_u32x2*>(wb + s * 32));
             if (TERMS == 3) {
                 const rn_u32x2 alu = {xl[s][0] & m01, xl[s][1] & m23};
                 const rn_s16x4 al = __builtin_bit_cast(rn_s16x4, alu);
-                const rn_s16x4 bl = *reinterpret_cast<const rn_s16x4*>(wb + 16 * RNM_PITCH + s * 32);
+                const rn_s16x4 bl = __builtin_bit_cast(rn_s16x4, *reinterpret_cast<const rn_u32x2*>(wb + 16 * RNM_PITCH + s * 32));
                 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc, 0, 0, 0);
             }
@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256) void rn_fwd_mfma_kernel(const float* __restric
         }
     }
 }
+
+// (Round 3, built, parity-green and removed: the INPUT gradient the same way -- D^T[k, m] = W_r^T dzs_r^T per 16 columns on the 16x16x16 MFMA, the masked sum over
+// the ranks in registers, W_r^T through a four-slot LDS-DMA ring -- measured 70 us per branch against the fp32-MFMA kernel's 46: a rank's arithmetic (~1 000
+// cycles) is shorter than one DMA latency, and every register load the compiler can see inside the rank loop (mask bytes, the dzs fragment) makes it wait for
+// vmcnt(0) at the first use, i.e. for the prefetches issued in between; hiding the loads in inline asm with hand-counted waits moved nothing in the forward
+// kernel either (43.0 against 40.7 us).  The mask traffic itself is 7-8 us of each of these kernels (CTI_RN_ABL=1).)
 
 // ---- weight gradient: one workgroup per (64 input columns, rank); its 16 waves split the rows and meet in LDS in a fixed order ---------
 __global__ __launch_bounds__(1024) void rn_dw_kernel(const float* __restrict__ dzs, const float* __restrict__ x, const uint8_t* __restrict__ mask,
