@@ -559,8 +559,9 @@ def run_forward(args, world, rank, dev, dist):
             for i0 in range(0, c["B"], 16):
                 worst = max(worst, float((timed_out[i0:i0 + 16] - oxf[i0:i0 + 16]).abs().max()))
             bf16x3["every_sample_max_diff_of_the_timed_launch_vs_this_mode"] = worst / scale_
-            if not worst / scale_ < 1e-4:
-                raise SystemExit("bench.py: a sample of the timed %s launch is %.3g from the bf16x3 launch (tolerance 1e-4) -- no number printed" % (args.precision, worst / scale_))
+            tol_all = 2e-2 if args.precision == "bf16" else 1e-4
+            if not worst / scale_ < tol_all:
+                raise SystemExit("bench.py: a sample of the timed %s launch is %.3g from the bf16x3 launch (tolerance %.0e) -- no number printed" % (args.precision, worst / scale_, tol_all))
             oxf = None
             del res_holder["out"]
         timed_out = None
