@@ -382,3 +382,55 @@ def test_full_batch_graph_replay_equals_eager_on_every_row(config, prec):
                     assert torch.equal(a, b), (config, prec, float((a - b).abs().max()))
     finally:
         cti_amd.set_precision(old)
+
+
+def test_mc_ban_full_batch_forward_and_gradients_across_precisions():
+    """The fourth model family (MC BAN, src/MC/base_model.py: BiAttention with two glimpses over question + answer tokens) at B = 256: every row of the forward in
+    the plain-bf16 / bf16x3 / f16f6 modes against the exact-fp32 mode, and every parameter gradient bf16x3 against fp32 (L2 metrics)."""
+    import types
+    B, ntoken = 256, 20000
+    ds = types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=ntoken), v_dim=2048, num_ans_candidates=2)
+    margs = types.SimpleNamespace(op="c", num_hid=1024, gamma=2, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+    g = torch.Generator().manual_seed(21)
+    v = torch.randn(B, 36, 2048, generator=g).abs()
+    nv = torch.randint(10, 37, (B,), generator=g)
+    v[torch.arange(36)[None, :] >= nv[:, None]] = 0
+    v = v.to(DEV)
+
+    def toks(L):
+        t = torch.randint(0, ntoken, (B, L), generator=g)
+        n = torch.randint(3, L + 1, (B,), generator=g)
+        t[torch.arange(L)[None, :] >= n[:, None]] = ntoken
+        return t.to(DEV)
+    q, a = toks(12), toks(6)
+    boxes = torch.rand(B, 36, 6, generator=g).to(DEV)
+    old = cti_amd.get_precision()
+    outs, grads = {}, {}
+    try:
+        for prec in ("bf16", "bf16x3", "f16f6", "fp32"):
+            cti_amd.set_precision(prec)
+            torch.manual_seed(8)
+            m = cti_amd.build_mc_ban(margs, ds).to(DEV).eval()
+            if prec in ("bf16x3", "fp32"):
+                o = m(v, boxes, q, a)[0]
+                (o * torch.tensor([1.0, -0.5], device=DEV)).sum().div(B).backward()
+                grads[prec] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+                outs[prec] = o.detach().float()
+            else:
+                with torch.no_grad():
+                    outs[prec] = m(v, boxes, q, a)[0].float()
+    finally:
+        cti_amd.set_precision(old)
+    for prec, tol in (("bf16", 3e-2), ("bf16x3", 2e-4), ("f16f6", 2e-4)):
+        per_row = (outs[prec] - outs["fp32"]).abs().flatten(1).amax(1) / outs["fp32"].abs().max()
+        assert float(per_row.max()) < tol, (prec, float(per_row.max()), int(per_row.argmax()))
+    flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
+    flatx = torch.cat([grads["bf16x3"][n].double().flatten() for n in grads["fp32"]])
+    gnorm = float(flat32.norm())
+    assert float((flatx - flat32).norm()) / gnorm < 2e-3
+    for n, g32 in grads["fp32"].items():
+        den = float(g32.double().norm())
+        if den < 1e-5 * gnorm:
+            continue
+        e = float((grads["bf16x3"][n].double() - g32.double()).norm()) / den
+        assert e < 5e-2, (n, e)
