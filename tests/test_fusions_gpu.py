@@ -434,3 +434,47 @@ def test_mc_ban_full_batch_forward_and_gradients_across_precisions():
             continue
         e = float((grads["bf16x3"][n].double() - g32.double()).norm()) / den
         assert e < 5e-2, (n, e)
+
+
+def test_full_batch_training_mode_step_agrees_across_precisions():
+    """The fusion block in TRAIN mode (dropout on: the rank nets' R masks per branch, the projections' input dropout) at B = 256: with the dropout streams reset to
+    the same state the masks are identical in every precision mode, so loss and every gradient of the bf16x3 step (matrix-core rank-net forward, M-build backward)
+    can be held against the exact-fp32 step (fp32-MFMA rank-net kernels, VALU M-build backward) -- the train-mode kernels at the data-parallel step's shapes."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ops = cti_amd.pkg.ops
+    B = 256
+    g = torch.Generator().manual_seed(12)
+    v = torch.randn(B, 36, 2048, generator=g).abs_()
+    for b in range(B):
+        v[b, int(torch.randint(10, 37, (1,), generator=g)):] = 0
+    v = v.to(DEV)
+    q = torch.tanh(torch.randn(B, 12, 1024, generator=g)).to(DEV); a = torch.tanh(torch.randn(B, 3, 1024, generator=g)).to(DEV)
+    y = (torch.rand(B, 3129, generator=g) > 0.999).float().to(DEV)
+    crit = cti_amd.BCEWithLogitsSum()
+    old = cti_amd.get_precision()
+    grads, losses = {}, {}
+    try:
+        for prec in ("bf16x3", "fp32"):
+            cti_amd.set_precision(prec)
+            torch.manual_seed(4)
+            ops.reset_dropout_rng()
+            model = bench.CTIFusionBlock(cti_amd).to(DEV).train()
+            loss = crit(model(v, q, a), y) / B
+            loss.backward()
+            losses[prec] = float(loss.detach())
+            grads[prec] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        cti_amd.set_precision(old)
+    assert abs(losses["bf16x3"] - losses["fp32"]) < 1e-4 * abs(losses["fp32"]), losses          # same masks: the losses agree to fp32 grade
+    flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
+    flatx = torch.cat([grads["bf16x3"][n].double().flatten() for n in grads["fp32"]])
+    gnorm = float(flat32.norm())
+    assert float((flatx - flat32).norm()) / gnorm < 2e-3
+    for n, g32 in grads["fp32"].items():
+        den = float(g32.double().norm())
+        if den < 1e-5 * gnorm:
+            continue
+        e = float((grads["bf16x3"][n].double() - g32.double()).norm()) / den
+        assert e < 5e-2, (n, e)
