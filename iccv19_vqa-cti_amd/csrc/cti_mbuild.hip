@@ -425,6 +425,7 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
         }
     }
 #undef CTI_MM_LOAD
+#undef CTI_MM_LANE
 }
 
 // =====================================================================================================
@@ -445,23 +446,26 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
     extern __shared__ __attribute__((aligned(16))) float X2[];
     float* hold = X2 + (size_t)V * G * HR * MB_XP;
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int l31 = lane & 31, kg = lane >> 5;
+    const int lane0 = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: its multiples live in SGPRs, not in (spilled) VGPRs
     const int K = R * HR;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // uniform bases + 32-bit per-lane element offsets (global loads with an SGPR base): four 64-bit per-lane pointers less in a kernel at its register ceiling
     const float* vb = Vr + (int64_t)b * V * K;
     const float* qb = Qr + (int64_t)b * Q * K;
-    const unsigned ov0 = (unsigned)(l31 * K + kg * 8), ov1 = (unsigned)((32 + l31) * K + kg * 8), ot = (unsigned)((wid * 32 + l31) * HR + kg * 8);
-    const int v0 = l31, v1 = 32 + l31;
-    const bool v0ok = v0 < V, v1ok = v1 < V, qok = l31 < Q;
-    const int c1 = wid * 32 + l31;
-    const int xk = l31 >> 1, xg = l31 & 1;
     const int64_t rows_b = (int64_t)b * V * Q * G;
+    // Lane coordinates are re-derived from an opaque copy wherever a rank iteration needs them (round 3): as loop invariants the per-lane offsets of both steps
+    // were hoisted out of the rank loop, 27 registers of them spilled in a kernel at its 128-register ceiling, and a scratch reload waits for vmcnt(0).
+#define CTI_MM_LANE()                                                                                                    \
+    int lane = lane0;                                                                                                    \
+    asm volatile("" : "+v"(lane));                                                                                       \
+    const int l31 = lane & 31, kg = lane >> 5;                                                                           \
+    const unsigned ov0 = (unsigned)(l31 * K + kg * 8), ov1 = (unsigned)((32 + l31) * K + kg * 8), ot = (unsigned)((wid * 32 + l31) * HR + kg * 8); \
+    const bool v0ok = l31 < V, v1ok = 32 + l31 < V, qok = l31 < Q;
     typedef float mbf_f32x4 __attribute__((ext_vector_type(4)));
     float4 a00 = z4, a01 = z4, a10 = z4, a11 = z4, t0 = z4, t1 = z4, q0 = z4, q1 = z4;
 #define CTI_MM_LOAD(rr)                                                                                             \
     {                                                                                                               \
+        CTI_MM_LANE()                                                                                               \
         const unsigned o_ = (unsigned)((rr) * HR);                                                                  \
         if (v0ok) { a00 = *reinterpret_cast<const float4*>(vb + (ov0 + o_)); a01 = *reinterpret_cast<const float4*>(vb + (ov0 + o_ + 4)); } \
         if (v1ok) { a10 = *reinterpret_cast<const float4*>(vb + (ov1 + o_)); a11 = *reinterpret_cast<const float4*>(vb + (ov1 + o_ + 4)); } \
@@ -491,6 +495,9 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
         }
         __syncthreads();
+        CTI_MM_LANE()
+        (void)ov0; (void)ov1; (void)ot; (void)v0ok; (void)v1ok;
+        const int xk = l31 >> 1, xg = l31 & 1;
         mb_store_x(X2, x0, x1, V, kg, xg, xk, wid, lane);
         __syncthreads();
         const int sg = l31 >> 4, sk = l31 & 15;
