@@ -453,12 +453,15 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     //          non-finite sweep of V^ / Q^ / T_eff;
     //   middle (main stream, right behind the rank nets' product, while the main stream would otherwise just wait for chain B): A^;
     //   final  (main stream, behind the join): M's 8 MB of scale bytes, then the verdict -- ~10 us in front of the mode-3 product.
-    // Without an auxiliary stream everything is in stream order anyway: early = weights + fp32 sweeps, final = the four encoded tensors.
+    // Without an auxiliary stream everything is in stream order anyway: early = the fp32 sweeps, final = the a-side weights (per-call weights are
+    // encoded inside side(2), AFTER the early scan: scanning them early read uninitialised workspace) + the four encoded tensors.
     auto early_scan = [&](bool with_a) -> int {
         GuardArgs gb{};
         gb.words = p.guard;
-        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
-        gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        if (with_a) {                                            // (no auxiliary stream: per-call weights are encoded inside side(2) BELOW -- the final scan takes them)
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_wta, h, 1);
+            gb.seg[gb.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        }
         if (with_a) {
             gb.seg[gb.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             gb.seg[gb.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
@@ -532,6 +535,8 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
         ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
         if (!aux_stream) {
+            ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h, 1);             // written by side(2) above when the caller keeps no prepared block
+            ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h, 2);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
         }

@@ -432,6 +432,9 @@ def tcnet_prepare(tucker, rank, T_g, prec=None):
     return block, pr
 
 
+_debug_ws_fill = None      # tests only: byte value the fused forward's workspace is filled with before the call
+
+
 def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=None, prepared=None, want_sm_partials=False, _tri=False, _v_tucked=None, _v_rep=1):
     """Whole TCNet.forward in one C-ABI call.  tucker / rank: 3-lists (v, q, a order) of (weight_v, weight_g, bias);
     the rank entries are PACKED: weight_v (h, h), weight_g (R,), bias (h,).  prepared: the (block, precision) pair of tcnet_prepare for
@@ -483,6 +486,8 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
     wsb = (lib.cti_triattention_workspace_bytes if _tri else lib.cti_tcnet_forward_workspace_bytes)(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
+    if _debug_ws_fill is not None:              # tests: the library must not read workspace bytes it has not written (0xFF reads as saturated scale bytes)
+        ws.fill_(_debug_ws_fill)
     ev0 = ev1 = None
     if _prof is not None:                       # hipEvents around the mode-3 GEMM, recorded by the library on the launch stream
         ev0, ev1 = lib.cti_event_create(), lib.cti_event_create()

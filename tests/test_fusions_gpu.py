@@ -138,6 +138,41 @@ def test_linear_residual_declines_what_it_cannot_do():
     assert ops.linear_residual(x, ops.split_operand(torch.randn(6, 8, device=DEV)), None, 1, None, seq) is None
 
 
+@pytest.mark.parametrize("mode", ["sync", "poison"])
+def test_range_guard_reads_no_unwritten_workspace_without_an_auxiliary_stream(precision, mode):
+    """with no auxiliary stream and per-call weights (prepared=None) the early scan used to read the a-side weights' scale planes BEFORE
+    side(2) encoded them.  On a workspace pre-filled with 0xFF (saturated scale bytes) in-range inputs must neither trip ('sync') nor come back as
+    NaN ('poison')."""
+    if precision != "f16f6":
+        pytest.skip("the guard belongs to the f16f6 kernels")
+    torch.manual_seed(11)
+    net = cti_amd.TCNet(48, 40, 24, 64, 1, 4, 2).to(DEV).eval()
+    rs = np.random.RandomState(5)
+    v = T(np.abs(rs.standard_normal((2, 9, 48))).astype(np.float32))
+    q = T(rs.standard_normal((2, 5, 40)).astype(np.float32))
+    a = T(rs.standard_normal((2, 40, 24)).astype(np.float32))
+    tucker, rank = net._fused_args()
+    old_aux, old_fill = ops.use_aux_stream, ops._debug_ws_fill
+    ops.use_aux_stream = False
+    ops._range_log.update(consecutive=0, skip=0)
+    cti_amd.set_range_check(mode)
+    try:
+        with torch.no_grad():
+            ref = net(v, q, a).cpu().numpy()                     # the module's own path (prepared block): the reference for this test
+        before = ops.f16f6_range_status()
+        ops._debug_ws_fill = 0xFF
+        with torch.no_grad():
+            out = ops.tcnet_forward(v, q, a, tucker, rank, net.T_g.detach(), prepared=None).cpu().numpy()
+        after = ops.f16f6_range_status()
+    finally:
+        ops.use_aux_stream, ops._debug_ws_fill = old_aux, old_fill
+        cti_amd.set_range_check("sync")
+        ops._range_log.update(consecutive=0, skip=0)
+    assert after["trips"] == before["trips"], after
+    assert np.isfinite(out).all()
+    assert np.max(np.abs(out - ref)) <= 1e-5 * np.max(np.abs(ref))
+
+
 def test_range_guard_without_an_auxiliary_stream(precision):
     """CTI_NO_AUX_STREAM: both guard scans run on the launch stream; clean inputs pass, scaled inputs trip and the re-run is fp32-grade."""
     if precision != "f16f6":
