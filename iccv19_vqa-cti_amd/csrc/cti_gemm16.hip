@@ -1,0 +1,315 @@
+// cti_gemm16.hip -- plain-bf16 NT GEMM on chunk-major hi planes, round-4 schedule ("two wave groups, one interval apart").
+//
+// The plain-bf16 arithmetic mode (one v_mfma per product: precision='bf16', BASELINE configs[2] / [3]) ran on gemm_planes_kernel<1> of
+// cti_gemm_bf16x3.hip: 256 x 256 tile, every wave through the same phases (LDS reads -> MFMAs) behind one barrier per 16- or 32-deep K step:
+// 600-740 TFLOP/s where the vendor GEMM reaches 1 075-1 140 on the same shapes (tools/ref_gemm_rate.py; reference src/fc.py:22-29 is the
+// layer this serves).  The matrix pipe idles while all eight waves read, the LDS idles while all eight multiply.  Here (prototype with
+// measurements: tools/mb/mb_gemm16.hip, profiles/r04_mb_gemm16.txt -- 1 149 TFLOP/s at 4096^3, 874 without the stagger):
+//   * 256 x 256 tile, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator registers), taken
+//     TRANSPOSED (D = B_tile A_tile^T) so that a lane holds four consecutive columns of one output row: 16-B stores without a shuffle;
+//   * an NS-slot LDS ring of 32-deep K stages (A 256 rows x 64 B | B 256 x 64 B = 32 KiB; NS = 4), filled by global_load_lds_dwordx4 straight from
+//     the chunk-major planes ([K/16][rows][16]: one piece = 16 rows x 64 B gathers each row's two 32-B chunk halves); the 16-B unit c of row r
+//     lands at unit c ^ ((-(r >> 2)) & 3): conflict-free ds_read_b128 fragments for the 16 x 16 x 32 operand layout (lane = row l & 15, K group l >> 4);
+//   * every wave alternates a LOAD interval (12 fragment reads of the stage, its 4 DMA pieces of the stage NS - 1 ahead, the previous tile's
+//     epilogue when one is pending, counted vmcnt + lgkmcnt(0)) with a COMPUTE interval (32 MFMAs), one raw s_barrier between intervals, and waves
+//     4-7 -- the SIMD partners of waves 0-3 -- run ONE INTERVAL BEHIND: on every SIMD one wave's MFMAs run beside the other's LDS reads and DMA issue;
+//   * a workgroup's tiles are one stream of stages (persistent, XCD-aware tile order): the ring never drains at a tile boundary;
+//   * bias and weight-norm scale of the tile's 64 columns per wave travel through LDS too (two global_load_lds_dword per wave and tile, double
+//     buffered): an ordinary global load in the epilogue would make the compiler drain vmcnt(0) -- the whole ring -- in front of it.
+// Epilogues: fp32 rows (scale / bias / ReLU; 16-B stores) and chunk-major hi / lo planes.  Everything else (3-term products, interleaved outputs,
+// fp32 A operands, other tiles) stays on cti_gemm_bf16x3.hip; gemm_nt_planes() routes.
+#include "cti_common.h"
+
+namespace cti {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int G16_BM = 256, G16_BN = 256, G16_ROWB = 64;             // ROWB: bytes of K per stage row (32 bf16)
+constexpr int G16_STAGE = (G16_BM + G16_BN) * G16_ROWB;              // 32 KiB
+constexpr int G16_NS = 4;
+constexpr int G16_EPI_LDS = 8 * 2 * 2 * 256;                         // per wave: 2 buffers x (bias | scale) x 64 floats
+constexpr int G16_LDS = G16_NS * G16_STAGE + G16_EPI_LDS;
+
+struct G16P {
+    const char* Ah; const char* Bh;
+    float* C; unsigned short* Ph; unsigned short* Pl;
+    const float* scale; const float* bias;
+    int64_t pitchA, pitchB;                    // chunk pitches in BYTES
+    int64_t rA1, rA2, rB1, rB2, kc2;           // batch strides in rows; split-K chunk offset per b2
+    int64_t ldc_m, sC1, sC2, pitchP;           // pitchP in elements
+    int64_t scale_bs, bias_bs;
+    int nb2, M, N, Np, nk, scale_div, relu;
+    int tiles_m, tiles_n, total_tiles;
+};
+typedef const __attribute__((address_space(4))) G16P G16P_K;
+__device__ __forceinline__ const G16P_K* g16_kernarg() { return __builtin_bit_cast(const G16P_K*, __builtin_amdgcn_kernarg_segment_ptr()); }
+
+__device__ __forceinline__ void g16_dma16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void g16_dma4(const float* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+template <int V> __device__ __forceinline__ void g16_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V) : "memory"); }
+#define G16_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__device__ __forceinline__ unsigned short g16_bf16_bits(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
+__device__ __forceinline__ float g16_bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+enum { G16_EPI_F32 = 0, G16_EPI_PLANES = 1 };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
+    constexpr int NS = G16_NS, STAGE = G16_STAGE, BM = G16_BM, BN = G16_BN;
+    constexpr int NSTORE = 32;                                       // fp32 epilogue: stores per wave of a tile without an edge
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int total_tiles = p.total_tiles;
+    if ((int)blockIdx.x >= total_tiles) return;
+    const int nk = p.nk;
+    const int my_tiles = (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int total = my_tiles * nk;
+    const bool has_bias = p.bias != nullptr, has_scale = p.scale != nullptr;
+
+    // fragment addresses inside a slot: lane = (row lr of a 16-row MFMA tile, K group g of 8 elements = 16 B); unit' = g ^ f(row)
+    const int lr = lane & 15, g = lane >> 4;
+    const int fsw = (0 - (lr >> 2)) & 3;
+    const int a_off = (wr * 128 + lr) * G16_ROWB + ((g ^ fsw) << 4);
+    const int b_off = BM * G16_ROWB + (wc * 64 + lr) * G16_ROWB + ((g ^ fsw) << 4);
+    char* const epi_lds = smem + NS * STAGE + wid * 1024;           // [buffer][bias 256 B | scale 256 B]
+
+    // ---- DMA side: piece = 16 rows x 64 B; lane -> row (lane >> 2) of the piece, LDS unit' = lane & 3 <- source unit c = (lane & 3) ^ f(row):
+    // K chunk c >> 1 of the stage's two, half c & 1 of that chunk's 32 B.  Wave w issues pieces w and w + 8 of either operand.
+    const int drow = lane >> 2, dc = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    const unsigned voA0 = (unsigned)((dc >> 1) * p.pitchA) + (unsigned)((wid * 16 + drow) * 32 + (dc & 1) * 16), voA1 = voA0 + 128 * 32;
+    const unsigned voB0 = (unsigned)((dc >> 1) * p.pitchB) + (unsigned)((wid * 16 + drow) * 32 + (dc & 1) * 16), voB1 = voB0 + 128 * 32;
+    const int64_t ksA = 2 * p.pitchA, ksB = 2 * p.pitchB;
+    int iss_tile = blockIdx.x, iss_kb = 0, issued = 0, iss_par = 0;
+    const char* Ab = nullptr; const char* Bb = nullptr;              // wave-uniform: the issue tile's operand origins at the current K stage
+    const float* ep_bias = nullptr; const float* ep_scale = nullptr; // per-lane sources of this wave's epilogue constants for the issue tile
+    auto issue_tile_setup = [&]() {
+        const G16P_K* q = g16_kernarg();
+        asm volatile("" : "+s"(q));                                  // re-read once per tile instead of living in SGPRs across the K loop
+        int z, tm, tn;
+        tile_coords(iss_tile, q->total_tiles, q->tiles_m, q->tiles_n, z, tm, tn);
+        const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
+        Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * 32 + b2 * q->kc2 * q->pitchA;
+        Bb = q->Bh + (b1 * q->rB1 + b2 * q->rB2 + (int64_t)tn * BN) * 32 + b2 * q->kc2 * q->pitchB;
+        const int n = min(tn * BN + wc * 64 + lane, q->N - 1);
+        ep_bias = q->bias + b1 * q->bias_bs + n;
+        ep_scale = q->scale + b1 * q->scale_bs + n / q->scale_div;
+    };
+    auto issue_next = [&](int slot) {
+        if (issued >= total) return;
+        char* sb = smem + slot * STAGE + wid * 1024;
+        g16_dma16(Ab + voA0, sb);
+        g16_dma16(Ab + voA1, sb + 8192);
+        g16_dma16(Bb + voB0, sb + 16384);
+        g16_dma16(Bb + voB1, sb + 24576);
+        if (iss_kb == 0) {                                           // the tile's epilogue constants ride behind its first stage
+            if (has_bias) g16_dma4(ep_bias, epi_lds + iss_par * 512);
+            if (has_scale) g16_dma4(ep_scale, epi_lds + iss_par * 512 + 256);
+        }
+        Ab += ksA; Bb += ksB;
+        ++issued;
+        if (++iss_kb == nk) {
+            iss_kb = 0; iss_tile += (int)gridDim.x; iss_par ^= 1;
+            if (iss_tile < total_tiles) issue_tile_setup();
+        }
+    };
+
+    issue_tile_setup();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_next(s);
+    if (total > NS - 2) g16_wait<4 * (NS - 2)>(); else g16_wait<0>();
+    G16_BAR();
+    if (wr == 1) G16_BAR();                                          // waves 4-7 run one interval behind
+
+    f32x4 acc[8][4];
+    bf16x8 fa[8], fb[4];
+    int vtile = blockIdx.x, kb = 0, slot = 0;
+    int ep_z = 0, ep_tm = 0, ep_tn = 0, ep_age = 1000, ep_par = 0;
+    bool ep_pending = false, ep_full = false;
+
+    auto epilogue = [&](int z, int tm, int tn, int par) -> bool {
+        const G16P_K* q = g16_kernarg();
+        asm volatile("" : "+s"(q));
+        const int pM = q->M, pN = q->N;
+        const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
+        const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
+        const int ncols = EPI == G16_EPI_PLANES ? q->Np : pN;
+        const bool full = (tm * BM + BM <= pM) && (tn * BN + BN <= pN);
+        const bool relu = q->relu != 0;
+        // the wave's 64 bias / scale values: lane holds columns 16 j + 4 g + (0 .. 3)
+        f32x4 bi[4], sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bi[j] = has_bias ? *reinterpret_cast<const f32x4*>(epi_lds + par * 512 + (j * 16 + 4 * g) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sc[j] = has_scale ? *reinterpret_cast<const f32x4*>(epi_lds + par * 512 + 256 + (j * 16 + 4 * g) * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+        if (EPI == G16_EPI_F32) {
+            float* cp = q->C + b1 * q->sC1 + b2 * q->sC2 + (int64_t)(m0 + lr) * q->ldc_m + n0 + 4 * g;
+            const int64_t rstep = 16 * q->ldc_m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i * 16 + lr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 x = acc[i][j] * sc[j] + bi[j];
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = relu_nan(x[e]);
+                    }
+                    const int n = n0 + j * 16 + 4 * g;
+                    if (full) *reinterpret_cast<f32x4*>(cp + j * 16) = x;
+                    else if (m < pM) {
+                        if (n + 4 <= pN) *reinterpret_cast<f32x4*>(cp + j * 16) = x;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (n + e < pN) cp[j * 16 + e] = x[e];
+                        }
+                    }
+                }
+                cp += rstep;
+            }
+        } else {
+            // chunk-major planes: element (row, n) at (n >> 4) * pitchP + row * 16 + (n & 15); a lane's 4 columns are 8 B of one chunk row
+            const int64_t prow0 = b1 * q->sC1 + b2 * q->sC2 + m0 + lr;
+            const int64_t pitchP = q->pitchP;
+            unsigned short* const Ph = q->Ph; unsigned short* const Pl = q->Pl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i * 16 + lr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 x = acc[i][j] * sc[j] + bi[j];
+                    const int n = n0 + j * 16 + 4 * g;
+                    unsigned short hb[4], lb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = relu ? relu_nan(x[e]) : x[e];
+                        if (n + e >= pN) v = 0.f;                    // columns N .. Np - 1 of the planes are zero
+                        hb[e] = g16_bf16_bits(v); lb[e] = g16_bf16_bits(v - g16_bf16_f32(hb[e]));
+                    }
+                    const int64_t o = (int64_t)(n >> 4) * pitchP + (prow0 + i * 16) * 16 + (n & 15);
+                    const u32x2 hv = {hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16)};
+                    const u32x2 lv = {lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16)};
+                    if (full || (m < pM && n < ncols)) {
+                        *reinterpret_cast<u32x2*>(Ph + o) = hv;
+                        *reinterpret_cast<u32x2*>(Pl + o) = lv;
+                    }
+                }
+            }
+        }
+        return full;
+    };
+
+    for (int i = 0; i < total; ++i) {
+        // ================= LOAD interval =================
+        {
+            const char* s = smem + slot * STAGE;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(s + a_off + u * 1024);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(s + b_off + u * 1024);
+        }
+        issue_next(slot == 0 ? NS - 1 : slot - 1);
+        if (ep_pending) {
+            if (nk < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // short K: the tile's bias / scale pieces may still be in flight
+            ep_full = epilogue(ep_z, ep_tm, ep_tn, ep_par);
+            ep_pending = false; ep_age = 0;
+        }
+        {
+            const int rem = total - 2 - i;                           // stages beyond i + 1 that exist; min(NS - 2, rem) of them may stay in flight
+            const bool st = EPI == G16_EPI_F32 && ep_full && ep_age <= NS - 2 && nk > NS - 2;   // the last epilogue's stores were all unconditional and sit inside the window (planes: 64 stores exceed vmcnt's 6 bits)
+            if (rem >= 2) { if (st) g16_wait<8 + NSTORE>(); else g16_wait<8>(); }
+            else if (rem == 1) { if (st) g16_wait<4 + NSTORE>(); else g16_wait<4>(); }
+            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
+            ++ep_age;
+        }
+        G16_BAR();
+        // ================= COMPUTE interval =================
+        __builtin_amdgcn_s_setprio(1);
+        if (kb == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        if (++kb == nk) {
+            kb = 0;
+            const G16P_K* q = g16_kernarg();
+            asm volatile("" : "+s"(q));
+            tile_coords(vtile, q->total_tiles, q->tiles_m, q->tiles_n, ep_z, ep_tm, ep_tn);
+            ep_pending = true; ep_par = ((vtile - (int)blockIdx.x) / (int)gridDim.x) & 1;
+            vtile += (int)gridDim.x;
+        }
+        G16_BAR();
+    }
+    if (ep_pending) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)epilogue(ep_z, ep_tm, ep_tn, ep_par);
+    }
+    if (wr == 0) G16_BAR();
+}
+
+}  // namespace
+
+// Takes the plain-bf16 products gemm_nt_planes() would run on its 256 x 256 tile; false = not eligible (the caller's own kernel runs)
+bool gemm16_eligible(const PlaneGemmArgs& a) {
+    if (a.terms != 1 || a.Af || !(a.epi == 0 || a.epi == 1) || a.ksplit > 1) return false;
+    if (a.Kp % 32 != 0 || a.Kp <= 0) return false;
+    if ((a.bias || a.scale) && a.Kp / 32 < 4) return false;                 // the epilogue constants' double buffer assumes tiles of at least 4 stages
+    const int64_t rowsA = a.rows_allocA, rowsB = a.rows_allocB;
+    if (rowsA * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32) || rowsB * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32)) return false;   // 32-bit per-lane offsets inside a plane
+    if (a.epi == 0) {
+        if (a.ldc_n != 1 || (a.ldc_m & 3) || (a.sC1 & 3) || (a.sC2 & 3) || (reinterpret_cast<uintptr_t>(a.C) & 15)) return false;
+    } else {
+        if (!a.Ph || !a.Pl || (a.Np & 15)) return false;
+    }
+    return true;
+}
+
+int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
+    G16P p{};
+    p.Ah = reinterpret_cast<const char*>(a.Ah); p.Bh = reinterpret_cast<const char*>(a.Bh);
+    p.C = a.C; p.Ph = a.Ph; p.Pl = a.Pl; p.scale = a.scale; p.bias = a.bias;
+    p.pitchA = a.rows_allocA * 32; p.pitchB = a.rows_allocB * 32;
+    p.rA1 = a.rA1; p.rA2 = a.rA2; p.rB1 = a.rB1; p.rB2 = a.rB2; p.kc2 = a.kc2;
+    p.ldc_m = a.ldc_m; p.sC1 = a.sC1; p.sC2 = a.sC2; p.pitchP = a.rows_allocP * 16;
+    p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
+    p.nb2 = a.nb2 > 0 ? a.nb2 : 1; p.M = a.M; p.N = a.N; p.Np = a.Np; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
+    const int ncols = a.epi == 1 ? a.Np : a.N;
+    p.tiles_m = (a.M + G16_BM - 1) / G16_BM; p.tiles_n = (ncols + G16_BN - 1) / G16_BN;
+    const long long total = (long long)a.nb1 * p.nb2 * p.tiles_m * p.tiles_n;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm16_planes: %lld tiles", total);
+    p.total_tiles = (int)total;
+    void (*kern)(G16P) = a.epi == 1 ? gemm16_planes_kernel<G16_EPI_PLANES> : gemm16_planes_kernel<G16_EPI_F32>;
+    static thread_local int attr_dev[2] = {-1, -1};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev[a.epi] != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS);
+        if (e != hipSuccess) return fail((int)e, "gemm16_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev[a.epi] = dev;
+    }
+    static thread_local int n_cu = 0;
+    if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const long long grid = total < n_cu ? total : n_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G16_LDS, st, p);
+    return launch_status("gemm16_planes");
+}
+
+}  // namespace cti

@@ -809,6 +809,9 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     cfg = CTI_FORCE_CFG;
 #endif
     if (tuning_gemm_cfg() >= 0) cfg = tuning_gemm_cfg();                   // cti_set_tuning(CTI_TUNE_GEMM_CFG): tests reach every geometry at small shapes
+    // plain-bf16 products on the 256 x 256 tile: the round-4 kernel (cti_gemm16.hip; CTI_GEMM16=0 keeps this file's kernel: A/B)
+    static const bool use16 = [] { const char* e = getenv("CTI_GEMM16"); return !(e && e[0] == '0'); }();
+    if (use16 && cfg == 2 && gemm16_eligible(a)) return gemm16_planes(a, st);
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
     const int key = (a.terms == 3 ? 4 : 0) + epi;
     switch (key) {
