@@ -73,6 +73,7 @@ SIGNATURES = {
     "cti_split_operand": (_int, [_vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_pb": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _int, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_pb_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "cti_gemm_bf16_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _int, _i64, _i64, _int, _int, _int, _int, _vp, _int, _i64, _vp, _i64, _int, _vp]),
     "cti_gru_forward_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
     "cti_gru_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_gru_backward_workspace_bytes": (_sz, [_int, _int, _int, _int]),

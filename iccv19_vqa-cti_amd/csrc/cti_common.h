@@ -99,12 +99,15 @@ struct PlaneGemmArgs {
     // Af != NULL: the A operand is the fp32 matrix itself (rows x Kreal, row stride ldaf, 16-B aligned rows, Kreal % 4 == 0):
     // its rows are LDS-DMA'd as fp32 and split into hi/lo at fragment-read time (no split pass, no A planes); rA1/rA2 in rows.
     const float* Af; int64_t ldaf; int Kreal;
+    // Abf != NULL (plain-bf16 products through cti_gemm16.hip only): the A operand is a row-major bf16 matrix (row stride ldabf elements, a multiple
+    // of 8; 16-B aligned; K % 32 == 0 or zero-padded to Kp by the caller): no split pass, no A planes; rA1 / rA2 in rows
+    const void* Abf; int64_t ldabf;
     int64_t rows_allocA, rows_allocB;          // allocated rows (the chunk pitch is rows_alloc * 16 elements)
     int64_t rA1, rA2, rB1, rB2;                // batch strides of the operands in ROWS
     int nb1, nb2;
     int M, N, Kp;
     int terms;                                 // 3 = bf16x3 (hi*hi + hi*lo + lo*hi), 1 = plain bf16 (hi planes only)
-    int epi;                                   // 0 fp32 C, 1 hi/lo planes out, 3 fp32 C with G-interleaved rows, 4 f16f6 planes out (f6out)
+    int epi;                                   // 0 fp32 C, 1 hi/lo planes out, 3 fp32 C with G-interleaved rows, 4 f16f6 planes out (f6out), 5 bf16 rows out (C = bf16 storage, ldc_m / sC in elements; cti_gemm16.hip only)
     const F6Planes* f6out;                     // epi 4: output planes (logical row b1*sC1 + m -> f6_prow); Np = padded column count
     float* C; int64_t ldc_m, ldc_n, sC1, sC2;  // fp32 output (epi 0/3); for epi 1 sC1/sC2 are batch strides in plane ROWS
     unsigned short* Ph; unsigned short* Pl; int64_t rows_allocP; int Np;     // planes output (epi 1)

@@ -27,17 +27,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int G16_BM = 256, G16_BN = 256, G16_ROWB = 64;             // ROWB: bytes of K per stage row (32 bf16)
-constexpr int G16_STAGE = (G16_BM + G16_BN) * G16_ROWB;              // 32 KiB
+constexpr int G16_ROWB = 64;                                         // bytes of K per stage row (32 bf16)
 constexpr int G16_NS = 4;
 constexpr int G16_EPI_LDS = 8 * 2 * 2 * 256;                         // per wave: 2 buffers x (bias | scale) x 64 floats
-constexpr int G16_LDS = G16_NS * G16_STAGE + G16_EPI_LDS;
 
 struct G16P {
     const char* Ah; const char* Bh;
     float* C; unsigned short* Ph; unsigned short* Pl;
     const float* scale; const float* bias;
-    int64_t pitchA, pitchB;                    // chunk pitches in BYTES
+    int64_t pitchA, pitchB;                    // chunk pitches in BYTES (A planes form); AROW: pitchA = the row stride of A in bytes
     int64_t rA1, rA2, rB1, rB2, kc2;           // batch strides in rows; split-K chunk offset per b2
     int64_t ldc_m, sC1, sC2, pitchP;           // pitchP in elements
     int64_t scale_bs, bias_bs;
@@ -53,18 +51,31 @@ __device__ __forceinline__ void g16_dma16(const char* src, char* lds_wave_base) 
 __device__ __forceinline__ void g16_dma4(const float* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
-template <int V> __device__ __forceinline__ void g16_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V) : "memory"); }
+template <int V> __device__ __forceinline__ void g16_wait() { static_assert(V >= 0 && V < 64, "vmcnt has six bits"); asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(V) : "memory"); }
 #define G16_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 __device__ __forceinline__ unsigned short g16_bf16_bits(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
 __device__ __forceinline__ float g16_bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-enum { G16_EPI_F32 = 0, G16_EPI_PLANES = 1 };
+enum { G16_EPI_F32 = 0, G16_EPI_PLANES = 1, G16_EPI_BF16 = 2 };
 
-template <int EPI>
+// Geometry: 8 waves as 2 (M) x 4 (N); a wave owns TMW x TNW MFMA tiles of 16 x 16: workgroup tile (32 TMW) x (64 TNW).  (8, 4) = 256 x 256;
+// (9, 3) = 288 x 192 (9216 x 3072 outputs: 512 tiles = two full rounds of 256 workgroups instead of 432 tiles = 1.69 rounds of the square tile).
+template <int TMW_, int TNW_>
+struct G16Geo {
+    static constexpr int TMW = TMW_, TNW = TNW_, BM = 32 * TMW_, BN = 64 * TNW_;
+    static constexpr int PA = BM / 16, PB = BN / 16, P = PA + PB;                // LDS-DMA pieces (16 rows x 64 B) per stage
+    static constexpr int UMAX = (P + 7) / 8, CQ = P / 8, CR = P % 8;             // waves < CR issue CQ + 1 pieces per stage, the others CQ
+    static constexpr int STAGE = (BM + BN) * G16_ROWB;
+    static constexpr int LDS = G16_NS * STAGE + G16_EPI_LDS;
+    static constexpr int NSTORE = TMW * TNW;                                     // fp32 / bf16-row epilogue: one store per accumulator tile
+    static_assert(LDS <= 160 * 1024 && TNW <= 4, "ring + epilogue constants must fit the CU's LDS; a wave's columns fit one 64-lane dword piece");
+    static_assert((G16_NS - 2) * (CQ + 1) + NSTORE < 64, "the store window must fit vmcnt's six bits");
+};
+
+template <int EPI, class G, bool AROW>
 __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
-    constexpr int NS = G16_NS, STAGE = G16_STAGE, BM = G16_BM, BN = G16_BN;
-    constexpr int NSTORE = 32;                                       // fp32 epilogue: stores per wave of a tile without an edge
+    constexpr int NS = G16_NS, STAGE = G::STAGE, BM = G::BM, BN = G::BN, TMW = G::TMW, TNW = G::TNW, UMAX = G::UMAX, NSTORE = G::NSTORE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,20 +86,30 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
     const int my_tiles = (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int total = my_tiles * nk;
     const bool has_bias = p.bias != nullptr, has_scale = p.scale != nullptr;
+    const bool hiw = wid < G::CR;                                    // this wave issues CQ + 1 pieces per stage
 
     // fragment addresses inside a slot: lane = (row lr of a 16-row MFMA tile, K group g of 8 elements = 16 B); unit' = g ^ f(row)
     const int lr = lane & 15, g = lane >> 4;
     const int fsw = (0 - (lr >> 2)) & 3;
-    const int a_off = (wr * 128 + lr) * G16_ROWB + ((g ^ fsw) << 4);
-    const int b_off = BM * G16_ROWB + (wc * 64 + lr) * G16_ROWB + ((g ^ fsw) << 4);
+    const int a_off = (wr * 16 * TMW + lr) * G16_ROWB + ((g ^ fsw) << 4);
+    const int b_off = BM * G16_ROWB + (wc * 16 * TNW + lr) * G16_ROWB + ((g ^ fsw) << 4);
     char* const epi_lds = smem + NS * STAGE + wid * 1024;           // [buffer][bias 256 B | scale 256 B]
 
-    // ---- DMA side: piece = 16 rows x 64 B; lane -> row (lane >> 2) of the piece, LDS unit' = lane & 3 <- source unit c = (lane & 3) ^ f(row):
-    // K chunk c >> 1 of the stage's two, half c & 1 of that chunk's 32 B.  Wave w issues pieces w and w + 8 of either operand.
+    // ---- DMA side: piece = 16 rows x 64 B of the stage's row list [A rows | B rows]; lane -> row (lane >> 2) of the piece, LDS unit' = lane & 3 <-
+    // source unit c = (lane & 3) ^ f(row).  Planes: K chunk c >> 1 of the stage's two, half c & 1 of that chunk's 32 B; AROW: bytes 16 c of the
+    // row's 64.  Wave w issues pieces w, w + 8, ...; piece g lands at g KiB of the slot.
     const int drow = lane >> 2, dc = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-    const unsigned voA0 = (unsigned)((dc >> 1) * p.pitchA) + (unsigned)((wid * 16 + drow) * 32 + (dc & 1) * 16), voA1 = voA0 + 128 * 32;
-    const unsigned voB0 = (unsigned)((dc >> 1) * p.pitchB) + (unsigned)((wid * 16 + drow) * 32 + (dc & 1) * 16), voB1 = voB0 + 128 * 32;
-    const int64_t ksA = 2 * p.pitchA, ksB = 2 * p.pitchB;
+    unsigned voff[UMAX]; bool pa[UMAX], pv[UMAX];
+    const unsigned pitchA32 = (unsigned)p.pitchA, pitchB32 = (unsigned)p.pitchB;
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+        const int gp = wid + 8 * u;
+        pv[u] = gp < G::P; pa[u] = gp < G::PA;
+        const int row = (pa[u] ? gp : gp - G::PA) * 16 + drow;
+        if (pa[u] && AROW) voff[u] = 0;                              // per issue tile (rows past the matrix re-read its last row: no slack rows there)
+        else voff[u] = (unsigned)(dc >> 1) * (pa[u] ? pitchA32 : pitchB32) + (unsigned)(row * 32 + (dc & 1) * 16);
+    }
+    const int64_t ksA = AROW ? 64 : 2 * p.pitchA, ksB = 2 * p.pitchB;
     int iss_tile = blockIdx.x, iss_kb = 0, issued = 0, iss_par = 0;
     const char* Ab = nullptr; const char* Bb = nullptr;              // wave-uniform: the issue tile's operand origins at the current K stage
     const float* ep_bias = nullptr; const float* ep_scale = nullptr; // per-lane sources of this wave's epilogue constants for the issue tile
@@ -98,19 +119,26 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         int z, tm, tn;
         tile_coords(iss_tile, q->total_tiles, q->tiles_m, q->tiles_n, z, tm, tn);
         const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
-        Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * 32 + b2 * q->kc2 * q->pitchA;
+        if (AROW) {
+            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * q->pitchA + b2 * q->kc2 * 32;
+            const int last = q->M - 1 - tm * BM;
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u)
+                if (pa[u]) voff[u] = (unsigned)min((wid + 8 * u) * 16 + drow, last) * pitchA32 + (unsigned)(dc * 16);
+        } else {
+            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * 32 + b2 * q->kc2 * q->pitchA;
+        }
         Bb = q->Bh + (b1 * q->rB1 + b2 * q->rB2 + (int64_t)tn * BN) * 32 + b2 * q->kc2 * q->pitchB;
-        const int n = min(tn * BN + wc * 64 + lane, q->N - 1);
+        const int n = min(tn * BN + wc * 16 * TNW + min(lane, 16 * TNW - 1), q->N - 1);
         ep_bias = q->bias + b1 * q->bias_bs + n;
         ep_scale = q->scale + b1 * q->scale_bs + n / q->scale_div;
     };
     auto issue_next = [&](int slot) {
         if (issued >= total) return;
         char* sb = smem + slot * STAGE + wid * 1024;
-        g16_dma16(Ab + voA0, sb);
-        g16_dma16(Ab + voA1, sb + 8192);
-        g16_dma16(Bb + voB0, sb + 16384);
-        g16_dma16(Bb + voB1, sb + 24576);
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u)
+            if (pv[u]) g16_dma16((pa[u] ? Ab : Bb) + voff[u], sb + u * 8192);
         if (iss_kb == 0) {                                           // the tile's epilogue constants ride behind its first stage
             if (has_bias) g16_dma4(ep_bias, epi_lds + iss_par * 512);
             if (has_scale) g16_dma4(ep_scale, epi_lds + iss_par * 512 + 256);
@@ -122,16 +150,30 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
             if (iss_tile < total_tiles) issue_tile_setup();
         }
     };
+    // all but this wave's youngest `stages` stages of pieces (and, with `st`, the NSTORE unconditional stores issued behind them) have landed
+    auto wait_stages = [&](int stages, bool st) {
+        constexpr int CH = G::CQ + 1, CL = G::CQ;
+        if (hiw) {
+            if (stages >= 2) { if (st) g16_wait<2 * CH + NSTORE>(); else g16_wait<2 * CH>(); }
+            else if (stages == 1) { if (st) g16_wait<CH + NSTORE>(); else g16_wait<CH>(); }
+            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
+        } else {
+            if (stages >= 2) { if (st) g16_wait<2 * CL + NSTORE>(); else g16_wait<2 * CL>(); }
+            else if (stages == 1) { if (st) g16_wait<CL + NSTORE>(); else g16_wait<CL>(); }
+            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
+        }
+    };
+    static_assert(NS == 4, "wait_stages is written for two stages in flight behind the one awaited");
 
     issue_tile_setup();
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_next(s);
-    if (total > NS - 2) g16_wait<4 * (NS - 2)>(); else g16_wait<0>();
+    wait_stages(total - 1, false);
     G16_BAR();
     if (wr == 1) G16_BAR();                                          // waves 4-7 run one interval behind
 
-    f32x4 acc[8][4];
-    bf16x8 fa[8], fb[4];
+    f32x4 acc[TMW][TNW];
+    bf16x8 fa[TMW], fb[TNW];
     int vtile = blockIdx.x, kb = 0, slot = 0;
     int ep_z = 0, ep_tm = 0, ep_tn = 0, ep_age = 1000, ep_par = 0;
     bool ep_pending = false, ep_full = false;
@@ -141,37 +183,46 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         asm volatile("" : "+s"(q));
         const int pM = q->M, pN = q->N;
         const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
-        const int m0 = tm * BM + wr * 128, n0 = tn * BN + wc * 64;
+        const int m0 = tm * BM + wr * 16 * TMW, n0 = tn * BN + wc * 16 * TNW;
         const int ncols = EPI == G16_EPI_PLANES ? q->Np : pN;
         const bool full = (tm * BM + BM <= pM) && (tn * BN + BN <= pN);
         const bool relu = q->relu != 0;
-        // the wave's 64 bias / scale values: lane holds columns 16 j + 4 g + (0 .. 3)
-        f32x4 bi[4], sc[4];
+        // the wave's bias / scale values: lane holds columns 16 j + 4 g + (0 .. 3)
+        f32x4 bi[TNW], sc[TNW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TNW; ++j) {
             bi[j] = has_bias ? *reinterpret_cast<const f32x4*>(epi_lds + par * 512 + (j * 16 + 4 * g) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             sc[j] = has_scale ? *reinterpret_cast<const f32x4*>(epi_lds + par * 512 + 256 + (j * 16 + 4 * g) * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
-        if (EPI == G16_EPI_F32) {
-            float* cp = q->C + b1 * q->sC1 + b2 * q->sC2 + (int64_t)(m0 + lr) * q->ldc_m + n0 + 4 * g;
-            const int64_t rstep = 16 * q->ldc_m;
+        if (EPI == G16_EPI_F32 || EPI == G16_EPI_BF16) {
+            // rows of fp32 (16-B stores) or bf16 (8-B stores: the next layer's A operand as it stands)
+            constexpr int ESZ = EPI == G16_EPI_F32 ? 4 : 2;
+            char* cp = reinterpret_cast<char*>(q->C) + (b1 * q->sC1 + b2 * q->sC2 + (int64_t)(m0 + lr) * q->ldc_m + n0 + 4 * g) * ESZ;
+            const int64_t rstep = 16 * q->ldc_m * ESZ;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < TMW; ++i) {
                 const int m = m0 + i * 16 + lr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNW; ++j) {
                     f32x4 x = acc[i][j] * sc[j] + bi[j];
                     if (relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = relu_nan(x[e]);
                     }
                     const int n = n0 + j * 16 + 4 * g;
-                    if (full) *reinterpret_cast<f32x4*>(cp + j * 16) = x;
-                    else if (m < pM) {
-                        if (n + 4 <= pN) *reinterpret_cast<f32x4*>(cp + j * 16) = x;
-                        else {
+                    const bool whole = full || (m < pM && n + 4 <= pN);
+                    if (EPI == G16_EPI_F32) {
+                        if (whole) *reinterpret_cast<f32x4*>(cp + j * 64) = x;
+                        else if (m < pM) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (n + e < pN) cp[j * 16 + e] = x[e];
+                            for (int e = 0; e < 4; ++e) if (n + e < pN) reinterpret_cast<float*>(cp + j * 64)[e] = x[e];
+                        }
+                    } else {
+                        const u32x2 hv = {g16_bf16_bits(x[0]) | ((unsigned)g16_bf16_bits(x[1]) << 16), g16_bf16_bits(x[2]) | ((unsigned)g16_bf16_bits(x[3]) << 16)};
+                        if (whole) *reinterpret_cast<u32x2*>(cp + j * 32) = hv;
+                        else if (m < pM) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (n + e < pN) reinterpret_cast<unsigned short*>(cp + j * 32)[e] = g16_bf16_bits(x[e]);
                         }
                     }
                 }
@@ -183,10 +234,10 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
             const int64_t pitchP = q->pitchP;
             unsigned short* const Ph = q->Ph; unsigned short* const Pl = q->Pl;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < TMW; ++i) {
                 const int m = m0 + i * 16 + lr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNW; ++j) {
                     f32x4 x = acc[i][j] * sc[j] + bi[j];
                     const int n = n0 + j * 16 + 4 * g;
                     unsigned short hb[4], lb[4];
@@ -201,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
                     const u32x2 lv = {lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16)};
                     if (full || (m < pM && n < ncols)) {
                         *reinterpret_cast<u32x2*>(Ph + o) = hv;
-                        *reinterpret_cast<u32x2*>(Pl + o) = lv;
+                        if (Pl) *reinterpret_cast<u32x2*>(Pl + o) = lv;
                     }
                 }
             }
@@ -214,37 +265,31 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         {
             const char* s = smem + slot * STAGE;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(s + a_off + u * 1024);
+            for (int u = 0; u < TMW; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(s + a_off + u * 1024);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(s + b_off + u * 1024);
+            for (int u = 0; u < TNW; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(s + b_off + u * 1024);
         }
         issue_next(slot == 0 ? NS - 1 : slot - 1);
         if (ep_pending) {
-            if (nk < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // short K: the tile's bias / scale pieces may still be in flight
             ep_full = epilogue(ep_z, ep_tm, ep_tn, ep_par);
             ep_pending = false; ep_age = 0;
         }
-        {
-            const int rem = total - 2 - i;                           // stages beyond i + 1 that exist; min(NS - 2, rem) of them may stay in flight
-            const bool st = EPI == G16_EPI_F32 && ep_full && ep_age <= NS - 2 && nk > NS - 2;   // the last epilogue's stores were all unconditional and sit inside the window (planes: 64 stores exceed vmcnt's 6 bits)
-            if (rem >= 2) { if (st) g16_wait<8 + NSTORE>(); else g16_wait<8>(); }
-            else if (rem == 1) { if (st) g16_wait<4 + NSTORE>(); else g16_wait<4>(); }
-            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
-            ++ep_age;
-        }
+        // (planes epilogue: up to 64 stores + the pieces exceed vmcnt's six bits: no store window there)
+        wait_stages(total - 2 - i, EPI != G16_EPI_PLANES && ep_full && ep_age <= NS - 2 && nk > NS - 2);
+        ++ep_age;
         G16_BAR();
         // ================= COMPUTE interval =================
         __builtin_amdgcn_s_setprio(1);
         if (kb == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < TMW; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                for (int v = 0; v < TNW; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < TMW; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < TNW; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         slot = slot == NS - 1 ? 0 : slot + 1;
@@ -265,51 +310,74 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
     if (wr == 0) G16_BAR();
 }
 
+template <int EPI, class G, bool AROW>
+int g16_launch(G16P& p, int nb, int ncols, hipStream_t st) {
+    p.tiles_m = (p.M + G::BM - 1) / G::BM; p.tiles_n = (ncols + G::BN - 1) / G::BN;
+    const long long total = (long long)nb * p.tiles_m * p.tiles_n;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm16_planes: %lld tiles", total);
+    p.total_tiles = (int)total;
+    void (*kern)(G16P) = gemm16_planes_kernel<EPI, G, AROW>;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        if (e != hipSuccess) return fail((int)e, "gemm16_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
+    static thread_local int n_cu = 0;
+    if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const long long grid = total < n_cu ? total : n_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, st, p);
+    return launch_status("gemm16_planes");
+}
+
+using G16Sq = G16Geo<8, 4>;                    // 256 x 256
+using G16Wide = G16Geo<9, 3>;                  // 288 x 192
+
 }  // namespace
 
 // Takes the plain-bf16 products gemm_nt_planes() would run on its 256 x 256 tile; false = not eligible (the caller's own kernel runs)
 bool gemm16_eligible(const PlaneGemmArgs& a) {
-    if (a.terms != 1 || a.Af || !(a.epi == 0 || a.epi == 1) || a.ksplit > 1) return false;
+    if (a.terms != 1 || a.Af || !(a.epi == 0 || a.epi == 1 || a.epi == 5) || a.ksplit > 1) return false;
     if (a.Kp % 32 != 0 || a.Kp <= 0) return false;
     if ((a.bias || a.scale) && a.Kp / 32 < 4) return false;                 // the epilogue constants' double buffer assumes tiles of at least 4 stages
     const int64_t rowsA = a.rows_allocA, rowsB = a.rows_allocB;
-    if (rowsA * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32) || rowsB * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32)) return false;   // 32-bit per-lane offsets inside a plane
+    if (rowsB * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32)) return false;      // 32-bit per-lane offsets inside a plane
+    if (a.Abf) {
+        if ((a.ldabf & 7) || (reinterpret_cast<uintptr_t>(a.Abf) & 15) || a.ldabf * 2 * 288 >= (1ll << 32)) return false;
+    } else if (rowsA * 32 * (int64_t)(a.Kp / 16) >= (1ll << 32)) return false;
     if (a.epi == 0) {
         if (a.ldc_n != 1 || (a.ldc_m & 3) || (a.sC1 & 3) || (a.sC2 & 3) || (reinterpret_cast<uintptr_t>(a.C) & 15)) return false;
+    } else if (a.epi == 5) {
+        if (a.ldc_n != 1 || (a.ldc_m & 3) || (a.sC1 & 3) || (a.sC2 & 3) || (reinterpret_cast<uintptr_t>(a.C) & 7)) return false;
     } else {
-        if (!a.Ph || !a.Pl || (a.Np & 15)) return false;
+        if (!a.Ph || (a.Np & 15) || a.Abf) return false;
     }
     return true;
 }
 
 int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
     G16P p{};
-    p.Ah = reinterpret_cast<const char*>(a.Ah); p.Bh = reinterpret_cast<const char*>(a.Bh);
+    p.Ah = a.Abf ? reinterpret_cast<const char*>(a.Abf) : reinterpret_cast<const char*>(a.Ah); p.Bh = reinterpret_cast<const char*>(a.Bh);
     p.C = a.C; p.Ph = a.Ph; p.Pl = a.Pl; p.scale = a.scale; p.bias = a.bias;
-    p.pitchA = a.rows_allocA * 32; p.pitchB = a.rows_allocB * 32;
+    p.pitchA = a.Abf ? a.ldabf * 2 : a.rows_allocA * 32; p.pitchB = a.rows_allocB * 32;
     p.rA1 = a.rA1; p.rA2 = a.rA2; p.rB1 = a.rB1; p.rB2 = a.rB2; p.kc2 = a.kc2;
     p.ldc_m = a.ldc_m; p.sC1 = a.sC1; p.sC2 = a.sC2; p.pitchP = a.rows_allocP * 16;
     p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
     p.nb2 = a.nb2 > 0 ? a.nb2 : 1; p.M = a.M; p.N = a.N; p.Np = a.Np; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
     const int ncols = a.epi == 1 ? a.Np : a.N;
-    p.tiles_m = (a.M + G16_BM - 1) / G16_BM; p.tiles_n = (ncols + G16_BN - 1) / G16_BN;
-    const long long total = (long long)a.nb1 * p.nb2 * p.tiles_m * p.tiles_n;
-    if (total <= 0 || total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm16_planes: %lld tiles", total);
-    p.total_tiles = (int)total;
-    void (*kern)(G16P) = a.epi == 1 ? gemm16_planes_kernel<G16_EPI_PLANES> : gemm16_planes_kernel<G16_EPI_F32>;
-    static thread_local int attr_dev[2] = {-1, -1};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (attr_dev[a.epi] != dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS);
-        if (e != hipSuccess) return fail((int)e, "gemm16_planes: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_dev[a.epi] = dev;
-    }
-    static thread_local int n_cu = 0;
-    if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    const long long grid = total < n_cu ? total : n_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G16_LDS, st, p);
-    return launch_status("gemm16_planes");
+    const int nb = a.nb1 * p.nb2;
+    if (a.epi == 1) return g16_launch<G16_EPI_PLANES, G16Sq, false>(p, nb, ncols, st);
+    // Tile: 256 x 256.  The 288 x 192 geometry (CTI_GEMM16_TILE=1; 9216 x 3072 outputs = 512 tiles = two FULL rounds of the 256 workgroups instead of 1.69)
+    // is built and under test but measured no faster where its rounds are fewer (126.0 vs 128.5 us at 9216 x 3072 x 2048) and 20 % slower where they are equal
+    // (539 vs 451 us at 9216 x 11264 x 2048): its COMPUTE interval is 27 MFMAs = 432 cycles against a LOAD interval of ~480 (12 fragment reads, 3-4 DMA
+    // pieces at ~50 cycles of issue each, the LDS round trip): the square tile's 512-cycle COMPUTE interval is what just covers the LOAD interval.
+    static const bool wide = [] { const char* e = getenv("CTI_GEMM16_TILE"); return e && atoi(e) == 1; }();
+#define G16_GO(EPI, GEO) (a.Abf ? g16_launch<EPI, GEO, true>(p, nb, ncols, st) : g16_launch<EPI, GEO, false>(p, nb, ncols, st))
+    if (a.epi == 5) return wide ? G16_GO(G16_EPI_BF16, G16Wide) : G16_GO(G16_EPI_BF16, G16Sq);
+    return wide ? G16_GO(G16_EPI_F32, G16Wide) : G16_GO(G16_EPI_F32, G16Sq);
+#undef G16_GO
 }
 
 }  // namespace cti

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     }
     const int64_t o = (int64_t)(k0 >> 4) * pitch + row * 16 + (k0 & 15);
     *reinterpret_cast<uint4*>(hi + o) = pack8(h);
-    *reinterpret_cast<uint4*>(lo + o) = pack8(l);
+    if (lo) *reinterpret_cast<uint4*>(lo + o) = pack8(l);           // lo == NULL: the plain-bf16 mode's operands (one product per pair reads the hi plane only)
 }
 
 // Transposing split: x is (M x n) row-major; the planes hold x^T, i.e. rows = the n columns of x, depth = M (zero-filled up to Mp).

@@ -748,6 +748,25 @@ def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None,
     return out
 
 
+def gemm_bf16_rows(A, B_planes, rowsB, nb1=1, rA1=0, rB1=0, M=None, N=None, out_dtype=torch.float32, scale=None, scale_div=1, scale_bs=0, bias=None,
+                   bias_bs=0, relu=False):
+    """C[z][m,n] = act(scale * sum_k A[z*rA1 + m, k] * W[z*rB1 + n, k] + bias) in the plain-bf16 arithmetic with A a row-major torch.bfloat16
+    matrix read as it stands (no split pass) and W = split_operand(..., prec='bf16') planes of a (rowsB, K) weight; out_dtype float32 or bfloat16
+    (bf16 rows = the next layer's A operand).  cti_gemm_bf16_rows; K % 32 == 0."""
+    _req(A, "A", torch.bfloat16)
+    A2 = A.reshape(-1, A.shape[-1])
+    if A2.stride(1) != 1:
+        A2 = A2.contiguous()
+    K = A2.shape[1]
+    M = A2.shape[0] if M is None else M
+    N = rowsB if N is None else N
+    out = torch.empty((nb1, M, N) if nb1 > 1 else (M, N), device=A.device, dtype=out_dtype)
+    L.check(L.lib().cti_gemm_bf16_rows(A2.data_ptr(), A2.stride(0), A2.shape[0], rA1, B_planes.data_ptr(), rowsB, rB1, out.data_ptr(),
+                                       1 if out_dtype == torch.bfloat16 else 0, N, M * N, nb1, M, N, K, _ptr(scale), int(scale_div), int(scale_bs),
+                                       _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, _stream()), "cti_gemm_bf16_rows")
+    return out
+
+
 def split_operand(w, prec=None):
     """A (rows, K) fp32 matrix -> its resident bf16 hi/lo operand planes (one uint8 block) for gemm_nt(..., B_planes=...): split a weight
     once, multiply against it many times.  Returns None in the exact-fp32 mode (no planes there)."""

@@ -284,6 +284,13 @@ int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1
                    float* C, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
                    const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
+/* The same product in the plain-bf16 arithmetic with A given as a row-major bf16 matrix (row stride lda elements, a multiple of 8; 16-B aligned; K % 32
+ * == 0): read as it stands -- no split pass, no workspace -- by the round-4 kernel (csrc/cti_gemm16.hip: 256 x 256 / 288 x 192 tiles, two wave groups one
+ * interval apart).  C: fp32 rows (c_bf16 = 0; 16-B aligned, ldc_m % 4 == 0) or bf16 rows (c_bf16 = 1; 8-B aligned): the output of one layer of reference
+ * src/fc.py:22-29 as the next layer's A operand.  BASELINE configs[2] / [3] ("bf16") run their projections through this. */
+int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                       void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
+                       int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* stream);
 
 /* The "f16f6" operand format (csrc/cti_f16f6.h): an fp32 matrix as an f16 hi plane plus ONE block-scaled fp6 (e2m3) plane -- the codes of the
  * residual -- and two E8M0 scales per 32 elements (of the hi part, whose fp6 codes the GEMM derives in registers, and of the residual): 2.81

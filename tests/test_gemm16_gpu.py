@@ -88,3 +88,50 @@ def test_planes_epilogue_through_the_fused_forward():
     nrm = np.abs(ref).max()
     assert np.abs(y_big - ref).max() / nrm < 2e-2
     assert np.abs(y_big - y_default).max() / nrm < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,nb,out_dtype", [
+    (256, 256, 128, 1, torch.float32), (1000, 776, 320, 1, torch.float32), (513, 260, 160, 1, torch.bfloat16), (700, 520, 256, 3, torch.bfloat16),
+    (9216, 3072, 512, 1, torch.float32),
+    (9216, 3072, 256, 1, torch.bfloat16), (2305, 1024, 2048, 1, torch.bfloat16),
+])
+def test_row_major_bf16_operand_and_bf16_rows_output(M, N, K, nb, out_dtype):
+    """cti_gemm_bf16_rows: A read as a row-major bf16 matrix (no split pass), fp32 or bf16 rows out; both tile geometries"""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = bf16r(torch.randn(nb * N, K, generator=g) / 4)
+    b = torch.randn(nb * N, generator=g)
+    wp = ops.split_operand(w.to(DEV), prec="bf16")
+    y = ops.gemm_bf16_rows(a.to(DEV), wp, nb * N, nb1=nb, rA1=0, rB1=N, M=M, N=N, out_dtype=out_dtype, bias=b.to(DEV), bias_bs=N, relu=True)
+    assert y.dtype == out_dtype
+    ref = torch.relu((a.double() @ w.double().t() + b.double()).view(M, nb, N).permute(1, 0, 2))
+    err = float((y.double().cpu().view(nb, M, N) - ref).abs().max() / ref.abs().max())
+    print("gemm_bf16_rows %dx%dx%d nb=%d %s: %.2e" % (M, N, K, nb, out_dtype, err))
+    assert err < (3e-6 if out_dtype == torch.float32 else 4e-3), err       # bf16 rows: one rounding of the result to 8 significant bits
+
+
+def test_wide_tile_geometry_in_a_child_process():
+    """CTI_GEMM16_TILE=1 (288 x 192 tiles; read once per process): every entry of two products against float64"""
+    import os, subprocess, sys
+    code = r"""
+import torch, cti_amd
+ops = cti_amd.ops
+g = torch.Generator().manual_seed(3)
+for M, N, K in ((1000, 776, 320), (9216, 3072, 256)):
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16); w = (torch.randn(N, K, generator=g) / 4).to(torch.bfloat16).float(); b = torch.randn(N, generator=g)
+    y = ops.gemm_bf16_rows(a.cuda(), ops.split_operand(w.cuda(), prec='bf16'), N, bias=b.cuda(), relu=True)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, (M, N, K, err)
+print('wide ok')
+"""
+    env = dict(os.environ, CTI_GEMM16_TILE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_bf16_rows_entry_refuses_what_the_kernel_cannot_read():
+    a = torch.randn(64, 40, device=DEV).to(torch.bfloat16)                  # K = 40: not whole 64-B stages
+    wp = ops.split_operand(torch.randn(32, 40, device=DEV), prec="bf16")
+    with pytest.raises(Exception):
+        ops.gemm_bf16_rows(a, wp, 32)
