@@ -130,6 +130,27 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
+def dist_info(dist, world, rank, dev):
+    """What a multi-GPU line needs to be self-checking: how many ranks actually met in the RCCL communicator (an all-reduce of
+    ones on the device), which physical GPU every rank ran on, and the RCCL version.  None without a process group."""
+    if dist is None or not dist.is_initialized():
+        return None
+    ones = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(ones)
+    pr = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_device": dev.index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+            "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:                                                # pragma: no cover
+        ver = "unknown (%s)" % type(e).__name__
+    ids = {(d["uuid"], d["pci"]) for d in every}
+    return {"ranks_seen": int(round(float(ones.item()))), "world_size": world, "distinct_devices": len(ids), "devices": every,
+            "rccl_version": ver, "backend": dist.get_backend()}
+
+
 def whole_job_rate(world, batch_per_rank, steps, elapsed):
     """samples/s of the whole job: every rank processed batch_per_rank * steps samples in `elapsed` (max over ranks)."""
     return world * batch_per_rank * steps / elapsed
@@ -254,6 +275,28 @@ def run_train(args, world, rank, dev, dist):
         step_fn()
     host_ms = (time.perf_counter() - t0) / 10 * 1e3
     torch.cuda.synchronize()
+    dinfo = dist_info(dist, world, rank, dev)
+    ar = None
+    if dist.is_initialized():
+        # the step's ONE collective alone: the flat gradient buffer through RCCL, HIP events around the eager calls on the current stream;
+        # bus bandwidth = bytes x 2 (N - 1) / N / time (what a ring all-reduce moves per link)
+        flat = torch.zeros(opt.n_params, device=dev, dtype=torch.float32)
+        for _ in range(3):
+            dist.all_reduce(flat)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); dist.barrier()
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        t = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        nbytes = opt.n_params * 4
+        ar = {"bytes": nbytes, "ms": ms, "algbw_GBps": nbytes / ms / 1e6, "busbw_GBps": nbytes * 2 * (world - 1) / max(world, 1) / ms / 1e6,
+              "note": "max over ranks of the mean of 10 eager all-reduces of the flat fp32 gradient buffer; busbw = bytes * 2 (N - 1) / N / time"}
+        del flat
     if dist.is_initialized():                                   # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
@@ -266,11 +309,12 @@ def run_train(args, world, rank, dev, dist):
                           "config": {"workload": "BASELINE configs[4] shape: TriAttention + 2 x (TCNet.forward_with_weights, q_prj, a_prj) + SimpleClassifier "
                                                  "+ BCE, train mode (dropout on), fwd + bwd + one all-reduce + fused clip/Adamax",
                                      "global_batch": world * B, "parameters": opt.n_params, "parallelism": "dp%d" % world, "collective": coll,
-                                     "launch": launch, "host_issue_ms_per_step": round(host_ms, 3)}}))
+                                     "launch": launch, "host_issue_ms_per_step": round(host_ms, 3)},
+                          "distributed": dinfo, "allreduce": ar}))
 
 
 # ---- full-model forwards: BASELINE configs[2] (c3: MC CTI, Visual7W shapes) and configs[3] (c4: FFOE BAN + CTI teacher) ---------------
-def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, rep=1):
+def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, rep=1, executed=False):
     """SURVEY.md 8(d) formulas summed over the module calls of the model forward (per BATCH, flops = 2 MAC).  `rep`: the MC pipeline feeds
     every image `rep` times; the reference projects v for every row, so the algorithmic count does too (the de-duplicated kernels do less)."""
     hr = h // R
@@ -284,6 +328,10 @@ def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, 
         fww = G * (2 * d * (V * vd + Q * nh + A * nh) + 2 * d * (V * Q * A + V * Q + V))
         prj = G * 2 * 2 * nh * nh
         per = tucker + rank + core + fww + prj + gru(Q, 600) + gru(A, 600) + cls(n_ans)
+        if executed:
+            # what the de-duplicating kernels run: the terms that depend on the image alone once per image instead of once per row
+            v_only = 2 * h * V * vd + 2 * h * h * V + 2 * V * R * hr * hr * G * hr + G * 2 * d * V * vd
+            return B * (per - v_only) + (B // rep) * v_only
         return B * per
     if kind == "ban":
         d3 = 3 * nh
@@ -295,7 +343,7 @@ def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, 
     raise ValueError(kind)
 
 
-MODEL_TOL = {"bf16": 5e-2, "bf16x3": 1e-4, "f16f6": 1e-4, "fp32": 1e-4}     # normalised max error of the model logits vs the fp32 oracle, per arithmetic mode
+MODEL_TOL = {"bf16": 2e-2, "bf16x3": 1e-4, "f16f6": 1e-4, "fp32": 1e-4}     # normalised max error of the model logits vs the fp32 oracle, per arithmetic mode
 
 
 def model_setup(config, B, rank, dev):
@@ -343,7 +391,8 @@ def model_setup(config, B, rank, dev):
             from oracle import cti_models as OM
             ref = OM.mc_tan_forward(v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
             return [("mc_cti logits", out[:n].cpu().numpy(), ref)]
-        return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2),
+        return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2), rep=rep,
+                    executed_flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2, rep=rep, executed=True),
                     workload="BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B)
     v = torch.randn(B, 36, 2048, generator=g).abs()
     nv = torch.randint(10, 37, (B,), generator=g)
@@ -431,6 +480,7 @@ def run_model(args, world, rank, dev, dist):
     graphed = not args.no_graph
     el, parity = model_measure(setup, args.steps, args.warmup, world, dist, dev, graphed, prec)
     flops, workload = setup["flops"], setup["workload"]
+    dinfo = dist_info(dist, world, rank, dev)
     if dist.is_initialized():
         dist.barrier(); dist.destroy_process_group()
     flush_c_stdio()
@@ -442,11 +492,13 @@ def run_model(args, world, rank, dev, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[prec], "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "precision": prec, "parallelism": "replicas x%d" % world,
-                       "gflop_per_batch": round(flops / 1e9, 3), "launch": "hipGraph replay of the captured forward" if graphed else "eager"},
+                       "gflop_per_batch": round(flops / 1e9, 3), "executed_gflop_per_batch": round(setup.get("executed_flops", flops) / 1e9, 3),
+                       "io_dtype": "fp32 activations in and out (token ids int64); products in %s" % prec,
+                       "launch": "hipGraph replay of the captured forward" if graphed else "eager"},
             "roofline": {"bound": "mfma", "kernel": "whole forward (launch sequence; dominant kernels are the projection GEMMs)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "note": "algorithmic flops of SURVEY.md 8(d) summed over the module calls / wall time of the forward"},
-            "parity_of_timed_forward": parity}), flush=True)
+            "parity_of_timed_forward": parity, "distributed": dinfo}), flush=True)
 
 
 def model_subrecord(config, dev):
@@ -458,12 +510,28 @@ def model_subrecord(config, dev):
         setup = model_setup(config, 256, 0, dev)
         steps = 200 if config == "c3" else 100
         el, parity = model_measure(setup, steps, 10, 1, None, dev, True, "bf16")
+        as_called = None
+        if setup.get("rep", 1) > 1:
+            # the reference's own calling convention (src/MC/train.py:75-79 replicates the image rows and says nothing): no de-duplication hint
+            for m in setup["models"].values():
+                m.v_replication = 1
+            el1, _ = model_measure(setup, steps, 10, 1, None, dev, True, "bf16")
+            as_called = {"v_replication": 1, "value": 256 * steps / el1, "unit": "samples/s", "ms_per_step": el1 / steps * 1e3,
+                         "achieved_tflops": setup["flops"] * steps / el1 / 1e12, "frac_of_bf16_peak": setup["flops"] * steps / el1 / 1e12 / PEAK_TFLOPS["bf16"],
+                         "note": "every row's image projected (what a drop-in caller gets without setting TanModel.v_replication)"}
     finally:
         cti_amd.set_precision(old)
     ach = setup["flops"] * steps / el / 1e12
-    return {"workload": setup["workload"], "value": 256 * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-            "dtype": DTYPE_NAME["bf16"], "launch": "hipGraph replay of the captured forward", "gflop_per_batch": round(setup["flops"] / 1e9, 3),
-            "achieved_tflops": ach, "frac_of_bf16_peak": ach / PEAK_TFLOPS["bf16"], "parity_of_timed_forward": parity}
+    exe = setup.get("executed_flops", setup["flops"]) * steps / el / 1e12
+    rec = {"workload": setup["workload"], "value": 256 * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "dtype": DTYPE_NAME["bf16"], "io_dtype": "fp32 activations in and out; bf16 products", "launch": "hipGraph replay of the captured forward",
+           "gflop_per_batch": round(setup["flops"] / 1e9, 3), "executed_gflop_per_batch": round(setup.get("executed_flops", setup["flops"]) / 1e9, 3),
+           "achieved_tflops": ach, "frac_of_bf16_peak": ach / PEAK_TFLOPS["bf16"],
+           "executed_tflops": exe, "executed_frac_of_bf16_peak": exe / PEAK_TFLOPS["bf16"], "parity_of_timed_forward": parity}
+    if as_called is not None:
+        rec["v_replication"] = setup["rep"]
+        rec["as_the_reference_calls_it"] = as_called
+    return rec
 
 
 def aside_kernels(c, dev):
@@ -650,11 +718,13 @@ def run_forward(args, world, rank, dev, dist):
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(c, state, (v, q, a), gpu_first, args.cpu_budget)
+    dinfo = dist_info(dist, world, rank, dev)
     if dist.is_initialized():                                    # tear RCCL down first: the JSON line must be the last line of stdout
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
+        res["distributed"] = dinfo
         print(json.dumps(res), flush=True)
 
 

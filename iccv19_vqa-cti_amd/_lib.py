@@ -38,6 +38,7 @@ SIGNATURES = {
     "cti_triattention_hoist_ok": (_int, [_int] * 8),
     "cti_tcnet_forward_guard_bytes": (_sz, [_int] * 11),
     "cti_guard_read": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint32)]),
+    "cti_guard_read_ratio": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "cti_masked_softmax_tri_from_partials_fwd": (_int, [_vp, _vp, _vp, _sz, _vp, _int, _int, _i64, _int, _vp, _sz, _vp]),
     "cti_tcnet_prepare": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _sz, _vp]),
     "cti_tcnet_prepared_bytes": (_sz, [_int] * 7),

@@ -94,7 +94,8 @@ class BanModel(nn.Module):
         total = None
         fused_sum = not torch.is_grad_enabled()
         if fused_sum:                                                        # inference: the per-glimpse sums accumulate inside the residual pass
-            total = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32)
+            # (beta = 0 at g == 0 initialises it; with no glimpse at all the classifier must see zeros, not uninitialised memory: ADVICE r3)
+            total = (torch.zeros if self.glimpse == 0 else torch.empty)(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32)
         for g in range(self.glimpse):
             w_g = att[:, g, :, :]
             b_emb = self.b_net[g].forward_with_weights(v, q_emb, w_g) if vp is None else self.b_net[g]._pool_projected(vp[g], q_emb, w_g)
@@ -136,13 +137,18 @@ class _TriModel(nn.Module):
         # `v_replication` = r > 1 (set by the caller; the MC pipeline feeds every image once per candidate answer, src/MC/train.py:75-79, so
         # rows b*r .. b*r+r-1 of v are identical): the projections -- and the attention's whole v side -- run once per image
         rep = int(getattr(self, "v_replication", 1))
+        # the attention takes the hoisted v projection only on its fused few-answer path (same predicate as ops.tcnet_forward / cti_triattention_forward):
+        # otherwise its 512-wide layer stays out of the batched GEMM instead of being computed and discarded
+        tc = t_att.TriAtt
+        want_pad = (ops.get_precision() != "fp32" and tc._act == 'ReLU' and t_att.glimpse >= 2 and tc._fusable(v, q_emb, ans_emb) and v.dim() == 3
+                    and bool(ops.triattention_hoist_ok(v.shape[0], v.shape[1], q_emb.shape[1], ans_emb.shape[1], tc.h_dim, tc.rank, t_att.glimpse)))
         if rep > 1 and v.shape[0] % rep == 0:
             if _os.environ.get("CTI_CHECK_REPLICATION", "0") == "1":
                 assert torch.equal(v.view(v.shape[0] // rep, rep, *v.shape[1:])[:, :1].expand(-1, rep, -1, -1).reshape(v.shape), v), "v_replication does not hold"
-            vp = self._v_hoist.maybe(v[::rep])
+            vp = self._v_hoist.maybe(v[::rep], use_padded=want_pad)
         else:
             rep = 1
-            vp = self._v_hoist.maybe(v)
+            vp = self._v_hoist.maybe(v, use_padded=want_pad)
         if vp is not None:
             pad = self._v_hoist.last_padded
             att, logits = t_att(v, q_emb, ans_emb, _v_tucked=pad[0] if pad else None, _v_rep=rep)        # b x v x q x a x g

@@ -124,7 +124,7 @@ struct F6GemmArgs {
     const F6Planes* out;
 };
 // ---- range guard (cti_f16f6_guard.hip): the guard block is GUARD_WORDS uint32 at the head of cti_tcnet_forward's workspace
-constexpr int GUARD_WORDS = 64, GUARD_W_STATUS = 0, GUARD_W_DONE = 1, GUARD_W_SEG = 4, GUARD_MAX_SEG = 12;
+constexpr int GUARD_WORDS = 64, GUARD_W_STATUS = 0, GUARD_W_DONE = 1, GUARD_W_RATIO = 2, GUARD_W_SEG = 4, GUARD_MAX_SEG = 12;
 struct GuardSeg {
     const void* p;                             // kind 0: an S plane ([Kb][rows_allocS][2 B]); kind 1: fp32 values
     int kind, Kb, slot;                        // slot: which word of the guard block collects this tensor's maximum
@@ -144,6 +144,14 @@ inline GuardSeg guard_seg_f32(const float* x, int64_t n, int slot) { GuardSeg s{
 int guard_reset(unsigned* words, hipStream_t st);
 int guard_scan(const GuardArgs& g, hipStream_t st);
 int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st);
+// Cancellation estimate of the mode-3 product (round 4): per batch, 32 x 32 sampled (row of M, row of A^) pairs from the f16 hi planes ->
+// words[GUARD_W_RATIO] = rho = max over batches of  max_pairs sum_k |m_k a_k|  /  max_pairs |sum_k m_k a_k|  (float bits, atomicMax).
+// Measured at the BASELINE configs[1] widths against the float64 oracle (tests/test_accuracy_envelope_gpu.py): the whole TCNet.forward's error
+// normalised by the largest output is ~1e-5 rho in the f16f6 mode (rho 2-4 on the synthetic tensors: 2.7e-5), ~4e-6 rho as bf16x3 (the
+// operands M and A^ carry their own 2^-17 relative errors, which a cancelling sum amplifies just the same), ~5e-8 rho in exact fp32.  The final
+// guard scan turns rho into CTI_GUARD_CANCEL (f16f6 -> bf16x3) / CTI_GUARD_CANCEL_HEAVY (-> fp32).  A no-op (rho 0) when K > 1024.
+constexpr float GUARD_RATIO_BF16X3 = 10.f, GUARD_RATIO_FP32 = 20.f;
+int guard_cancel(const F6Planes& M, int64_t mrows, const F6Planes& A, int64_t arows, int nb, unsigned* words, hipStream_t st);
 
 int f6_sm_chunks(int M, int N);                // partial (max, sum) pairs per batch and g that gemm_nt_f16f6 writes for an M x N product
 int gemm_nt_f16f6(const F6GemmArgs& a, hipStream_t st);

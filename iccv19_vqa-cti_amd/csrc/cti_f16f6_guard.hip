@@ -15,7 +15,8 @@
 //
 // status bits: 1 = a block at or beyond the f16 range (|x| > 61440, incl. inf / NaN in an encoded tensor), 2 = a tensor that is not all zero
 // but whose largest block lies below 2^-12 (hi parts subnormal: absolute error 2^-29 stops being small against the tensor), 4 = non-finite
-// values in V^ / Q^ / T_eff (the M build's encoder would swallow them).  The host reads the word after ev_core_begin (cti_guard_read) and
+// values in V^ / Q^ / T_eff (the M build's encoder would swallow them), 8 / 16 = the mode-3 product cancels so heavily that the f16f6 (8) or even the
+// bf16x3 (16) rounding may exceed 1e-4 of the largest output (guard_cancel's sampled estimate).  The host reads the word after ev_core_begin (cti_guard_read) and
 // re-runs the call in the bf16x3 mode; under hipGraph capture, where the host cannot look, the NaN fill is the signal.
 #include "cti_common.h"
 #include "cti_f16f6.h"
@@ -107,7 +108,67 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
             if ((m & GB_NONZERO) && !(m & GB_HEALTHY)) status |= CTI_GUARD_UNDERFLOW;
         }
     }
+    // cancellation estimate of the mode-3 product (guard_cancel, stream-ordered in front of this scan): the estimated normalised error is
+    // ~2^-17 x ratio for the f16f6 product, ~2^-19 x ratio for bf16x3 -- beyond 1e-4 the call belongs in the next mode up
+    const float ratio = __builtin_bit_cast(float, atomicOr(&g.words[GUARD_W_RATIO], 0u));
+    if (ratio > GUARD_RATIO_BF16X3) status |= CTI_GUARD_CANCEL;
+    if (ratio > GUARD_RATIO_FP32) status |= CTI_GUARD_CANCEL_HEAVY;
     atomicExch(&g.words[GUARD_W_STATUS], status);
+}
+
+// ---- cancellation estimate (see cti_f16f6.h).  One workgroup per batch: 32 rows of M and 32 rows of A^ (evenly spaced, offset by the batch index)
+// are copied from the f16 hi planes into LDS (row pitch K * 2 + 16 B: the eight threads that share an M row read eight different A^ rows without a
+// bank conflict), thread t multiplies the pairs (t >> 3, (t & 7) + 8 u), u < 4, with v_dot2_f32_f16 -- once as they stand, once with the sign
+// bits cleared: 1 024 pairs per batch.
+typedef _Float16 gc_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gc_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int GC_ROWS = 32;
+__global__ __launch_bounds__(256) void guard_cancel_kernel(const char* MH, int64_t m_ra, int64_t m_rstride, int mrows, const char* AH, int64_t a_ra, int64_t a_rstride,
+                                                            int arows, int Kb, unsigned* words) {
+    extern __shared__ __attribute__((aligned(16))) char gc_lds[];
+    __shared__ float red[2][4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int pitch = Kb * 64 + 16;
+    // copy: 64 rows x Kb blocks of 64 B; thread -> (row, block, 16-B piece)
+    for (int it = t; it < 2 * GC_ROWS * Kb * 4; it += 256) {
+        const int piece = it & 3, kb = (it >> 2) % Kb, row = (it >> 2) / Kb;
+        const bool isA = row >= GC_ROWS;
+        const int i = row & (GC_ROWS - 1);
+        const int64_t r = isA ? ((int64_t)i * arows / GC_ROWS + 11 * b) % arows : ((int64_t)i * mrows / GC_ROWS + 5 * b) % mrows;
+        const char* src = isA ? AH + (((int64_t)kb * a_ra + (int64_t)b * a_rstride + r) * 64 + piece * 16)
+                              : MH + (((int64_t)kb * m_ra + (int64_t)b * m_rstride + r) * 64 + piece * 16);
+        *reinterpret_cast<gc_u32x4*>(gc_lds + row * pitch + kb * 64 + piece * 16) = *reinterpret_cast<const gc_u32x4*>(src);
+    }
+    __syncthreads();
+    const char* mr = gc_lds + (t >> 3) * pitch;
+    const char* ar = gc_lds + (GC_ROWS + (t & 7)) * pitch;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Kb * 4; ++c) {
+        const gc_u32x4 m = *reinterpret_cast<const gc_u32x4*>(mr + c * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const gc_u32x4 a = *reinterpret_cast<const gc_u32x4*>(ar + u * 8 * pitch + c * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dot[u] = __builtin_amdgcn_fdot2(__builtin_bit_cast(gc_f16x2, m[e]), __builtin_bit_cast(gc_f16x2, a[e]), dot[u], false);
+                ab[u] = __builtin_amdgcn_fdot2(__builtin_bit_cast(gc_f16x2, m[e] & 0x7fff7fffu), __builtin_bit_cast(gc_f16x2, a[e] & 0x7fff7fffu), ab[u], false);
+            }
+        }
+    }
+    float md = wave_max(fmaxf(fmaxf(fabsf(dot[0]), fabsf(dot[1])), fmaxf(fabsf(dot[2]), fabsf(dot[3]))));
+    float ma = wave_max(fmaxf(fmaxf(ab[0], ab[1]), fmaxf(ab[2], ab[3])));
+    if ((t & 63) == 0) { red[0][t >> 6] = md; red[1][t >> 6] = ma; }
+    __syncthreads();
+    if (t == 0) {
+        md = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        ma = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        // non-finite sums are the range bits' business; an all-zero batch (ma == 0) has nothing to cancel
+        const float ratio = (ma > 0.f && ma < 3.0e38f) ? fminf(ma / fmaxf(md, 1e-30f), 3.0e38f) : 0.f;
+        if (ratio > 0.f) {
+            const unsigned bits = __builtin_bit_cast(unsigned, ratio);
+            if (bits > __atomic_load_n(&words[GUARD_W_RATIO], __ATOMIC_RELAXED)) atomicMax(&words[GUARD_W_RATIO], bits);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void guard_poison_kernel(const unsigned* words, float* out, int64_t n) {
@@ -137,6 +198,22 @@ int guard_scan(const GuardArgs& g, hipStream_t st) {
     return launch_status("guard_scan");
 }
 
+int guard_cancel(const F6Planes& M, int64_t mrows, const F6Planes& A, int64_t arows, int nb, unsigned* words, hipStream_t st) {
+    if (M.Kb != A.Kb || M.Kb <= 0 || M.Kb > 32 || mrows <= 0 || arows <= 0 || nb <= 0) return CTI_OK;       // (deep contractions: no estimate, the range bits still hold)
+    const int lds = 2 * GC_ROWS * (M.Kb * 64 + 16);
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(guard_cancel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GC_ROWS * (32 * 64 + 16));
+        if (e != hipSuccess) return fail((int)e, "guard_cancel: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(guard_cancel_kernel, dim3((unsigned)nb), dim3(256), lds, st, reinterpret_cast<const char*>(M.H), M.rows_alloc, nb > 1 ? M.rstride : 0, (int)mrows,
+                       reinterpret_cast<const char*>(A.H), A.rows_alloc, nb > 1 ? A.rstride : 0, (int)arows, M.Kb, words);
+    return launch_status("guard_cancel");
+}
+
 int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(guard_poison_kernel, dim3(2048), dim3(256), 0, st, words, out, n);
     return launch_status("guard_poison");
@@ -145,6 +222,13 @@ int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st) {
 }  // namespace cti
 
 using namespace cti;
+
+extern "C" int cti_guard_read_ratio(const void* workspace, void* stream, float* ratio_host) {
+    CTI_REQUIRE_PTR(workspace); CTI_REQUIRE_PTR(ratio_host);
+    hipError_t e = hipMemcpyAsync(ratio_host, static_cast<const unsigned*>(workspace) + GUARD_W_RATIO, sizeof(float), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    return e == hipSuccess ? CTI_OK : fail((int)e, "cti_guard_read_ratio: %s", hipGetErrorString(e));
+}
 
 extern "C" int cti_guard_read(const void* workspace, void* ev_core_begin, void* stream, uint32_t* status_host) {
     CTI_REQUIRE_PTR(workspace); CTI_REQUIRE_PTR(ev_core_begin); CTI_REQUIRE_PTR(status_host);

@@ -248,6 +248,10 @@ extern "C" size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int 
     return small_a(d) ? 0 : sizeof(unsigned) * GUARD_WORDS;
 }
 
+// CTI_F6_GUARD_ABLATE=1 (measurement only): the guard's scan / estimate / poison kernels are not launched (the block is still reset, so the host reads
+// status 0): the guard-on vs guard-off A/B of the step, profiles/r04_guard_ab.txt
+static bool guard_ablate() { static const bool v = [] { const char* e = getenv("CTI_F6_GUARD_ABLATE"); return e && e[0] == '1'; }(); return v; }
+
 static bool sm_partials_supported(int h, int G, int prec) { return prec == CTI_PREC_F16F6 && G == 2 && h % 32 == 0; }
 
 extern "C" size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec) {
@@ -469,6 +473,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
         gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
         gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
+        if (guard_ablate()) return CTI_OK;
         return guard_scan(gb, sb);
     };
     if (f6 && aux_stream) {
@@ -520,7 +525,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         GuardArgs gm{};
         gm.words = p.guard;
         gm.seg[gm.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
-        rc = guard_scan(gm, st); if (rc) return finish(rc);
+        if (!guard_ablate()) { rc = guard_scan(gm, st); if (rc) return finish(rc); }
     }
     if (aux_stream && !early_join) (void)hipStreamWaitEvent(st, ev_join, 0);
     if (f6) {
@@ -541,12 +546,15 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
         }
         if (!aux_stream || early_join) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
-        rc = guard_scan(ga, st); if (rc) return finish(rc);
+        if (!guard_ablate()) {
+            rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, st); if (rc) return finish(rc);   // the estimate the final scan's verdict reads
+            rc = guard_scan(ga, st); if (rc) return finish(rc);
+        }
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         if (rc) return finish(rc);
-        return finish(guard_poison(p.guard, out, (int64_t)B * V * Q * A * G, st));
+        return finish(guard_ablate() ? CTI_OK : guard_poison(p.guard, out, (int64_t)B * V * Q * A * G, st));
     }
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample
     c.Ah = p.Mp.hi; c.Al = p.Mp.lo; c.Bh = p.Arp.hi; c.Bl = p.Arp.lo;

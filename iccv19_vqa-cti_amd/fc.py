@@ -149,17 +149,20 @@ class HoistedProjection:
             extra = []                                   # a narrower network of another form (e.g. act='Tanh'): the main ones still batch
         return main + extra
 
-    def maybe(self, x):
-        """x (..., in) -> list of (..., out) tensors, one per network, or None."""
+    def maybe(self, x, use_padded=True):
+        """x (..., in) -> list of (..., out) tensors, one per network, or None.  use_padded = False: the narrower networks stay out of the batch
+        (their consumer will not take the hoisted output on this call: the extra rows would be computed and discarded)."""
         self.last_padded = []
-        if len(self.nets) + len(self.padded) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets + self.padded for p in n.parameters())):
+        if len(self.nets) + (len(self.padded) if use_padded else 0) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets + self.padded for p in n.parameters())):
             return None
         if any(n.training for n in self.nets):
             return None
         layers = self._layers()
         if layers is None:
             return None
-        key = (ops._param_epoch[0], ops.get_precision()) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
+        if not use_padded:
+            layers = layers[:len(self.nets)]
+        key = (ops._param_epoch[0], ops.get_precision(), bool(use_padded)) + tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight_v, l.weight_g, l.bias))
         if key != self._key:
             with torch.no_grad():
                 od = layers[0].out_features

@@ -17,7 +17,17 @@ _default_prec = "f16f6"
 def set_precision(name):
     """'fp32' (exact fp32 MFMA), 'bf16x3' (3-term split-bf16, fp32-grade), 'f16f6' (the default: fused TCNet.forward on f16 + block-scaled fp6
     products, fp32-grade INSIDE the format's domain -- magnitudes in f16's normal range, 6e-5 ... 65504, finite -- and guarded outside it: the
-    call is re-run as bf16x3, see set_range_check; everything else as bf16x3) or 'bf16'."""
+    call is re-run as bf16x3, see set_range_check; everything else as bf16x3) or 'bf16'.
+
+    A-priori accuracy of the mode-3 product  out = sum_k M_k A^_k  (K = 512 at BASELINE configs[1]), as absolute error per output:
+        fp32 (the reference, src/Tensor.py:16-20)   ~2^-24 sum_k |M_k A^_k|
+        bf16x3                                      ~2^-19 sum_k |M_k A^_k|   (dropped lo x lo term + bf16 roundings of the lo parts; 2^-17 worst case)
+        f16f6                                       ~2^-17 sum_k |M_k A^_k|   (each cross term rounded to the 4 bits of e2m3; 2^-15 worst case)
+    so the error NORMALISED by the largest output grows with rho = sum_k |M_k A^_k| / max |out|.  Measured on the whole forward at the configs[1]
+    widths (tests/test_accuracy_envelope_gpu.py; the operands M and A^ carry their own rounding, which a cancelling sum amplifies just the same):
+    ~1e-5 rho as f16f6 (2.7e-5 on the synthetic tensors, rho 2-4), ~4e-6 rho as bf16x3, ~5e-8 rho in fp32.  The guard estimates rho on the device
+    from 1 024 sampled (row, answer) pairs per sample and re-runs the call as bf16x3 when it exceeds 10, as exact fp32 when it exceeds 20
+    (include/cti_hip.h: CTI_GUARD_CANCEL / _HEAVY)."""
     global _default_prec
     if name not in _PREC:
         raise ValueError("precision must be one of %s" % sorted(_PREC))
@@ -35,7 +45,8 @@ def get_precision():
 # re-runs the call in the bf16x3 mode: the caller always gets fp32-grade numbers.  'poison': no host wait (what hipGraph capture forces): an
 # out-of-range call returns NaN, never clamped numbers.
 _range_check = __import__("os").environ.get("CTI_RANGE_CHECK", "sync")      # (the environment variable: A/B of the host wait)
-_range_log = {"calls": 0, "trips": 0, "last_status": 0, "consecutive": 0, "skip": 0}
+_range_log = {"calls": 0, "trips": 0, "last_status": 0, "consecutive": 0, "skip": 0, "last_ratio": None}
+_range_debug = False       # tests / diagnostics: also read the cancellation estimate rho of every guarded call (one more small host read) into last_ratio
 _guard_res = {}
 
 
@@ -47,8 +58,9 @@ def set_range_check(mode):
 
 
 def f16f6_range_status():
-    """Counters of the f16f6 range guard in this process: guarded calls, trips (calls re-run as bf16x3), the last status word
-    (bit 0 saturation / non-finite in an encoded operand, bit 1 underflow, bit 2 non-finite V^ / Q^ / T_eff)."""
+    """Counters of the f16f6 range guard in this process: guarded calls, trips (calls re-run as bf16x3 / fp32), the last status word
+    (bit 0 saturation / non-finite in an encoded operand, bit 1 underflow, bit 2 non-finite V^ / Q^ / T_eff, bit 3 / 4 heavy cancellation in the
+    mode-3 product: re-run as bf16x3 / as exact fp32), last_ratio = the cancellation estimate rho (only with ops._range_debug = True)."""
     return dict(_range_log)
 
 
@@ -483,7 +495,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     if wait_guard and _range_log["skip"] > 0:
         # this process keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
         _range_log["skip"] -= 1
-        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
+        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, _range_log.get("skip_mode", "bf16x3"), None, want_sm_partials, _tri, _v_tucked, _v_rep)
     wsb = (lib.cti_triattention_workspace_bytes if _tri else lib.cti_tcnet_forward_workspace_bytes)(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
     if _debug_ws_fill is not None:              # tests: the library must not read workspace bytes it has not written (0xFF reads as saturated scale bytes)
@@ -529,6 +541,10 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         status = _C.c_uint32(0)
         L.check(lib.cti_guard_read(ws.data_ptr(), ev0, _guard_resources(v.device)[2].cuda_stream, _C.byref(status)), "cti_guard_read")
         _range_log["last_status"] = int(status.value)
+        if _range_debug:
+            ratio = _C.c_float(0.0)
+            L.check(lib.cti_guard_read_ratio(ws.data_ptr(), _guard_resources(v.device)[2].cuda_stream, _C.byref(ratio)), "cti_guard_read_ratio")
+            _range_log["last_ratio"] = float(ratio.value)
         if status.value:
             # an operand left the f16f6 format's domain (the output of this launch has been NaN-filled on the device): the reference's
             # full-range fp32 semantics come from the bf16x3 kernels
@@ -536,17 +552,29 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
             _range_log["consecutive"] += 1
             if _range_log["consecutive"] >= 2:
                 _range_log["skip"] = 64
+                _range_log["skip_mode"] = "fp32" if status.value & 16 else "bf16x3"
             if _range_log["trips"] == 1:
                 import warnings
-                warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the bf16x3 mode; see ops.f16f6_range_status()"
-                              % (status.value, ", ".join(n for b, n in ((1, "saturation / non-finite"), (2, "underflow"), (4, "non-finite V^/Q^/T")) if status.value & b)))
-            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
+                warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the %s mode; see ops.f16f6_range_status()"
+                              % (status.value, ", ".join(n for b, n in ((1, "saturation / non-finite"), (2, "underflow"), (4, "non-finite V^/Q^/T"),
+                                                                        (8, "heavy cancellation"), (16, "very heavy cancellation")) if status.value & b),
+                                 "fp32" if status.value & 16 else "bf16x3"))
+            # (heavy cancellation: even the 3-term split's 2^-19 constant may exceed the tolerance -- the exact-fp32 kernels are the reference's arithmetic)
+            return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "fp32" if status.value & 16 else "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
         _range_log["consecutive"] = 0
     if _tri:
         return p_att, out
     if want_sm_partials:
         return out, mask, part
     return (out, mask) if want_mask else out
+
+
+def triattention_hoist_ok(B, V, Q, A, h, R, G, prec=None):
+    """True when cti_triattention_forward takes a hoisted v projection at this shape and precision (its fused few-answer path)."""
+    pr = _prec(prec, fused=True)
+    if pr == L.PREC_F16F6 and h % 32:
+        pr = L.PREC_BF16X3
+    return bool(L.lib().cti_triattention_hoist_ok(int(B), int(V), int(Q), int(A), int(h), int(R), int(G), pr))
 
 
 def triattention_forward(v, q, a, tucker, rank, T_g, relu=True, prec=None, prepared=None, v_tucked=None, v_rep=1):

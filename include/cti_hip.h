@@ -177,7 +177,14 @@ size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G
  * cti_guard_read waits on the HOST for ev_core_begin (i.e. while the mode-3 product is still running), copies the status word through
  * `stream` (any stream of the caller that is idle by then, e.g. the call's aux_stream) and returns it: a non-zero value means "re-run
  * this call with CTI_PREC_BF16X3" (what the shipped Python wrapper does).  It is the only entry point of the library that synchronises. */
-enum { CTI_GUARD_SATURATED = 1, CTI_GUARD_UNDERFLOW = 2, CTI_GUARD_NONFINITE = 4 };
+/* Accuracy (round 4): inside the range the f16f6 product's error is ~2^-17 sum_k |M_k A^_k| per output (2^-15 worst case) against fp32's 2^-24: it
+ * is 1e-4 of the LARGEST output only while the contraction does not cancel too heavily.  The guard therefore also samples 32 x 32 (M row, A^ row)
+ * pairs per batch from the f16 planes and forms  rho = max sum_k |m_k a_k| / max |sum_k m_k a_k|  (2-4 on the synthetic BASELINE tensors; the
+ * measured error of the whole forward is ~1e-5 rho as f16f6, ~4e-6 rho as bf16x3, ~5e-8 rho in fp32);
+ * CTI_GUARD_CANCEL: rho > 10 -- re-run with CTI_PREC_BF16X3;  CTI_GUARD_CANCEL_HEAVY: rho > 20 -- re-run with CTI_PREC_F32.
+ * cti_guard_read_ratio copies rho (diagnostics / tests; it synchronises `stream`). */
+enum { CTI_GUARD_SATURATED = 1, CTI_GUARD_UNDERFLOW = 2, CTI_GUARD_NONFINITE = 4, CTI_GUARD_CANCEL = 8, CTI_GUARD_CANCEL_HEAVY = 16 };
+int cti_guard_read_ratio(const void* workspace, void* stream, float* ratio_host);
 size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
 int cti_guard_read(const void* workspace, void* ev_core_begin, void* stream, uint32_t* status_host);
 /* The batch-independent part of cti_tcnet_forward, computed once per parameter update: the six weight-norm scales, T_eff (and its
