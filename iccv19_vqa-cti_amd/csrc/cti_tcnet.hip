@@ -252,6 +252,14 @@ extern "C" size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int 
 // status 0): the guard-on vs guard-off A/B of the step, profiles/r04_guard_ab.txt
 static bool guard_ablate() { static const bool v = [] { const char* e = getenv("CTI_F6_GUARD_ABLATE"); return e && e[0] == '1'; }(); return v; }
 
+// Guard scheduling.  Round 3 spread the scans so that only M's 8 MB of scale bytes sat in front of the mode-3 product: `a`, a~, the weights and the fp32 sweep
+// on the auxiliary stream (behind an event wait for the a side's Tucker product), A^ behind the rank product.  The round-4 A/B (profiles/r04_guard_ab.txt)
+// priced the guard at 0.15-0.19 ms per step: 1 024-workgroup scans beside persistent GEMMs that hold every CU wait for the GEMM to end, and chain B -- whose
+// M build IS the tail of the critical path -- waited for an event of the main stream.  CTI_F6_GUARD_LATE=1 (experiment): ONE scan of everything (~100 MB at
+// configs[1]) behind the join, unstarved, in front of the mode-3 product -- measured SLOWER than the spread placement (4.52-4.54 vs 4.45-4.50 ms per step,
+// no guard kernels at all: 4.34-4.47; profiles/r04_guard_ab.txt): the spread scans do hide, what shows of the guard is ~0.1 ms.
+static bool guard_late() { static const bool v = [] { const char* e = getenv("CTI_F6_GUARD_LATE"); return e && e[0] == '1'; }(); return v; }
+
 static bool sm_partials_supported(int h, int G, int prec) { return prec == CTI_PREC_F16F6 && G == 2 && h % 32 == 0; }
 
 extern "C" size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G, int prec) {
@@ -480,9 +488,11 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         // host order matters: the main stream's first half (encode `a`, Tucker product, ev_at) is enqueued BEFORE chain B waits for ev_at
         a_phase = 1;
         rc = side(2, st); if (rc) return finish(rc);
-        (void)hipStreamWaitEvent(sb, ev_at, 0);
-        rc = early_scan(true); if (rc) return finish(rc);
-    } else if (f6) {
+        if (!guard_late()) {
+            (void)hipStreamWaitEvent(sb, ev_at, 0);
+            rc = early_scan(true); if (rc) return finish(rc);
+        }
+    } else if (f6 && !guard_late()) {
         rc = early_scan(false); if (rc) return finish(rc);
     }
     if (f6) {
@@ -521,7 +531,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     const bool early_join = f6 && aux_stream && join_before_rank;
     if (early_join) (void)hipStreamWaitEvent(st, ev_join, 0);
     rc = side(2, st); if (rc) return finish(rc);
-    if (f6 && aux_stream && !early_join) {                   // middle scan: A^, while the main stream would otherwise only wait for chain B
+    if (f6 && aux_stream && !early_join && !guard_late()) {  // middle scan: A^, while the main stream would otherwise only wait for chain B
         GuardArgs gm{};
         gm.words = p.guard;
         gm.seg[gm.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
@@ -539,13 +549,18 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         GuardArgs ga{};
         ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
         ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
-        if (!aux_stream) {
+        if (!aux_stream || guard_late()) {
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h, 1);             // written by side(2) above when the caller keeps no prepared block
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h, 2);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
         }
-        if (!aux_stream || early_join) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
+        if (!aux_stream || early_join || guard_late()) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
+        if (guard_late()) {                                  // ONE scan for everything, behind the join (see guard_late)
+            ga.seg[ga.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
+            ga.seg[ga.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
+            ga.seg[ga.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
+        }
         if (!guard_ablate()) {
             rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, st); if (rc) return finish(rc);   // the estimate the final scan's verdict reads
             rc = guard_scan(ga, st); if (rc) return finish(rc);
