@@ -17,6 +17,7 @@
 // conversions or stores takes 10-18 % off; no single phase dominates.
 #include "cti_common.h"
 #include "cti_f16f6.h"
+#include <cstdlib>
 
 namespace cti {
 namespace {
@@ -26,6 +27,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));   // 8-B LDS loads.  NOT HIP's uint2 / uint8_t: loads through struct or char types make hipcc
                                                               // drain vmcnt(0) -- every LDS-DMA in flight -- in front of them (may-alias with the DMA's LDS store)
+
+__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 // ---- encoder: fp32 rows -> f16f6 planes.  A wave stages a 64-row x 32-column tile through a private LDS patch: the global loads are
 // coalesced (8 lanes x 16 B = one row's block, 8 rows per instruction), then every lane encodes one row from LDS (pitch 36 floats:
@@ -61,6 +66,72 @@ __global__ __launch_bounds__(256) void quantize_f16f6_kernel(const float* __rest
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // same wave writes and reads its patch: in-order LDS, no barrier
     const int64_t row = row0 + lane;
     if (row < rows) f6_encode_row32_lds(st + lane * 36, p, f6_prow(p, row), kb);
+}
+
+// ---- the same encoder for a DENSE matrix (ld == K) of short rows: a workgroup takes QR CONSECUTIVE rows -- one contiguous run of QR x K floats -- into LDS
+// by LDS-DMA (whole 1-KiB pieces, no straddled cache lines, no over-fetch: the kernel above reads a 128-B piece of every row per block, and rows of
+// 1 200 B start at 48 r mod 128), then wave w encodes K blocks w, w + 4, ... with lane = row.  Row pitch K floats: for K = 300 a 16-lane group's 16-B reads
+// fall on 16 distinct 4-bank groups (44 r mod 64).  Same planes, bit for bit.  configs[1]'s `a` (801 024 x 300): 0.53 -> see profiles/r04_quantize.txt.
+constexpr int QR = 48;              // rows per workgroup: 48 x 1 200 B + the four waves' output images = 75 KB: two workgroups per CU
+__global__ __launch_bounds__(256) void quantize_rows_f16f6_kernel(const float* __restrict__ x, int64_t rows, int K, F6Planes p, const float* __restrict__ row_scale,
+                                                                   int scale_div) {
+    extern __shared__ __attribute__((aligned(16))) char qsm[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * QR;
+    const int nrows = (int)(rows - row0 < QR ? rows - row0 : QR);
+    const int nbytes = nrows * K * 4;                                   // valid bytes of this workgroup's run (a multiple of 16: K % 4 == 0)
+    const int npieces = (QR * K * 4 + 1023) / 1024;
+    const char* src0 = reinterpret_cast<const char*>(x + row0 * K);
+    for (int pc = wid; pc < npieces; pc += 4) {
+        int off = pc * 1024 + lane * 16;
+        if (off > nbytes - 16) off = nbytes - 16;                       // a short last workgroup / the last piece's tail: re-read valid bytes (rows beyond nrows are not encoded)
+        dma16(src0 + off, qsm + pc * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int Kb = (K + 31) / 32;
+    const int64_t row = row0 + lane;
+    const float rs = (row_scale && lane < nrows) ? row_scale[row / scale_div] : 1.f;
+    const int64_t prow = f6_prow(p, lane < nrows ? row : row0);
+    const float* rsrc = reinterpret_cast<const float*>(qsm) + lane * K;
+    // Every (row, block) item is encoded in registers into a wave-private LDS image of the three plane runs it belongs to -- 64 rows of one K block are
+    // 4 KiB of H, 1.5 KiB of FL and 128 B of S, each CONTIGUOUS in its plane when the 64 plane rows are consecutive -- and leaves as whole 16-B pieces of
+    // consecutive addresses (the direct form's stores are 16-B / 8-B / 2-B pieces 64 / 24 / 2 B apart across the lanes).
+    __shared__ __attribute__((aligned(16))) char stage[4][QR * 64 + QR * 24 + 128];
+    char* const sH = stage[wid]; char* const sF = sH + QR * 64; char* const sS = sF + QR * 24;
+    const int64_t prow_first = f6_prow(p, row0);
+    const bool run_ok = f6_prow(p, row0 + nrows - 1) - prow_first == nrows - 1 && (prow_first & 7) == 0;     // consecutive plane rows, 16-B aligned runs
+    for (int kb = wid; kb < Kb; kb += 4) {
+        const int nv = K - kb * 32;
+        float xv[32];
+        if (lane < nrows) {
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                f6_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q4 * 4 < nv) v = *reinterpret_cast<const f6_f32x4*>(rsrc + kb * 32 + q4 * 4);       // K % 4 == 0: a 16-B piece is all valid or all tail
+                v *= rs;
+                xv[q4 * 4] = v[0]; xv[q4 * 4 + 1] = v[1]; xv[q4 * 4 + 2] = v[2]; xv[q4 * 4 + 3] = v[3];
+            }
+            const int64_t o = (int64_t)kb * p.rows_alloc + prow;
+            if (run_ok) f6_encode_row32_regs(xv, -__builtin_huge_valf(), sH + lane * 64, sF + lane * 24, sS + lane * 2);
+            else f6_encode_row32_regs(xv, -__builtin_huge_valf(), reinterpret_cast<char*>(p.H) + o * 64, reinterpret_cast<char*>(p.FL) + o * 24,
+                                      reinterpret_cast<char*>(p.S) + ((int64_t)kb * p.rows_allocS + prow) * 2);
+        }
+        if (!run_ok) continue;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the wave's own image: in-order LDS, no barrier
+        typedef unsigned qu4 __attribute__((ext_vector_type(4)));
+        char* gH = reinterpret_cast<char*>(p.H) + ((int64_t)kb * p.rows_alloc + prow_first) * 64;
+        char* gF = reinterpret_cast<char*>(p.FL) + ((int64_t)kb * p.rows_alloc + prow_first) * 24;
+        char* gS = reinterpret_cast<char*>(p.S) + ((int64_t)kb * p.rows_allocS + prow_first) * 2;
+        const int nH = nrows * 64, nF = nrows * 24, nS = nrows * 2;      // bytes of the three runs (nrows < 64 only in the last workgroup)
+#pragma unroll
+        for (int u = 0; u < (QR * 64 + 1023) / 1024; ++u) { const int off = (u * 64 + lane) * 16; if (off < nH) *reinterpret_cast<qu4*>(gH + off) = *reinterpret_cast<const qu4*>(sH + off); }
+#pragma unroll
+        for (int u = 0; u < (QR * 24 + 1023) / 1024; ++u) { const int off = (u * 64 + lane) * 16; if (off + 16 <= nF) *reinterpret_cast<qu4*>(gF + off) = *reinterpret_cast<const qu4*>(sF + off);
+                                      else if (off < nF) *reinterpret_cast<u32x2*>(gF + off) = *reinterpret_cast<const u32x2*>(sF + off); }
+        { const int off = lane * 2; if (off < nS) *reinterpret_cast<unsigned short*>(gS + off) = *reinterpret_cast<const unsigned short*>(sS + off); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the image is read before the next block's items overwrite it
+    }
 }
 
 // (Round 3, measured and removed: a row-walking form -- one wave keeps its 64 rows and walks all their K blocks, block kb + 1 loaded into registers under the
@@ -113,9 +184,6 @@ using GeoF6 = GeoF6T<4, 2, 2, 3>;                    // 8 waves of 64 x 96, two 
 // other phase) overlaps the other's K loop instead of idling the matrix pipe.  Price: 43 % more DMA bytes per flop and one block in flight.
 using GeoF6Half = GeoF6T<2, 2, 2, 3, 2>;
 
-__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 #ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fp6 conversion, 8 no epilogue stores, 64 no lane swaps,
 #define CTI_F6_ABL 0        // 256 the A operand's LDS fragment reads only in a tile's first K block, 512 no conversion of the A fragments, 1024 no DMA of the A
@@ -614,6 +682,24 @@ int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
 
 int quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, const F6Planes& p, hipStream_t st, const float* row_scale, int scale_div) {
     if (rows <= 0 || K <= 0) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d", (long long)rows, K);
+#ifndef CTI_F6_QROWS
+#define CTI_F6_QROWS 1
+#endif
+    static const bool qrows = [] { const char* e = getenv("CTI_F6_QROWS"); return e ? e[0] != '0' : (CTI_F6_QROWS != 0); }();
+    if (qrows && ld == K && (K & 3) == 0 && K >= 32 && QR * K * 4 <= 72 * 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (rows + QR - 1) / QR < (1ll << 31)) {
+        // dense short rows (configs[1]'s `a`: 300 floats): whole 64-row runs through LDS-DMA
+        const int lds = ((QR * K * 4 + 1023) / 1024) * 1024;
+        static thread_local int attr_dev = -1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (attr_dev != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quantize_rows_f16f6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 73 * 1024);
+            if (e != hipSuccess) return fail((int)e, "quantize_f16f6: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_dev = dev;
+        }
+        hipLaunchKernelGGL(quantize_rows_f16f6_kernel, dim3((unsigned)((rows + QR - 1) / QR)), dim3(256), lds, st, x, rows, K, p, row_scale, scale_div > 0 ? scale_div : 1);
+        return launch_status("quantize_f16f6(rows)");
+    }
     const int64_t bx = (rows + 255) / 256;
     const int64_t gz = (bx + 65534) / 65535, gy = (bx + gz - 1) / gz;          // row blocks spread over (y, z): y <= 65535
     if (gz > 65535) return fail(CTI_E_SHAPE, "quantize_f16f6: rows=%lld K=%d exceed the grid", (long long)rows, K);
