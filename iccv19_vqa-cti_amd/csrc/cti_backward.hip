@@ -2,6 +2,7 @@
 // gradient, and the generic strided batched NT GEMM entry the gradient contractions are expressed with.
 // All byte movers: coalesced along the contiguous axis, LDS tile transpose, wave-shuffle + LDS-tree reductions.
 #include "cti_common.h"
+#include <cstdlib>
 
 namespace cti {
 namespace {
@@ -528,6 +529,11 @@ extern "C" int cti_gemm_nn(const float* a, int64_t lda, const float* b, int64_t 
     return gemm_nt_planes(g, st);
 }
 
+// CTI_AF32_PB=1 (experiment; built, under test, measured SLOWER and therefore off): products against resident planes below 128 tiles of 256 x 256 read their
+// fp32 A rows directly instead of a split launch in front of each -- MC CTI forward 0.910 -> 0.940 ms, FFOE BAN + CTI 2.558 -> 2.600 ms: the 41 splits cost
+// 5-7 us each, but every column tile of the small-tile kernel then moves twice the A bytes through LDS-DMA and converts the same rows again
+static bool af32_pb() { static const bool v = [] { const char* e = getenv("CTI_AF32_PB"); return e && e[0] == '1'; }(); return v; }
+
 // cti_gemm_nt with the B operand given as resident planes (cti_split_operand of the (rowsB_total x K) matrix): only A is split here.
 extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
@@ -554,8 +560,14 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     unsigned short* al = ah + (size_t)ra * Kp;
     const unsigned short* bh = static_cast<const unsigned short*>(B_planes);
     const unsigned short* bl = bh + (size_t)rb * Kp;
-    int rc = split_planes(A, lda, rowsA_total, K, ah, prec == CTI_PREC_BF16 ? nullptr : al, ra, as_stream(stream)); if (rc) return rc;   // plain bf16: the products read the hi plane only
+    // fp32 A operand read as it stands (no split launch, no A planes) wherever the product is not one of the big ones (those take the 256 x 256 tiles:
+    // plain bf16 -> cti_gemm16.hip on a hi plane; bf16x3 -> the planes kernel, whose fp32-A form measured slower at that size)
+    const long long tiles256 = (long long)nb1 * ((M + 255) / 256) * ((N + 255) / 256);
+    const bool af32 = af32_pb() && tiles256 < 128 && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    int rc = CTI_OK;
+    if (!af32) { rc = split_planes(A, lda, rowsA_total, K, ah, prec == CTI_PREC_BF16 ? nullptr : al, ra, as_stream(stream)); if (rc) return rc; }   // plain bf16: the products read the hi plane only
     PlaneGemmArgs g{};
+    if (af32) { g.Af = A; g.ldaf = lda; g.Kreal = K; }
     g.Ah = ah; g.Al = al; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb;
     g.rA1 = rA1; g.rB1 = rB1; g.nb1 = nb1; g.nb2 = 1;
     g.M = M; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1;

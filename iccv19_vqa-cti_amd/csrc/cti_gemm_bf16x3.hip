@@ -207,7 +207,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     constexpr int NW = LW > 0 ? LW : WM * WN;                           // waves that issue the DMA
     constexpr int NPLANE = TERMS == 3 ? 2 : 1;
     static_assert(G::PL >= NPLANE, "a hi-only slot cannot feed the 3-term products");
-    constexpr int PAT = NPLANE * BM / 32, PBT = NPLANE * BN / 32;       // pieces per slot of the A / B operand (hi [+ lo])
+    constexpr int PAT = (AF32 ? 2 : NPLANE) * BM / 32, PBT = NPLANE * BN / 32;       // pieces per slot of the A / B operand (hi [+ lo]; fp32 A rows: 64 B per row = 16 rows per piece)
     constexpr bool EXACT = (PAT % NW == 0) && (PBT % NW == 0);          // every issuing wave issues the same count
     constexpr int PA = (PAT + NW - 1) / NW, PB = (PBT + NW - 1) / NW;
     constexpr int NPLG = SPB * (PA + PB);                               // DMA instructions per issuing wave per barrier group
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
     const int64_t pitchA = p.pitchA, pitchB = p.pitchB;                 // locals: lambdas must not capture the argument struct
     const unsigned short* Ah = p.Ah + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16 + b2 * p.kc2 * pitchA;
     const unsigned short* Al = p.Al + (b1 * p.rA1 + b2 * p.rA2 + m0) * 16 + b2 * p.kc2 * pitchA;
-    const float* Af = AF32 ? p.Af + (b1 * p.rA1 + b2 * p.rA2 + m0) * p.ldaf : nullptr;
-    const int64_t ldaf = p.ldaf; const int Kreal = p.Kreal, rows_valid = p.M - m0;
+    const float* Af = AF32 ? p.Af + (b1 * p.rA1 + b2 * p.rA2 + m0) * p.ldaf + b2 * p.kc2 * 16 : nullptr;      // split-K: batch b2 starts kc2 * b2 chunks of 16 into the rows
+    const int64_t ldaf = p.ldaf; const int Kreal = p.Kreal - (AF32 ? (int)(b2 * p.kc2 * 16) : 0), rows_valid = p.M - m0;
     const unsigned short* Bh = p.Bh + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16 + b2 * p.kc2 * pitchB;
     const unsigned short* Bl = p.Bl + (b1 * p.rB1 + b2 * p.rB2 + n0) * 16 + b2 * p.kc2 * pitchB;
 
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 dma_pieces<BN, PB, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + G::PL * A_PLANE, iw, NW, lane);
             } else {                                                     // uneven split (plain-bf16 mode only): waves beyond the piece count idle
 #pragma unroll
-                for (int u = 0; u < PA; ++u) if (iw + u * NW < PAT) dma_pieces<BM, 1, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw + u * NW, NW, lane);
+                for (int u = 0; u < PA; ++u) if (iw + u * NW < PAT) {
+                    if (AF32) dma_pieces_f32<1>(Af, ldaf, (int)kc * 16, Kreal, rows_valid, s, iw + u * NW, NW, lane);
+                    else      dma_pieces<BM, 1, TERMS == 3>(Ah + kc * pitchA, Al + kc * pitchA, s, iw + u * NW, NW, lane);
+                }
 #pragma unroll
                 for (int u = 0; u < PB; ++u) if (iw + u * NW < PBT) dma_pieces<BN, 1, TERMS == 3>(Bh + kc * pitchB, Bl + kc * pitchB, s + G::PL * A_PLANE, iw + u * NW, NW, lane);
             }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
                 for (int e = 0; e < 8; ++e) {
                     const __bf16 hv = static_cast<__bf16>(xs[e]);
                     ah[i][e] = hv;
-                    al[i][e] = static_cast<__bf16>(xs[e] - static_cast<float>(hv));
+                    if (TERMS == 3) al[i][e] = static_cast<__bf16>(xs[e] - static_cast<float>(hv));
                 }
             }
         } else {
@@ -663,13 +666,18 @@ int launch_cfg(const PlaneGemmP& p, long long nb, int ncols, hipStream_t st) {
 
 template <int TERMS, int EPI>
 int launch_epi(const PlaneGemmP& p, long long nb, int ncols, int cfg, hipStream_t st) {
-    if (p.Af) {                                              // fp32 A operand: built for the fp32-grade mode and the row-major epilogues
+    if (p.Af) {                                              // fp32 A operand: the row-major epilogues; the slot's A region holds 64 B per row (= both planes' room)
         if constexpr (TERMS == 3 && (EPI == 0 || EPI == 1 || EPI == 4)) {
             switch (cfg) {
                 case 2: return launch_cfg<TERMS, EPI, GeoBig, true>(p, nb, ncols, st);
                 case 1: return launch_cfg<TERMS, EPI, GeoMid, true>(p, nb, ncols, st);
                 default: return launch_cfg<TERMS, EPI, GeoSmall, true>(p, nb, ncols, st);
             }
+        } else if constexpr (TERMS == 1 && EPI == 0) {
+            // plain bf16 (round 4): the batch-sized GEMMs of the model forwards read their fp32 activations directly -- no split launch in front of
+            // every product (41 per FFOE forward).  The hi-only 256 x 256 geometry has no room for fp32 rows: the 256 x 128 tile takes its place.
+            if (cfg >= 1) return launch_cfg<TERMS, EPI, GeoMid, true>(p, nb, ncols, st);
+            return launch_cfg<TERMS, EPI, GeoSmall, true>(p, nb, ncols, st);
         } else {
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: fp32 A operand with terms=%d epi=%d", TERMS, EPI);
         }
@@ -766,7 +774,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
     if (a.f6out) p.F6 = *a.f6out;
     if (a.ksplit > 1) {
-        if (a.nb1 != 1 || a.nb2 != 1 || a.epi != 0 || a.Af || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
+        if (a.nb1 != 1 || a.nb2 != 1 || a.epi != 0 || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
         PlaneGemmArgs b = a;
         b.ksplit = 1; b.partial = nullptr;

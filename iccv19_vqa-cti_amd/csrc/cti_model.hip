@@ -2,6 +2,7 @@
 // cti_gru.hip), Swish, the residual broadcast-add / sequence sums of the model forwards, and
 // the two losses.  All of it is HBM-bound elementwise or row-reduction work: coalesced accesses, one pass over the data.
 #include "cti_common.h"
+#include <cstdlib>
 
 namespace cti {
 namespace {
@@ -289,8 +290,13 @@ int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, co
     float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255));
     const unsigned short* bh = static_cast<const unsigned short*>(W_planes);
     const unsigned short* bl = bh + (size_t)rb * Kp;
-    int rc = split_planes(x, ldx, B, K, ah, al_, ra, st); if (rc) return rc;
+    // the (B, K) activation is read as fp32 rows by the product itself (no split launch) when its rows are 16-B aligned
+    static const bool af32_ok = [] { const char* e = getenv("CTI_AF32_PB"); return e && e[0] == '1'; }();       // (experiment, measured slower: cti_backward.hip af32_pb)
+    const bool af32 = af32_ok && (K & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    int rc = CTI_OK;
+    if (!af32) { rc = split_planes(x, ldx, B, K, ah, prec == CTI_PREC_BF16 ? nullptr : al_, ra, st); if (rc) return rc; }
     PlaneGemmArgs g{};
+    if (af32) { g.Af = x; g.ldaf = ldx; g.Kreal = K; }
     g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
     g.M = B; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
     const int S = plan_ksplit(B, N, Kp, 1);

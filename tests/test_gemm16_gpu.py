@@ -135,3 +135,24 @@ def test_bf16_rows_entry_refuses_what_the_kernel_cannot_read():
     wp = ops.split_operand(torch.randn(32, 40, device=DEV), prec="bf16")
     with pytest.raises(Exception):
         ops.gemm_bf16_rows(a, wp, 32)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 1024), (256, 3129, 2048), (3584, 1024, 1024), (130, 520, 328), (256, 1024, 600)])
+def test_fp32_rows_read_directly_by_the_plain_bf16_product(M, N, K):
+    """CTI_AF32_PB=1 (experiment, off by default: measured slower): the batch-sized products of the model forwards (cti_gemm_nt_pb below 128 tiles of
+    256 x 256) take their fp32 activations as they stand -- no split launch -- also under split-K (a K range per workgroup offsets the fp32 rows); every
+    entry against float64 on the bf16-rounded operands.  The knob is read once per process: a child process."""
+    import os, subprocess, sys
+    if os.environ.get("CTI_AF32_PB") != "1":
+        env = dict(os.environ, CTI_AF32_PB="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_fp32_rows_read_directly and %d-%d-%d" % (M, N, K)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf16r(torch.randn(M, K, generator=g)); w = bf16r(torch.randn(N, K, generator=g) / 8); b = torch.randn(N, generator=g)
+    wp = ops.split_operand(w.to(DEV), prec="bf16")
+    y = ops.gemm_nt(a.to(DEV), w.to(DEV), prec="bf16", B_planes=wp, bias=b.to(DEV), relu=True)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
