@@ -534,6 +534,42 @@ def model_subrecord(config, dev):
     return rec
 
 
+def projection_gemm_record(dev):
+    """The projection GEMM of the bf16 configurations alone (north star: >= 0.40 of the bf16 MFMA peak on the projection GEMMs): the hoisted v
+    projections' shape of BASELINE configs[2] / [3] -- 9 216 rows (256 x 36 objects) x 2 048 against three 1 024-wide layers -- through
+    cti_gemm_bf16_rows (csrc/cti_gemm16.hip): bf16 rows in, bias + ReLU, bf16 rows out; random operands; every row checked against float64 on a
+    strided sample of columns."""
+    import cti_amd
+    ops = cti_amd.ops
+    M, N, K = 9216, 3072, 2048
+    g = torch.Generator(device="cpu").manual_seed(SEED + 11)
+    a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / 8).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    wp = ops.split_operand(w, prec="bf16")
+    out = {}
+    for name, dt in (("bf16_out", torch.bfloat16), ("fp32_out", torch.float32)):
+        fn = lambda: ops.gemm_bf16_rows(a, wp, N, out_dtype=dt, bias=b, relu=True)      # noqa: E731
+        for _ in range(3):
+            y = fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            y = fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        cols = torch.arange(0, N, 97, device=dev)
+        ref = torch.relu(a.double() @ w.to(torch.bfloat16).double()[cols].t() + b.double()[cols])
+        err = float((y[:, cols].double() - ref).abs().max() / ref.abs().max())
+        tol = 4e-3 if dt == torch.bfloat16 else 3e-6
+        if not err < tol:
+            raise SystemExit("bench.py: projection GEMM (%s) is %.3g from float64 (tolerance %.0e) -- no number printed" % (name, err, tol))
+        tf = 2.0 * M * N * K / us * 1e-6
+        out[name] = {"us": us, "tflops": tf, "frac_of_bf16_peak": tf / PEAK_TFLOPS["bf16"], "norm_max_err_every_row_sampled_columns_vs_float64": err}
+    return {"kernel": "gemm16_planes_kernel (cti_gemm_bf16_rows): plain-bf16 NT GEMM, 256 x 256 tile, two wave groups one interval apart",
+            "shape": "%d x %d x %d (bf16 rows x resident weight planes, bias + ReLU epilogue)" % (M, N, K), "bound": "mfma", "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s", **out}
+
+
 def aside_kernels(c, dev):
     """The a-side kernels of the f16f6 step, launched stand-alone at the configs[1] shapes through their own C-ABI entry points and timed with
     HIP events on the launch stream: inside cti_tcnet_forward they run back to back on the main stream (only the mode-3 product has events of
@@ -715,6 +751,7 @@ def run_forward(args, world, rank, dev, dist):
             # BASELINE configs[2] / [3] on the same clock: full-model forwards, bf16, hipGraph replay, each checked against the oracle
             torch.cuda.empty_cache()
             res["configs"] = {"c3": model_subrecord("c3", dev), "c4": model_subrecord("c4", dev)}
+            res["projection_gemm"] = projection_gemm_record(dev)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is reported at N=1 only
             state = {k: t_.detach().cpu().numpy() for k, t_ in net.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(c, state, (v, q, a), gpu_first, args.cpu_budget)

@@ -185,6 +185,9 @@ using GeoF6 = GeoF6T<4, 2, 2, 3>;                    // 8 waves of 64 x 96, two 
 using GeoF6Half = GeoF6T<2, 2, 2, 3, 2>;
 
 
+#ifndef CTI_F6_PHASE
+#define CTI_F6_PHASE 0
+#endif
 #ifndef CTI_F6_ABL          // timing-only ablations (wrong results): 1 no refill DMA, 2 no MFMA, 4 no fp6 conversion, 8 no epilogue stores, 64 no lane swaps,
 #define CTI_F6_ABL 0        // 256 the A operand's LDS fragment reads only in a tile's first K block, 512 no conversion of the A fragments, 1024 no DMA of the A
 #endif                      // operand's pieces  (256 | 512 | 1024 = "the A operand is free": the ceiling of any scheme that takes it out of the LDS path)
@@ -458,6 +461,13 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
 
 #if CTI_F6_ABL & 128                                                 // clock probe: shader cycles / 100 MHz ticks of this workgroup -> C[2 bx], C[2 bx + 1]
     const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if CTI_F6_PHASE > 0                                                 // workgroups start up to CTI_F6_PHASE us apart (bit-reversed index: neighbours far apart in time)
+    if (p.total_tiles > 2 * (int)gridDim.x) {
+        const unsigned long long ph_t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned ph_d = (__builtin_bitreverse32(blockIdx.x) >> 24) * (CTI_F6_PHASE * 100u) / 256u;
+        while (__builtin_amdgcn_s_memrealtime() - ph_t0 < ph_d) __builtin_amdgcn_s_sleep(16);
+    }
 #endif
     issue_tile_setup();
 #pragma unroll
