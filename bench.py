@@ -404,7 +404,11 @@ def model_setup(config, B, rank, dev):
     cti = cti_amd.build_cti(margs(2), ds(3129)).to(dev).eval()
 
     def fwd():
-        return ban(v, boxes, q, None)[0], cti(v, q, a)
+        # two models, one batch, nothing shared but the inputs: on sibling streams (ops.run_concurrently) unless CTI_BENCH_SERIAL_MODELS=1
+        if os.environ.get("CTI_BENCH_SERIAL_MODELS", "0") == "1":
+            return ban(v, boxes, q, None)[0], cti(v, q, a)
+        c, b = cti_amd.ops.run_concurrently(lambda: cti(v, q, a), lambda: ban(v, boxes, q, None)[0])      # (the CTI model forks its own auxiliary stream: it keeps the caller's)
+        return b, c
 
     def oracle(n, out):
         from oracle import cti_models as OM
@@ -413,7 +417,9 @@ def model_setup(config, B, rank, dev):
                 ("cti logits", out[1][:n].cpu().numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
     return dict(fwd=fwd, oracle=oracle, models={"ban": ban, "cti": cti}, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129),
                 workload=("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
-                          ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes" % B))
+                          ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes; %s" % (
+                              B, "one model after the other" if os.environ.get("CTI_BENCH_SERIAL_MODELS", "0") == "1" else
+                              "the two models on sibling streams (ops.run_concurrently; CTI_BENCH_SERIAL_MODELS=1 = one after the other)")))
 
 
 def model_measure(setup, steps, warmup, world, dist, dev, graphed, prec):

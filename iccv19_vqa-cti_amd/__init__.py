@@ -9,7 +9,7 @@ from .tc import TCNet                                          # noqa: F401
 from .bc import BCNet                                          # noqa: F401
 from .attention import BiAttention, TriAttention, StackedAttention   # noqa: F401
 from .Tensor import ModeProduct                                # noqa: F401
-from .ops import set_precision, get_precision, invalidate_caches, set_range_check, f16f6_range_status   # noqa: F401
+from .ops import set_precision, get_precision, invalidate_caches, set_range_check, f16f6_range_status, run_concurrently   # noqa: F401
 from ._lib import CtiError                                     # noqa: F401
 from .dp import FlatAdamaxDP                                   # noqa: F401
 from .graph import GraphedTrainStep                            # noqa: F401

@@ -126,7 +126,8 @@ class _TriModel(nn.Module):
                 ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
             q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
             cur.wait_stream(side)
-            ans_emb.record_stream(cur)
+            if not torch.cuda.is_current_stream_capturing():
+                ans_emb.record_stream(cur)
         else:
             q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
             ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))

@@ -20,6 +20,14 @@ _NO_BATCH = __import__("os").environ.get("CTI_NO_BATCHED_SCALES", "0") == "1"   
 _scale_users = weakref.WeakSet()       # WNLinear layers that have asked for their scale: refreshed TOGETHER, in one launch pair, when stale
 
 
+def refresh_stale_scales(device):
+    """Refresh, on the CURRENT stream, the cached g / ||V||_F of every layer that has ever asked for it and whose parameters changed since: what
+    ops.run_concurrently does before it forks (a layer's first asker refreshes ALL stale layers on its own stream -- see WNLinear.scale)."""
+    stale = [m for m in _scale_users if m.weight_v.device == device and getattr(m, "_scale_key", None) != m._scale_key_now()]
+    if stale:
+        stale[0].scale()
+
+
 class WNLinear(nn.Module):
     """weight_norm(nn.Linear(in, out), dim=None) as parameters only: bias (out), weight_g (), weight_v (out, in),
     registered in the order torch's weight_norm leaves them (bias, weight_g, weight_v)."""

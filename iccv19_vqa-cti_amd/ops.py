@@ -137,19 +137,64 @@ use_aux_stream = _os.environ.get("CTI_NO_AUX_STREAM", "0") != "1"
 def _aux_stream(device):
     """One side stream per device for cti_tcnet_forward's second chain (None disables the overlap).  Buffers touched on it are
     allocated on the current stream and only reused after the call's join event, so the caching allocator stays consistent."""
-    if not use_aux_stream:
-        return None
-    return aux_stream_object(device).cuda_stream
+    o = aux_stream_object(device)
+    return None if o is None else o.cuda_stream
 
 
 def aux_stream_object(device):
     """The torch.cuda.Stream behind _aux_stream (one per device), or None when the overlap is disabled."""
-    if not use_aux_stream:
+    if not use_aux_stream or _no_nested_fork[0]:
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _aux:
         _aux[key] = torch.cuda.Stream(device=device, priority=_AUX_PRIORITY)
     return _aux[key]
+
+
+_sib = {}
+_no_nested_fork = [False]       # set while a sibling of run_concurrently runs under capture: its model forks no auxiliary stream of its own
+
+
+def run_concurrently(*fns):
+    """Independent forwards (e.g. the BAN and the CTI teacher of BASELINE configs[3]: two models, one batch, nothing shared but the inputs) on
+    sibling streams: fns[0] on the caller's stream, every other one on its own side stream forked from it here and joined before returning, so a
+    chain of small dependent launches in one model fills the compute units another model's chain leaves idle.  Results in call order.  Works eagerly and
+    under hipGraph capture (fork / join become graph edges).  Inference only: under autograd the backward would run on the side streams' graph.
+    Under capture a sibling runs without the library's auxiliary stream (ending a capture whose forked stream forked again takes this ROCm
+    runtime down -- measured, round 4): put the function that profits from it (the CTI models: answer GRU, v / q chain of TCNet) first."""
+    if len(fns) < 2 or torch.is_grad_enabled():
+        return tuple(f() for f in fns)
+    cur = torch.cuda.current_stream()
+    from . import fc as _fc
+    _fc.refresh_stale_scales(cur.device)             # the batched weight-norm refresh belongs before the fork (it serves layers of every model)
+    key = (cur.device.index, len(fns) - 1)
+    if key not in _sib:
+        _sib[key] = [torch.cuda.Stream(device=cur.device) for _ in fns[1:]]
+    outs = [None] * len(fns)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for i, s in enumerate(_sib[key]):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            _no_nested_fork[0] = capturing
+            try:
+                outs[i + 1] = fns[i + 1]()
+            finally:
+                _no_nested_fork[0] = False
+    outs[0] = fns[0]()
+    for i, s in enumerate(_sib[key]):
+        cur.wait_stream(s)
+        if not capturing:                        # (a capture's private pool keeps its blocks for the graph's lifetime)
+            for t in _tensors_of(outs[i + 1]):
+                t.record_stream(cur)             # allocated on the side stream, consumed on the caller's
+    return tuple(outs)
+
+
+def _tensors_of(o):
+    if isinstance(o, torch.Tensor):
+        return [o]
+    if isinstance(o, (tuple, list)):
+        return [t for x in o for t in _tensors_of(x)]
+    return []
 
 
 # ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------

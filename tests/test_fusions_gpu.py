@@ -111,6 +111,44 @@ def test_ffoe_models_on_the_fused_paths():
     assert O.norm_max_err(lb.cpu().numpy(), rb) < 1.5e-4
 
 
+@pytest.mark.parametrize("order", ["cti_first", "ban_first"])
+def test_two_models_on_sibling_streams_equal_the_serial_forwards(order):
+    """ops.run_concurrently (BASELINE configs[3]: BAN + CTI on one batch): same logits as one model after the other, eagerly and from a replayed
+    hipGraph -- in both orders (a sibling under capture runs without the library's auxiliary stream)."""
+    torch.manual_seed(33)
+    cti = cti_amd.build_cti(_args(2), _ds(50, 48, 11)).to(DEV).eval()
+    ban = cti_amd.build_ban(_args(4), _ds(50, 48, 11)).to(DEV).eval()
+    rs = np.random.RandomState(9)
+    v = T(np.abs(rs.standard_normal((6, 9, 48))).astype(np.float32))
+    q = T(rs.randint(0, 50, size=(6, 8)).astype(np.int64))
+    a = T(rs.randint(0, 50, size=(6, 3)).astype(np.int64))
+    f_cti, f_ban = (lambda: cti(v, q, a)), (lambda: ban(v, None, q, None)[0])
+
+    def both():
+        if order == "cti_first":
+            return ops.run_concurrently(f_cti, f_ban)
+        b, c = ops.run_concurrently(f_ban, f_cti)
+        return c, b
+    with torch.no_grad():
+        lc, lb = f_cti(), f_ban()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            c, b = both()
+        torch.cuda.synchronize()
+        assert torch.equal(c, lc) and torch.equal(b, lb)
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(gr, stream=side):
+                cg, bg = both()
+        torch.cuda.current_stream().wait_stream(side)
+        cg.zero_(); bg.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cg, lc) and torch.equal(bg, lb)
+
+
 @pytest.mark.parametrize("B,L,N,K", [(256, 14, 1024, 1024), (5, 3, 36, 40), (64, 12, 128, 96), (1, 1, 4, 8)])
 def test_linear_residual_reduces_adds_and_sums_in_one_pass(B, L, N, K):
     """out = seq + (scale * x @ W^T + bias)[:, None, :]; acc = beta * acc + out.sum(1): with a K split (256 x 1024 x 1024) and without."""
