@@ -407,7 +407,9 @@ def model_setup(config, B, rank, dev):
         # two models, one batch, nothing shared but the inputs: on sibling streams (ops.run_concurrently) unless CTI_BENCH_SERIAL_MODELS=1
         if os.environ.get("CTI_BENCH_SERIAL_MODELS", "0") == "1":
             return ban(v, boxes, q, None)[0], cti(v, q, a)
-        c, b = cti_amd.ops.run_concurrently(lambda: cti(v, q, a), lambda: ban(v, boxes, q, None)[0])      # (the CTI model forks its own auxiliary stream: it keeps the caller's)
+        if os.environ.get("CTI_BENCH_C4_ORDER", "cti_first") == "ban_first":               # (A/B knob: which model keeps the caller's stream and with it the auxiliary one)
+            return cti_amd.ops.run_concurrently(lambda: ban(v, boxes, q, None)[0], lambda: cti(v, q, a))
+        c, b = cti_amd.ops.run_concurrently(lambda: cti(v, q, a), lambda: ban(v, boxes, q, None)[0])
         return b, c
 
     def oracle(n, out):

@@ -27,9 +27,13 @@ class BiAttention(nn.Module):
         return p, logits
 
     def forward_all(self, v, q, v_mask=True):
+        return self._forward_all(v, q, v_mask)
+
+    def _forward_all(self, v, q, v_mask=True, _v_projected=None, _mask=None):
+        """forward_all; _v_projected / _mask (the model forwards' private arguments, eval only): logits.v_net(v) and zero_row_mask(v) already computed."""
         if not torch.is_grad_enabled() and not self.logits.training:
             # eval: logits, mask and softmax in ONE launch of the logits kernel (cti_biattention_fwd)
-            fused = self.logits._attention(v, q, ops.zero_row_mask(v) if v_mask else None)
+            fused = self.logits._attention(v, q, (ops.zero_row_mask(v) if _mask is None else _mask) if v_mask else None, v_projected=_v_projected)
             if fused is not None:
                 return fused
         logits = self.logits(v, q)                                  # b x g x v x q

@@ -10,6 +10,7 @@ through a generic broadcast), the sequence sums and the classifier.
 Outside the path (they raise): the counting module (`--use_counter`, src/counting.py) and the SAN baseline; tf-idf
 initialisation of the embeddings (`tfidf_loading`, src/utils.py) is data preparation -- load a checkpoint or call
 `WordEmbedding.init_embedding`."""
+import contextlib
 import os as _os
 
 import torch
@@ -21,6 +22,7 @@ from .attention import BiAttention, TriAttention
 from .bc import BCNet
 from .classifier import SimpleClassifier
 from .fc import FCNet, HoistedProjection, WNLinear
+from .fc import refresh_stale_scales as _refresh_scales
 from .language_model import QuestionEmbedding, WordEmbedding
 from .tc import TCNet, _needs_grad
 
@@ -87,10 +89,29 @@ class BanModel(nn.Module):
     def forward(self, v, b, q, labels):
         """v: [batch, num_objs, obj_dim]; b: boxes (read by the counter only); q: [batch, seq_length] token ids.
         return: logits (not probs), att"""
-        w_emb = self.w_emb(q)
-        q_emb = self.q_emb.forward_all(w_emb)                               # [batch, q_len, q_dim]
-        att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
-        vp = self._v_hoist.maybe(v)
+        side = None if torch.is_grad_enabled() or self.training else ops.aux_stream_object(v.device)
+        lg = self.v_att.logits
+        if side is not None and lg.h_out is not None and v.is_cuda:
+            # inference: everything that reads only `v` -- the attention's v projection, its zero-row mask, the glimpses' batched v projections --
+            # on the auxiliary stream beside the question GRU (14 dependent launches of 64 workgroups that leave most of the chip idle)
+            cur = torch.cuda.current_stream()
+            _refresh_scales(v.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                v_att = lg.v_net(v)
+                mask = ops.zero_row_mask(v)
+                vp = self._v_hoist.maybe(v)
+            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
+            cur.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t_ in [v_att, mask] + (vp or []):
+                    t_.record_stream(cur)
+            att, logits = self.v_att._forward_all(v, q_emb, True, v_att, mask)      # b x g x v x q
+        else:
+            w_emb = self.w_emb(q)
+            q_emb = self.q_emb.forward_all(w_emb)                           # [batch, q_len, q_dim]
+            att, logits = self.v_att.forward_all(v, q_emb)                  # b x g x v x q
+            vp = self._v_hoist.maybe(v)
         total = None
         fused_sum = not torch.is_grad_enabled()
         if fused_sum:                                                        # inference: the per-glimpse sums accumulate inside the residual pass
@@ -121,13 +142,11 @@ class _TriModel(nn.Module):
         if side is not None:
             # inference: the answer GRU (a few short, latency-bound steps) runs on the auxiliary stream beside the question GRU
             cur = torch.cuda.current_stream()
+            _refresh_scales(v.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
             q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
-            cur.wait_stream(side)
-            if not torch.cuda.is_current_stream_capturing():
-                ans_emb.record_stream(cur)
         else:
             q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
             ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
@@ -143,13 +162,20 @@ class _TriModel(nn.Module):
         tc = t_att.TriAtt
         want_pad = (ops.get_precision() != "fp32" and tc._act == 'ReLU' and t_att.glimpse >= 2 and tc._fusable(v, q_emb, ans_emb) and v.dim() == 3
                     and bool(ops.triattention_hoist_ok(v.shape[0], v.shape[1], q_emb.shape[1], ans_emb.shape[1], tc.h_dim, tc.rank, t_att.glimpse)))
-        if rep > 1 and v.shape[0] % rep == 0:
-            if _os.environ.get("CTI_CHECK_REPLICATION", "0") == "1":
-                assert torch.equal(v.view(v.shape[0] // rep, rep, *v.shape[1:])[:, :1].expand(-1, rep, -1, -1).reshape(v.shape), v), "v_replication does not hold"
-            vp = self._v_hoist.maybe(v[::rep], use_padded=want_pad)
-        else:
-            rep = 1
-            vp = self._v_hoist.maybe(v, use_padded=want_pad)
+        # (inference: the batched v projection follows the answer GRU on the auxiliary stream, beside the question GRU's 12-14 dependent launches)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if rep > 1 and v.shape[0] % rep == 0:
+                if _os.environ.get("CTI_CHECK_REPLICATION", "0") == "1":
+                    assert torch.equal(v.view(v.shape[0] // rep, rep, *v.shape[1:])[:, :1].expand(-1, rep, -1, -1).reshape(v.shape), v), "v_replication does not hold"
+                vp = self._v_hoist.maybe(v[::rep], use_padded=want_pad)
+            else:
+                rep = 1
+                vp = self._v_hoist.maybe(v, use_padded=want_pad)
+        if side is not None:
+            cur.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for t_ in [ans_emb] + (vp or []) + list(self._v_hoist.last_padded):
+                    t_.record_stream(cur)
         if vp is not None:
             pad = self._v_hoist.last_padded
             att, logits = t_att(v, q_emb, ans_emb, _v_tucked=pad[0] if pad else None, _v_rep=rep)        # b x v x q x a x g

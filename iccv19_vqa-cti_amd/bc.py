@@ -68,7 +68,7 @@ class BCNet(nn.Module):
             return self._logits(v_, q_, self.h_mat_v, self.h_mat_g, self.h_bias)
         return self._logits(v_, q_, self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias)
 
-    def _attention(self, v, q, mask):
+    def _attention(self, v, q, mask, v_projected=None):
         """BiAttention.forward_all on this network, eval / no-grad only: (p, logits) with the mask and the softmax applied in the logits kernel's own launch
         (ops.biattention_forward), or None when the caller must take forward() + the separate softmax (training, autograd, the pooled form)."""
         if self.h_out is None or self.training:
@@ -79,7 +79,7 @@ class BCNet(nn.Module):
             h, h_g, h_bias = self.h_net.weight_v, self.h_net.weight_g, self.h_net.bias
         if _needs_grad(v, q, h, h_g, h_bias) or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return None
-        v_ = self.v_net(v)
+        v_ = self.v_net(v) if v_projected is None else v_projected      # (the model forward may have projected v on its auxiliary stream, beside the GRU)
         q_ = self.q_net(q)
         G, D = (h.shape[-3] if h.dim() == 4 else h.shape[0]), h.shape[-1]
         h2 = h.reshape(G, D)

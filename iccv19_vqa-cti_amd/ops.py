@@ -152,7 +152,7 @@ def aux_stream_object(device):
 
 
 _sib = {}
-_no_nested_fork = [False]       # set while a sibling of run_concurrently runs under capture: its model forks no auxiliary stream of its own
+_no_nested_fork = [False]       # set while run_concurrently's functions run: their models fork no auxiliary stream of their own
 
 
 def run_concurrently(*fns):
@@ -160,8 +160,9 @@ def run_concurrently(*fns):
     sibling streams: fns[0] on the caller's stream, every other one on its own side stream forked from it here and joined before returning, so a
     chain of small dependent launches in one model fills the compute units another model's chain leaves idle.  Results in call order.  Works eagerly and
     under hipGraph capture (fork / join become graph edges).  Inference only: under autograd the backward would run on the side streams' graph.
-    Under capture a sibling runs without the library's auxiliary stream (ending a capture whose forked stream forked again takes this ROCm
-    runtime down -- measured, round 4): put the function that profits from it (the CTI models: answer GRU, v / q chain of TCNet) first."""
+    The functions run WITHOUT the library's auxiliary stream: with two chains in flight a third adds contention, not overlap (configs[3]: 127.8 k
+    samples/s without, 121.5-125.0 k with it on either model, profiles/r04_c4_concurrent_models.txt) -- and ending a capture in which a sibling
+    stream forks again takes this ROCm runtime down (hipStreamEndCapture segfault, measured in round 4)."""
     if len(fns) < 2 or torch.is_grad_enabled():
         return tuple(f() for f in fns)
     cur = torch.cuda.current_stream()
@@ -172,15 +173,18 @@ def run_concurrently(*fns):
         _sib[key] = [torch.cuda.Stream(device=cur.device) for _ in fns[1:]]
     outs = [None] * len(fns)
     capturing = torch.cuda.is_current_stream_capturing()
+
+    def no_aux(f):
+        _no_nested_fork[0] = True
+        try:
+            return f()
+        finally:
+            _no_nested_fork[0] = False
     for i, s in enumerate(_sib[key]):
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            _no_nested_fork[0] = capturing
-            try:
-                outs[i + 1] = fns[i + 1]()
-            finally:
-                _no_nested_fork[0] = False
-    outs[0] = fns[0]()
+            outs[i + 1] = no_aux(fns[i + 1])
+    outs[0] = no_aux(fns[0])
     for i, s in enumerate(_sib[key]):
         cur.wait_stream(s)
         if not capturing:                        # (a capture's private pool keeps its blocks for the graph's lifetime)
