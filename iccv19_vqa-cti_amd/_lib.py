@@ -121,6 +121,9 @@ SIGNATURES = {
     "cti_row_sum": (_int, [_vp, _vp, _i64, _int, _vp]),
     "cti_pool_dw_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
+    "cti_tri_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_axpby": (_int, [_vp, C.c_float, _vp, C.c_float, _vp, _i64, _vp]),
     "cti_bi_logits_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_biattention_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),

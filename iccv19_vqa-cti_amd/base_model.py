@@ -63,6 +63,43 @@ def _joint(q_emb, ans_emb):
     return ops.seq_sum(ans_emb, out=ops.seq_sum(q_emb), beta=1.0)
 
 
+_HOIST_LOOP = _os.environ.get("CTI_NO_HOISTED_LOOP", "0") != "1"      # A/B knob
+
+
+def _shift_of(layer, D):
+    """scale * W D (no bias, no activation): the projection of the accumulated residual D (B,H) through one glimpse's q / a layer."""
+    return ops.wn_linear(D, layer.weight_v, layer.scale(), layer.out_features, None, False, w_planes=layer.planes())
+
+
+def _hoisted_loop_ok(nets, prjs, x):
+    """The hoisted glimpse loop applies: inference, not the exact-fp32 mode (linear_residual's planes), every projection network the single
+    [Dropout, WNLinear, ReLU] FCNet and every residual projection a single WNLinear, at least two glimpses (HoistedProjection batches >= 2)."""
+    if not _HOIST_LOOP or torch.is_grad_enabled() or ops.get_precision() == "fp32" or len(nets) < 2 or not x.is_cuda:
+        return False
+    if any(HoistedProjection._layer_of(n) is None or n.training for n in nets) or any(_single_linear(p) is None or p.training for p in prjs):
+        return False
+    return all(_single_linear(p).out_features % 4 == 0 and _single_linear(p).out_features == x.shape[-1] for p in prjs)
+
+
+def _beside(device, fn):
+    """fn() on the second side stream, forked from the current stream here (inference, overlap enabled) -- returns (result, join) where join() must be
+    called on the current stream before the result is consumed; without a side stream fn runs in place and join is a no-op."""
+    side = None if torch.is_grad_enabled() else ops.aux_stream_object(device, 1)
+    if side is None:
+        return fn(), (lambda: None)
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        res = fn()
+
+    def join():
+        cur.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():
+            for t_ in ops._tensors_of(res):
+                t_.record_stream(cur)
+    return res, join
+
+
 def _no_counter(counter):
     if counter is not None:
         raise NotImplementedError("the counting module (src/counting.py, --use_counter) is outside the CTI path; build with counter=None")
@@ -106,12 +143,18 @@ class BanModel(nn.Module):
             if not torch.cuda.is_current_stream_capturing():
                 for t_ in [v_att, mask] + (vp or []):
                     t_.record_stream(cur)
+            Hq, join = _beside(v.device, lambda: self._hoist_prepare(q_emb, vp))      # (the glimpses' q projections beside the attention)
             att, logits = self.v_att._forward_all(v, q_emb, True, v_att, mask)      # b x g x v x q
+            join()
         else:
             w_emb = self.w_emb(q)
             q_emb = self.q_emb.forward_all(w_emb)                           # [batch, q_len, q_dim]
             att, logits = self.v_att.forward_all(v, q_emb)                  # b x g x v x q
             vp = self._v_hoist.maybe(v)
+            Hq = self._hoist_prepare(q_emb, vp)
+        hoisted = self._forward_hoisted(q_emb, att, vp, Hq)
+        if hoisted is not None:
+            return self.classifier(hoisted), att
         total = None
         fused_sum = not torch.is_grad_enabled()
         if fused_sum:                                                        # inference: the per-glimpse sums accumulate inside the residual pass
@@ -132,6 +175,45 @@ class BanModel(nn.Module):
                 total = ops.seq_sum(q_emb, out=total, beta=1.0 if total is not None else 0.0)
         logits = self.classifier(total)
         return logits, att
+
+
+def _ban_forward_hoisted(self, q_emb, att, vp, Hq):
+    """The glimpse loop of src/FFOE/base_model.py:53-64 without a (B*L, h) GEMM between two glimpses.  q_emb after glimpse g is q_emb_0 + D_g[:, None, :]
+    (D_g = the sum of the residual projections so far, one vector per sample), and q_net_g is linear before its ReLU, so
+        q_net_g(q_emb_g) = relu(H_g + (s_g W_g D_g)[:, None, :]),   H_g = s_g W_g q_emb_0 + bias_g:
+    the H_g of ALL glimpses are one batched GEMM up front (like the v projections), the per-glimpse work on the dependent chain is a (B, h) GEMM, the pool
+    (which forms relu(H + shift) as it loads the rows: cti_bi_pool_shift_fwd) and the residual projection; q_emb itself is never rebuilt.  The classifier
+    input sum_g q_emb_g.sum(1) is G * q_emb_0.sum(1) + L * sum_g D_g.  Returns it, or None when the form does not apply (the caller runs the literal loop)."""
+    if Hq is None:
+        return None
+    nets = [n.q_net for n in self.b_net]
+    B, Lq, H = q_emb.shape
+    acc = torch.zeros((2, B, H), device=q_emb.device, dtype=torch.float32)         # D_0 = 0 and the running sum of the D_g
+    D, E = acc[0], acc[1]
+    for g in range(self.glimpse):
+        lay, lin = HoistedProjection._layer_of(nets[g]), _single_linear(self.q_prj[g])
+        b_emb = ops.bi_pool_shift(vp[g], Hq[g], _shift_of(lay, D) if g > 0 else None, att[:, g, :, :].float())
+        if b_emb is None:
+            return None                                                  # (only at g == 0: no kernel takes this shape with the on-load shift)
+        out = ops.linear_residual(b_emb, lin.planes(), lin.scale(), lin.out_features, lin.bias, D.view(B, 1, H), acc=E, beta=1.0)
+        if out is None:
+            return None
+        D = out.view(B, H)
+    return ops.axpby(ops.seq_sum(q_emb), float(self.glimpse), E, float(Lq))
+
+
+def _ban_hoist_prepare(self, q_emb, vp):
+    """H_g = s_g W_g q_emb_0 + bias_g of every glimpse's q_net in one batched GEMM, or None when the hoisted loop does not apply."""
+    nets = [n.q_net for n in self.b_net]
+    if vp is None or self.glimpse < 2 or any(n.k != 1 for n in self.b_net) or not _hoisted_loop_ok(nets, list(self.q_prj), q_emb):
+        return None
+    if not hasattr(self, "_q_hoist"):
+        object.__setattr__(self, "_q_hoist", HoistedProjection(nets))
+    return self._q_hoist.maybe(q_emb, relu=False)
+
+
+BanModel._forward_hoisted = _ban_forward_hoisted
+BanModel._hoist_prepare = _ban_hoist_prepare
 
 
 class _TriModel(nn.Module):
@@ -178,9 +260,15 @@ class _TriModel(nn.Module):
                     t_.record_stream(cur)
         if vp is not None:
             pad = self._v_hoist.last_padded
+            H, join = _beside(v.device, lambda: self._hoist_prepare(q_emb, ans_emb))      # (the glimpses' q / a projections beside the attention)
             att, logits = t_att(v, q_emb, ans_emb, _v_tucked=pad[0] if pad else None, _v_rep=rep)        # b x v x q x a x g
+            join()
         else:
             att, logits = t_att(v, q_emb, ans_emb)
+        if vp is not None and H is not None:
+            joint = self._loop_hoisted(vp, q_emb, ans_emb, att, rep, H[0], H[1])
+            if joint is not None:
+                return self.classifier(joint), att
         fused_sum = not torch.is_grad_enabled()
         joint = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32) if fused_sum and self.glimpse > 0 else None
         for g in range(self.glimpse):
@@ -191,6 +279,45 @@ class _TriModel(nn.Module):
             q_emb = _residual(self.q_prj[g], b_emb, q_emb, acc=joint if last else None, beta=0.0)
             ans_emb = _residual(self.a_prj[g], b_emb, ans_emb, acc=joint if last else None, beta=1.0)
         return self.classifier(joint if joint is not None else _joint(q_emb, ans_emb)), att
+
+
+    def _hoist_prepare(self, q_emb, ans_emb):
+        """(Hq, Ha): the pre-activation q_tucker / a_tucker projections of every glimpse's pooling network in two batched GEMMs, or None."""
+        qn, an = [n.q_tucker for n in self.t_net], [n.a_tucker for n in self.t_net]
+        if self.glimpse < 2 or not _hoisted_loop_ok(qn, list(self.q_prj), q_emb) or not _hoisted_loop_ok(an, list(self.a_prj), ans_emb):
+            return None
+        if not hasattr(self, "_q_hoist"):
+            object.__setattr__(self, "_q_hoist", HoistedProjection(qn))
+            object.__setattr__(self, "_a_hoist", HoistedProjection(an))
+        Hq = self._q_hoist.maybe(q_emb, relu=False)
+        Ha = self._a_hoist.maybe(ans_emb, relu=False) if Hq is not None else None
+        return None if Hq is None or Ha is None else (Hq, Ha)
+
+    def _loop_hoisted(self, vp, q_emb, ans_emb, att, rep, Hq, Ha):
+        """The glimpse loop of src/FFOE/base_model.py:129-134 (src/MC/base_model.py:145-150) in the hoisted form of _ban_forward_hoisted, for both the
+        question and the answer sequence: q_tucker_g(q_emb_g) = relu(Hq_g + shift), a_tucker_g(ans_emb_g) = relu(Ha_g + shift), formed by the tri pool as it
+        loads the rows (cti_tri_pool_shift_fwd).  Returns q_emb_G.sum(1) + ans_emb_G.sum(1) = the initial sums + Lq * Dq + La * Da, or None."""
+        qn, an = [n.q_tucker for n in self.t_net], [n.a_tucker for n in self.t_net]
+        B, Lq, H = q_emb.shape
+        La = ans_emb.shape[1]
+        Dq = Da = None
+        for g in range(self.glimpse):
+            lq, la = HoistedProjection._layer_of(qn[g]), HoistedProjection._layer_of(an[g])
+            b_emb = ops.tri_pool_shift(vp[g], Hq[g], Ha[g], _shift_of(lq, Dq) if g > 0 else None, _shift_of(la, Da) if g > 0 else None,
+                                       att[:, :, :, :, g].float(), v_rep=rep)
+            if b_emb is None:
+                return None
+            pq, pa = _single_linear(self.q_prj[g]), _single_linear(self.a_prj[g])
+            if g == 0:
+                Dq, Da = self.q_prj[g](b_emb), self.a_prj[g](b_emb)
+            else:
+                oq = ops.linear_residual(b_emb, pq.planes(), pq.scale(), pq.out_features, pq.bias, Dq.view(B, 1, H))
+                oa = ops.linear_residual(b_emb, pa.planes(), pa.scale(), pa.out_features, pa.bias, Da.view(B, 1, H))
+                if oq is None or oa is None:
+                    return None
+                Dq, Da = oq.view(B, H), oa.view(B, H)
+        joint = _joint(q_emb, ans_emb)
+        return ops.axpby(ops.axpby(joint, 1.0, Dq, float(Lq), out=joint), 1.0, Da, float(La), out=joint)
 
 
 class CTIModel(_TriModel):

@@ -426,11 +426,20 @@ __global__ __launch_bounds__(256) void bi_pool_kernel(const float* __restrict__ 
 // 16-B loads in flight per thread (~24 KiB per workgroup, several workgroups per CU) -- before any of them is consumed.
 // TRI: out[b,d] = sum_v vt[v,d] * sum_q qt[q,d] * sum_a w[v,q,a] at[a,d];   BI: out[b,d] = sum_v vt[v,d] * sum_q w[v,q] qt[q,d].
 // =====================================================================================================
+// The "shifted" form of the sum-pools (cti_*_pool_shift_fwd, inference): the q / a operand is relu(row + add[b, :]) formed as the rows are loaded --
+// row = the hoisted pre-activation projection of the INITIAL sequence, add = the projection of the accumulated residual (one (B, D) vector per sample): the
+// glimpse loops of src/FFOE/base_model.py:53-61,129-132 then need no (B*L, D) projection GEMM between two glimpses (base_model.py here, _HoistedLoop).
+struct PoolShift { const float* qadd; const float* aadd; int relu; };
+__device__ __forceinline__ float shift1(float x, float a, int relu) { x += a; return relu ? fmaxf(x, 0.f) : x; }
+// `c ? *p : z` with two lvalues is an lvalue conditional: the constant would live in private memory (scratch) and be loaded from there -- select VALUES instead
+__device__ __forceinline__ float2 ld2_or_zero(bool c, const float* p) { float2 r = make_float2(0.f, 0.f); if (c) r = *reinterpret_cast<const float2*>(p); return r; }
+__device__ __forceinline__ float4 ld4_or_zero(bool c, const float* p) { float4 r = make_float4(0.f, 0.f, 0.f, 0.f); if (c) r = *reinterpret_cast<const float4*>(p); return r; }
+
 template <bool TRI, int AP, int NG, int QX>
 __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                           const float* __restrict__ at, const float* __restrict__ w,
                                                           int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                          float* __restrict__ out, int V, int Q, int A, int D) {
+                                                          float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh) {
 #ifndef CTI_POOL_VC
 #define CTI_POOL_VC 9
 #endif
@@ -464,11 +473,23 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
     float4 qr[QM];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < QM; ++q) qr[q] = (q < QL && q < Qn) ? *reinterpret_cast<const float4*>(qt + ((int64_t)b * Q + q) * D + dd) : z4;
+    for (int q = 0; q < QM; ++q) qr[q] = ld4_or_zero(q < QL && q < Qn, qt + ((int64_t)b * Q + q) * D + dd);
     float4 ar[AP];
     if (TRI) {
 #pragma unroll
-        for (int a = 0; a < AP; ++a) ar[a] = a < A ? *reinterpret_cast<const float4*>(at + ((int64_t)b * A + a) * D + dd) : z4;
+        for (int a = 0; a < AP; ++a) ar[a] = ld4_or_zero(a < A, at + ((int64_t)b * A + a) * D + dd);
+    }
+    if (sh.relu || sh.qadd || sh.aadd) {                             // shifted form: the real rows only (padding rows stay 0)
+        const float4 dq = ld4_or_zero(sh.qadd != nullptr, sh.qadd + (int64_t)b * D + dd);
+#pragma unroll
+        for (int q = 0; q < QM; ++q)
+            if (q < QL && q < Qn) { qr[q].x = shift1(qr[q].x, dq.x, sh.relu); qr[q].y = shift1(qr[q].y, dq.y, sh.relu); qr[q].z = shift1(qr[q].z, dq.z, sh.relu); qr[q].w = shift1(qr[q].w, dq.w, sh.relu); }
+        if (TRI) {
+            const float4 da = ld4_or_zero(sh.aadd != nullptr, sh.aadd + (int64_t)b * D + dd);
+#pragma unroll
+            for (int a = 0; a < AP; ++a)
+                if (a < A) { ar[a].x = shift1(ar[a].x, da.x, sh.relu); ar[a].y = shift1(ar[a].y, da.y, sh.relu); ar[a].z = shift1(ar[a].z, da.z, sh.relu); ar[a].w = shift1(ar[a].w, da.w, sh.relu); }
+        }
     }
     __syncthreads();
     const float* vb = vt + (int64_t)b * V * D + dd;
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
     for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
         float4 vr[VC];
 #pragma unroll
-        for (int u = 0; u < VC; ++u) vr[u] = v0 + u < v_hi ? *reinterpret_cast<const float4*>(vb + (int64_t)(v0 + u) * D) : z4;
+        for (int u = 0; u < VC; ++u) vr[u] = ld4_or_zero(v0 + u < v_hi, vb + (int64_t)(v0 + u) * D);
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -548,7 +569,7 @@ template <int QA, int NG, int AC>
 __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                                   const float* __restrict__ at, const float* __restrict__ w,
                                                                   int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                                  float* __restrict__ out, int V, int Q, int A, int D) {
+                                                                  float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh) {
     constexpr int QAP = (QA + 3) & ~3, VC = 9;
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [V][QAP]
     const int b = blockIdx.y, tt = threadIdx.x, t = tt & 127, grp = tt >> 7;
@@ -571,6 +592,14 @@ __global__ __launch_bounds__(128 * NG) void tri_pool_table_kernel(const float* _
     for (int a = 0; a < AC; ++a) ar[a] = *reinterpret_cast<const float2*>(at + ((int64_t)b * AC + a) * D + dd);
 #pragma unroll
     for (int q = 0; q < QC; ++q) qr[q] = *reinterpret_cast<const float2*>(qt + ((int64_t)b * QC + q) * D + dd);
+    if (sh.relu || sh.qadd || sh.aadd) {
+        const float2 dq = sh.qadd ? *reinterpret_cast<const float2*>(sh.qadd + (int64_t)b * D + dd) : make_float2(0.f, 0.f);
+        const float2 da = sh.aadd ? *reinterpret_cast<const float2*>(sh.aadd + (int64_t)b * D + dd) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < QC; ++q) { qr[q].x = shift1(qr[q].x, dq.x, sh.relu); qr[q].y = shift1(qr[q].y, dq.y, sh.relu); }
+#pragma unroll
+        for (int a = 0; a < AC; ++a) { ar[a].x = shift1(ar[a].x, da.x, sh.relu); ar[a].y = shift1(ar[a].y, da.y, sh.relu); }
+    }
     const float* wb = w + (int64_t)b * w_sb;
     if (!(CTI_TP_ABL & 8)) {
     for (int i = tt; i < V * QAP; i += NT) {
@@ -643,12 +672,12 @@ __global__ __launch_bounds__(128 * NG, 2) void bi_pool_k3_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < VC; ++u)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vr[u][c] = v_lo + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v_lo + u) * D + 2 * c) : z2;
+        for (int c = 0; c < 3; ++c) vr[u][c] = ld2_or_zero(v_lo + u < v_hi, vb + (int64_t)(v_lo + u) * D + 2 * c);
     float2 qr[QM][3];
 #pragma unroll
     for (int q = 0; q < QM; ++q)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qr[q][c] = q < Q ? *reinterpret_cast<const float2*>(qt + ((int64_t)b * Q + q) * D + dd + 2 * c) : z2;
+        for (int c = 0; c < 3; ++c) qr[q][c] = ld2_or_zero(q < Q, qt + ((int64_t)b * Q + q) * D + dd + 2 * c);
     if (w) {
         const float* wb = w + (int64_t)b * w_sb;
         for (int i = tt; i < V * QM; i += NT) { const int q = i % QM, v = i / QM; sm[i] = q < Q ? wb[v * w_sv + q * w_sq] : 0.f; }
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(128 * NG, 2) void bi_pool_k3_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < VC; ++u)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) vn[u][c] = v0 + VC + u < v_hi ? *reinterpret_cast<const float2*>(vb + (int64_t)(v0 + VC + u) * D + 2 * c) : z2;
+            for (int c = 0; c < 3; ++c) vn[u][c] = ld2_or_zero(v0 + VC + u < v_hi, vb + (int64_t)(v0 + VC + u) * D + 2 * c);
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -1020,7 +1049,7 @@ template <int A_, int KS>
 __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep) {
+                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh) {
     constexpr int QAP = KS * 16, MT = 2, WP = QAP + 4;             // W row pitch: +4 floats keeps b128 alignment and spreads the banks
     extern __shared__ __attribute__((aligned(16))) float sm[];     // Wc[64][WP]
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -1051,6 +1080,11 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
         const int d_ = (tile_) * 32 + l31;                                                                       \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) qr_[q] = q < Q ? qt[((int64_t)b * Q + q) * D + d_] : 0.f; \
         _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = at[((int64_t)b * A_ + a) * D + d_];              \
+        if (sh.relu || sh.qadd || sh.aadd) {                                                                     \
+            const float dq_ = sh.qadd ? sh.qadd[(int64_t)b * D + d_] : 0.f, da_ = sh.aadd ? sh.aadd[(int64_t)b * D + d_] : 0.f; \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) if (q < Q) qr_[q] = shift1(qr_[q], dq_, sh.relu);     \
+            _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = shift1(ar_[a], da_, sh.relu);                \
+        }                                                                                                        \
         const float* vb_ = vt + (int64_t)(b / v_rep) * V * D + d_;      /* v_rep > 1: one vt block per image, v_rep batch rows share it */ \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                         \
             const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;                                                       \
@@ -1416,10 +1450,13 @@ extern "C" int cti_masked_softmax_bi_fwd(float* logits, const uint8_t* mask, flo
     return launch_status("cti_masked_softmax_bi_fwd");
 }
 
-extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                                int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
+// sh set (the shifted form): only the table / streaming kernels take it -- any other shape returns CTI_E_UNSUPPORTED before anything is launched
+static int tri_pool_impl(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                         int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, PoolShift sh, void* stream) {
+    const bool shifted = sh.relu || sh.qadd || sh.aadd;
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
+    if (shifted && ((sh.qadd && !aligned16(sh.qadd)) || (sh.aadd && !aligned16(sh.aadd)))) return CTI_E_UNSUPPORTED;
 #ifndef CTI_TRI_TABLE
 #define CTI_TRI_TABLE 1
 #endif
@@ -1432,7 +1469,7 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
         const dim3 grid((D / 2 + 127) / 128, B);
         size_t lds_t = sizeof(float) * (size_t)V * ((QA + 3) & ~3);
         if (lds_t < sizeof(float2) * 128 * (NGT - 1)) lds_t = sizeof(float2) * 128 * (NGT - 1);
-#define CTI_TT(QAv, Av) hipLaunchKernelGGL((tri_pool_table_kernel<QAv, NGT, Av>), grid, dim3(128 * NGT), lds_t, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
+#define CTI_TT(QAv, Av) hipLaunchKernelGGL((tri_pool_table_kernel<QAv, NGT, Av>), grid, dim3(128 * NGT), lds_t, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh)
         if (lds_t <= 64 * 1024 && A == 3) {
             // measured at B = 256, D = 1024 (rocprofv3): QA = 42: 27.1 us (stream form 31.6); QA = 72: 53 us (stream form 46.5, kept there)
             if (QA == 42) { CTI_TT(42, 3); return launch_status("cti_tri_pool_fwd"); }
@@ -1450,13 +1487,14 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
         if (lds_p < sizeof(float4) * 128 * (NG - 1)) lds_p = sizeof(float4) * 128 * (NG - 1);
         if (lds_p <= 64 * 1024) {
             const dim3 grid((D / 4 + 127) / 128, B);
-#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D)
+#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh)
             if (AP == 4) { if (Q == 14) CTI_TP(4, 14); else if (Q == 12) CTI_TP(4, 12); else CTI_TP(4, 0); }
             else         { if (Q == 14) CTI_TP(8, 14); else if (Q == 12) CTI_TP(8, 12); else CTI_TP(8, 0); }
 #undef CTI_TP
             return launch_status("cti_tri_pool_fwd");
         }
     }
+    if (shifted) return CTI_E_UNSUPPORTED;
     if (A <= 8) {
         const int AP = A <= 4 ? 4 : 8;
         const size_t lds_s = sizeof(float) * ((size_t)V * Q * AP + 256 * (size_t)Q);
@@ -1475,9 +1513,16 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
     return launch_status("cti_tri_pool_fwd");
 }
 
-extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
-                               float* out, int B, int V, int Q, int D, int k, void* stream) {
+extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                                int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, void* stream) {
+    return tri_pool_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, PoolShift{nullptr, nullptr, 0}, stream);
+}
+
+static int bi_pool_impl(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                        float* out, int B, int V, int Q, int D, int k, PoolShift sh, void* stream) {
+    const bool shifted = sh.relu || sh.qadd;
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(out);
+    if (shifted && sh.qadd && !aligned16(sh.qadd)) return CTI_E_UNSUPPORTED;
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && D > 0 && k > 0 && B <= 65535, CTI_E_SHAPE, "cti_bi_pool_fwd: B=%d V=%d Q=%d D=%d k=%d", B, V, Q, D, k);
     CTI_REQUIRE(D >= k, CTI_E_SHAPE, "cti_bi_pool_fwd: D=%d < k=%d", D, k);
     if (k == 1 && Q <= 16 && D % 4 == 0 && (size_t)V * 16 * sizeof(float) <= 64 * 1024 && aligned16(vt) && aligned16(qt) && aligned16(out)) {
@@ -1488,11 +1533,12 @@ extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w,
         size_t lds_b = sizeof(float) * (size_t)V * 16;
         if (lds_b < sizeof(float4) * 128 * (NGB - 1)) lds_b = sizeof(float4) * 128 * (NGB - 1);
 #define CTI_BP(QXv) hipLaunchKernelGGL((pool_stream_kernel<false, 4, NGB, QXv>), dim3((D / 4 + 127) / 128, B), dim3(128 * NGB), lds_b, as_stream(stream), \
-                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D)
+                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D, sh)
         if (Q == 14) CTI_BP(14); else if (Q == 12) CTI_BP(12); else CTI_BP(0);
 #undef CTI_BP
         return launch_status("cti_bi_pool_fwd");
     }
+    if (shifted) return CTI_E_UNSUPPORTED;                         // (only the k = 1 streaming kernel forms relu(row + add) on load)
     if (k == 3 && Q <= 16 && D % 6 == 0 && (size_t)V * 16 * sizeof(float) <= 64 * 1024 && ((reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(out)) & 7) == 0) {
         constexpr int NG3 = 2;
         size_t lds3 = sizeof(float) * (size_t)V * 16;
@@ -1506,6 +1552,19 @@ extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w,
     hipLaunchKernelGGL(bi_pool_kernel, dim3((NO + 255) / 256, B), dim3(256), lds, as_stream(stream), vt, qt, w, w_sb, w_sv, w_sq,
                        out, V, Q, D, k);
     return launch_status("cti_bi_pool_fwd");
+}
+
+extern "C" int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                               float* out, int B, int V, int Q, int D, int k, void* stream) {
+    return bi_pool_impl(vt, qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, k, PoolShift{nullptr, nullptr, 0}, stream);
+}
+
+// out[b,d] = sum_v vt[b,v,d] * sum_q w[b,v,q] * relu(qt[b,q,d] + qadd[b,d])   (k = 1; qadd may be NULL = 0).  CTI_E_UNSUPPORTED when the shape is not the
+// streaming kernel's (Q <= 16, D % 4 == 0, 16-B aligned rows): nothing is launched, the caller materialises the operand and takes cti_bi_pool_fwd.
+extern "C" int cti_bi_pool_shift_fwd(const float* vt, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                                     float* out, int B, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(w);
+    return bi_pool_impl(vt, qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, 1, PoolShift{qadd, nullptr, 1}, stream);
 }
 
 extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
@@ -1570,8 +1629,8 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
     return launch_status("cti_bi_logits_mfma_fwd");
 }
 
-extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, void* stream) {
+static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                              int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, PoolShift sh, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
     CTI_REQUIRE(v_rep >= 1 && B % v_rep == 0, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: v_rep=%d does not divide B=%d", v_rep, B);
@@ -1589,11 +1648,31 @@ extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const flo
     const int tpw = tiles >= 32 ? CTI_TPM_TPW : 1;
     const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
     const size_t lds = sizeof(float) * 64 * (size_t)(KS * 16 + 4);
-#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep)
+#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh)
     if (A == 3) { if (KS <= 2) CTI_TM(3, 2); else CTI_TM(3, 3); }
     else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
 #undef CTI_TM
     return launch_status("cti_tri_pool_mfma_fwd");
+}
+
+extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
+                                     int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, void* stream) {
+    return tri_pool_mfma_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, v_rep, PoolShift{nullptr, nullptr, 0}, stream);
+}
+
+// out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d])   (qadd / aadd may be NULL = 0).
+// use_mfma != 0: the fp32-grade MFMA form where it applies (A = 6), else the product-table / streaming VALU kernels (v_rep must then be 1).
+// CTI_E_UNSUPPORTED when no kernel with the on-load shift takes the shape: nothing is launched, the caller materialises the operands.
+extern "C" int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
+                                      int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
+                                      int use_mfma, void* stream) {
+    const PoolShift sh{qadd, aadd, 1};
+    if (use_mfma) {
+        const int rc = tri_pool_mfma_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, v_rep, sh, stream);
+        if (rc != CTI_E_UNSUPPORTED) return rc;
+    }
+    if (v_rep != 1) return CTI_E_UNSUPPORTED;
+    return tri_pool_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, sh, stream);
 }
 
 extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float* qt, const float* at, float* dw, int B, int V, int Q, int A, int D,

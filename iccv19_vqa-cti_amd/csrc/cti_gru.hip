@@ -108,6 +108,9 @@ template <int N> __device__ __forceinline__ void gf_wait() { asm volatile("s_wai
 // KPB (round 3 experiment): 32-deep K sub-steps per barrier (a slot holds KPB sub-slots of the same layout).  Measured on the MC model forward (16 GRU steps
 // on its critical path; alternating runs on one box): KPB 1 / 2 / 4 (2-slot ring) / 2 (3-slot ring) = 0.913-0.923 / 0.923-0.927 / 0.927-0.932 / 0.922-0.924 ms:
 // the step kernel (11.7 us at B = 256, H = 1 024) is not bound by its 32 barrier rounds; default stays 1.
+#ifndef CTI_GF_DBG
+#define CTI_GF_DBG 0      // debugging only (wrong results): 1 no DMA of the lo planes, 2 no lo-plane MFMAs
+#endif
 template <int TERMS, int KPB>
 __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
                                                              const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl, int64_t pitchW,
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = wid * 4 + u;
-            if (NPL == 1 && ((q >> 2) & 1)) continue;              // plain bf16: the lo planes are not staged
+            if ((NPL == 1 || (CTI_GF_DBG & 1)) && ((q >> 2) & 1)) continue;              // plain bf16: the lo planes are not staged
             const unsigned short* s_ = src[u] + (int64_t)(kg * KPB + sub) * ((q >> 3) ? kstepW : kstepH);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
                                              (__attribute__((address_space(3))) void*)(gsm + pos * SLOT + sub * GF_SLOT + ldso[u]), 16, 0, 0);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
         for (int g = 0; g < 3; ++g) {
             const int go = g < 2 ? g * 512 : 1024;                 // gates r, z: rows 0-15, 16-31 of half 0; gate n: rows 0-15 of half 1
             const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(s + fb + go);
-            if (TERMS == 3) {
+            if (TERMS == 3 && !(CTI_GF_DBG & 2)) {
                 const g_bf16x8 bl = *reinterpret_cast<const g_bf16x8*>(s + fb + go + 4096);
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[g], 0, 0, 0);
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[g], 0, 0, 0);

@@ -88,6 +88,11 @@ __global__ void seq_sum_kernel(const float* __restrict__ x, float* __restrict__ 
     for (int l = 0; l < L; ++l) s += x[((int64_t)b * L + l) * H + h];
     out[idx] = (beta != 0.f ? beta * out[idx] : 0.f) + s;
 }
+// out = a x + b y  (the classifier input of the hoisted glimpse loops: G * q_emb_0.sum(1) + L * sum_g D_g)
+__global__ void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b, float* __restrict__ out, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = a * x[idx] + b * y[idx];
+}
 // out[b,l,h] = (x ? x[b,l,h] : 0) + y[b,h]
 __global__ void seq_bcast_add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int B, int L, int H) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,6 +270,13 @@ int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, voi
     if (B == 0) return CTI_OK;
     hipLaunchKernelGGL(seq_sum_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), x, out, B, L, H, beta);
     return launch_status("cti_seq_sum");
+}
+int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(n >= 0, CTI_E_SHAPE, "cti_axpby: n=%lld", (long long)n);
+    if (n == 0) return CTI_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), x, a, y, b, out, n);
+    return launch_status("cti_axpby");
 }
 size_t cti_linear_residual_workspace_bytes(int B, int N, int K, int prec) {
     if (B <= 0 || N <= 0 || K <= 0 || (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16)) return 0;

@@ -157,9 +157,10 @@ class HoistedProjection:
             extra = []                                   # a narrower network of another form (e.g. act='Tanh'): the main ones still batch
         return main + extra
 
-    def maybe(self, x, use_padded=True):
+    def maybe(self, x, use_padded=True, relu=True):
         """x (..., in) -> list of (..., out) tensors, one per network, or None.  use_padded = False: the narrower networks stay out of the batch
-        (their consumer will not take the hoisted output on this call: the extra rows would be computed and discarded)."""
+        (their consumer will not take the hoisted output on this call: the extra rows would be computed and discarded).
+        relu = False: the PRE-activation outputs scale * W x + bias (the hoisted glimpse loops add the residual's projection before the ReLU)."""
         self.last_padded = []
         if len(self.nets) + (len(self.padded) if use_padded else 0) < 2 or torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for n in self.nets + self.padded for p in n.parameters())):
             return None
@@ -185,7 +186,7 @@ class HoistedProjection:
         n, out_dim = len(layers), layers[0].out_features
         x2 = x.reshape(-1, x.shape[-1])
         y = ops.gemm_nt(x2, self._w, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, scale=self._s, scale_div=out_dim, scale_bs=1,
-                        bias=self._b, bias_bs=out_dim, relu=True, B_planes=self._wp)
+                        bias=self._b, bias_bs=out_dim, relu=bool(relu), B_planes=self._wp)
         outs = [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
         self.last_padded = outs[len(self.nets):]      # the narrower networks' outputs (full width; the first out_features columns count), possibly none
         return outs[:len(self.nets)]

@@ -141,11 +141,12 @@ def _aux_stream(device):
     return None if o is None else o.cuda_stream
 
 
-def aux_stream_object(device):
-    """The torch.cuda.Stream behind _aux_stream (one per device), or None when the overlap is disabled."""
+def aux_stream_object(device, which=0):
+    """The torch.cuda.Stream behind _aux_stream (one per device), or None when the overlap is disabled.  which = 1: a second side stream of the model
+    forwards (the hoisted q / a projections beside the attention, whose library call occupies the first one)."""
     if not use_aux_stream or _no_nested_fork[0]:
         return None
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     if key not in _aux:
         _aux[key] = torch.cuda.Stream(device=device, priority=_AUX_PRIORITY)
     return _aux[key]
@@ -732,6 +733,65 @@ def bi_pool(vt, qt, w, k=1):
         return out.zero_()
     L.check(L.lib().cti_bi_pool_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(w), sb, sv, sq, out.data_ptr(), B, V, Q, D, k, _stream()),
             "cti_bi_pool_fwd")
+    return out
+
+
+def bi_pool_shift(vt, qt, qadd, w):
+    """out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + qadd[b,d])  (k = 1; qadd (B,D) or None = 0), or None when no kernel forms the shifted
+    operand on load at this shape (the caller materialises it).  Inference only."""
+    _req(vt, "vt"); _req(qt, "qt"); _req(w, "w")
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    vt, qt = vt.contiguous(), qt.contiguous()
+    if tuple(w.shape) != (B, V, Q) or B == 0 or V * Q == 0:
+        return None
+    if qadd is not None:
+        _req(qadd, "qadd")
+        qadd = qadd.contiguous()
+    sb, sv, sq = w.stride()
+    out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
+    rc = L.lib().cti_bi_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(qadd), w.data_ptr(), sb, sv, sq, out.data_ptr(), B, V, Q, D, _stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "cti_bi_pool_shift_fwd")
+    return out
+
+
+def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
+    """out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d])  (qadd / aadd (B,D) or None = 0), or
+    None when no kernel forms the shifted operands on load at this shape.  Inference only."""
+    for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
+        _req(t, n)
+    v_rep = int(v_rep)
+    B, (V, D) = qt.shape[0], vt.shape[1:]
+    Q, A = qt.shape[1], at.shape[1]
+    if vt.shape[0] * v_rep != B or tuple(w.shape) != (B, V, Q, A) or B == 0 or V * Q * A == 0:
+        return None
+    vt, qt, at = vt.contiguous(), qt.contiguous(), at.contiguous()
+    qadd = None if qadd is None else qadd.contiguous()
+    aadd = None if aadd is None else aadd.contiguous()
+    out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
+    sb, sv, sq, sa = w.stride()
+    lib = L.lib()
+    use_mfma = int(get_precision() != "fp32" and _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") != "1")
+    rc = lib.cti_tri_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), _ptr(qadd), _ptr(aadd), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
+                                    B, V, Q, A, D, v_rep, use_mfma, _stream())
+    if rc == L.E_UNSUPPORTED and v_rep > 1:
+        rc = lib.cti_tri_pool_shift_fwd(vt.repeat_interleave(v_rep, 0).data_ptr(), qt.data_ptr(), at.data_ptr(), _ptr(qadd), _ptr(aadd), w.data_ptr(), sb, sv, sq, sa,
+                                        out.data_ptr(), B, V, Q, A, D, 1, use_mfma, _stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "cti_tri_pool_shift_fwd")
+    return out
+
+
+def axpby(x, a, y, b, out=None):
+    """a * x + b * y (same shape, fp32)."""
+    _req(x, "x"); _req(y, "y")
+    x, y = x.contiguous(), y.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().cti_axpby(x.data_ptr(), float(a), y.data_ptr(), float(b), out.data_ptr(), x.numel(), _stream()), "cti_axpby")
     return out
 
 

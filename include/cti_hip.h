@@ -243,6 +243,19 @@ int cti_tri_pool_fwd(const float* vt, const float* qt, const float* at, const fl
 int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
                           int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, void* stream);
 
+/* The "shifted" pools of the hoisted glimpse loops (inference; base_model.py `_HoistedLoop`, replacing the per-glimpse q_net / q_tucker / a_tucker
+ * GEMMs of src/FFOE/base_model.py:53-61,129-132 and src/MC/base_model.py:145-148): the q (and a) operand is relu(row + add[b, :]) formed as the
+ * rows are loaded -- row = the pre-activation projection of the INITIAL sequence (one batched GEMM for all glimpses), add = the projection of the
+ * residual accumulated so far, one (B, D) vector per sample, or NULL = 0.
+ *   tri: out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d]);  use_mfma != 0: the MFMA form
+ *        where it applies (else v_rep must be 1);   bi (k = 1): out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + qadd[b,d]).
+ * CTI_E_UNSUPPORTED (nothing launched, no message) when no kernel with the on-load shift takes the shape: materialise the operands instead. */
+int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
+                           int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
+                           int use_mfma, void* stream);
+int cti_bi_pool_shift_fwd(const float* vt, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                          float* out, int B, int V, int Q, int D, void* stream);
+
 /* out[b,n] = sum_{t<k} sum_{v,q} vt[b,v,n*k+t] * w[b,v,q] * qt[b,q,n*k+t],  n < D/k.  w == NULL means w = 1
  * (that is BCNet.forward with h_out=None, src/bc.py:42-47: out is then (B,1,D) with k = 1). */
 int cti_bi_pool_fwd(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
@@ -529,6 +542,8 @@ int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* s
 int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, void* stream);
 /* out[b,l,h] = x[b,l,h] + y[b,h]  (x NULL = 0)         (q_prj(b_emb.unsqueeze(1)) + q_emb, src/FFOE/base_model.py:61,131-132) */
 int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream);
+/* out[i] = a * x[i] + b * y[i], i < n (out may alias x or y). */
+int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream);
 /* The residual projection of a glimpse as ONE call (src/FFOE/base_model.py:61,131-132 `q_prj(b_emb.unsqueeze(1)) + q_emb`, and the sequence sums
  * of :66,134): y = scale * (x @ W^T) + bias with x (B, K) fp32 and W given as resident planes (cti_split_operand of the (N x K) weight_v);
  * out[b,l,:] = seq[b,l,:] + y[b,:]; acc (nullable) [b,:] = beta * acc[b,:] + sum_l out[b,l,:].  Three launches (split of x, split-K GEMM,

@@ -149,6 +149,114 @@ def test_two_models_on_sibling_streams_equal_the_serial_forwards(order):
         assert torch.equal(cg, lc) and torch.equal(bg, lb)
 
 
+@pytest.mark.parametrize("B,V,Q,A,D,rep", [(5, 9, 7, 3, 64, 1), (4, 36, 14, 3, 1024, 1), (8, 36, 12, 6, 1024, 4), (8, 36, 12, 6, 1024, 1), (3, 10, 5, 4, 72, 1), (2, 36, 12, 3, 96, 1)])
+def test_shifted_tri_pool_vs_float64(B, V, Q, A, D, rep):
+    """cti_tri_pool_shift_fwd: the q / a operands are relu(row + add[b]) formed on load (product-table, MFMA and streaming kernels, one v block per image)."""
+    rs = np.random.RandomState(B * 100 + A)
+    vt = rs.standard_normal((B // rep, V, D)).astype(np.float32)
+    qt, at = rs.standard_normal((B, Q, D)).astype(np.float32), rs.standard_normal((B, A, D)).astype(np.float32)
+    qa, aa = rs.standard_normal((B, D)).astype(np.float32), rs.standard_normal((B, D)).astype(np.float32)
+    w = rs.rand(B, V, Q, A, 2).astype(np.float32)
+    for use_q, use_a in ((True, True), (False, True), (False, False)):
+        out = ops.tri_pool_shift(T(vt), T(qt), T(at), T(qa) if use_q else None, T(aa) if use_a else None, T(w)[..., 1], v_rep=rep)
+        assert out is not None
+        q_ = np.maximum(qt.astype(np.float64) + (qa[:, None, :] if use_q else 0), 0)
+        a_ = np.maximum(at.astype(np.float64) + (aa[:, None, :] if use_a else 0), 0)
+        ref = np.einsum("bvd,bvqa,bqd,bad->bd", np.repeat(vt, rep, 0).astype(np.float64), w[..., 1].astype(np.float64), q_, a_)
+        assert O.norm_max_err(out.cpu().numpy(), ref) < TOL, (use_q, use_a)
+
+
+@pytest.mark.parametrize("B,V,Q,D", [(5, 9, 7, 64), (4, 36, 14, 1024), (3, 36, 12, 512), (2, 11, 16, 36)])
+def test_shifted_bi_pool_vs_float64(B, V, Q, D):
+    rs = np.random.RandomState(B * 10 + Q)
+    vt, qt = rs.standard_normal((B, V, D)).astype(np.float32), rs.standard_normal((B, Q, D)).astype(np.float32)
+    qa = rs.standard_normal((B, D)).astype(np.float32)
+    w = rs.rand(B, 3, V, Q).astype(np.float32)
+    for use_q in (True, False):
+        out = ops.bi_pool_shift(T(vt), T(qt), T(qa) if use_q else None, T(w)[:, 1])
+        assert out is not None
+        q_ = np.maximum(qt.astype(np.float64) + (qa[:, None, :] if use_q else 0), 0)
+        ref = np.einsum("bvd,bvq,bqd->bd", vt.astype(np.float64), w[:, 1].astype(np.float64), q_)
+        assert O.norm_max_err(out.cpu().numpy(), ref) < TOL, use_q
+    assert ops.bi_pool_shift(T(vt[:, :, :D - 2].copy()), T(qt[:, :, :D - 2].copy()), None, T(w)[:, 1]) is None      # D % 4 != 0: no kernel with the on-load shift
+
+
+def test_hoisted_glimpse_loops_equal_the_literal_loops():
+    """base_model's hoisted glimpse loops (q / a projections of the initial sequences in one batched GEMM, the residual's projection added in the pool)
+    against the literal loops of src/FFOE/base_model.py:53-64,129-134 -- same module, knob off -- and against the float64 oracle."""
+    bm = cti_amd.base_model
+    torch.manual_seed(34)
+    cti = cti_amd.build_cti(_args(3), _ds(50, 48, 11)).to(DEV).eval()
+    ban = cti_amd.build_ban(_args(4), _ds(50, 48, 11)).to(DEV).eval()
+    rs = np.random.RandomState(10)
+    v = np.abs(rs.standard_normal((6, 9, 48))).astype(np.float32)
+    v[1, 6:] = 0
+    q = rs.randint(0, 50, size=(6, 8)).astype(np.int64)
+    a = rs.randint(0, 50, size=(6, 3)).astype(np.int64)
+    calls = {"tri": 0, "bi": 0}
+    tps, bps = ops.tri_pool_shift, ops.bi_pool_shift
+    ops.tri_pool_shift = lambda *x, **k: (calls.__setitem__("tri", calls["tri"] + 1), tps(*x, **k))[1]
+    ops.bi_pool_shift = lambda *x, **k: (calls.__setitem__("bi", calls["bi"] + 1), bps(*x, **k))[1]
+    try:
+        with torch.no_grad():
+            lc, (lb, ab) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
+            assert calls == {"tri": 3, "bi": 4}, calls                     # the hoisted form is what ran
+            bm._HOIST_LOOP = False
+            lc0, (lb0, ab0) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
+            assert calls == {"tri": 3, "bi": 4}
+    finally:
+        bm._HOIST_LOOP = True
+        ops.tri_pool_shift, ops.bi_pool_shift = tps, bps
+    assert O.norm_max_err(lc.cpu().numpy(), lc0.cpu().numpy()) < 2e-5 and O.norm_max_err(lb.cpu().numpy(), lb0.cpu().numpy()) < 2e-5
+    assert O.norm_max_err(lc.cpu().numpy(), OM.ffoe_cti_forward(v, q, a, sd(cti), 3, dtype=np.float64)) < TOL
+    assert O.norm_max_err(lb.cpu().numpy(), OM.ffoe_ban_forward(v, q, sd(ban), 4, dtype=np.float64)[0]) < 1.5e-4
+
+
+def test_pools_beside_the_bf16x3_gru_on_another_stream():
+    """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
+    (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue
+    conditional `c ? *p : z4`) and the 64-byte scratch row did not survive.  The pools are scratch-free now (tests/test_abi.py pins the list of kernels
+    that have a private segment); this is the reproducer: 200 pool launches beside GRU forwards, every one bit-equal to a launch on an idle device."""
+    import types
+    old = cti_amd.get_precision()
+    cti_amd.set_precision("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(7)
+        B = 256
+        ds = types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=2000), v_dim=2048, num_ans_candidates=16)
+        ma = types.SimpleNamespace(op="c", num_hid=1024, gamma=2, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+        torch.manual_seed(3)
+        m = cti_amd.build_cti(ma, ds).to(DEV).eval()
+        q = torch.randint(0, 2000, (B, 14), generator=g).to(DEV)
+        vp = torch.randn(B, 36, 1024, generator=g).to(DEV)
+        qn = torch.randn(B, 14, 1024, generator=g).to(DEV)
+        an = torch.randn(B, 3, 1024, generator=g).to(DEV)
+        att = torch.rand(B, 36, 14, generator=g).to(DEV)
+        att3 = torch.rand(B, 36, 14, 3, generator=g).to(DEV)
+        v3 = torch.randn(B, 36, 3072, generator=g).to(DEV)
+        q3 = torch.randn(B, 14, 3072, generator=g).to(DEV)
+        big = torch.randn(6144, 6144, device=DEV)
+        side = torch.cuda.Stream()
+        with torch.no_grad():
+            emb = m.w_emb(q)
+            ref = [ops.bi_pool(vp, qn, att, 1).clone(), ops.bi_pool(v3, q3, att, 3).clone(), ops.tri_pool(vp, qn, an, att3).clone()]
+            torch.cuda.synchronize()
+            bad = 0
+            for rep in range(5):
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _ = big @ big                                           # head start for the host: the pools below are still queued when the GRU starts
+                    outs = [(ops.bi_pool(vp, qn, att, 1), ops.bi_pool(v3, q3, att, 3), ops.tri_pool(vp, qn, an, att3)) for _ in range(40)]
+                m.q_emb.forward_all(emb)
+                cur.wait_stream(side)
+                torch.cuda.synchronize()
+                bad += sum(0 if all(torch.equal(o, r) for o, r in zip(trip, ref)) else 1 for trip in outs)
+        assert bad == 0, "%d of 200 pool launches differ from the launch on an idle device" % bad
+    finally:
+        cti_amd.set_precision(old)
+
+
 @pytest.mark.parametrize("B,L,N,K", [(256, 14, 1024, 1024), (5, 3, 36, 40), (64, 12, 128, 96), (1, 1, 4, 8)])
 def test_linear_residual_reduces_adds_and_sums_in_one_pass(B, L, N, K):
     """out = seq + (scale * x @ W^T + bias)[:, None, :]; acc = beta * acc + out.sum(1): with a K split (256 x 1024 x 1024) and without."""
