@@ -532,7 +532,12 @@ extern "C" int cti_gemm_nn(const float* a, int64_t lda, const float* b, int64_t 
 // CTI_AF32_PB=1 (experiment; built, under test, measured SLOWER and therefore off): products against resident planes below 128 tiles of 256 x 256 read their
 // fp32 A rows directly instead of a split launch in front of each -- MC CTI forward 0.910 -> 0.940 ms, FFOE BAN + CTI 2.558 -> 2.600 ms: the 41 splits cost
 // 5-7 us each, but every column tile of the small-tile kernel then moves twice the A bytes through LDS-DMA and converts the same rows again
+#ifndef CTI_AF32_ROWS_DEFAULT
+#define CTI_AF32_ROWS_DEFAULT 256      // measured (tools/ab_af32_rows.sh): c3 296.6 -> 304 k samples/s, c4 137.8 -> 139.0 k; 512 and 4096 give less
+#endif
 static bool af32_pb() { static const bool v = [] { const char* e = getenv("CTI_AF32_PB"); return e && e[0] == '1'; }(); return v; }
+// the fp32-A form for SMALL row counts only (the batch-sized products of the model forwards' dependent chains: their split launch costs as much as they do)
+static int af32_rows() { static const int v = [] { const char* e = getenv("CTI_AF32_ROWS"); return e ? atoi(e) : CTI_AF32_ROWS_DEFAULT; }(); return v; }
 
 // cti_gemm_nt with the B operand given as resident planes (cti_split_operand of the (rowsB_total x K) matrix): only A is split here.
 extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
@@ -563,7 +568,7 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     // fp32 A operand read as it stands (no split launch, no A planes) wherever the product is not one of the big ones (those take the 256 x 256 tiles:
     // plain bf16 -> cti_gemm16.hip on a hi plane; bf16x3 -> the planes kernel, whose fp32-A form measured slower at that size)
     const long long tiles256 = (long long)nb1 * ((M + 255) / 256) * ((N + 255) / 256);
-    const bool af32 = af32_pb() && tiles256 < 128 && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool af32 = (af32_pb() || (int64_t)nb1 * M <= af32_rows()) && tiles256 < 128 && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     int rc = CTI_OK;
     if (!af32) { rc = split_planes(A, lda, rowsA_total, K, ah, prec == CTI_PREC_BF16 ? nullptr : al, ra, as_stream(stream)); if (rc) return rc; }   // plain bf16: the products read the hi plane only
     PlaneGemmArgs g{};

@@ -304,7 +304,8 @@ int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, co
     const unsigned short* bl = bh + (size_t)rb * Kp;
     // the (B, K) activation is read as fp32 rows by the product itself (no split launch) when its rows are 16-B aligned
     static const bool af32_ok = [] { const char* e = getenv("CTI_AF32_PB"); return e && e[0] == '1'; }();       // (experiment, measured slower: cti_backward.hip af32_pb)
-    const bool af32 = af32_ok && (K & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    static const int af32_rows = [] { const char* e = getenv("CTI_AF32_ROWS"); return e ? atoi(e) : 256; }();   // (as cti_gemm_nt_pb: batch-sized products read their fp32 rows themselves)
+    const bool af32 = (af32_ok || B <= af32_rows) && (K & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     int rc = CTI_OK;
     if (!af32) { rc = split_planes(x, ldx, B, K, ah, prec == CTI_PREC_BF16 ? nullptr : al_, ra, st); if (rc) return rc; }
     PlaneGemmArgs g{};
