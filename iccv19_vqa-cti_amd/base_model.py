@@ -238,7 +238,23 @@ class _TriModel(nn.Module):
             object.__setattr__(self, "_v_hoist", HoistedProjection([n.v_tucker for n in self.t_net], padded=[t_att.TriAtt.v_tucker]))
         # `v_replication` = r > 1 (set by the caller; the MC pipeline feeds every image once per candidate answer, src/MC/train.py:75-79, so
         # rows b*r .. b*r+r-1 of v are identical): the projections -- and the attention's whole v side -- run once per image
-        rep = int(getattr(self, "v_replication", 1))
+        rep, eq = getattr(self, "v_replication", 1), None
+        if rep == "auto":
+            # r is DETECTED once, on the first forward that is not being captured (a row-by-row comparison on the device + one read-back), and kept; every later
+            # forward re-checks its own batch on the device and NaN-fills its logits if the batch is not made of groups of r identical images
+            rep = 1
+            if not torch.is_grad_enabled() and v.is_cuda and v.dim() == 3:
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):      # (v-only work: beside the question GRU)
+                    eq = ops.rows_equal_prev(v)
+                    if eq is not None:
+                        if getattr(self, "_v_rep_auto", None) is None and not torch.cuda.is_current_stream_capturing():
+                            object.__setattr__(self, "_v_rep_auto", ops.replication_of(eq))
+                        rep = getattr(self, "_v_rep_auto", None) or 1
+                        if v.shape[0] % rep:
+                            rep = 1
+                if rep == 1:
+                    eq = None
+        rep = int(rep)
         # the attention takes the hoisted v projection only on its fused few-answer path (same predicate as ops.tcnet_forward / cti_triattention_forward):
         # otherwise its 512-wide layer stays out of the batched GEMM instead of being computed and discarded
         tc = t_att.TriAtt
@@ -256,7 +272,7 @@ class _TriModel(nn.Module):
         if side is not None:
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
-                for t_ in [ans_emb] + (vp or []) + list(self._v_hoist.last_padded):
+                for t_ in [ans_emb] + (vp or []) + list(self._v_hoist.last_padded) + ([eq] if eq is not None else []):
                     t_.record_stream(cur)
         if vp is not None:
             pad = self._v_hoist.last_padded
@@ -268,7 +284,8 @@ class _TriModel(nn.Module):
         if vp is not None and H is not None:
             joint = self._loop_hoisted(vp, q_emb, ans_emb, att, rep, H[0], H[1])
             if joint is not None:
-                return self.classifier(joint), att
+                logits = self.classifier(joint)
+                return (logits if eq is None or rep == 1 else ops.poison_unless_replicated(eq, rep, logits)), att
         fused_sum = not torch.is_grad_enabled()
         joint = torch.empty(q_emb.shape[0], q_emb.shape[2], device=q_emb.device, dtype=torch.float32) if fused_sum and self.glimpse > 0 else None
         for g in range(self.glimpse):
@@ -278,7 +295,8 @@ class _TriModel(nn.Module):
             last = joint is not None and g == self.glimpse - 1                # q_emb.sum(1) + ans_emb.sum(1) of :134 rides in the last residual passes
             q_emb = _residual(self.q_prj[g], b_emb, q_emb, acc=joint if last else None, beta=0.0)
             ans_emb = _residual(self.a_prj[g], b_emb, ans_emb, acc=joint if last else None, beta=1.0)
-        return self.classifier(joint if joint is not None else _joint(q_emb, ans_emb)), att
+        logits = self.classifier(joint if joint is not None else _joint(q_emb, ans_emb))
+        return (logits if eq is None or rep == 1 else ops.poison_unless_replicated(eq, rep, logits)), att
 
 
     def _hoist_prepare(self, q_emb, ans_emb):
@@ -359,7 +377,9 @@ class TanModel(_TriModel):
         self.a_prj = nn.ModuleList(a_prj)
         self.classifier = classifier
 
-    v_replication = 1       # set to the number of candidate answers per image (4 in the reference's Visual7W pipeline) to de-duplicate v
+    # number of candidate answers per image (4 in the reference's Visual7W pipeline, src/MC/train.py:75-79: rows b*r .. b*r+r-1 of v are one image) to de-duplicate the
+    # whole v side; 'auto' (the default): detected on the first forward, verified on the device on every later one (a batch that breaks it gives NaN logits); 1 = off
+    v_replication = "auto"
 
     def forward(self, v, b, q, ans):
         return self._forward(self.v_att, v, q, ans)

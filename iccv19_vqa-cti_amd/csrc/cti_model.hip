@@ -88,6 +88,37 @@ __global__ void seq_sum_kernel(const float* __restrict__ x, float* __restrict__ 
     for (int l = 0; l < L; ++l) s += x[((int64_t)b * L + l) * H + h];
     out[idx] = (beta != 0.f ? beta * out[idx] : 0.f) + s;
 }
+// eq[b] = 1 when rows b and b - 1 of x (row_bytes each, a multiple of 16) hold the same BITS, 0 otherwise (eq[0] = 0): the MC pipeline's repeated images
+// (src/MC/train.py:75-79 feeds every image once per candidate answer).  One workgroup per row; a mismatch anywhere clears the byte.
+__global__ __launch_bounds__(256) void rows_equal_prev_kernel(const uint4* __restrict__ x, int64_t row_vec, unsigned char* __restrict__ eq) {
+    const int b = blockIdx.x;
+    __shared__ int diff;
+    if (threadIdx.x == 0) diff = 0;
+    __syncthreads();
+    if (b > 0) {
+        const uint4* p = x + (int64_t)b * row_vec;
+        const uint4* q = p - row_vec;
+        int d = 0;
+        for (int64_t i = threadIdx.x; i < row_vec && !d; i += 256) {
+            const uint4 u = p[i], w = q[i];
+            d = (u.x != w.x) | (u.y != w.y) | (u.z != w.z) | (u.w != w.w);
+        }
+        if (d) diff = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) eq[b] = (b > 0 && !diff) ? 1 : 0;
+}
+// out[i] = NaN for every i unless eq says that the batch is made of groups of r identical rows (eq[b] == 1 for every b with b % r != 0): the check behind
+// TanModel.v_replication = 'auto' -- a batch that breaks the assumption the forward was run under gives NaNs, never a plausible wrong answer
+__global__ __launch_bounds__(256) void poison_unless_replicated_kernel(const unsigned char* __restrict__ eq, int B, int r, float* __restrict__ out, int64_t n) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += 256) if (b % r != 0 && !eq[b]) bad = 1;
+    __syncthreads();
+    if (!bad) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __builtin_nanf("");
+}
 // out = a x + b y  (the classifier input of the hoisted glimpse loops: G * q_emb_0.sum(1) + L * sum_g D_g)
 __global__ void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b, float* __restrict__ out, int64_t n) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,6 +301,20 @@ int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, voi
     if (B == 0) return CTI_OK;
     hipLaunchKernelGGL(seq_sum_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), x, out, B, L, H, beta);
     return launch_status("cti_seq_sum");
+}
+int cti_rows_equal_prev(const void* x, int64_t row_bytes, int B, unsigned char* eq, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(eq);
+    CTI_REQUIRE(B > 0 && B <= 65535 * 64 && row_bytes > 0, CTI_E_SHAPE, "cti_rows_equal_prev: B=%d row_bytes=%lld", B, (long long)row_bytes);
+    if (row_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return CTI_E_UNSUPPORTED;
+    hipLaunchKernelGGL(rows_equal_prev_kernel, dim3((unsigned)B), dim3(256), 0, as_stream(stream), static_cast<const uint4*>(x), row_bytes / 16, eq);
+    return launch_status("cti_rows_equal_prev");
+}
+int cti_poison_unless_replicated(const unsigned char* eq, int B, int r, float* out, int64_t n, void* stream) {
+    CTI_REQUIRE_PTR(eq); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B > 0 && r >= 1 && B % r == 0 && n >= 0, CTI_E_SHAPE, "cti_poison_unless_replicated: B=%d r=%d n=%lld", B, r, (long long)n);
+    if (n == 0 || r == 1) return CTI_OK;
+    hipLaunchKernelGGL(poison_unless_replicated_kernel, dim3((unsigned)(n >= 256 * 64 ? 64 : (n + 255) / 256)), dim3(256), 0, as_stream(stream), eq, B, r, out, n);
+    return launch_status("cti_poison_unless_replicated");
 }
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream) {
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);

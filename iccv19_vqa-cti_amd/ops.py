@@ -785,6 +785,38 @@ def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
     return out
 
 
+def rows_equal_prev(x):
+    """(B,) uint8: row b of x (B, ...) holds the same bits as row b - 1 (element 0 is 0), or None when the rows are not 16-B multiples."""
+    _req(x, "x")
+    xc = x.contiguous()
+    B = xc.shape[0]
+    eq = torch.empty(B, device=x.device, dtype=torch.uint8)
+    if B == 0:
+        return eq
+    rc = L.lib().cti_rows_equal_prev(xc.data_ptr(), xc[0].numel() * xc.element_size(), B, eq.data_ptr(), _stream())
+    if rc == L.E_UNSUPPORTED:
+        return None
+    L.check(rc, "cti_rows_equal_prev")
+    return eq
+
+
+def replication_of(eq):
+    """Largest r dividing the batch such that every row b with b % r != 0 equals its predecessor (HOST side: reads eq back -- one synchronisation)."""
+    e = eq.cpu().numpy().astype(bool)
+    B = e.shape[0]
+    for r in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
+        idx = [b for b in range(B) if b % r]
+        if all(e[idx]):
+            return r
+    return 1
+
+
+def poison_unless_replicated(eq, r, out):
+    """out.fill_(nan) on the device unless eq (rows_equal_prev of the batch) confirms groups of r identical rows."""
+    L.check(L.lib().cti_poison_unless_replicated(eq.data_ptr(), eq.shape[0], int(r), out.data_ptr(), out.numel(), _stream()), "cti_poison_unless_replicated")
+    return out
+
+
 def axpby(x, a, y, b, out=None):
     """a * x + b * y (same shape, fp32)."""
     _req(x, "x"); _req(y, "y")

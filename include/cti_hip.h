@@ -542,6 +542,12 @@ int cti_swish_bwd(const float* x, const float* dy, float* dx, int64_t n, void* s
 int cti_seq_sum(const float* x, float* out, int B, int L, int H, float beta, void* stream);
 /* out[b,l,h] = x[b,l,h] + y[b,h]  (x NULL = 0)         (q_prj(b_emb.unsqueeze(1)) + q_emb, src/FFOE/base_model.py:61,131-132) */
 int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream);
+/* Replicated batch rows (the MC pipeline feeds every image once per candidate answer, src/MC/train.py:75-79; `TanModel.v_replication = 'auto'`):
+ * cti_rows_equal_prev: eq[b] = 1 when rows b and b - 1 of x (row_bytes each, a multiple of 16, 16-B aligned; else CTI_E_UNSUPPORTED) hold the same bits, eq[0] = 0.
+ * cti_poison_unless_replicated: out[0..n) = NaN unless eq[b] == 1 for every b with b % r != 0 -- a forward that ran under the assumption "groups of r identical
+ * rows" gives NaNs on a batch that breaks it, never a plausible wrong answer. */
+int cti_rows_equal_prev(const void* x, int64_t row_bytes, int B, unsigned char* eq, void* stream);
+int cti_poison_unless_replicated(const unsigned char* eq, int B, int r, float* out, int64_t n, void* stream);
 /* out[i] = a * x[i] + b * y[i], i < n (out may alias x or y). */
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream);
 /* The residual projection of a glimpse as ONE call (src/FFOE/base_model.py:61,131-132 `q_prj(b_emb.unsqueeze(1)) + q_emb`, and the sequence sums

@@ -212,6 +212,44 @@ def test_hoisted_glimpse_loops_equal_the_literal_loops():
     assert O.norm_max_err(lb.cpu().numpy(), OM.ffoe_ban_forward(v, q, sd(ban), 4, dtype=np.float64)[0]) < 1.5e-4
 
 
+def test_mc_model_detects_replicated_images_by_itself():
+    """TanModel.v_replication = 'auto' (the default; src/MC/train.py:75-79 repeats every image per candidate answer and tells the model nothing): the factor is
+    detected on the first forward, the logits equal those of the explicit hint bit for bit and those of the literal all-rows forward to rounding; a later batch
+    that is NOT replicated gives NaN logits (the per-forward device check), never a plausible wrong answer; a model whose first batch has no repeats runs as before."""
+    torch.manual_seed(35)
+    m = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
+    assert m.v_replication == "auto"
+    rs = np.random.RandomState(11)
+    vu = np.abs(rs.standard_normal((3, 9, 48))).astype(np.float32)
+    v = np.repeat(vu, 4, axis=0)
+    q = np.repeat(rs.randint(0, 50, size=(3, 7)), 4, axis=0).astype(np.int64)
+    a = rs.randint(0, 50, size=(12, 6)).astype(np.int64)
+    eq = ops.rows_equal_prev(T(v))
+    assert eq.cpu().tolist() == [0, 1, 1, 1] * 3 and ops.replication_of(eq) == 4
+    with torch.no_grad():
+        out_auto, _ = m(T(v), None, T(q), T(a))
+        assert m._v_rep_auto == 4
+        m.v_replication = 4
+        out_hint, _ = m(T(v), None, T(q), T(a))
+        m.v_replication = 1
+        out_off, _ = m(T(v), None, T(q), T(a))
+        m.v_replication = "auto"
+        assert torch.equal(out_auto, out_hint)
+        assert O.norm_max_err(out_auto.cpu().numpy(), out_off.cpu().numpy()) < 2e-5
+        assert O.norm_max_err(out_auto.cpu().numpy(), OM.mc_tan_forward(v, q, a, sd(m), 2, dtype=np.float64)[0]) < TOL
+        v_bad = v.copy()
+        v_bad[5, 2, 7] += 1.0                                                  # one element of one repeated row
+        out_bad, _ = m(T(v_bad), None, T(q), T(a))
+        assert bool(torch.isnan(out_bad).all())
+        out_again, _ = m(T(v), None, T(q), T(a))
+        assert torch.equal(out_again, out_auto)
+        m2 = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
+        v_plain = np.abs(rs.standard_normal((12, 9, 48))).astype(np.float32)
+        out_plain, _ = m2(T(v_plain), None, T(q), T(a))
+        assert m2._v_rep_auto == 1 and bool(torch.isfinite(out_plain).all())
+        assert O.norm_max_err(out_plain.cpu().numpy(), OM.mc_tan_forward(v_plain, q, a, sd(m2), 2, dtype=np.float64)[0]) < TOL
+
+
 def test_pools_beside_the_bf16x3_gru_on_another_stream():
     """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
     (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue

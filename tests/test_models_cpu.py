@@ -81,3 +81,17 @@ def test_unsupported_pieces_raise():
         q.forward_all(torch.zeros(1, 2, 8))
     with pytest.raises(cti_amd.CtiError):           # no CPU path
         cti_amd.WordEmbedding(5, 300, 0.0, "")(torch.zeros(1, 2, dtype=torch.int64))
+
+
+def test_replication_factor_from_the_row_equality_bytes():
+    """ops.replication_of (host side of TanModel.v_replication = 'auto'): the largest r dividing the batch with every row b, b % r != 0, equal to its predecessor."""
+    import torch
+    from cti_amd import ops
+    f = lambda bits: ops.replication_of(torch.tensor(bits, dtype=torch.uint8))
+    assert f([0, 1, 1, 1, 0, 1, 1, 1]) == 4
+    assert f([0, 1, 0, 1, 0, 1, 0, 1]) == 2
+    assert f([0, 1, 1, 1, 1, 1, 1, 1]) == 8                      # one image for the whole batch
+    assert f([0, 1, 1, 0, 1, 1]) == 3
+    assert f([0, 1, 1, 1, 0, 1, 1, 0]) == 1                      # ragged groups: no de-duplication
+    assert f([0, 0, 0, 0]) == 1
+    assert f([0]) == 1

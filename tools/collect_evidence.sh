@@ -12,6 +12,7 @@ python bench.py --precision bf16 --no-cpu-baseline --no-fp32-exact --no-subrecor
 python bench.py --mode train > $E/bench_train.log 2>&1; tail -1 $E/bench_train.log | cut -c1-200
 CTI_BENCH_FORCE_DIST=1 python bench.py --mode train > $E/bench_train_rccl_world1.log 2>&1; tail -1 $E/bench_train_rccl_world1.log | cut -c1-200   # two graphs around an eager RCCL all-reduce
 python bench.py --config c3 > $E/bench_c3.log 2>&1; python bench.py --config c4 > $E/bench_c4.log 2>&1
+CTI_BENCH_SERIAL_MODELS=1 python bench.py --config c4 > $E/bench_c4_serial.log 2>&1            # the two models one after the other (what rounds 1-3 timed)
 CTI_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-fp32-exact --no-subrecords --steps 10 > $E/bench_rccl_world1.log 2>&1; tail -1 $E/bench_rccl_world1.log | cut -c1-120
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $E/stats -o fwd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-exact --no-subrecords > $E/rocprof_stats.log 2>&1
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-exact --no-subrecords"
@@ -22,7 +23,19 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/pmc$i -o p -- $B > $E/pmc$i.log 2>&1 || echo "pmc pass $i ($grp) failed/timeout"
 done
+# the plain-bf16 projection GEMM (cti_gemm16.hip) on its own: kernel stats + matrix-pipe busy cycles + clock, separate passes
+G="python3 tools/bench_gemm16.py 20"
+timeout 300 $G > $E/gemm16_vs_vendor.json 2>$E/gemm16.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $E/g16stats -o g -- $G > $E/g16stats.log 2>&1
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d $E/g16pmc$i -o p -- $G > $E/g16pmc$i.log 2>&1 || echo "gemm16 pmc pass $i ($grp) failed/timeout"
+done
+mkdir -p $E/g16; python tools/pmc_summary.py $E/g16/pmc_summary_gemm16.json $E $E/g16stats/g_kernel_stats.csv --only gemm16 > $E/g16/pmc_summary_gemm16.log 2>&1
 if [ "${1:-all}" != "quick" ]; then
+bash tools/trace_models.sh > $E/trace_models.log 2>&1
+python tools/print_forward_timeline.py gpurun_out/pc_c3/m_kernel_trace.csv > $E/model_c3_timeline.txt 2>&1; python tools/print_forward_timeline.py gpurun_out/pc_c4/m_kernel_trace.csv > $E/model_c4_timeline.txt 2>&1
 timeout 300 python tools/bench_model.py --steps 50 > $E/model_fwd.jsonl 2>$E/model_fwd.err
 timeout 300 python tools/bench_model.py --train --steps 50 > $E/model_train.jsonl 2>$E/model_train.err
 timeout 300 python tools/bench_model.py --precision bf16 --steps 50 > $E/model_fwd_bf16.jsonl 2>/dev/null

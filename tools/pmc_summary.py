@@ -21,21 +21,28 @@ def short(n):
 
 
 def main():
+    only = None
+    if "--only" in sys.argv:
+        i = sys.argv.index("--only")
+        only = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     out, d = sys.argv[1], sys.argv[2]
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        if (os.sep + "g16pmc" in f) != (only == "gemm16"):           # the gemm16 passes ran another program: their own summary
+            continue
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             a = acc[k][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"])
             a[1] += 1
     dur = {}
-    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True) + sys.argv[3:]:
+    for f in ([] if only else glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)) + sys.argv[3:]:
         for row in csv.DictReader(open(f)):
             dur[short(row["Name"])] = float(row["AverageNs"]) / 1e3
     res = {}
     for k, cs in acc.items():
-        if not k.startswith(("gemm_planes", "gemm_f16f6", "mbuild", "split_kernel", "quantize_f16f6")):
+        if not k.startswith(("gemm_planes", "gemm_f16f6", "gemm16", "mbuild", "split_kernel", "quantize_f16f6", "quantize_rows", "guard_")) or (only and not k.startswith(only)):
             continue
         e = {c: v[0] / v[1] for c, v in cs.items()}
         e["calls_seen"] = max(v[1] for v in cs.values())
@@ -49,6 +56,9 @@ def main():
             e["l2_hit_rate"] = round(e["TCC_HIT_sum"] / max(1.0, e["TCC_HIT_sum"] + e["TCC_MISS_sum"]), 4)
         if "GRBM_GUI_ACTIVE" in e and "_dur_us" in e:
             e["effective_clock_ghz"] = round(e["GRBM_GUI_ACTIVE"] / 8 / e["_dur_us"] / 1e3, 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
+            # busy cycles are summed over the 1 024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: busy fraction of the launch = (busy / 1024) / (active / 8)
+            e["mfma_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8), 4)
         res[k] = e
     json.dump({"notes": __doc__.strip().split("\n\n")[0], "kernels": res}, open(out, "w"), indent=1)
     for k, e in res.items():
