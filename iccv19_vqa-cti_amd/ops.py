@@ -64,8 +64,22 @@ def f16f6_range_status():
     return dict(_range_log)
 
 
+_range_owner = {}          # (device, T_g storage) -> {"consecutive", "skip", "skip_mode"}: the repeat-offender shortcut is per TCNet, not per process
+
+
+def _owner_state(device, T_g):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), T_g.data_ptr())
+    st = _range_owner.get(key)
+    if st is None:
+        if len(_range_owner) > 256:
+            _range_owner.clear()
+        st = _range_owner[key] = {"consecutive": 0, "skip": 0, "skip_mode": "bf16x3"}
+    return st
+
+
 def _guard_resources(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    # one event pair + stream per device AND host thread: two threads driving one device must not wait on each other's records
+    key = (device.index if device.index is not None else torch.cuda.current_device(), __import__("threading").get_ident())
     r = _guard_res.get(key)
     if r is None:
         lib = L.lib()
@@ -542,10 +556,12 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     lib = L.lib()
     guarded = pr == L.PREC_F16F6 and lib.cti_tcnet_forward_guard_bytes(B, V, Q, A, vd, qd, ad, h, R, G, pr) > 0
     wait_guard = guarded and _range_check == "sync" and not torch.cuda.is_current_stream_capturing()
-    if wait_guard and _range_log["skip"] > 0:
-        # this process keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
-        _range_log["skip"] -= 1
-        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, _range_log.get("skip_mode", "bf16x3"), None, want_sm_partials, _tri, _v_tucked, _v_rep)
+    own = _owner_state(v.device, T_g) if wait_guard else None
+    if wait_guard and own["skip"] > 0:
+        # THIS network keeps leaving the format's domain (two trips in a row): go straight to bf16x3 for a while instead of paying for both forms
+        own["skip"] -= 1
+        _range_log["skip"] = own["skip"]
+        return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, own["skip_mode"], None, want_sm_partials, _tri, _v_tucked, _v_rep)
     wsb = (lib.cti_triattention_workspace_bytes if _tri else lib.cti_tcnet_forward_workspace_bytes)(B, V, Q, A, vd, qd, ad, h, R, G, pr)
     ws = torch.empty(wsb, device=v.device, dtype=torch.uint8)
     if _debug_ws_fill is not None:              # tests: the library must not read workspace bytes it has not written (0xFF reads as saturated scale bytes)
@@ -599,10 +615,11 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
             # an operand left the f16f6 format's domain (the output of this launch has been NaN-filled on the device): the reference's
             # full-range fp32 semantics come from the bf16x3 kernels
             _range_log["trips"] += 1
-            _range_log["consecutive"] += 1
-            if _range_log["consecutive"] >= 2:
-                _range_log["skip"] = 64
-                _range_log["skip_mode"] = "fp32" if status.value & 16 else "bf16x3"
+            own["consecutive"] += 1
+            _range_log["consecutive"] = own["consecutive"]
+            if own["consecutive"] >= 2:
+                own["skip"] = _range_log["skip"] = 64
+                own["skip_mode"] = _range_log["skip_mode"] = "fp32" if status.value & 16 else "bf16x3"
             if _range_log["trips"] == 1:
                 import warnings
                 warnings.warn("cti: f16f6 range guard tripped (status %d: %s) -- this call was re-run in the %s mode; see ops.f16f6_range_status()"
@@ -611,7 +628,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
                                  "fp32" if status.value & 16 else "bf16x3"))
             # (heavy cancellation: even the 3-term split's 2^-19 constant may exceed the tolerance -- the exact-fp32 kernels are the reference's arithmetic)
             return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, "fp32" if status.value & 16 else "bf16x3", None, want_sm_partials, _tri, _v_tucked, _v_rep)
-        _range_log["consecutive"] = 0
+        own["consecutive"] = _range_log["consecutive"] = 0
     if _tri:
         return p_att, out
     if want_sm_partials:

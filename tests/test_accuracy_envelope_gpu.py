@@ -27,13 +27,13 @@ def T(x):
 def f16f6_mode():
     old = cti_amd.get_precision()
     cti_amd.set_precision("f16f6")
-    ops._range_log.update(consecutive=0, skip=0)
+    ops._range_log.update(consecutive=0, skip=0); ops._range_owner.clear()
     ops._range_debug = True
     yield
     ops._range_debug = False
     cti_amd.set_precision(old)
     cti_amd.set_range_check("sync")
-    ops._range_log.update(consecutive=0, skip=0)
+    ops._range_log.update(consecutive=0, skip=0); ops._range_owner.clear()
 
 
 def _case(A=640, B=2):

@@ -27,11 +27,11 @@ def T(x):
 def f16f6_mode():
     old = cti_amd.get_precision()
     cti_amd.set_precision("f16f6")
-    ops._range_log.update(consecutive=0, skip=0)
+    ops._range_log.update(consecutive=0, skip=0); ops._range_owner.clear()
     yield
     cti_amd.set_precision(old)
     cti_amd.set_range_check("sync")
-    ops._range_log.update(consecutive=0, skip=0)
+    ops._range_log.update(consecutive=0, skip=0); ops._range_owner.clear()
 
 
 def _net(params):
@@ -166,3 +166,20 @@ def test_repeated_trips_go_straight_to_bf16x3_for_a_while():
             outs = [m(*big) for _ in range(4)]
     st = ops.f16f6_range_status()
     assert st["skip"] > 0 and all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_the_repeat_offender_shortcut_is_per_network():
+    """two trips of ONE TCNet must not route every other network's calls to bf16x3 -- the counters are keyed by the network's own parameters."""
+    params, v, q, a = _case(A=64)
+    big = [T(x * np.float32(1e3)) for x in (v, q, a)]
+    m, m2 = _net(params), _net(params)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            for _ in range(3):
+                m(*big)
+            assert ops.f16f6_range_status()["skip"] > 0
+            calls0 = ops.f16f6_range_status()["calls"]
+            o2 = m2(T(v), T(q), T(a))
+            assert ops.f16f6_range_status()["calls"] == calls0 + 1 and ops.f16f6_range_status()["last_status"] == 0     # the guarded f16f6 form ran, in range
+    assert bool(torch.isfinite(o2).all())
