@@ -21,7 +21,7 @@ from . import ops
 from .attention import BiAttention, TriAttention
 from .bc import BCNet
 from .classifier import SimpleClassifier
-from .fc import FCNet, HoistedProjection, WNLinear
+from .fc import BatchedLinears, FCNet, HoistedProjection, WNLinear
 from .fc import refresh_stale_scales as _refresh_scales
 from .language_model import QuestionEmbedding, WordEmbedding
 from .tc import TCNet, _needs_grad
@@ -318,24 +318,21 @@ class _TriModel(nn.Module):
         qn, an = [n.q_tucker for n in self.t_net], [n.a_tucker for n in self.t_net]
         B, Lq, H = q_emb.shape
         La = ans_emb.shape[1]
-        Dq = Da = None
+        if not hasattr(self, "_prj_pairs"):
+            # the two sequences' products of a glimpse as ONE batched launch each: the residual projections (q_prj[g], a_prj[g]) of the pooled vector, and the
+            # shift projections (q_tucker[g], a_tucker[g] without bias / activation) of the two accumulated residuals
+            object.__setattr__(self, "_prj_pairs", [BatchedLinears([_single_linear(self.q_prj[g]), _single_linear(self.a_prj[g])]) for g in range(self.glimpse)])
+            object.__setattr__(self, "_shift_pairs", [BatchedLinears([HoistedProjection._layer_of(qn[g]), HoistedProjection._layer_of(an[g])]) for g in range(self.glimpse)])
+        D = None                                                             # (2, B, H): the residuals accumulated so far, question and answer sequence
         for g in range(self.glimpse):
-            lq, la = HoistedProjection._layer_of(qn[g]), HoistedProjection._layer_of(an[g])
-            b_emb = ops.tri_pool_shift(vp[g], Hq[g], Ha[g], _shift_of(lq, Dq) if g > 0 else None, _shift_of(la, Da) if g > 0 else None,
-                                       att[:, :, :, :, g].float(), v_rep=rep)
+            sh = self._shift_pairs[g].stacked(D, bias=False) if g > 0 else None
+            b_emb = ops.tri_pool_shift(vp[g], Hq[g], Ha[g], sh[0] if g > 0 else None, sh[1] if g > 0 else None, att[:, :, :, :, g].float(), v_rep=rep)
             if b_emb is None:
                 return None
-            pq, pa = _single_linear(self.q_prj[g]), _single_linear(self.a_prj[g])
-            if g == 0:
-                Dq, Da = self.q_prj[g](b_emb), self.a_prj[g](b_emb)
-            else:
-                oq = ops.linear_residual(b_emb, pq.planes(), pq.scale(), pq.out_features, pq.bias, Dq.view(B, 1, H))
-                oa = ops.linear_residual(b_emb, pa.planes(), pa.scale(), pa.out_features, pa.bias, Da.view(B, 1, H))
-                if oq is None or oa is None:
-                    return None
-                Dq, Da = oq.view(B, H), oa.view(B, H)
+            y = self._prj_pairs[g].shared(b_emb)
+            D = y if g == 0 else ops.axpby(D, 1.0, y, 1.0, out=y)
         joint = _joint(q_emb, ans_emb)
-        return ops.axpby(ops.axpby(joint, 1.0, Dq, float(Lq), out=joint), 1.0, Da, float(La), out=joint)
+        return ops.axpby(ops.axpby(joint, 1.0, D[0], float(Lq), out=joint), 1.0, D[1], float(La), out=joint)
 
 
 class CTIModel(_TriModel):

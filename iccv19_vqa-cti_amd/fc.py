@@ -190,3 +190,38 @@ class HoistedProjection:
         outs = [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
         self.last_padded = outs[len(self.nets):]      # the narrower networks' outputs (full width; the first out_features columns count), possibly none
         return outs[:len(self.nets)]
+
+
+class BatchedLinears:
+    """n WNLinear layers of one (in, out) shape as ONE batched GEMM (inference): on a shared input (`shared`: the residual projections q_prj[g] / a_prj[g] of one
+    pooled vector) or on n stacked inputs (`stacked`: the shift projections of the hoisted glimpse loops' two sequences).  Weights, scales and biases are
+    concatenated once and cached until a parameter changes, like HoistedProjection."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._key = None
+
+    def _refresh(self):
+        ls = self.layers
+        key = (ops._param_epoch[0], ops.get_precision()) + tuple((p.data_ptr(), p._version) for l in ls for p in (l.weight_v, l.weight_g, l.bias))
+        if key != self._key:
+            with torch.no_grad():
+                self._w = torch.cat([l.weight_v.detach() for l in ls], 0).contiguous()
+                self._b = torch.cat([l.bias.detach() for l in ls], 0).contiguous()
+                self._s = torch.cat([l.scale().view(1) for l in ls], 0).contiguous()
+                self._wp = ops.split_operand(self._w)
+            self._key = key
+        return len(ls), ls[0].out_features
+
+    def shared(self, x, relu=False):
+        """x (rows, in) -> (n, rows, out) = act(scale_i W_i x + bias_i)."""
+        n, od = self._refresh()
+        return ops.gemm_nt(x, self._w, nb1=n, rA1=0, rB1=od, M=x.shape[0], N=od, scale=self._s, scale_div=od, scale_bs=1, bias=self._b, bias_bs=od, relu=bool(relu),
+                           B_planes=self._wp)
+
+    def stacked(self, x, bias=True, relu=False):
+        """x (n, rows, in) contiguous -> (n, rows, out) = act(scale_i W_i x_i [+ bias_i])."""
+        n, od = self._refresh()
+        rows = x.shape[1]
+        return ops.gemm_nt(x.reshape(n * rows, x.shape[2]), self._w, nb1=n, rA1=rows, rB1=od, M=rows, N=od, scale=self._s, scale_div=od, scale_bs=1,
+                           bias=self._b if bias else None, bias_bs=od if bias else 0, relu=bool(relu), B_planes=self._wp)
