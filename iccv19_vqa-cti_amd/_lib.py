@@ -128,6 +128,7 @@ SIGNATURES = {
     "cti_poison_unless_replicated": (_int, [_vp, _int, _int, _vp, _i64, _vp]),
     "cti_bi_logits_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_logits_prec_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_biattention_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
 }
 

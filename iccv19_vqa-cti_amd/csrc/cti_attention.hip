@@ -875,7 +875,17 @@ __global__ __launch_bounds__(512) void bi_logits_mfma_kernel(const float* __rest
 // ONCE per workgroup into LDS (double-buffered, one barrier per slice); a wave owns two 16-column tiles of (g, q) -- its h*qt fragments are
 // formed and split once and meet all V/16 row tiles -- on the 16x16x32 MFMA (36 rows pad to 48 instead of 64, 112 columns are 7 tiles exactly).
 typedef float lf32x4 __attribute__((ext_vector_type(4)));
+template <int TERMS>
+__device__ __forceinline__ void split8t(const float4 a, const float4 b, lbf16x8& hi, lbf16x8& lo) {
+    if (TERMS == 3) { split8(a, b, hi, lo); return; }
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = static_cast<__bf16>(x[e]);
+    lo = hi;                                                       // (unused)
+}
 
+// TERMS = 1 (round 4): the plain-bf16 mode's form -- one product per pair, no lo parts: half the split work (the kernel's bound) and a third of the MFMAs
+template <int TERMS>
 __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ h,
                                                             const float* __restrict__ h_scale, const float* __restrict__ h_bias,
                                                             float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW,
@@ -915,9 +925,9 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         float4 a0 = z4, a1 = z4;
         if (sok && d_lo < d_hi) { a0 = *reinterpret_cast<const float4*>(sp + d_lo); a1 = *reinterpret_cast<const float4*>(sp + d_lo + 4); }
         lbf16x8 hi, lo;
-        split8(a0, a1, hi, lo);
+        split8t<TERMS>(a0, a1, hi, lo);
         *reinterpret_cast<lbf16x8*>(&As[0][0][sr][skq * 8]) = hi;
-        *reinterpret_cast<lbf16x8*>(&As[0][1][sr][skq * 8]) = lo;
+        if (TERMS == 3) *reinterpret_cast<lbf16x8*>(&As[0][1][sr][skq * 8]) = lo;
     }
     __syncthreads();
     float4 rh0[2], rh1[2], rq0[2], rq1[2];                           // raw h / qt fragments of the CURRENT slice (loaded one slice ahead)
@@ -936,8 +946,8 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             if (wid + 4 * j < NTW && ct0 + wid + 4 * j < NT)        // uniform
-                split8(make_float4(rh0[j].x * rq0[j].x, rh0[j].y * rq0[j].y, rh0[j].z * rq0[j].z, rh0[j].w * rq0[j].w),
-                       make_float4(rh1[j].x * rq1[j].x, rh1[j].y * rq1[j].y, rh1[j].z * rq1[j].z, rh1[j].w * rq1[j].w), bh[j], bl[j]);
+                split8t<TERMS>(make_float4(rh0[j].x * rq0[j].x, rh0[j].y * rq0[j].y, rh0[j].z * rq0[j].z, rh0[j].w * rq0[j].w),
+                               make_float4(rh1[j].x * rq1[j].x, rh1[j].y * rq1[j].y, rh1[j].z * rq1[j].z, rh1[j].w * rq1[j].w), bh[j], bl[j]);
         float4 n0 = z4, n1 = z4;
         if (more) {                                                  // the next slice's loads fly under this slice's MFMAs
             if (sok) { n0 = *reinterpret_cast<const float4*>(sp + d0 + 32); n1 = *reinterpret_cast<const float4*>(sp + d0 + 36); }
@@ -952,12 +962,15 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         for (int m = 0; m < 4; ++m) {
             if (m < MT) {                                            // uniform
                 const lbf16x8 ah = *reinterpret_cast<const lbf16x8*>(&As[buf][0][m * 16 + l15][kq * 8]);
-                const lbf16x8 al = *reinterpret_cast<const lbf16x8*>(&As[buf][1][m * 16 + l15][kq * 8]);
+                lbf16x8 al = ah;
+                if (TERMS == 3) al = *reinterpret_cast<const lbf16x8*>(&As[buf][1][m * 16 + l15][kq * 8]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (wid + 4 * j < NTW && ct0 + wid + 4 * j < NT) {
-                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j][m], 0, 0, 0);
-                        acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j][m], 0, 0, 0);
+                        if (TERMS == 3) {
+                            acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j][m], 0, 0, 0);
+                            acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j][m], 0, 0, 0);
+                        }
                         acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j][m], 0, 0, 0);
                     }
                 }
@@ -965,9 +978,9 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         }
         if (more) {
             lbf16x8 hi, lo;
-            split8(n0, n1, hi, lo);
+            split8t<TERMS>(n0, n1, hi, lo);
             *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][0][sr][skq * 8]) = hi;
-            *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][1][sr][skq * 8]) = lo;
+            if (TERMS == 3) *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][1][sr][skq * 8]) = lo;
         }
         __syncthreads();                                             // the next slice is complete; everyone is done reading this one
     }
@@ -1577,11 +1590,18 @@ extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* 
 }
 
 static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
-                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt);
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms = 3);
 
 extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                                       float* logits, int B, int G, int V, int Q, int D, void* stream) {
     return bi_logits_mfma_impl(vt, qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, nullptr, nullptr, nullptr);
+}
+
+// cti_bi_logits_mfma_fwd in the arithmetic of `prec`: CTI_PREC_BF16 = one bf16 product per pair (the plain-bf16 mode of the model forwards), anything else the
+// fp32-grade three-product form.  The single-product form exists for the LDS-staged kernel only (V <= 64, G*Q <= 128, D % 32 == 0): other shapes run fp32-grade.
+extern "C" int cti_bi_logits_prec_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                                      float* logits, int B, int G, int V, int Q, int D, int prec, void* stream) {
+    return bi_logits_mfma_impl(vt, qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, nullptr, nullptr, nullptr, prec == CTI_PREC_BF16 ? 1 : 3);
 }
 
 // BiAttention.forward_all's logits + mask + softmax in ONE launch (reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the bilinear
@@ -1596,7 +1616,7 @@ extern "C" int cti_biattention_fwd(const float* vt, const float* qt, const float
 }
 
 static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
-                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt) {
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
     CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_mfma_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
     if (D % 16 != 0 || !aligned16(vt) || !aligned16(qt) || !aligned16(h))
@@ -1607,7 +1627,8 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
     const bool lds_form = CTI_BL_LDS && V <= 64 && G * Q <= 128 && D % 32 == 0;
     if (sm_p && !lds_form) return CTI_E_UNSUPPORTED;                 // the fused mask + softmax lives in the LDS form only
     if (lds_form) {                                                  // left operand split once per workgroup (see bi_logits_lds_kernel)
-        const int KS = D >= 1024 ? 2 : 1;
+        static const int ks_env = [] { const char* e = getenv("CTI_BL_KS"); return e ? atoi(e) : 0; }();        // (A/B knob: K ranges per sample)
+        const int KS = ks_env > 0 ? ks_env : (D >= 3072 ? 3 : (D >= 1024 ? 2 : 1));     // measured at B = 256, G = 8, D = 3072: 2 -> 99 us, 3 -> 91, 4 -> 126 (atomics), 8 -> 141
         const int dper = ((D / 32 + KS - 1) / KS) * 32;
         if (KS > 1) { int rcz = zero_fill(logits, (int64_t)B * G * V * Q, as_stream(stream)); if (rcz) return rcz; }
         // column tiles per workgroup: four (one per wave) once that still gives every CU several workgroups' worth of loads in flight
@@ -1617,8 +1638,12 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
 #endif                      // (profiles/r03_hbm_kernels.jsonl): 8 -> 96 us, 4 -> 135, 2 -> 174, 1 -> 262: every extra workgroup re-splits the vt slice, and that VALU work is the bound
         static const int ntw_max = [] { const char* e = getenv("CTI_BL_NTW"); const int v = e ? atoi(e) : CTI_BL_NTW; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // (A/B knob; 8 = the round-2 form)
         const int NTW = NT > ntw_max ? ntw_max : NT, NZ = (NT + NTW - 1) / NTW;
-        hipLaunchKernelGGL(bi_logits_lds_kernel, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
-                           NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
+        if (terms == 1)
+            hipLaunchKernelGGL(bi_logits_lds_kernel<1>, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
+                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
+        else
+            hipLaunchKernelGGL(bi_logits_lds_kernel<3>, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
+                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
         return launch_status("cti_bi_logits_mfma_fwd");
     }
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;

@@ -856,11 +856,11 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     if out.numel() == 0:
         return out
     lib = L.lib()
-    if get_precision() != "fp32":                       # fp32-grade MFMA form; the exact-fp32 mode keeps the fp32 VALU kernel
-        rc = lib.cti_bi_logits_mfma_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D,
-                                        _stream())
+    if get_precision() != "fp32":                       # MFMA form (fp32-grade: three bf16 products; plain-bf16 mode: one); the exact-fp32 mode keeps the fp32 VALU kernel
+        rc = lib.cti_bi_logits_prec_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D,
+                                        _prec(None), _stream())
         if rc != L.E_UNSUPPORTED:
-            L.check(rc, "cti_bi_logits_mfma_fwd")
+            L.check(rc, "cti_bi_logits_prec_fwd")
             return out
     L.check(lib.cti_bi_logits_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V,
                                   Q, D, _stream()), "cti_bi_logits_fwd")

@@ -272,6 +272,10 @@ int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const fl
  * cti_bi_logits_fwd then. */
 int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                            float* logits, int B, int G, int V, int Q, int D, void* stream);
+/* cti_bi_logits_mfma_fwd in the arithmetic of `prec`: CTI_PREC_BF16 = ONE bf16 product per pair (the plain-bf16 mode of the model forwards: half the operand
+ * splitting, a third of the MFMAs), any other value the fp32-grade three-product form.  Same shapes, same CTI_E_UNSUPPORTED rule. */
+int cti_bi_logits_prec_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                           float* logits, int B, int G, int V, int Q, int D, int prec, void* stream);
 
 /* BiAttention.forward_all's logits + mask + softmax in ONE launch (round 3; reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the
  * bilinear logits as cti_bi_logits_mfma_fwd, then the last workgroup to add into a sample's logits fills the rows of `mask` ((B, V) bytes, 1 = all-zero object

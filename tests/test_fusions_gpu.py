@@ -250,6 +250,31 @@ def test_mc_model_detects_replicated_images_by_itself():
         assert O.norm_max_err(out_plain.cpu().numpy(), OM.mc_tan_forward(v_plain, q, a, sd(m2), 2, dtype=np.float64)[0]) < TOL
 
 
+@pytest.mark.parametrize("B,G,V,Q,D", [(4, 8, 36, 14, 3072), (3, 2, 9, 7, 96), (2, 4, 50, 16, 128)])
+def test_bi_logits_in_the_plain_bf16_mode(B, G, V, Q, D):
+    """cti_bi_logits_prec_fwd with CTI_PREC_BF16: ONE bf16 product per pair (what set_precision('bf16') asks for) -- against the float64 contraction of the
+    bf16-rounded operands (tight: only the accumulation order differs) and of the fp32 operands (the mode's 1e-2 class)."""
+    rs = np.random.RandomState(B + D)
+    vt, qt = rs.standard_normal((B, V, D)).astype(np.float32), rs.standard_normal((B, Q, D)).astype(np.float32)
+    h, hb = (rs.standard_normal((G, D)) / np.sqrt(D)).astype(np.float32), rs.standard_normal(G).astype(np.float32)
+    hs = np.array([1.3], np.float32)
+    old = cti_amd.get_precision()
+    try:
+        cti_amd.set_precision("bf16")
+        out = ops.bi_logits(T(vt), T(qt), T(h), T(hs), T(hb)).cpu().numpy()
+        cti_amd.set_precision("bf16x3")
+        out3 = ops.bi_logits(T(vt), T(qt), T(h), T(hs), T(hb)).cpu().numpy()
+    finally:
+        cti_amd.set_precision(old)
+    bf = lambda x: torch.from_numpy(x).to(torch.bfloat16).to(torch.float64).numpy()
+    hq = bf((h[None, :, None, :] * qt[:, None, :, :]).astype(np.float32))                      # (B, G, Q, D): the right operand is formed in fp32, then rounded
+    ref_bf = 1.3 * np.einsum("bvd,bgqd->bgvq", bf(vt), hq) + hb[None, :, None, None]
+    ref = 1.3 * np.einsum("bvd,gd,bqd->bgvq", vt.astype(np.float64), h.astype(np.float64), qt.astype(np.float64)) + hb[None, :, None, None]
+    assert O.norm_max_err(out, ref_bf) < 2e-5
+    assert O.norm_max_err(out, ref) < 1e-2
+    assert O.norm_max_err(out3, ref) < TOL
+
+
 def test_pools_beside_the_bf16x3_gru_on_another_stream():
     """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
     (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue

@@ -56,6 +56,10 @@ def main(reps=20):
     h = torch.randn(8, D3, device=DEV); hb = torch.randn(8, device=DEV); hs = torch.ones(1, device=DEV)
     report("bi_logits G=8 (BiAttention logits)", timeit(lambda: ops.bi_logits(vt3, qt3, h, hs, hb), reps),
            f * (B * (V * D3 + Q * D3 + 8 * V * Q) + 8 * D3), Q=Q, D=D3, G=8)
+    cti_amd.set_precision("bf16")
+    report("bi_logits G=8, plain-bf16 mode (one product per pair)", timeit(lambda: ops.bi_logits(vt3, qt3, h, hs, hb), reps),
+           f * (B * (V * D3 + Q * D3 + 8 * V * Q) + 8 * D3), Q=Q, D=D3, G=8)
+    cti_amd.set_precision("bf16x3")
     v = torch.randn(B, V, 2048, device=DEV).abs(); v[:, 30:] = 0
     report("zero_row_mask", timeit(lambda: ops.zero_row_mask(v), reps), f * B * V * 2048 + B * V)
     mask = ops.zero_row_mask(v)

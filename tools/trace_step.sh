@@ -1,0 +1,22 @@
+#!/bin/bash
+# kernel timeline of ONE configs[1] step (eager launches): gpurun_out/step_trace/timeline.txt
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/step_trace; mkdir -p gpurun_out/step_trace
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/step_trace -o s -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-fp32-exact --no-subrecords > gpurun_out/step_trace/log 2>&1
+python3 - <<'PY' > gpurun_out/step_trace/timeline.txt
+import csv, glob, re
+f = glob.glob('gpurun_out/step_trace/**/*kernel_trace.csv', recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+q = [i for i, r in enumerate(rows) if 'quantize_rows_f16f6' in r['Kernel_Name']]
+a, b = q[-3], q[-2]
+# a step starts a few launches before the encoder pass: walk back to the guard reset
+while a > 0 and 'guard_reset' not in rows[a]['Kernel_Name']: a -= 1
+while b > 0 and 'guard_reset' not in rows[b]['Kernel_Name']: b -= 1
+t0 = int(rows[a]['Start_Timestamp'])
+for r in rows[a:b]:
+    n = re.sub(r'cti::\(anonymous namespace\)::', '', r['Kernel_Name']); n = re.sub(r'^void ', '', n)[:80]
+    print("%8.1f %8.1f q%s g%-6d %s" % ((int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Queue_Id'],
+                                        int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), n))
+print("step length %.1f us" % ((int(rows[b]['Start_Timestamp']) - t0) / 1e3))
+PY
+find gpurun_out/step_trace -name "*kernel_trace.csv" -delete
