@@ -90,15 +90,13 @@ __global__ __launch_bounds__(256) void guard_scan_kernel(GuardArgs g) {
             if (mine & ~seen) atomicOr(&g.words[GUARD_W_SEG + threadIdx.x], mine & ~seen);
         }
     }
-    if (!g.final) return;                      // (the early scan: the final one is stream-ordered behind it)
-    // last workgroup out: evaluate.  (Device-scope atomics execute at the memory side on gfx950: every workgroup's bits are visible to the
-    // atomic reads below once its own fence + counter increment have been performed.)
-    __shared__ bool last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&g.words[GUARD_W_DONE], 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!last || threadIdx.x != 0) return;
+}
+
+// The verdict, as its OWN one-thread launch behind the final scan (stream order makes every workgroup's bits visible).  Round 4: as a last-arriver pass inside the
+// scan it cost one atomic increment of ONE word per workgroup -- 1 024 of them serialise at the memory side: 72 us for a scan of 8 MB, in front of the mode-3 product
+// (profiles/r04_step_timeline.txt); the extra launch costs ~5.
+__global__ void guard_verdict_kernel(GuardArgs g) {
+    if (threadIdx.x != 0) return;
     unsigned status = 0u;
     for (int k = 0; k < g.n_slots; ++k) {
         const unsigned m = atomicOr(&g.words[GUARD_W_SEG + k], 0u);
@@ -195,6 +193,7 @@ int guard_scan(const GuardArgs& g, hipStream_t st) {
         if (sg.kind == 1 && (reinterpret_cast<uintptr_t>(sg.p) & 15)) return fail(CTI_E_ALIGN, "guard_scan: fp32 segment %d is not 16-B aligned", s);
     }
     hipLaunchKernelGGL(guard_scan_kernel, dim3(1024), dim3(256), 0, st, g);
+    if (g.final) hipLaunchKernelGGL(guard_verdict_kernel, dim3(1), dim3(64), 0, st, g);
     return launch_status("guard_scan");
 }
 
