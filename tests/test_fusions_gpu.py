@@ -481,7 +481,7 @@ def test_full_batch_model_forward_agrees_across_precisions_on_every_row(config):
             with torch.no_grad():
                 o = s["fwd"]()
             outs[prec] = [t.float() for t in (o if isinstance(o, (tuple, list)) else (o,))]
-        for prec, tol in (("bf16", 3e-2), ("bf16x3", 2e-4), ("f16f6", 2e-4)):           # against the exact-fp32 mode, every row
+        for prec, tol in (("bf16", 2e-2), ("bf16x3", 1e-4), ("f16f6", 1e-4)):           # against the exact-fp32 mode, every row (north_star's tolerance)
             for a, b in zip(outs[prec], outs["fp32"]):
                 assert a.shape == b.shape and torch.isfinite(a).all()
                 per_row = (a - b).abs().flatten(1).amax(1) / b.abs().max()
@@ -665,7 +665,7 @@ def test_mc_ban_full_batch_forward_and_gradients_across_precisions():
                     outs[prec] = m(v, boxes, q, a)[0].float()
     finally:
         cti_amd.set_precision(old)
-    for prec, tol in (("bf16", 3e-2), ("bf16x3", 2e-4), ("f16f6", 2e-4)):
+    for prec, tol in (("bf16", 2e-2), ("bf16x3", 1e-4), ("f16f6", 1e-4)):
         per_row = (outs[prec] - outs["fp32"]).abs().flatten(1).amax(1) / outs["fp32"].abs().max()
         assert float(per_row.max()) < tol, (prec, float(per_row.max()), int(per_row.argmax()))
     flat32 = torch.cat([t.double().flatten() for t in grads["fp32"].values()])
