@@ -1059,31 +1059,24 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
 // accumulator the Hadamard with vt and the sum over v are in-lane (+ one exchange between the two k-halves).
 // =====================================================================================================
 template <int A_, int KS>
-__global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
+__global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
                                                             float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh) {
-    constexpr int QAP = KS * 16, MT = 2, WP = QAP + 4;             // W row pitch: +4 floats keeps b128 alignment and spreads the banks
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // Wc[64][WP]
+    // Round 4: the sample's compacted attention slice is split into bf16 hi / lo ONCE per workgroup, into LDS, and the MFMA fragments are read from there at
+    // every use (20 ds_read_b128 per tile) instead of living in 80 registers per wave: eight waves fit the register file (two per SIMD), ONE workgroup per sample
+    // covers its 32 channel tiles, and the set-up -- what this kernel's time is made of -- is paid once per sample.
+    constexpr int QAP = KS * 16, MT = 2, WPH = QAP + 8;            // row pitch in bf16: (QAP + 8) * 2 B = an odd number of 16-B units -> conflict-free ds_read_b128
+    extern __shared__ __attribute__((aligned(16))) unsigned short wsm[];     // Wh[64][WPH], Wl[64][WPH]
+    unsigned short* const WH = wsm;
+    unsigned short* const WL = wsm + 64 * WPH;
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     const int QA = Q * A_;
     const float* wb = w + (int64_t)b * w_sb;
-    for (int i = t; i < 64 * QAP; i += 256) {
-        const int qa = i % QAP, v = i / QAP, q = qa / A_, a = qa - q * A_;
-        sm[v * WP + qa] = (v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
-    }
-    __syncthreads();
-    lbf16x8 wh[MT][KS], wl[MT][KS];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float* wr = sm + (mt * 32 + l31) * WP + ks * 16 + kg * 8;
-            split8(*reinterpret_cast<const float4*>(wr), *reinterpret_cast<const float4*>(wr + 4), wh[mt][ks], wl[mt][ks]);
-        }
+    const int nthr = blockDim.x, nwave = blockDim.x >> 6;
     const bool two = V > 32;
-    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    const int tile0 = (blockIdx.x * nwave + wid) * tiles_per_wave;
     const int ntile = min(tiles_per_wave, D / 32 - tile0);
     // The per-tile operands (Q + A + up to 20 vt values per lane, all coalesced 128-B rows) are loaded one tile AHEAD into the other
     // register set: a wave's loads, P formation, MFMA chain and Hadamard would otherwise run strictly one after the other.
@@ -1105,6 +1098,21 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
             v1_[e] = (two && v + 32 < V) ? vb_[(int64_t)(v + 32) * D] : 0.f;                                     \
         }                                                                                                        \
     }
+    if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)              // (in flight while the attention slice is compacted and split below)
+    for (int it = t; it < 64 * (QAP / 8); it += nthr) {             // (row v, eight consecutive (q, a) columns)
+        const int v = it / (QAP / 8), c0 = (it - v * (QAP / 8)) * 8;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qa = c0 + e, q = qa / A_, a = qa - q * A_;
+            x[e] = (v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+        }
+        lbf16x8 hi, lo;
+        split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), hi, lo);
+        *reinterpret_cast<lbf16x8*>(WH + v * WPH + c0) = hi;
+        *reinterpret_cast<lbf16x8*>(WL + v * WPH + c0) = lo;
+    }
+    __syncthreads();
 #define CTI_TPM_COMPUTE(qr_, ar_, v0_, v1_, tile_)                                                               \
     {                                                                                                            \
         lf32x16 u0, u1;                                                                                          \
@@ -1120,19 +1128,23 @@ __global__ __launch_bounds__(256) void tri_pool_mfma_kernel(const float* __restr
             const float4 pb = kg ? make_float4(p1[4], p1[5], p1[6], p1[7]) : make_float4(p0[4], p0[5], p0[6], p0[7]); \
             lbf16x8 ph, pl;                                                                                      \
             split8(pa, pb, ph, pl);                                                                              \
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[0][ks], ph, u0, 0, 0, 0);                            \
-            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[1][ks], ph, u1, 0, 0, 0);                   \
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][ks], pl, u0, 0, 0, 0);                            \
-            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], pl, u1, 0, 0, 0);                   \
-            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][ks], ph, u0, 0, 0, 0);                            \
-            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], ph, u1, 0, 0, 0);                   \
+            const int wo_ = l31 * WPH + ks * 16 + kg * 8;                                                        \
+            const lbf16x8 wh0 = *reinterpret_cast<const lbf16x8*>(WH + wo_), wl0 = *reinterpret_cast<const lbf16x8*>(WL + wo_); \
+            lbf16x8 wh1 = wh0, wl1 = wl0;                                                                        \
+            if (two) { wh1 = *reinterpret_cast<const lbf16x8*>(WH + wo_ + 32 * WPH); wl1 = *reinterpret_cast<const lbf16x8*>(WL + wo_ + 32 * WPH); } \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl0, ph, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl1, ph, u1, 0, 0, 0);                   \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, pl, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, pl, u1, 0, 0, 0);                   \
+            u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, ph, u0, 0, 0, 0);                            \
+            if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, ph, u1, 0, 0, 0);                   \
+            __builtin_amdgcn_sched_barrier(0);     /* (the scheduler would hoist all 20 fragment reads of a tile: 80 registers) */ \
         }                                                                                                        \
         float acc = 0.f;                                                                                         \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) { acc = fmaf(u0[e], v0_[e], acc); acc = fmaf(u1[e], v1_[e], acc); } \
         acc += __shfl_xor(acc, 32, 64);                                                                          \
         if (kg == 0) out[(int64_t)b * D + (tile_) * 32 + l31] = acc;                                             \
     }
-    if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)
     for (int ti = 0; ti < ntile; ti += 2) {
         if (ti + 1 < ntile) CTI_TPM_LOAD(qB, aB, vB, wB, tile0 + ti + 1)
         CTI_TPM_COMPUTE(qA, aA, vA, wA, tile0 + ti)
@@ -1661,21 +1673,24 @@ static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at,
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
     CTI_REQUIRE(v_rep >= 1 && B % v_rep == 0, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: v_rep=%d does not divide B=%d", v_rep, B);
-    // measured at B = 256, D = 1024 (rocprofv3): A = 6: 35.4 us here vs 46.5 us in the streaming VALU form; A = 3: 29.1 us here vs 27.1 us in the
-    // product-table VALU form -- so A = 3 stays there (CTI_TRI_MFMA_A3 builds it in for experiments)
+    // measured at B = 256, D = 1024: round 3 (fragments in registers, two workgroups per sample): A = 6 35.4 us here vs 46.5 in the streaming VALU form, A = 3 29.1 here
+    // vs 27.1 in the product-table VALU form; round 4 (split slice in LDS, eight waves, one workgroup per sample): A = 6 19.8 us, A = 3 18.8 -- both take this kernel now
 #ifndef CTI_TRI_MFMA_A3
-#define CTI_TRI_MFMA_A3 0
+#define CTI_TRI_MFMA_A3 1
 #endif
     if (!(A == 6 || (A == 3 && CTI_TRI_MFMA_A3)) || Q > 16 || V > 64 || D % 32 != 0) return CTI_E_UNSUPPORTED;   // the caller takes cti_tri_pool_fwd
     const int KS = (Q * A + 15) / 16;
     const int tiles = D / 32;
-#ifndef CTI_TPM_TPW
-#define CTI_TPM_TPW 4
-#endif
-    const int tpw = tiles >= 32 ? CTI_TPM_TPW : 1;
-    const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), B);
-    const size_t lds = sizeof(float) * 64 * (size_t)(KS * 16 + 4);
-#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(256), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh)
+    static const int tpw_env = [] { const char* e = getenv("CTI_TPM_TPW"); return e ? atoi(e) : 0; }();       // (A/B knob)
+    // ONE workgroup per sample where the sample has 32 tiles or more: every workgroup compacts and splits the sample's 64 x QA attention slice, a second workgroup
+    // repeats that, and that set-up is what the kernel's time is made of (round 4, A = 6, D = 1 024: 4 waves x 4 tiles = two workgroups per sample 37.6 us, 4 x 8 = one
+    // 29.4, 4 x 2 51, 4 x 1 80; eight waves per workgroup do not fit the register file: 212 B of scratch, 37-60 us)
+    static const int nw_env = [] { const char* e = getenv("CTI_TPM_NW"); return e ? atoi(e) : 0; }();
+    const int nw = (nw_env == 4 || nw_env == 8) ? nw_env : 8;
+    const int tpw = tpw_env > 0 ? tpw_env : (tiles >= 32 ? (tiles + nw - 1) / nw : 1);
+    const dim3 grid((tiles + nw * tpw - 1) / (nw * tpw), B);
+    const size_t lds = sizeof(unsigned short) * 2 * 64 * (size_t)(KS * 16 + 8);
+#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh)
     if (A == 3) { if (KS <= 2) CTI_TM(3, 2); else CTI_TM(3, 3); }
     else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
 #undef CTI_TM
