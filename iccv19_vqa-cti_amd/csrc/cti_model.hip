@@ -119,6 +119,36 @@ __global__ __launch_bounds__(256) void poison_unless_replicated_kernel(const uns
     if (!bad) return;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __builtin_nanf("");
 }
+// y[r, n] = act(scale * sum_k x[r, k] W[n, k] + bias[n]) for a HANDFUL of outputs (N <= 8: the MC models' answer head, src/classifier.py:26 with out_dim = 2) in exact fp32:
+// one workgroup per row, its threads stride over K with N running sums, one block reduction.  The GEMM path costs this 256 x 2 x 2 048 product a split-K launch pair.
+template <int N>
+__global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw, const float* __restrict__ scale,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int64_t ldy, int K, int relu) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* xr = x + (int64_t)r * ldx;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int k = t; k < K; k += 256) {
+        const float xv = xr[k];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, W[(int64_t)n * ldw + k], acc[n]);
+    }
+    __shared__ float red[N][4];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((t & 63) == 0) red[n][t >> 6] = v;
+    }
+    __syncthreads();
+    if (t < N) {
+        float v = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+        v = v * (scale ? scale[0] : 1.f) + (bias ? bias[t] : 0.f);
+        y[(int64_t)r * ldy + t] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
 // out = a x + b y  (the classifier input of the hoisted glimpse loops: G * q_emb_0.sum(1) + L * sum_g D_g)
 __global__ void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b, float* __restrict__ out, int64_t n) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,6 +345,18 @@ int cti_poison_unless_replicated(const unsigned char* eq, int B, int r, float* o
     if (n == 0 || r == 1) return CTI_OK;
     hipLaunchKernelGGL(poison_unless_replicated_kernel, dim3((unsigned)(n >= 256 * 64 ? 64 : (n + 255) / 256)), dim3(256), 0, as_stream(stream), eq, B, r, out, n);
     return launch_status("cti_poison_unless_replicated");
+}
+int cti_linear_small_n(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* scale, const float* bias, float* y, int64_t ldy, int rows, int K, int N,
+                       int relu, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(W); CTI_REQUIRE_PTR(y);
+    CTI_REQUIRE(rows > 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N, CTI_E_SHAPE, "cti_linear_small_n: rows=%d K=%d N=%d", rows, K, N);
+    if (N > 8) return CTI_E_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+#define CTI_LS(Nv) hipLaunchKernelGGL(linear_small_n_kernel<Nv>, dim3((unsigned)rows), dim3(256), 0, st, x, ldx, W, ldw, scale, bias, y, ldy, K, relu)
+    switch (N) { case 1: CTI_LS(1); break; case 2: CTI_LS(2); break; case 3: CTI_LS(3); break; case 4: CTI_LS(4); break;
+                 case 5: CTI_LS(5); break; case 6: CTI_LS(6); break; case 7: CTI_LS(7); break; default: CTI_LS(8); break; }
+#undef CTI_LS
+    return launch_status("cti_linear_small_n");
 }
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream) {
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);

@@ -338,6 +338,13 @@ def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None, w_planes=Non
         return y
     pr = _prec(prec)
     lib = L.lib()
+    if out_dim <= 8 and scale_div >= out_dim and not torch.is_grad_enabled():
+        # a handful of outputs (the MC models' answer head: 2): one exact-fp32 kernel instead of a split-K GEMM launch pair
+        rc = lib.cti_linear_small_n(x2.data_ptr(), ldx, w.data_ptr(), w.stride(0), _ptr(scale), _ptr(bias), y.data_ptr(), out_dim, rows, in_dim, out_dim, int(bool(relu)),
+                                    _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_linear_small_n")
+            return y
     if w_planes is not None and pr != L.PREC_F32:
         y2 = y.view(-1, out_dim)
         gemm_nt(x2, w, M=rows, N=out_dim, out=y2, c_strides=(out_dim, 1), scale=scale, scale_div=scale_div, bias=bias, relu=relu, prec=prec,

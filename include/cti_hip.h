@@ -552,6 +552,10 @@ int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, 
  * rows" gives NaNs on a batch that breaks it, never a plausible wrong answer. */
 int cti_rows_equal_prev(const void* x, int64_t row_bytes, int B, unsigned char* eq, void* stream);
 int cti_poison_unless_replicated(const unsigned char* eq, int B, int r, float* out, int64_t n, void* stream);
+/* y[r, n] = act(scale[0] * sum_k x[r, k] W[n, k] + bias[n]) in exact fp32 for N <= 8 outputs (the MC models' answer head: src/classifier.py:26 with out_dim = 2,
+ * `weight_norm(Linear)` as scale = g / ||V||_F); scale / bias may be NULL; relu != 0 applies max(., 0).  CTI_E_UNSUPPORTED for N > 8 (use cti_wn_linear_fwd). */
+int cti_linear_small_n(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* scale, const float* bias, float* y, int64_t ldy, int rows, int K, int N,
+                       int relu, void* stream);
 /* out[i] = a * x[i] + b * y[i], i < n (out may alias x or y). */
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream);
 /* The residual projection of a glimpse as ONE call (src/FFOE/base_model.py:61,131-132 `q_prj(b_emb.unsqueeze(1)) + q_emb`, and the sequence sums

@@ -275,6 +275,21 @@ def test_bi_logits_in_the_plain_bf16_mode(B, G, V, Q, D):
     assert O.norm_max_err(out3, ref) < TOL
 
 
+@pytest.mark.parametrize("rows,K,N", [(256, 2048, 2), (7, 100, 1), (33, 513, 8), (5, 64, 3)])
+def test_linear_with_a_handful_of_outputs(rows, K, N):
+    """cti_linear_small_n (the MC models' answer head, src/classifier.py:26 with out_dim = 2): exact fp32, scale + bias + optional ReLU, against float64."""
+    rs = np.random.RandomState(rows + N)
+    x, w = rs.standard_normal((rows, K)).astype(np.float32), (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias, scale = rs.standard_normal(N).astype(np.float32), np.array([0.7], np.float32)
+    with torch.no_grad():
+        for relu in (False, True):
+            y = ops.wn_linear(T(x), T(w), T(scale), N, T(bias), relu)
+            ref = 0.7 * (x.astype(np.float64) @ w.astype(np.float64).T) + bias
+            assert O.norm_max_err(y.cpu().numpy(), np.maximum(ref, 0) if relu else ref) < 2e-6, relu
+        y = ops.wn_linear(T(x), T(w), None, N, None, False)
+        assert O.norm_max_err(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+
+
 def test_pools_beside_the_bf16x3_gru_on_another_stream():
     """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
     (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue
