@@ -124,6 +124,7 @@ SIGNATURES = {
     "cti_bi_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
     "cti_tri_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_axpby": (_int, [_vp, C.c_float, _vp, C.c_float, _vp, _i64, _vp]),
+    "cti_joint_sums": (_int, [_vp, _int, C.c_float, _vp, _int, C.c_float, _vp, C.c_float, _vp, C.c_float, _vp, _int, _int, _vp]),
     "cti_linear_small_n": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
     "cti_rows_equal_prev": (_int, [_vp, _i64, _int, _vp, _vp]),
     "cti_poison_unless_replicated": (_int, [_vp, _int, _int, _vp, _i64, _vp]),

@@ -199,7 +199,7 @@ def _ban_forward_hoisted(self, q_emb, att, vp, Hq):
         if out is None:
             return None
         D = out.view(B, H)
-    return ops.axpby(ops.seq_sum(q_emb), float(self.glimpse), E, float(Lq))
+    return ops.joint_sums(q_emb, float(self.glimpse), Dq=E, dq=float(Lq))
 
 
 def _ban_hoist_prepare(self, q_emb, vp):
@@ -331,8 +331,7 @@ class _TriModel(nn.Module):
                 return None
             y = self._prj_pairs[g].shared(b_emb)
             D = y if g == 0 else ops.axpby(D, 1.0, y, 1.0, out=y)
-        joint = _joint(q_emb, ans_emb)
-        return ops.axpby(ops.axpby(joint, 1.0, D[0], float(Lq), out=joint), 1.0, D[1], float(La), out=joint)
+        return ops.joint_sums(q_emb, 1.0, ans_emb, 1.0, D[0], float(Lq), D[1], float(La))
 
 
 class CTIModel(_TriModel):

@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
 // N = d: lane = channel, so qt / at / vt are read as coalesced 128-B rows and P is formed per lane; with rows = v in the
 // accumulator the Hadamard with vt and the sum over v are in-lane (+ one exchange between the two k-halves).
 // =====================================================================================================
-template <int A_, int KS>
+template <int A_, int KS, int TERMS>
 __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
@@ -1108,9 +1108,9 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
             x[e] = (v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
         }
         lbf16x8 hi, lo;
-        split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), hi, lo);
+        split8t<TERMS>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), hi, lo);       // TERMS = 1 (plain-bf16 mode): hi only, one product per pair
         *reinterpret_cast<lbf16x8*>(WH + v * WPH + c0) = hi;
-        *reinterpret_cast<lbf16x8*>(WL + v * WPH + c0) = lo;
+        if (TERMS == 3) *reinterpret_cast<lbf16x8*>(WL + v * WPH + c0) = lo;
     }
     __syncthreads();
 #define CTI_TPM_COMPUTE(qr_, ar_, v0_, v1_, tile_)                                                               \
@@ -1127,15 +1127,19 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
             const float4 pa = kg ? make_float4(p1[0], p1[1], p1[2], p1[3]) : make_float4(p0[0], p0[1], p0[2], p0[3]); \
             const float4 pb = kg ? make_float4(p1[4], p1[5], p1[6], p1[7]) : make_float4(p0[4], p0[5], p0[6], p0[7]); \
             lbf16x8 ph, pl;                                                                                      \
-            split8(pa, pb, ph, pl);                                                                              \
+            split8t<TERMS>(pa, pb, ph, pl);                                                                      \
             const int wo_ = l31 * WPH + ks * 16 + kg * 8;                                                        \
-            const lbf16x8 wh0 = *reinterpret_cast<const lbf16x8*>(WH + wo_), wl0 = *reinterpret_cast<const lbf16x8*>(WL + wo_); \
+            const lbf16x8 wh0 = *reinterpret_cast<const lbf16x8*>(WH + wo_);                                     \
+            lbf16x8 wl0 = wh0;                                                                                   \
+            if (TERMS == 3) wl0 = *reinterpret_cast<const lbf16x8*>(WL + wo_);                                   \
             lbf16x8 wh1 = wh0, wl1 = wl0;                                                                        \
-            if (two) { wh1 = *reinterpret_cast<const lbf16x8*>(WH + wo_ + 32 * WPH); wl1 = *reinterpret_cast<const lbf16x8*>(WL + wo_ + 32 * WPH); } \
+            if (two) { wh1 = *reinterpret_cast<const lbf16x8*>(WH + wo_ + 32 * WPH); if (TERMS == 3) wl1 = *reinterpret_cast<const lbf16x8*>(WL + wo_ + 32 * WPH); } \
+            if (TERMS == 3) {                                                                                    \
             u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl0, ph, u0, 0, 0, 0);                            \
             if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl1, ph, u1, 0, 0, 0);                   \
             u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, pl, u0, 0, 0, 0);                            \
             if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, pl, u1, 0, 0, 0);                   \
+            }                                                                                                    \
             u0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, ph, u0, 0, 0, 0);                            \
             if (two) u1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, ph, u1, 0, 0, 0);                   \
             __builtin_amdgcn_sched_barrier(0);     /* (the scheduler would hoist all 20 fragment reads of a tile: 80 registers) */ \
@@ -1669,7 +1673,7 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
 }
 
 static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                              int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, PoolShift sh, void* stream) {
+                              int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, PoolShift sh, void* stream, int terms = 3) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
     CTI_REQUIRE(v_rep >= 1 && B % v_rep == 0, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: v_rep=%d does not divide B=%d", v_rep, B);
@@ -1690,9 +1694,10 @@ static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at,
     const int tpw = tpw_env > 0 ? tpw_env : (tiles >= 32 ? (tiles + nw - 1) / nw : 1);
     const dim3 grid((tiles + nw * tpw - 1) / (nw * tpw), B);
     const size_t lds = sizeof(unsigned short) * 2 * 64 * (size_t)(KS * 16 + 8);
-#define CTI_TM(Av, KSv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh)
-    if (A == 3) { if (KS <= 2) CTI_TM(3, 2); else CTI_TM(3, 3); }
-    else        { if (KS <= 4) CTI_TM(6, 4); else if (KS == 5) CTI_TM(6, 5); else CTI_TM(6, 6); }
+#define CTI_TM(Av, KSv) { if (terms == 1) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 1>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh); \
+                          else hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 3>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh); }
+    if (A == 3) { if (KS <= 2) CTI_TM(3, 2) else CTI_TM(3, 3) }
+    else        { if (KS <= 4) CTI_TM(6, 4) else if (KS == 5) CTI_TM(6, 5) else CTI_TM(6, 6) }
 #undef CTI_TM
     return launch_status("cti_tri_pool_mfma_fwd");
 }
@@ -1703,14 +1708,15 @@ extern "C" int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const flo
 }
 
 // out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d])   (qadd / aadd may be NULL = 0).
-// use_mfma != 0: the fp32-grade MFMA form where it applies (A = 6), else the product-table / streaming VALU kernels (v_rep must then be 1).
+// use_mfma: 1 = the fp32-grade MFMA form (three bf16 products per pair) where it applies (A = 3 or 6), 2 = the same with ONE product per pair (the plain-bf16 mode),
+// 0 or no such kernel for the shape = the product-table / streaming VALU kernels (v_rep must then be 1).
 // CTI_E_UNSUPPORTED when no kernel with the on-load shift takes the shape: nothing is launched, the caller materialises the operands.
 extern "C" int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
                                       int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
                                       int use_mfma, void* stream) {
     const PoolShift sh{qadd, aadd, 1};
     if (use_mfma) {
-        const int rc = tri_pool_mfma_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, v_rep, sh, stream);
+        const int rc = tri_pool_mfma_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, v_rep, sh, stream, use_mfma == 2 ? 1 : 3);
         if (rc != CTI_E_UNSUPPORTED) return rc;
     }
     if (v_rep != 1) return CTI_E_UNSUPPORTED;

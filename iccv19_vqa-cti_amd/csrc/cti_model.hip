@@ -149,6 +149,21 @@ __global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __rest
         y[(int64_t)r * ldy + t] = relu ? fmaxf(v, 0.f) : v;
     }
 }
+// out[b,h] = cq * sum_l q[b,l,h] + ca * sum_l a[b,l,h] + dq * Dq[b,h] + da * Da[b,h]   (a / Dq / Da may be NULL): the classifier input of the hoisted glimpse
+// loops in ONE pass -- CTI: q_emb_0.sum(1) + ans_emb_0.sum(1) + Lq Dq + La Da (src/FFOE/base_model.py:134); BAN: G q_emb_0.sum(1) + L sum_g D_g (:63-64)
+__global__ void joint_sums_kernel(const float* __restrict__ q, int Lq, float cq, const float* __restrict__ a, int La, float ca, const float* __restrict__ Dq, float dq,
+                                  const float* __restrict__ Da, float da, float* __restrict__ out, int B, int H) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int b = (int)(idx / H), h = (int)(idx % H);
+    float sq = 0.f, sa = 0.f;
+    for (int l = 0; l < Lq; ++l) sq += q[((int64_t)b * Lq + l) * H + h];
+    if (a) for (int l = 0; l < La; ++l) sa += a[((int64_t)b * La + l) * H + h];
+    float v = cq * sq + ca * sa;
+    if (Dq) v += dq * Dq[idx];
+    if (Da) v += da * Da[idx];
+    out[idx] = v;
+}
 // out = a x + b y  (the classifier input of the hoisted glimpse loops: G * q_emb_0.sum(1) + L * sum_g D_g)
 __global__ void axpby_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b, float* __restrict__ out, int64_t n) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +372,13 @@ int cti_linear_small_n(const float* x, int64_t ldx, const float* W, int64_t ldw,
                  case 5: CTI_LS(5); break; case 6: CTI_LS(6); break; case 7: CTI_LS(7); break; default: CTI_LS(8); break; }
 #undef CTI_LS
     return launch_status("cti_linear_small_n");
+}
+int cti_joint_sums(const float* q, int Lq, float cq, const float* a, int La, float ca, const float* Dq, float dq, const float* Da, float da, float* out, int B, int H,
+                   void* stream) {
+    CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE(B > 0 && H > 0 && Lq > 0 && (!a || La > 0), CTI_E_SHAPE, "cti_joint_sums: B=%d H=%d Lq=%d La=%d", B, H, Lq, La);
+    hipLaunchKernelGGL(joint_sums_kernel, dim3(blocks_for((int64_t)B * H, 256)), dim3(256), 0, as_stream(stream), q, Lq, cq, a, La, ca, Dq, dq, Da, da, out, B, H);
+    return launch_status("cti_joint_sums");
 }
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream) {
     CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);

@@ -797,7 +797,7 @@ def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
     out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
     sb, sv, sq, sa = w.stride()
     lib = L.lib()
-    use_mfma = int(get_precision() != "fp32" and _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") != "1")
+    use_mfma = 0 if (get_precision() == "fp32" or _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") == "1") else (2 if get_precision() == "bf16" else 1)
     rc = lib.cti_tri_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), _ptr(qadd), _ptr(aadd), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
                                     B, V, Q, A, D, v_rep, use_mfma, _stream())
     if rc == L.E_UNSUPPORTED and v_rep > 1:
@@ -838,6 +838,20 @@ def replication_of(eq):
 def poison_unless_replicated(eq, r, out):
     """out.fill_(nan) on the device unless eq (rows_equal_prev of the batch) confirms groups of r identical rows."""
     L.check(L.lib().cti_poison_unless_replicated(eq.data_ptr(), eq.shape[0], int(r), out.data_ptr(), out.numel(), _stream()), "cti_poison_unless_replicated")
+    return out
+
+
+def joint_sums(q, cq, a=None, ca=0.0, Dq=None, dq=0.0, Da=None, da=0.0):
+    """cq * q.sum(1) + ca * a.sum(1) + dq * Dq + da * Da  -> (B,H); q (B,Lq,H), a (B,La,H) or None, Dq / Da (B,H) or None: one pass."""
+    _req(q, "q")
+    q = q.contiguous()
+    B, Lq, H = q.shape
+    a = None if a is None else a.contiguous()
+    Dq = None if Dq is None else Dq.contiguous()
+    Da = None if Da is None else Da.contiguous()
+    out = torch.empty((B, H), device=q.device, dtype=torch.float32)
+    L.check(L.lib().cti_joint_sums(q.data_ptr(), Lq, float(cq), _ptr(a), 0 if a is None else a.shape[1], float(ca), _ptr(Dq), float(dq), _ptr(Da), float(da),
+                                   out.data_ptr(), B, H, _stream()), "cti_joint_sums")
     return out
 
 

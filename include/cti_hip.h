@@ -247,8 +247,8 @@ int cti_tri_pool_mfma_fwd(const float* vt, const float* qt, const float* at, con
  * GEMMs of src/FFOE/base_model.py:53-61,129-132 and src/MC/base_model.py:145-148): the q (and a) operand is relu(row + add[b, :]) formed as the
  * rows are loaded -- row = the pre-activation projection of the INITIAL sequence (one batched GEMM for all glimpses), add = the projection of the
  * residual accumulated so far, one (B, D) vector per sample, or NULL = 0.
- *   tri: out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d]);  use_mfma != 0: the MFMA form
- *        where it applies (else v_rep must be 1);   bi (k = 1): out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + qadd[b,d]).
+ *   tri: out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d]);  use_mfma: 1 = the fp32-grade MFMA form
+ *        where it applies, 2 = the same with ONE bf16 product per pair (plain-bf16 mode), 0 = the VALU kernels (v_rep must then be 1);   bi (k = 1): out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + qadd[b,d]).
  * CTI_E_UNSUPPORTED (nothing launched, no message) when no kernel with the on-load shift takes the shape: materialise the operands instead. */
 int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
                            int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
@@ -556,6 +556,10 @@ int cti_poison_unless_replicated(const unsigned char* eq, int B, int r, float* o
  * `weight_norm(Linear)` as scale = g / ||V||_F); scale / bias may be NULL; relu != 0 applies max(., 0).  CTI_E_UNSUPPORTED for N > 8 (use cti_wn_linear_fwd). */
 int cti_linear_small_n(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* scale, const float* bias, float* y, int64_t ldy, int rows, int K, int N,
                        int relu, void* stream);
+/* out[b,h] = cq * sum_l q[b,l,h] + ca * sum_l a[b,l,h] + dq * Dq[b,h] + da * Da[b,h]; q (B,Lq,H), a (B,La,H) or NULL, Dq / Da (B,H) or NULL: the classifier
+ * input of the hoisted glimpse loops in one pass (src/FFOE/base_model.py:63-64,134). */
+int cti_joint_sums(const float* q, int Lq, float cq, const float* a, int La, float ca, const float* Dq, float dq, const float* Da, float da, float* out, int B, int H,
+                   void* stream);
 /* out[i] = a * x[i] + b * y[i], i < n (out may alias x or y). */
 int cti_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream);
 /* The residual projection of a glimpse as ONE call (src/FFOE/base_model.py:61,131-132 `q_prj(b_emb.unsqueeze(1)) + q_emb`, and the sequence sums

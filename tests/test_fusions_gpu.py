@@ -290,6 +290,27 @@ def test_linear_with_a_handful_of_outputs(rows, K, N):
         assert O.norm_max_err(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
 
 
+def test_shifted_tri_pool_and_sums_in_the_plain_bf16_mode():
+    """set_precision('bf16'): the MFMA tri pool with ONE bf16 product per pair (use_mfma = 2) in the mode's 1e-2 class; cti_joint_sums against float64."""
+    rs = np.random.RandomState(77)
+    B, V, Q, A, D = 8, 36, 12, 6, 1024
+    vt, qt, at = rs.standard_normal((B, V, D)).astype(np.float32), rs.standard_normal((B, Q, D)).astype(np.float32), rs.standard_normal((B, A, D)).astype(np.float32)
+    qa, aa = rs.standard_normal((B, D)).astype(np.float32), rs.standard_normal((B, D)).astype(np.float32)
+    w = rs.rand(B, V, Q, A).astype(np.float32)
+    ref = np.einsum("bvd,bvqa,bqd,bad->bd", vt.astype(np.float64), w.astype(np.float64), np.maximum(qt.astype(np.float64) + qa[:, None], 0), np.maximum(at.astype(np.float64) + aa[:, None], 0))
+    old = cti_amd.get_precision()
+    try:
+        cti_amd.set_precision("bf16")
+        out = ops.tri_pool_shift(T(vt), T(qt), T(at), T(qa), T(aa), T(w))
+    finally:
+        cti_amd.set_precision(old)
+    assert out is not None and 1e-6 < O.norm_max_err(out.cpu().numpy(), ref) < 1e-2
+    js = ops.joint_sums(T(qt), 2.0, T(at), 1.0, T(qa), 12.0, T(aa), 6.0).cpu().numpy()
+    assert O.norm_max_err(js, 2.0 * qt.astype(np.float64).sum(1) + at.astype(np.float64).sum(1) + 12.0 * qa + 6.0 * aa) < 2e-6
+    js = ops.joint_sums(T(qt), 8.0, Dq=T(qa), dq=14.0).cpu().numpy()
+    assert O.norm_max_err(js, 8.0 * qt.astype(np.float64).sum(1) + 14.0 * qa) < 2e-6
+
+
 def test_pools_beside_the_bf16x3_gru_on_another_stream():
     """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
     (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue
