@@ -539,6 +539,7 @@ static bool af32_pb() { static const bool v = [] { const char* e = getenv("CTI_A
 // the fp32-A form for SMALL row counts only (the batch-sized products of the model forwards' dependent chains: their split launch costs as much as they do)
 static int af32_rows() { static const int v = [] { const char* e = getenv("CTI_AF32_ROWS"); return e ? atoi(e) : CTI_AF32_ROWS_DEFAULT; }(); return v; }
 
+constexpr size_t PB_BATCHED_PARTIALS = sizeof(float) * 288 * 128 * 128;
 // cti_gemm_nt with the B operand given as resident planes (cti_split_operand of the (rowsB_total x K) matrix): only A is split here.
 extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {
     if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0) return 0;
@@ -548,6 +549,8 @@ extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t ro
         const int S = plan_ksplit((int)rowsA_total, (int)rowsB_total, planes_kp(K), 1);
         if (S > 1) n += al(sizeof(float) * (size_t)S * (size_t)rowsA_total * (size_t)rowsB_total);
     }
+    // batches of skinny products (round 4: split K too): the planner never asks for more than 288 tiles of 128 x 128 partials
+    if (rowsA_total <= 8192) n = n > al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + PB_BATCHED_PARTIALS ? n : al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + PB_BATCHED_PARTIALS;
     return n;
 }
 extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
@@ -582,6 +585,11 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     if (nb1 == 1 && M == rowsA_total && N == rowsB_total) {
         const int S = plan_ksplit(M, N, Kp, 1);
         if (S > 1) { g.ksplit = S; g.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + ((planes_bytes(ra, K) + 255) & ~(size_t)255)); }
+    } else if (nb1 > 1 && rowsA_total <= 8192) {
+        // a batch of skinny products (the two sequences of the CTI models' glimpse loop: 2 x (256 x 1 024 x 1 024)): K ranges as a second batch axis, one reduce pass
+        const int S = plan_ksplit(M, N, Kp, nb1);
+        const size_t off = (planes_bytes(ra, K) + 255) & ~(size_t)255;
+        if (S > 1 && off + sizeof(float) * (size_t)S * nb1 * M * N <= workspace_bytes) { g.ksplit = S; g.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + off); }
     }
     return gemm_nt_planes(g, as_stream(stream));
 }

@@ -570,15 +570,20 @@ __global__ __launch_bounds__(G::NTHR) void gemm_planes_kernel(PlaneGemmP p) {
 }
 
 // split-K reduce + epilogue: C[m, n] = act(scale[n / div] * sum_s part[s][m][n] + bias[n]); one float4 of a row per thread
+// (round 4: nb batches -- rows z * M + m of the partials, C / scale / bias advanced by sC1 / scale_bs / bias_bs per batch)
 __global__ __launch_bounds__(256) void ksplit_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ C,
                                                             int64_t ldc_m, const float* __restrict__ scale, int scale_div,
-                                                            const float* __restrict__ bias, int relu) {
+                                                            const float* __restrict__ bias, int relu, int nb, int64_t sC1, int64_t scale_bs, int64_t bias_bs) {
     const int n4 = (N + 3) >> 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)M * n4) return;
-    const int m = (int)(idx / n4), n0 = (int)(idx % n4) * 4;
-    const int64_t MN = (int64_t)M * N;
-    const float* src = part + (int64_t)m * N + n0;
+    if (idx >= (int64_t)nb * M * n4) return;
+    const int mz = (int)(idx / n4), n0 = (int)(idx % n4) * 4;
+    const int z = mz / M, m = mz - z * M;
+    const int64_t MN = (int64_t)nb * M * N;
+    const float* src = part + (int64_t)mz * N + n0;
+    C += (int64_t)z * sC1;
+    if (scale) scale += (int64_t)z * scale_bs;
+    if (bias) bias += (int64_t)z * bias_bs;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     const bool vec = (N & 3) == 0;
     for (int s = 0; s < S; ++s) {
@@ -699,8 +704,8 @@ int plan_ksplit(int M, int N, int Kp, long long nb) {
 #ifdef CTI_NO_KSPLIT
     return 1;
 #endif
-    if (nb != 1 || Kp < 256) return 1;
-    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    if (nb < 1 || Kp < 256) return 1;
+    const long long tiles = nb * (long long)((M + 127) / 128) * ((N + 127) / 128);       // (round 4: batches of skinny products split too)
     if (tiles > 96) return 1;
     int best = 1;
     for (int s = 2; s <= 16; ++s) {
@@ -774,19 +779,19 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
     if (a.f6out) p.F6 = *a.f6out;
     if (a.ksplit > 1) {
-        if (a.nb1 != 1 || a.nb2 != 1 || a.epi != 0 || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
+        if (a.nb1 < 1 || a.nb2 != 1 || a.epi != 0 || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
         PlaneGemmArgs b = a;
         b.ksplit = 1; b.partial = nullptr;
         b.nb2 = a.ksplit; b.rA2 = 0; b.rB2 = 0; b.Kp = a.Kp / a.ksplit;
-        b.C = a.partial; b.ldc_m = a.N; b.ldc_n = 1; b.sC2 = (int64_t)a.M * a.N;
+        b.C = a.partial; b.ldc_m = a.N; b.ldc_n = 1; b.sC1 = (int64_t)a.M * a.N; b.sC2 = (int64_t)a.nb1 * a.M * a.N;       // partials [K range][batch][M][N]
         b.scale = nullptr; b.bias = nullptr; b.relu = 0;
         b.kc2 = a.Kp / a.ksplit / 16;
         int rc = gemm_nt_planes(b, st); if (rc) return rc;
         if (a.partials_only) return CTI_OK;                   // the caller's own kernel reduces them (cti_linear_residual_pb)
-        const int64_t items = (int64_t)a.M * ((a.N + 3) / 4);
+        const int64_t items = (int64_t)a.nb1 * a.M * ((a.N + 3) / 4);
         hipLaunchKernelGGL(ksplit_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a.partial, a.ksplit, a.M, a.N, a.C,
-                           a.ldc_m, a.scale, a.scale_div > 0 ? a.scale_div : 1, a.bias, a.relu);
+                           a.ldc_m, a.scale, a.scale_div > 0 ? a.scale_div : 1, a.bias, a.relu, a.nb1, a.sC1, a.scale_bs, a.bias_bs);
         return launch_status("gemm_nt_planes/ksplit_reduce");
     }
     p.kc2 = a.kc2;

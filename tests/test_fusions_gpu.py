@@ -311,6 +311,30 @@ def test_shifted_tri_pool_and_sums_in_the_plain_bf16_mode():
     assert O.norm_max_err(js, 8.0 * qt.astype(np.float64).sum(1) + 14.0 * qa) < 2e-6
 
 
+@pytest.mark.parametrize("n,rows,K,N", [(2, 256, 1024, 1024), (3, 64, 512, 256), (2, 5, 96, 40)])
+def test_batched_linears_with_and_without_a_k_split(n, rows, K, N):
+    """fc.BatchedLinears (the CTI glimpse loop's paired projections): n layers on a shared input / on n stacked inputs as ONE batched GEMM -- at 2 x (256 x 1024 x 1024)
+    the batch splits K too (partials [K range][batch][M][N], one batched reduce pass) -- against float64, every entry."""
+    BatchedLinears, WNLinear = cti_amd.pkg.fc.BatchedLinears, cti_amd.WNLinear
+    torch.manual_seed(40 + n)
+    layers = [WNLinear(K, N).to(DEV) for _ in range(n)]
+    for l in layers:
+        l.bias.data.normal_()
+    bl = BatchedLinears(layers)
+    rs = np.random.RandomState(n * 7 + rows)
+    x = rs.standard_normal((rows, K)).astype(np.float32)
+    xs = rs.standard_normal((n, rows, K)).astype(np.float32)
+    with torch.no_grad():
+        ys, yt, yn = bl.shared(T(x)), bl.stacked(T(xs)), bl.stacked(T(xs), bias=False, relu=True)
+    for i, l in enumerate(layers):
+        w = l.weight_v.detach().cpu().numpy().astype(np.float64)
+        sc = float(l.weight_g.detach().cpu()) / np.linalg.norm(w)
+        b_ = l.bias.detach().cpu().numpy().astype(np.float64)
+        assert O.norm_max_err(ys[i].cpu().numpy(), sc * (x.astype(np.float64) @ w.T) + b_) < TOL
+        assert O.norm_max_err(yt[i].cpu().numpy(), sc * (xs[i].astype(np.float64) @ w.T) + b_) < TOL
+        assert O.norm_max_err(yn[i].cpu().numpy(), np.maximum(sc * (xs[i].astype(np.float64) @ w.T), 0)) < TOL
+
+
 def test_pools_beside_the_bf16x3_gru_on_another_stream():
     """Round 4: with the BAN and the CTI forward on sibling streams, bi-pool launches that ran while the other stream's fp32-grade GRU step kernel
     (gru_step_fused_kernel<3, 1>) was resident came back with 16 lanes of one register wrong -- the pool kept a zero float4 in SCRATCH (an lvalue
