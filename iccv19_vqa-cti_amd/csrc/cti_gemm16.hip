@@ -327,7 +327,10 @@ int g16_launch(G16P& p, int nb, int ncols, hipStream_t st) {
     }
     static thread_local int n_cu = 0;
     if (n_cu == 0) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    const long long grid = total < n_cu ? total : n_cu;
+    // CTI_GEMM16_LEAVE=n (experiment): the persistent launch takes n compute units fewer, so that another stream's chain of small kernels keeps running beside it
+    static const int leave = [] { const char* e = getenv("CTI_GEMM16_LEAVE"); return e ? atoi(e) : 0; }();
+    const int cus = (leave > 0 && leave < n_cu && total > n_cu - leave) ? n_cu - leave : n_cu;
+    const long long grid = total < cus ? total : cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, st, p);
     return launch_status("gemm16_planes");
 }
