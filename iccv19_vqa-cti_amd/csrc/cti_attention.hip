@@ -1655,7 +1655,10 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
 #define CTI_BL_NTW 8        // column tiles per workgroup.  8 = all of them (one workgroup per sample and K half).  Measured at B = 256, G = 8, D = 3072
 #endif                      // (profiles/r03_hbm_kernels.jsonl): 8 -> 96 us, 4 -> 135, 2 -> 174, 1 -> 262: every extra workgroup re-splits the vt slice, and that VALU work is the bound
         static const int ntw_max = [] { const char* e = getenv("CTI_BL_NTW"); const int v = e ? atoi(e) : CTI_BL_NTW; return v < 1 ? 1 : (v > 8 ? 8 : v); }();   // (A/B knob; 8 = the round-2 form)
-        const int NTW = NT > ntw_max ? ntw_max : NT, NZ = (NT + NTW - 1) / NTW;
+        static const bool ntw_set = getenv("CTI_BL_NTW") != nullptr;
+        // (one product per pair: the vt slice is only converted, not split, so a second workgroup per sample and K range pays: 89 -> 81 us at B = 256, G = 8, D = 3072)
+        const int ntw_lim = (terms == 1 && !ntw_set) ? 4 : ntw_max;
+        const int NTW = NT > ntw_lim ? ntw_lim : NT, NZ = (NT + NTW - 1) / NTW;
         if (terms == 1)
             hipLaunchKernelGGL(bi_logits_lds_kernel<1>, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
                                NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
