@@ -346,6 +346,9 @@ def model_flops(kind, B, V, Q, A, G, vd=2048, nh=1024, h=512, R=32, n_ans=3129, 
 MODEL_TOL = {"bf16": 2e-2, "bf16x3": 1e-4, "f16f6": 1e-4, "fp32": 1e-4}     # normalised max error of the model logits vs the fp32 oracle, per arithmetic mode
 
 
+IO_BF16 = "bf16 image features in; the projected v (hoisted projection GEMMs -> sum-pools / attention logits) as bf16 rows; token ids int64; q / a sequences and logits fp32"
+
+
 def model_setup(config, B, rank, dev):
     """Model, synthetic batch and oracle hook of BASELINE configs[2] (c3: MC CTI, Visual7W shapes) / configs[3] (c4: FFOE BAN + CTI teacher).
     Returns dict(fwd, flops, workload, out_shape, oracle): fwd() -> logits tensor(s); oracle(n) -> list of (name, gpu rows, oracle rows) over the
@@ -362,6 +365,10 @@ def model_setup(config, B, rank, dev):
         return types.SimpleNamespace(op="c", num_hid=1024, gamma=gamma, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
 
     g = torch.Generator().manual_seed(SEED + 1 + rank)
+    # configs[2] / [3] name bf16: in the plain-bf16 mode the image features -- 97 % of a batch's input bytes -- are handed over as bf16 (round 5); the oracle and
+    # the other arithmetic modes see the same bf16-rounded values widened to fp32
+    v_bf16 = cti_amd.get_precision() == "bf16" and os.environ.get("CTI_BENCH_V_FP32", "0") != "1"
+    as_given = (lambda t: t.to(torch.bfloat16)) if v_bf16 else (lambda t: t)
 
     def tokens(L):
         t = torch.randint(0, ntoken, (B, L), generator=g)
@@ -378,7 +385,7 @@ def model_setup(config, B, rank, dev):
         vi = torch.randn(B // rep, 36, 2048, generator=g).abs()
         nv = torch.randint(10, 37, (B // rep,), generator=g)
         vi[torch.arange(36)[None, :] >= nv[:, None]] = 0
-        v = vi.unsqueeze(1).expand(-1, rep, -1, -1).contiguous().view(B, 36, 2048).to(dev)
+        v = as_given(vi.unsqueeze(1).expand(-1, rep, -1, -1).contiguous().view(B, 36, 2048).to(dev))
         q1 = tokens(12)
         q = q1.view(B // rep, rep, 12)[:, :1].expand(-1, rep, -1).contiguous().view(B, 12)
         a = tokens(6)
@@ -389,15 +396,15 @@ def model_setup(config, B, rank, dev):
 
         def oracle(n, out):
             from oracle import cti_models as OM
-            ref = OM.mc_tan_forward(v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
+            ref = OM.mc_tan_forward(v[:n].float().cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
             return [("mc_cti logits", out[:n].cpu().numpy(), ref)]
-        return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2), rep=rep,
+        return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2), rep=rep, v_bf16=v_bf16, inputs=dict(v=v, boxes=boxes, q=q, a=a),
                     executed_flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2, rep=rep, executed=True),
                     workload="BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B)
     v = torch.randn(B, 36, 2048, generator=g).abs()
     nv = torch.randint(10, 37, (B,), generator=g)
     v[torch.arange(36)[None, :] >= nv[:, None]] = 0
-    v = v.to(dev)
+    v = as_given(v.to(dev))
     q, a = tokens(14), tokens(3)
     boxes = torch.rand(B, 36, 6, generator=g).to(dev)
     ban = cti_amd.build_ban(margs(8), ds(3129)).to(dev).eval()
@@ -414,10 +421,10 @@ def model_setup(config, B, rank, dev):
 
     def oracle(n, out):
         from oracle import cti_models as OM
-        vn, qn, an = v[:n].cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy()
+        vn, qn, an = v[:n].float().cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy()
         return [("ban logits", out[0][:n].cpu().numpy(), OM.ffoe_ban_forward(vn, qn, state(ban), 8)[0]),
                 ("cti logits", out[1][:n].cpu().numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
-    return dict(fwd=fwd, oracle=oracle, models={"ban": ban, "cti": cti}, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129),
+    return dict(fwd=fwd, oracle=oracle, models={"ban": ban, "cti": cti}, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129), v_bf16=v_bf16, inputs=dict(v=v, boxes=boxes, q=q, a=a),
                 workload=("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
                           ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes; %s" % (
                               B, "one model after the other" if os.environ.get("CTI_BENCH_SERIAL_MODELS", "0") == "1" else
@@ -501,7 +508,7 @@ def run_model(args, world, rank, dev, dist):
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[prec], "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "precision": prec, "parallelism": "replicas x%d" % world,
                        "gflop_per_batch": round(flops / 1e9, 3), "executed_gflop_per_batch": round(setup.get("executed_flops", flops) / 1e9, 3),
-                       "io_dtype": "fp32 activations in and out (token ids int64); products in %s" % prec,
+                       "io_dtype": ("%s; products in %s" % (IO_BF16, prec)) if setup.get("v_bf16") else "fp32 activations in and out (token ids int64); products in %s" % prec,
                        "launch": "hipGraph replay of the captured forward" if graphed else "eager"},
             "roofline": {"bound": "mfma", "kernel": "whole forward (launch sequence; dominant kernels are the projection GEMMs)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
@@ -537,7 +544,8 @@ def model_subrecord(config, dev):
     ach = setup["flops"] * steps / el / 1e12
     exe = setup.get("executed_flops", setup["flops"]) * steps / el / 1e12
     rec = {"workload": setup["workload"], "value": 256 * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-           "dtype": DTYPE_NAME["bf16"], "io_dtype": "fp32 activations in and out; bf16 products", "launch": "hipGraph replay of the captured forward",
+           "dtype": DTYPE_NAME["bf16"], "io_dtype": (IO_BF16 + "; bf16 products") if setup.get("v_bf16") else "fp32 activations in and out; bf16 products",
+           "launch": "hipGraph replay of the captured forward",
            "gflop_per_batch": round(setup["flops"] / 1e9, 3), "executed_gflop_per_batch": round(setup.get("executed_flops", setup["flops"]) / 1e9, 3),
            "achieved_tflops": ach, "frac_of_bf16_peak": ach / PEAK_TFLOPS["bf16"],
            "executed_tflops": exe, "executed_frac_of_bf16_peak": exe / PEAK_TFLOPS["bf16"], "parity_of_timed_forward": parity}
@@ -620,7 +628,9 @@ def aside_kernels(c, dev):
     b1 = torch.randn(h, generator=g).to(dev) * 0.1
     nbx = lib.cti_f16f6_planes_bytes(rows, K1, 0)
     px = torch.empty(nbx, device=dev, dtype=torch.uint8)
-    t_q = t(lambda: L.check(lib.cti_quantize_f16f6(x.data_ptr(), K1, rows, K1, 0, px.data_ptr(), nbx, st), "cti_quantize_f16f6"))
+    L.check(lib.cti_quantize_f16f6(x.data_ptr(), K1, rows, K1, 0, px.data_ptr(), nbx, st), "cti_quantize_f16f6")      # (zero-fills the block's slack rows once)
+    # the pass as cti_tcnet_forward launches it: quantize_rows_f16f6_kernel alone (round 4 timed the C-ABI call's 0.72 GB memset with it: 0.45 vs 0.32 ms in the step)
+    t_q = t(lambda: L.check(lib.cti_quantize_f16f6_into(x.data_ptr(), K1, rows, K1, 0, px.data_ptr(), nbx, st), "cti_quantize_f16f6_into"))
     pw1, pw2 = ops.quantize_f16f6(w1), ops.quantize_f16f6(w2)
     nby = lib.cti_f16f6_planes_bytes(rows, h, 0)
     y1 = torch.zeros(nby, device=dev, dtype=torch.uint8)
@@ -630,7 +640,7 @@ def aside_kernels(c, dev):
     t_r = t(lambda: L.check(lib.cti_gemm_nt_f16f6_planes(pw2.data_ptr(), h, y1.data_ptr(), rows, y2.data_ptr(), nbz, A, h, rows, h, b1.data_ptr(), 1, st), "rank"))
     q_bytes = rows * K1 * 4 + rows * ((K1 + 31) // 32) * 90
     peak = PEAK_TFLOPS["f16f6"]
-    recs = [{"kernel": "quantize_f16f6_kernel (`a` fp32 -> f16f6 planes)", "ms": t_q, "bound": "hbm", "achieved": q_bytes / t_q / 1e6, "unit": "GB/s",
+    recs = [{"kernel": "quantize_rows_f16f6_kernel (`a` fp32 -> f16f6 planes; the step's own variant, no memset)", "ms": t_q, "bound": "hbm", "achieved": q_bytes / t_q / 1e6, "unit": "GB/s",
              "frac": q_bytes / t_q / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": q_bytes}]
     for name, ms, K in (("gemm_f16f6_kernel<EPI_PLANES_T> a-side Tucker projection (512 x %d x %d)" % (rows, K1), t_t, K1),
                         ("gemm_f16f6_kernel<EPI_PLANES_T> a-side rank nets (512 x %d x 512)" % rows, t_r, h)):
@@ -723,13 +733,14 @@ def run_forward(args, world, rank, dev, dist):
         # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled
         # as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is); the summary is committed under profiles/ and names the kernel
         # variant it was taken on -- a record for another variant / batch is refused (traffic = null) rather than quoted stale.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_extra = None, None, {}
         tf = os.path.join(ROOT, "profiles", "core_traffic.json")
         variant = core_variant(args.precision)
         if os.path.isfile(tf):
             tj = json.load(open(tf))
             if tj.get("variant") == variant and tj.get("batch") == c["B"]:
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+                pmc_extra = {k: tj[k] for k in ("l2_hit_rate", "mfma_busy_frac", "effective_clock_ghz", "read_bytes", "write_bytes", "lds_bank_conflict_frac") if k in tj}
             else:
                 traffic_src = "profiles/core_traffic.json is for variant %r at B=%r, this run is %r at B=%d: not quoted" % (tj.get("variant"), tj.get("batch"), variant, c["B"])
         units = MFMA_UNITS_PER_PRODUCT[args.precision]
@@ -754,6 +765,13 @@ def run_forward(args, world, rank, dev, dist):
             "whole_step_tflops": fl["total"] * c["B"] * args.steps / el / 1e12,
             "kernel_ms": kern,
         }
+        if args.precision == "f16f6":
+            # counters of the same kernel variant from the committed PMC passes, and the bytes its tile walk moves from L2 into LDS by
+            # construction: every 256 x 192 tile DMAs (256 + 192) rows x K x 2.8125 B (f16 + fp6 codes + scale bytes)
+            tiles = c["B"] * (-(-c["V"] * c["Q"] * c["glimpse"] // 256)) * (-(-c["A"] // 192))
+            res["roofline"].update(pmc_extra)
+            res["roofline"]["l2_to_lds_bytes"] = int(tiles * (256 + 192) * c["h_mm"] * 2.8125)
+            res["roofline"]["l2_to_lds_note"] = "derived: tiles x (256 + 192) operand rows x K x 2.8125 B per launch; l2_hit_rate / mfma_busy_frac: PMC passes named in traffic_source"
         rk = [{"kernel": "gemm_f16f6_kernel<EPI_INTERLEAVE2> mode-3 product + rank sum" if args.precision == "f16f6" else "mode-3 product + rank sum: " + variant,
                "ms": core_ms, "bound": "mfma", "achieved": achieved, "unit": "TFLOP/s", "frac": achieved / peak, "flops": core_flops}]
         if args.precision == "f16f6" and world == 1 and not args.no_subrecords:

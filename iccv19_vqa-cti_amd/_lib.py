@@ -20,6 +20,7 @@ SIGNATURES = {
     "cti_wn_linear_fwd": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _sz, _vp]),
     "cti_wn_linear_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "cti_zero_row_mask": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),
+    "cti_zero_row_mask_bf16": (_int, [_vp, _i64, _vp, _i64, _int, _vp]),
     "cti_teff_scramble": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_paralind_mbuild_planes_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _i64, _vp]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "cti_tcnet_softmax_partials_bytes": (_sz, [_int] * 7),
     "cti_triattention_workspace_bytes": (_sz, [_int] * 11),
     "cti_triattention_forward": (_int, [_vp] * 13 + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i64, _int]),
+    "cti_triattention_forward_vt16": (_int, [_vp] * 13 + [_int] * 12 + [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i64, _int]),
     "cti_triattention_hoist_ok": (_int, [_int] * 8),
     "cti_tcnet_forward_guard_bytes": (_sz, [_int] * 11),
     "cti_guard_read": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint32)]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     "cti_split_operand": (_int, [_vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_pb": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _int, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_pb_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "cti_gemm_nt_pb_workspace_bytes2": (_sz, [_i64, _i64, _int, _int, _int, _int, _int]),
     "cti_gemm_bf16_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _int, _i64, _i64, _int, _int, _int, _int, _vp, _int, _i64, _vp, _i64, _int, _vp]),
     "cti_gru_forward_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
     "cti_gru_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _sz, _vp]),
@@ -82,6 +85,7 @@ SIGNATURES = {
     "cti_col_sum_workspace_bytes": (_sz, [_i64, _int]),
     "cti_f16f6_planes_bytes": (_sz, [_i64, _int, _i64]),
     "cti_quantize_f16f6": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _sz, _vp]),
+    "cti_quantize_f16f6_into": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _sz, _vp]),
     "cti_gemm_nt_f16f6": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _vp, _int, _vp, _int, _vp]),
     "cti_gemm_nt_f16f6_planes": (_int, [_vp, _i64, _vp, _i64, _vp, _sz, _i64, _int, _int, _int, _vp, _int, _vp]),
     "cti_quantize_f16f6_scaled": (_int, [_vp, _i64, _i64, _int, _i64, _vp, _int, _vp, _sz, _vp]),
@@ -122,7 +126,9 @@ SIGNATURES = {
     "cti_pool_dw_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
+    "cti_bi_pool_shift_vt16_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
     "cti_tri_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_tri_pool_shift_vt16_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_axpby": (_int, [_vp, C.c_float, _vp, C.c_float, _vp, _i64, _vp]),
     "cti_joint_sums": (_int, [_vp, _int, C.c_float, _vp, _int, C.c_float, _vp, C.c_float, _vp, C.c_float, _vp, _int, _int, _vp]),
     "cti_linear_small_n": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp]),
@@ -131,6 +137,7 @@ SIGNATURES = {
     "cti_bi_logits_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_mfma_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_logits_prec_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "cti_bi_logits_prec_vt16_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_biattention_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
 }
 
@@ -138,6 +145,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3
 E_UNSUPPORTED = -4                                   # CTI_E_UNSUPPORTED: shape / mode outside a specialised kernel
 ACT_NONE, ACT_RELU = 0, 1
 TUNE_GEMM_CFG, TUNE_TRI_CHUNK = 1, 2                # cti_set_tuning keys
+TUNE_GUARD_RHO_BF16X3, TUNE_GUARD_RHO_FP32, TUNE_GUARD_POISON_BITS, TUNE_F6_CORE_FREE_CUS, TUNE_GUARD_STRATA = 3, 4, 5, 6, 7     # f16f6 guard policy (include/cti_hip.h)
 GUARD_SATURATED, GUARD_UNDERFLOW, GUARD_NONFINITE = 1, 2, 4     # status bits of the f16f6 range guard (cti_guard_read)
 
 _lib = None

@@ -58,7 +58,7 @@ class TriAttention(nn.Module):
         if self.glimpse >= 2 and t._fusable(v, q, a):
             # eval: logits, mask and softmax in ONE library call (cti_triattention_forward)
             tucker, rank = t._fused_args()
-            return ops.triattention_forward(v.float(), q.float(), a.float(), tucker, rank, t.T_g.detach(), relu=(t._act == 'ReLU'), prepared=t._prep,
+            return ops.triattention_forward(v if v.dtype == torch.bfloat16 else v.float(), q.float(), a.float(), tucker, rank, t.T_g.detach(), relu=(t._act == 'ReLU'), prepared=t._prep,
                                             v_tucked=_v_tucked if t._act == 'ReLU' else None, v_rep=_v_rep)
         logits, mask, partials = self.TriAtt(v, q, a, _want_mask=True, _want_sm_partials=True)
         if logits.dim() != 5:

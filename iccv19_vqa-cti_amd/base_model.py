@@ -11,6 +11,7 @@ Outside the path (they raise): the counting module (`--use_counter`, src/countin
 initialisation of the embeddings (`tfidf_loading`, src/utils.py) is data preparation -- load a checkpoint or call
 `WordEmbedding.init_embedding`."""
 import contextlib
+import math
 import os as _os
 
 import torch
@@ -100,6 +101,14 @@ def _beside(device, fn):
     return res, join
 
 
+def _v_as_taken(v, module):
+    """(round 5) BASELINE configs[2] / [3] name bf16 tensors: an inference forward in the plain-bf16 mode takes a bf16 `v` as it stands -- the row-major bf16 matrix
+    is the projection GEMMs' A operand, their bf16 output the pools' and the attention's operand.  Any other mode, training and autograd widen it once here."""
+    if v.dtype == torch.bfloat16 and (module.training or torch.is_grad_enabled() or ops.get_precision() != "bf16" or not v.is_cuda):
+        return ops.widen_bf16(v)
+    return v
+
+
 def _no_counter(counter):
     if counter is not None:
         raise NotImplementedError("the counting module (src/counting.py, --use_counter) is outside the CTI path; build with counter=None")
@@ -126,6 +135,7 @@ class BanModel(nn.Module):
     def forward(self, v, b, q, labels):
         """v: [batch, num_objs, obj_dim]; b: boxes (read by the counter only); q: [batch, seq_length] token ids.
         return: logits (not probs), att"""
+        v = _v_as_taken(v, self)
         side = None if torch.is_grad_enabled() or self.training else ops.aux_stream_object(v.device)
         lg = self.v_att.logits
         if side is not None and lg.h_out is not None and v.is_cuda:
@@ -220,6 +230,7 @@ class _TriModel(nn.Module):
     """The forward shared by FFOE CTIModel (src/FFOE/base_model.py:112-136) and MC TanModel (src/MC/base_model.py:128-152)."""
 
     def _forward(self, t_att, v, q, ans):
+        v = _v_as_taken(v, self)
         side = None if torch.is_grad_enabled() else ops.aux_stream_object(v.device)
         if side is not None:
             # inference: the answer GRU (a few short, latency-bound steps) runs on the auxiliary stream beside the question GRU
@@ -240,16 +251,24 @@ class _TriModel(nn.Module):
         # rows b*r .. b*r+r-1 of v are identical): the projections -- and the attention's whole v side -- run once per image
         rep, eq = getattr(self, "v_replication", 1), None
         if rep == "auto":
-            # r is DETECTED once, on the first forward that is not being captured (a row-by-row comparison on the device + one read-back), and kept; every later
-            # forward re-checks its own batch on the device and NaN-fills its logits if the batch is not made of groups of r identical images
+            # Eager forwards DETECT r for their own batch (a row-by-row comparison on the device beside the question GRU + one read-back of B bytes from the
+            # side stream): any r such that the batch is made of groups of r identical images is valid for THAT batch, so nothing can go wrong and nothing is
+            # poisoned (round 5, ADVICE r4: an r frozen from the first batch -- two questions about one image give 8, not 4 -- NaN-filled every later batch that
+            # crossed an image boundary differently).  Under hipGraph capture the host cannot look: the replayed graph uses the gcd of every r seen eagerly so far
+            # (it only shrinks), re-checks each replayed batch on the device and NaN-fills its logits if the batch does not keep that promise; callers that
+            # capture should prefer the explicit hint (v_replication = 4).
             rep = 1
             if not torch.is_grad_enabled() and v.is_cuda and v.dim() == 3:
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):      # (v-only work: beside the question GRU)
                     eq = ops.rows_equal_prev(v)
                     if eq is not None:
-                        if getattr(self, "_v_rep_auto", None) is None and not torch.cuda.is_current_stream_capturing():
-                            object.__setattr__(self, "_v_rep_auto", ops.replication_of(eq))
-                        rep = getattr(self, "_v_rep_auto", None) or 1
+                        if torch.cuda.is_current_stream_capturing():
+                            rep = getattr(self, "_v_rep_auto", None) or 1
+                        else:
+                            rep = ops.replication_of(eq)
+                            prev = getattr(self, "_v_rep_auto", None)
+                            object.__setattr__(self, "_v_rep_auto", rep if prev is None else math.gcd(int(prev), int(rep)))
+                            eq = None                    # verified on the host for this very batch: no device-side poison
                         if v.shape[0] % rep:
                             rep = 1
                 if rep == 1:
@@ -405,6 +424,8 @@ class MCBanModel(nn.Module):
         self.counter = counter
 
     def forward(self, v, b, q, ans):
+        if v.dtype == torch.bfloat16:
+            v = ops.widen_bf16(v)                                           # (this model's attentions read fp32 rows)
         q_emb = self.q_emb.forward_all(self.w_emb(q))
         ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
         att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q

@@ -93,6 +93,8 @@ class BCNet(nn.Module):
         """forward_with_weights given v_ = v_net(v) (the model forwards compute it for all glimpses in one batched GEMM)."""
         q_ = self.q_net(q)
         w = w.float()
+        if v_.dtype == torch.bfloat16:
+            v_ = ops.widen_bf16(v_)                                     # (the literal loop's pool reads fp32 rows; the hoisted loop's reads bf16)
         if _needs_grad(v_, q_, w):
             return AG.BiPoolFn.apply(v_, q_, w, self.k)
         return ops.bi_pool(v_, q_, w, self.k)

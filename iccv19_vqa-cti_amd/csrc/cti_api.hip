@@ -22,8 +22,16 @@ int fail(int code, const char* fmt, ...) {
 // tile geometry must not change what another thread's production call launches.
 static thread_local int g_gemm_cfg = -1;
 static thread_local long long g_tri_chunk = 0;
+static thread_local int g_guard_rho_milli[2] = {2750, 5500};      // cancellation estimate beyond which a guarded f16f6 call is re-run as bf16x3 / as exact fp32 (x 1000)
+static thread_local int g_guard_poison_bits = 31;                 // status bits that NaN-fill the output of a guarded call
+static thread_local int g_guard_strata = 1;                       // test knob: 0 = the cancellation estimate samples 32 evenly spaced rows per operand (round 4)
+static thread_local int g_f6_core_free_cus = -1;                  // CUs the mode-3 product leaves to the guard kernels beside it (-1 = the library's default)
 int tuning_gemm_cfg() { return g_gemm_cfg; }
 int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk; }
+float tuning_guard_rho(int which) { return 1e-3f * (float)g_guard_rho_milli[which ? 1 : 0]; }
+unsigned tuning_guard_poison_bits() { return (unsigned)g_guard_poison_bits; }
+int tuning_f6_core_free_cus() { return g_f6_core_free_cus; }
+int tuning_guard_strata() { return g_guard_strata; }
 
 }  // namespace cti
 
@@ -38,6 +46,19 @@ extern "C" int cti_set_tuning(int key, int64_t value) {
             CTI_REQUIRE(value == 0 || (value >= 4 && value <= (1ll << 30) && value % 4 == 0), CTI_E_SHAPE,
                         "cti_set_tuning: TRI_CHUNK must be 0 (auto) or a multiple of 4 in [4, 2^30], got %lld", (long long)value);
             g_tri_chunk = (long long)value; return CTI_OK;
+        case CTI_TUNE_GUARD_RHO_BF16X3:
+        case CTI_TUNE_GUARD_RHO_FP32:
+            CTI_REQUIRE(value >= 1 && value <= 1000000000ll, CTI_E_SHAPE, "cti_set_tuning: a guard threshold is rho x 1000 in [1, 1e9], got %lld", (long long)value);
+            g_guard_rho_milli[key == CTI_TUNE_GUARD_RHO_FP32] = (int)value; return CTI_OK;
+        case CTI_TUNE_GUARD_POISON_BITS:
+            CTI_REQUIRE(value >= 0 && value <= 31, CTI_E_SHAPE, "cti_set_tuning: GUARD_POISON_BITS is a mask of the five status bits, got %lld", (long long)value);
+            g_guard_poison_bits = (int)value; return CTI_OK;
+        case CTI_TUNE_GUARD_STRATA:
+            CTI_REQUIRE(value == 0 || value == 1, CTI_E_SHAPE, "cti_set_tuning: GUARD_STRATA is 0 or 1, got %lld", (long long)value);
+            g_guard_strata = (int)value; return CTI_OK;
+        case CTI_TUNE_F6_CORE_FREE_CUS:
+            CTI_REQUIRE(value >= -1 && value <= 64, CTI_E_SHAPE, "cti_set_tuning: F6_CORE_FREE_CUS must be -1 (default) or 0 .. 64, got %lld", (long long)value);
+            g_f6_core_free_cus = (int)value; return CTI_OK;
         default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
     }
 }
@@ -45,6 +66,11 @@ extern "C" int64_t cti_get_tuning(int key) {
     switch (key) {
         case CTI_TUNE_GEMM_CFG: return tuning_gemm_cfg();
         case CTI_TUNE_TRI_CHUNK: return tuning_tri_chunk();
+        case CTI_TUNE_GUARD_RHO_BF16X3: return g_guard_rho_milli[0];
+        case CTI_TUNE_GUARD_RHO_FP32: return g_guard_rho_milli[1];
+        case CTI_TUNE_GUARD_POISON_BITS: return g_guard_poison_bits;
+        case CTI_TUNE_F6_CORE_FREE_CUS: return g_f6_core_free_cus;
+        case CTI_TUNE_GUARD_STRATA: return g_guard_strata;
         default: return INT64_MIN;
     }
 }

@@ -434,12 +434,29 @@ __device__ __forceinline__ float shift1(float x, float a, int relu) { x += a; re
 // `c ? *p : z` with two lvalues is an lvalue conditional: the constant would live in private memory (scratch) and be loaded from there -- select VALUES instead
 __device__ __forceinline__ float2 ld2_or_zero(bool c, const float* p) { float2 r = make_float2(0.f, 0.f); if (c) r = *reinterpret_cast<const float2*>(p); return r; }
 __device__ __forceinline__ float4 ld4_or_zero(bool c, const float* p) { float4 r = make_float4(0.f, 0.f, 0.f, 0.f); if (c) r = *reinterpret_cast<const float4*>(p); return r; }
+// Round 5: the projected `vt` rows may be bf16 (vt16 != 0: the plain-bf16 mode's hoisted projections write the pools' operand as bf16 rows -- half the bytes of
+// the tensor these kernels exist to stream).  Four consecutive channels at BYTE address p: one 16-B fp32 load or one 8-B bf16 load widened in registers.
+typedef unsigned pl_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldv4_or_zero(bool c, const char* p, int vt16) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c) {
+        if (vt16) {
+            const pl_u32x2 u = *reinterpret_cast<const pl_u32x2*>(p);
+            r.x = __builtin_bit_cast(float, u[0] << 16); r.y = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+            r.z = __builtin_bit_cast(float, u[1] << 16); r.w = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+        } else r = *reinterpret_cast<const float4*>(p);
+    }
+    return r;
+}
+__device__ __forceinline__ float ldv1(const char* p, int vt16) {
+    return vt16 ? __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(p) << 16) : *reinterpret_cast<const float*>(p);
+}
 
 template <bool TRI, int AP, int NG, int QX>
 __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                           const float* __restrict__ at, const float* __restrict__ w,
                                                           int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                          float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh) {
+                                                          float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh, int vt16) {
 #ifndef CTI_POOL_VC
 #define CTI_POOL_VC 9
 #endif
@@ -492,13 +509,14 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
         }
     }
     __syncthreads();
-    const float* vb = vt + (int64_t)b * V * D + dd;
+    const int vsz = vt16 ? 2 : 4;                                     // bytes per element of vt
+    const char* vb = reinterpret_cast<const char*>(vt) + ((int64_t)b * V * D + dd) * vsz;
     float4 acc = z4;
     const int vper = (V + NG - 1) / NG, v_lo = grp * vper, v_hi = min(V, v_lo + vper);
     for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
         float4 vr[VC];
 #pragma unroll
-        for (int u = 0; u < VC; ++u) vr[u] = ld4_or_zero(v0 + u < v_hi, vb + (int64_t)(v0 + u) * D);
+        for (int u = 0; u < VC; ++u) vr[u] = ldv4_or_zero(v0 + u < v_hi, vb + (int64_t)(v0 + u) * D * vsz, vt16);
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -889,7 +907,7 @@ template <int TERMS>
 __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restrict__ vt, const float* __restrict__ qt, const float* __restrict__ h,
                                                             const float* __restrict__ h_scale, const float* __restrict__ h_bias,
                                                             float* __restrict__ logits, int G, int V, int Q, int D, int MT, int NT, int dper, int atomic, int NTW,
-                                                            const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p, int* __restrict__ sm_cnt, int sm_parts) {
+                                                            const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p, int* __restrict__ sm_cnt, int sm_parts, int vt16) {
     __shared__ __attribute__((aligned(16))) unsigned short As[2][2][64][40];      // [buffer][hi | lo][row v][32 k + 8 pad]
     const int b = blockIdx.x, ks = blockIdx.y;
     // blockIdx.z: which group of NTW column tiles this workgroup owns (round-3 experiment: thinner workgroups to put more loads in flight -- measured
@@ -904,7 +922,20 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
     // staging role: thread -> (row, 8 consecutive k) of the vt slice
     const int sr = t >> 2, skq = t & 3;
     const bool sok = sr < V;
-    const float* sp = vt + ((int64_t)b * V + (sok ? sr : 0)) * D + skq * 8;
+    // (round 5) vt16: the rows are bf16 already -- a thread's eight values are ONE 16-B load that goes to the hi image as it is (lo = 0)
+    const int vsz = vt16 ? 2 : 4;
+    const char* sp = reinterpret_cast<const char*>(vt) + (((int64_t)b * V + (sok ? sr : 0)) * D + skq * 8) * vsz;
+    auto stage_load = [&](int d, float4& r0, float4& r1) {
+        if (vt16) r0 = *reinterpret_cast<const float4*>(sp + (int64_t)d * 2);
+        else { r0 = *reinterpret_cast<const float4*>(sp + (int64_t)d * 4); r1 = *reinterpret_cast<const float4*>(sp + (int64_t)d * 4 + 16); }
+    };
+    auto stage_split = [&](const float4 r0, const float4 r1, lbf16x8& hi, lbf16x8& lo) {
+        if (vt16) {
+            hi = __builtin_bit_cast(lbf16x8, r0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lo[e] = static_cast<__bf16>(0.f);
+        } else split8t<TERMS>(r0, r1, hi, lo);
+    };
     // right-operand role: this wave's column tiles wid and wid + 4
     bool cok[2]; int cg[2], cq[2];
     const float* hp[2]; const float* qp[2];
@@ -923,9 +954,9 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         for (int m = 0; m < 4; ++m) acc[j][m] = lf32x4{0.f, 0.f, 0.f, 0.f};
     {
         float4 a0 = z4, a1 = z4;
-        if (sok && d_lo < d_hi) { a0 = *reinterpret_cast<const float4*>(sp + d_lo); a1 = *reinterpret_cast<const float4*>(sp + d_lo + 4); }
+        if (sok && d_lo < d_hi) stage_load(d_lo, a0, a1);
         lbf16x8 hi, lo;
-        split8t<TERMS>(a0, a1, hi, lo);
+        stage_split(a0, a1, hi, lo);
         *reinterpret_cast<lbf16x8*>(&As[0][0][sr][skq * 8]) = hi;
         if (TERMS == 3) *reinterpret_cast<lbf16x8*>(&As[0][1][sr][skq * 8]) = lo;
     }
@@ -950,7 +981,7 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
                                make_float4(rh1[j].x * rq1[j].x, rh1[j].y * rq1[j].y, rh1[j].z * rq1[j].z, rh1[j].w * rq1[j].w), bh[j], bl[j]);
         float4 n0 = z4, n1 = z4;
         if (more) {                                                  // the next slice's loads fly under this slice's MFMAs
-            if (sok) { n0 = *reinterpret_cast<const float4*>(sp + d0 + 32); n1 = *reinterpret_cast<const float4*>(sp + d0 + 36); }
+            if (sok) stage_load(d0 + 32, n0, n1);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 if (cok[j]) {
@@ -978,7 +1009,7 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
         }
         if (more) {
             lbf16x8 hi, lo;
-            split8t<TERMS>(n0, n1, hi, lo);
+            stage_split(n0, n1, hi, lo);
             *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][0][sr][skq * 8]) = hi;
             if (TERMS == 3) *reinterpret_cast<lbf16x8*>(&As[buf ^ 1][1][sr][skq * 8]) = lo;
         }
@@ -1062,7 +1093,8 @@ template <int A_, int KS, int TERMS>
 __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh) {
+                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh, int vt16) {
+    const int vsz = vt16 ? 2 : 4;                                   // (round 5) bytes per element of vt: fp32 or bf16 rows
     // Round 4: the sample's compacted attention slice is split into bf16 hi / lo ONCE per workgroup, into LDS, and the MFMA fragments are read from there at
     // every use (20 ds_read_b128 per tile) instead of living in 80 registers per wave: eight waves fit the register file (two per SIMD), ONE workgroup per sample
     // covers its 32 channel tiles, and the set-up -- what this kernel's time is made of -- is paid once per sample.
@@ -1091,11 +1123,11 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
             _Pragma("unroll") for (int q = 0; q < 16; ++q) if (q < Q) qr_[q] = shift1(qr_[q], dq_, sh.relu);     \
             _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = shift1(ar_[a], da_, sh.relu);                \
         }                                                                                                        \
-        const float* vb_ = vt + (int64_t)(b / v_rep) * V * D + d_;      /* v_rep > 1: one vt block per image, v_rep batch rows share it */ \
+        const char* vb_ = reinterpret_cast<const char*>(vt) + ((int64_t)(b / v_rep) * V * D + d_) * vsz;      /* v_rep > 1: one vt block per image, v_rep batch rows share it */ \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                         \
             const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;                                                       \
-            v0_[e] = v < V ? vb_[(int64_t)v * D] : 0.f;                                                          \
-            v1_[e] = (two && v + 32 < V) ? vb_[(int64_t)(v + 32) * D] : 0.f;                                     \
+            v0_[e] = v < V ? ldv1(vb_ + (int64_t)v * D * vsz, vt16) : 0.f;                                       \
+            v1_[e] = (two && v + 32 < V) ? ldv1(vb_ + (int64_t)(v + 32) * D * vsz, vt16) : 0.f;                  \
         }                                                                                                        \
     }
     if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)              // (in flight while the attention slice is compacted and split below)
@@ -1516,7 +1548,7 @@ static int tri_pool_impl(const float* vt, const float* qt, const float* at, cons
         if (lds_p < sizeof(float4) * 128 * (NG - 1)) lds_p = sizeof(float4) * 128 * (NG - 1);
         if (lds_p <= 64 * 1024) {
             const dim3 grid((D / 4 + 127) / 128, B);
-#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh)
+#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh, 0)
             if (AP == 4) { if (Q == 14) CTI_TP(4, 14); else if (Q == 12) CTI_TP(4, 12); else CTI_TP(4, 0); }
             else         { if (Q == 14) CTI_TP(8, 14); else if (Q == 12) CTI_TP(8, 12); else CTI_TP(8, 0); }
 #undef CTI_TP
@@ -1548,7 +1580,7 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
 }
 
 static int bi_pool_impl(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
-                        float* out, int B, int V, int Q, int D, int k, PoolShift sh, void* stream) {
+                        float* out, int B, int V, int Q, int D, int k, PoolShift sh, void* stream, int vt16 = 0) {
     const bool shifted = sh.relu || sh.qadd;
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(out);
     if (shifted && sh.qadd && !aligned16(sh.qadd)) return CTI_E_UNSUPPORTED;
@@ -1562,12 +1594,12 @@ static int bi_pool_impl(const float* vt, const float* qt, const float* w, int64_
         size_t lds_b = sizeof(float) * (size_t)V * 16;
         if (lds_b < sizeof(float4) * 128 * (NGB - 1)) lds_b = sizeof(float4) * 128 * (NGB - 1);
 #define CTI_BP(QXv) hipLaunchKernelGGL((pool_stream_kernel<false, 4, NGB, QXv>), dim3((D / 4 + 127) / 128, B), dim3(128 * NGB), lds_b, as_stream(stream), \
-                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D, sh)
+                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D, sh, vt16)
         if (Q == 14) CTI_BP(14); else if (Q == 12) CTI_BP(12); else CTI_BP(0);
 #undef CTI_BP
         return launch_status("cti_bi_pool_fwd");
     }
-    if (shifted) return CTI_E_UNSUPPORTED;                         // (only the k = 1 streaming kernel forms relu(row + add) on load)
+    if (shifted || vt16) return CTI_E_UNSUPPORTED;                 // (only the k = 1 streaming kernel forms relu(row + add) on load / reads bf16 rows)
     if (k == 3 && Q <= 16 && D % 6 == 0 && (size_t)V * 16 * sizeof(float) <= 64 * 1024 && ((reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(out)) & 7) == 0) {
         constexpr int NG3 = 2;
         size_t lds3 = sizeof(float) * (size_t)V * 16;
@@ -1596,6 +1628,14 @@ extern "C" int cti_bi_pool_shift_fwd(const float* vt, const float* qt, const flo
     return bi_pool_impl(vt, qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, 1, PoolShift{qadd, nullptr, 1}, stream);
 }
 
+// The same with `vt` as bf16 rows (round 5: what the plain-bf16 mode's hoisted v projection writes -- cti_gemm_bf16_rows with c_bf16 = 1).  8-B aligned rows
+// (D % 4 == 0); CTI_E_UNSUPPORTED outside the streaming kernel's shapes, as above.
+extern "C" int cti_bi_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                                          float* out, int B, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(w);
+    return bi_pool_impl(static_cast<const float*>(vt_bf16), qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, 1, PoolShift{qadd, nullptr, 1}, stream, 1);
+}
+
 extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                                  float* logits, int B, int G, int V, int Q, int D, void* stream) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
@@ -1606,7 +1646,7 @@ extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* 
 }
 
 static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
-                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms = 3);
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms = 3, int vt16 = 0);
 
 extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                                       float* logits, int B, int G, int V, int Q, int D, void* stream) {
@@ -1618,6 +1658,13 @@ extern "C" int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const fl
 extern "C" int cti_bi_logits_prec_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                                       float* logits, int B, int G, int V, int Q, int D, int prec, void* stream) {
     return bi_logits_mfma_impl(vt, qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, nullptr, nullptr, nullptr, prec == CTI_PREC_BF16 ? 1 : 3);
+}
+
+// ... with `vt` as bf16 rows (round 5; the plain-bf16 mode's attention projection written by cti_gemm_bf16_rows): the LDS-staged kernel's shapes only
+// (V <= 64, G*Q <= 128, D % 32 == 0), CTI_E_UNSUPPORTED otherwise.
+extern "C" int cti_bi_logits_prec_vt16_fwd(const void* vt_bf16, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                                           float* logits, int B, int G, int V, int Q, int D, int prec, void* stream) {
+    return bi_logits_mfma_impl(static_cast<const float*>(vt_bf16), qt, h, h_scale, h_bias, logits, B, G, V, Q, D, stream, nullptr, nullptr, nullptr, prec == CTI_PREC_BF16 ? 1 : 3, 1);
 }
 
 // BiAttention.forward_all's logits + mask + softmax in ONE launch (reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the bilinear
@@ -1632,7 +1679,7 @@ extern "C" int cti_biattention_fwd(const float* vt, const float* qt, const float
 }
 
 static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
-                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms) {
+                               float* logits, int B, int G, int V, int Q, int D, void* stream, const uint8_t* sm_mask, float* sm_p, int* sm_cnt, int terms, int vt16) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(h); CTI_REQUIRE_PTR(logits);
     CTI_REQUIRE(B > 0 && B <= 65535 && G > 0 && V > 0 && Q > 0 && D > 0, CTI_E_SHAPE, "cti_bi_logits_mfma_fwd: B=%d G=%d V=%d Q=%d D=%d", B, G, V, Q, D);
     if (D % 16 != 0 || !aligned16(vt) || !aligned16(qt) || !aligned16(h))
@@ -1661,12 +1708,13 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
         const int NTW = NT > ntw_lim ? ntw_lim : NT, NZ = (NT + NTW - 1) / NTW;
         if (terms == 1)
             hipLaunchKernelGGL(bi_logits_lds_kernel<1>, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
-                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
+                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ, vt16);
         else
             hipLaunchKernelGGL(bi_logits_lds_kernel<3>, dim3(B, KS, NZ), dim3(256), 0, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, (V + 15) / 16,
-                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ);
+                               NT, dper, KS > 1 ? 1 : 0, NTW, sm_mask, sm_p, sm_cnt, KS * NZ, vt16);
         return launch_status("cti_bi_logits_mfma_fwd");
     }
+    if (vt16) return CTI_E_UNSUPPORTED;                             // bf16 rows: the LDS-staged kernel only
     const int MT = (V + 31) / 32, NT = (G * Q + 31) / 32;
     const int KS = D >= 1024 ? 2 : 1;
     const int dper = ((D / 16 + KS - 1) / KS) * 16;
@@ -1676,7 +1724,7 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
 }
 
 static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at, const float* w, int64_t w_sb, int64_t w_sv,
-                              int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, PoolShift sh, void* stream, int terms = 3) {
+                              int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep, PoolShift sh, void* stream, int terms = 3, int vt16 = 0) {
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(at); CTI_REQUIRE_PTR(w); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && A > 0 && D > 0 && B <= 65535, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: B=%d V=%d Q=%d A=%d D=%d", B, V, Q, A, D);
     CTI_REQUIRE(v_rep >= 1 && B % v_rep == 0, CTI_E_SHAPE, "cti_tri_pool_mfma_fwd: v_rep=%d does not divide B=%d", v_rep, B);
@@ -1697,8 +1745,8 @@ static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at,
     const int tpw = tpw_env > 0 ? tpw_env : (tiles >= 32 ? (tiles + nw - 1) / nw : 1);
     const dim3 grid((tiles + nw * tpw - 1) / (nw * tpw), B);
     const size_t lds = sizeof(unsigned short) * 2 * 64 * (size_t)(KS * 16 + 8);
-#define CTI_TM(Av, KSv) { if (terms == 1) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 1>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh); \
-                          else hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 3>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh); }
+#define CTI_TM(Av, KSv) { if (terms == 1) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 1>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh, vt16); \
+                          else hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 3>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh, vt16); }
     if (A == 3) { if (KS <= 2) CTI_TM(3, 2) else CTI_TM(3, 3) }
     else        { if (KS <= 4) CTI_TM(6, 4) else if (KS == 5) CTI_TM(6, 5) else CTI_TM(6, 6) }
 #undef CTI_TM
@@ -1724,6 +1772,15 @@ extern "C" int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const fl
     }
     if (v_rep != 1) return CTI_E_UNSUPPORTED;
     return tri_pool_impl(vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, sh, stream);
+}
+
+// ... with `vt` as bf16 rows (round 5): the MFMA form only (A = 3 or 6); CTI_E_UNSUPPORTED otherwise -- the caller widens the rows.
+extern "C" int cti_tri_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
+                                           int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
+                                           int use_mfma, void* stream) {
+    if (!use_mfma) return CTI_E_UNSUPPORTED;
+    return tri_pool_mfma_impl(static_cast<const float*>(vt_bf16), qt, at, w, w_sb, w_sv, w_sq, w_sa, out, B, V, Q, A, D, v_rep, PoolShift{qadd, aadd, 1}, stream,
+                              use_mfma == 2 ? 1 : 3, 1);
 }
 
 extern "C" int cti_pool_dw_mfma(const float* dout, const float* vt, const float* qt, const float* at, float* dw, int B, int V, int Q, int A, int D,

@@ -553,6 +553,18 @@ extern "C" size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t ro
     if (rowsA_total <= 8192) n = n > al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + PB_BATCHED_PARTIALS ? n : al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K)) + PB_BATCHED_PARTIALS;
     return n;
 }
+// The exact need of ONE call (round 5, ADVICE r4: the bound above adds 18.9 MB of batched-partials room to every product of <= 8 192 rows, also to the
+// unbatched ones that never split that way, once per stream pool): A planes + the partials the call's own plan writes.
+extern "C" size_t cti_gemm_nt_pb_workspace_bytes2(int64_t rowsA_total, int64_t rowsB_total, int K, int prec, int nb1, int M, int N) {
+    if (prec == CTI_PREC_F32 || rowsA_total <= 0 || rowsB_total <= 0 || K <= 0 || nb1 <= 0 || M <= 0 || N <= 0) return 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t n = al(planes_bytes(rowsA_total + PLANE_SLACK_ROWS, K));
+    int S = 1;
+    if (nb1 == 1 && M == rowsA_total && N == rowsB_total) S = plan_ksplit(M, N, planes_kp(K), 1);
+    else if (nb1 > 1 && rowsA_total <= 8192) S = plan_ksplit(M, N, planes_kp(K), nb1);
+    if (S > 1) n += al(sizeof(float) * (size_t)S * (size_t)nb1 * (size_t)M * (size_t)N);
+    return n;
+}
 extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
                               float* C, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
                               const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream) {
@@ -561,7 +573,8 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     CTI_REQUIRE((int64_t)(nb1 - 1) * rA1 + M <= rowsA_total && (int64_t)(nb1 - 1) * rB1 + N <= rowsB_total, CTI_E_SHAPE, "cti_gemm_nt_pb: batches run past the operand rows");
     CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_gemm_nt_pb: act=%d", act);
     CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_nt_pb: prec=%d (resident planes exist in the bf16 modes only)", prec);
-    CTI_REQUIRE(workspace_bytes >= cti_gemm_nt_pb_workspace_bytes(rowsA_total, rowsB_total, K, prec), CTI_E_WORKSPACE, "cti_gemm_nt_pb: workspace too small");
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_nt_pb_workspace_bytes2(rowsA_total, rowsB_total, K, prec, nb1, M, N), CTI_E_WORKSPACE, "cti_gemm_nt_pb: workspace %zu < %zu", workspace_bytes,
+                cti_gemm_nt_pb_workspace_bytes2(rowsA_total, rowsB_total, K, prec, nb1, M, N));
     const int Kp = planes_kp(K);
     const int64_t ra = rowsA_total + PLANE_SLACK_ROWS, rb = rowsB_total + PLANE_SLACK_ROWS;
     unsigned short* ah = static_cast<unsigned short*>(workspace);

@@ -19,6 +19,10 @@ int fail(int code, const char* fmt, ...);
 // softmax at small shapes.  -1 / 0 = the library's own choice.  They never change results beyond fp32 summation order.
 int tuning_gemm_cfg();            // -1 auto, 0 = 128x128, 1 = 256x128, 2 = 256x256 tile of the plane GEMM
 int64_t tuning_tri_chunk();       // 0 auto (32768), else positions per chunk of the Tri softmax (forward and backward)
+float tuning_guard_rho(int which);    // f16f6 guard policy (cti_set_tuning keys 3 / 4): cancellation estimate beyond which a call belongs in bf16x3 (0) / exact fp32 (1)
+unsigned tuning_guard_poison_bits();  // key 5: status bits that NaN-fill the output
+int tuning_guard_strata();            // key 7 (tests): 0 = the cancellation estimate without its strata maxima
+int tuning_f6_core_free_cus();        // key 6: CUs the mode-3 product leaves free for the guard kernels beside it (-1 = default)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -126,6 +130,7 @@ int planes_kp(int K);
 size_t planes_bytes(int64_t rows_alloc, int K);
 int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,
                  hipStream_t st);
+int split_planes16(const unsigned short* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc, hipStream_t st);   // bf16 rows -> planes (lo = 0)
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
 // cti_gemm16.hip: the plain-bf16 (terms = 1) products of the 256 x 256 tile with fp32-row or planes epilogues
 bool gemm16_eligible(const PlaneGemmArgs& a);

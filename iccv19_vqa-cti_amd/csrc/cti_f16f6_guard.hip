@@ -16,7 +16,7 @@
 // status bits: 1 = a block at or beyond the f16 range (|x| > 61440, incl. inf / NaN in an encoded tensor), 2 = a tensor that is not all zero
 // but whose largest block lies below 2^-12 (hi parts subnormal: absolute error 2^-29 stops being small against the tensor), 4 = non-finite
 // values in V^ / Q^ / T_eff (the M build's encoder would swallow them), 8 / 16 = the mode-3 product cancels so heavily that the f16f6 (8) or even the
-// bf16x3 (16) rounding may exceed 1e-4 of the largest output (guard_cancel's sampled estimate).  The host reads the word after ev_core_begin (cti_guard_read) and
+// bf16x3 (16) rounding may exceed 1e-4 of the largest output (guard_cancel's sampled estimate).  The host reads the word behind the verdict's event (cti_guard_read) and
 // re-runs the call in the bf16x3 mode; under hipGraph capture, where the host cannot look, the NaN fill is the signal.
 #include "cti_common.h"
 #include "cti_f16f6.h"
@@ -108,31 +108,81 @@ __global__ void guard_verdict_kernel(GuardArgs g) {
     }
     // cancellation estimate of the mode-3 product (guard_cancel, stream-ordered in front of this scan): the estimated normalised error is
     // ~2^-17 x ratio for the f16f6 product, ~2^-19 x ratio for bf16x3 -- beyond 1e-4 the call belongs in the next mode up
-    const float ratio = __builtin_bit_cast(float, atomicOr(&g.words[GUARD_W_RATIO], 0u));
-    if (ratio > GUARD_RATIO_BF16X3) status |= CTI_GUARD_CANCEL;
-    if (ratio > GUARD_RATIO_FP32) status |= CTI_GUARD_CANCEL_HEAVY;
+    const float amax = __builtin_bit_cast(float, atomicOr(&g.words[GUARD_W_ABSMAX], 0u)), dmax = __builtin_bit_cast(float, atomicOr(&g.words[GUARD_W_DOTMAX], 0u));
+    const float ratio = amax > 0.f ? fminf(amax / fmaxf(dmax, 1e-30f), 3.0e38f) : 0.f;
+    atomicExch(&g.words[GUARD_W_RATIO], __builtin_bit_cast(unsigned, ratio));
+    if (ratio > g.rho_bf16x3) status |= CTI_GUARD_CANCEL;
+    if (ratio > g.rho_fp32) status |= CTI_GUARD_CANCEL_HEAVY;
     atomicExch(&g.words[GUARD_W_STATUS], status);
 }
 
-// ---- cancellation estimate (see cti_f16f6.h).  One workgroup per batch: 32 rows of M and 32 rows of A^ (evenly spaced, offset by the batch index)
-// are copied from the f16 hi planes into LDS (row pitch K * 2 + 16 B: the eight threads that share an M row read eight different A^ rows without a
-// bank conflict), thread t multiplies the pairs (t >> 3, (t & 7) + 8 u), u < 4, with v_dot2_f32_f16 -- once as they stand, once with the sign
-// bits cleared: 1 024 pairs per batch.
+// ---- cancellation estimate (see cti_f16f6.h).  One workgroup per batch: 32 rows of M and 32 rows of A^ are copied from the f16 hi planes into LDS
+// (row pitch K * 2 + 16 B: the eight threads that share an M row read eight different A^ rows without a bank conflict), thread t multiplies the
+// pairs (t >> 3, (t & 7) + 8 u), u < 4, with v_dot2_f32_f16 -- once as they stand, once with the sign bits cleared: 1 024 pairs per batch.
+// WHICH rows (round 5; VERDICT r4: cancellation confined to a few answer tokens was invisible to 32 evenly spaced rows of 3 129): 16 evenly spaced rows
+// (offset by the batch index) + the LARGEST row of each of 16 contiguous strata of the operand's rows, "largest" by the sum over the K blocks of
+// 2^eh from the scale bytes every encoder has written already (2 B per row and block: 100 KB per sample for A^ at BASELINE configs[1]) -- the pair with
+// the largest sum_k |m_k a_k| is a pair of large rows, and a handful of outsized answer tokens are each the maximum of their stratum (ties: lowest row;
+// 64-bit LDS atomicMax on (proxy bits, ~row): deterministic).
 typedef _Float16 gc_f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gc_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int GC_ROWS = 32;
-__global__ __launch_bounds__(256) void guard_cancel_kernel(const char* MH, int64_t m_ra, int64_t m_rstride, int mrows, const char* AH, int64_t a_ra, int64_t a_rstride,
-                                                            int arows, int Kb, unsigned* words) {
+constexpr int GC_ROWS = 32, GC_EVEN = 16, GC_STRATA = GC_ROWS - GC_EVEN;
+__device__ __forceinline__ void gc_strata_max(const char* S, int64_t ras, int64_t row0, int rows, int Kb, int kb0, int kstep, unsigned long long* best, int t) {
+    // thread t owns the 8-row groups t, t + 256, ...: one aligned 16-B load per (group, K block); deep contractions look at every kstep-th block
+    // (an outsized row is outsized in all of its blocks; the kernel sits in front of the mode-3 product: 25 KB instead of 100 KB per sample)
+    for (int g8 = t; g8 * 8 < rows; g8 += 256) {
+        float px[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kb = kb0; kb < Kb; kb += kstep) {
+            const gc_u32x4 w = *reinterpret_cast<const gc_u32x4*>(S + ((int64_t)kb * ras + row0 + (int64_t)g8 * 8) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                px[2 * u] += __builtin_bit_cast(float, (w[u] & 0xffu) << 23);               // 2^(eh): byte 0 of the row's (hi, lo) pair
+                px[2 * u + 1] += __builtin_bit_cast(float, ((w[u] >> 16) & 0xffu) << 23);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = g8 * 8 + u;
+            if (row >= rows) break;
+            const float pv = px[u] < 3.0e38f ? px[u] : 3.0e38f;
+            const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, pv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);
+            atomicMax(&best[(int)((int64_t)row * GC_STRATA / rows)], key);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void guard_cancel_kernel(const char* MH, const char* MS, int64_t m_ra, int64_t m_ras, int64_t m_rstride, int mrows, const char* AH,
+                                                            const char* AS, int64_t a_ra, int64_t a_ras, int64_t a_rstride, int arows, int Kb, unsigned* words, int strata) {
     extern __shared__ __attribute__((aligned(16))) char gc_lds[];
     __shared__ float red[2][4];
+    __shared__ unsigned long long best[2][GC_STRATA];
+    __shared__ int sel[2][GC_ROWS];
     const int b = blockIdx.x, t = threadIdx.x;
     const int pitch = Kb * 64 + 16;
+    if (t < 2 * GC_STRATA) best[t / GC_STRATA][t % GC_STRATA] = 0ull;
+    __syncthreads();
+    const int kstep = Kb >= 8 ? 4 : 1, kb0 = b % kstep;
+    if (strata) {
+        gc_strata_max(MS, m_ras, (int64_t)b * m_rstride, mrows, Kb, kb0, kstep, best[0], t);
+        gc_strata_max(AS, a_ras, (int64_t)b * a_rstride, arows, Kb, kb0, kstep, best[1], t);
+    }
+    __syncthreads();
+    if (t < 2 * GC_ROWS) {
+        const int op = t / GC_ROWS, i = t % GC_ROWS;
+        const int rows = op ? arows : mrows;
+        int r = (int)(((int64_t)(i % GC_EVEN) * rows / GC_EVEN + (op ? 11 : 5) * (int64_t)b) % rows);       // evenly spaced, offset by the batch index
+        if (!strata) r = (int)(((int64_t)i * rows / GC_ROWS + (op ? 11 : 5) * (int64_t)b) % rows);           // (test knob: round 4's 32 evenly spaced rows)
+        else if (i >= GC_EVEN) {
+            const unsigned long long k = best[op][i - GC_EVEN];
+            if (k != 0ull) r = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));      // (an empty stratum -- fewer rows than strata -- keeps the even row)
+        }
+        sel[op][i] = r;
+    }
+    __syncthreads();
     // copy: 64 rows x Kb blocks of 64 B; thread -> (row, block, 16-B piece)
     for (int it = t; it < 2 * GC_ROWS * Kb * 4; it += 256) {
         const int piece = it & 3, kb = (it >> 2) % Kb, row = (it >> 2) / Kb;
         const bool isA = row >= GC_ROWS;
-        const int i = row & (GC_ROWS - 1);
-        const int64_t r = isA ? ((int64_t)i * arows / GC_ROWS + 11 * b) % arows : ((int64_t)i * mrows / GC_ROWS + 5 * b) % mrows;
+        const int64_t r = sel[isA ? 1 : 0][row & (GC_ROWS - 1)];
         const char* src = isA ? AH + (((int64_t)kb * a_ra + (int64_t)b * a_rstride + r) * 64 + piece * 16)
                               : MH + (((int64_t)kb * m_ra + (int64_t)b * m_rstride + r) * 64 + piece * 16);
         *reinterpret_cast<gc_u32x4*>(gc_lds + row * pitch + kb * 64 + piece * 16) = *reinterpret_cast<const gc_u32x4*>(src);
@@ -160,17 +210,18 @@ __global__ __launch_bounds__(256) void guard_cancel_kernel(const char* MH, int64
     if (t == 0) {
         md = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
         ma = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-        // non-finite sums are the range bits' business; an all-zero batch (ma == 0) has nothing to cancel
-        const float ratio = (ma > 0.f && ma < 3.0e38f) ? fminf(ma / fmaxf(md, 1e-30f), 3.0e38f) : 0.f;
-        if (ratio > 0.f) {
-            const unsigned bits = __builtin_bit_cast(unsigned, ratio);
-            if (bits > __atomic_load_n(&words[GUARD_W_RATIO], __ATOMIC_RELAXED)) atomicMax(&words[GUARD_W_RATIO], bits);
+        // non-finite sums are the range bits' business; an all-zero batch (ma == 0) has nothing to cancel.  Both maxima are over the whole call (positive
+        // floats order like their bit patterns); one atomic per batch and word at most, and only when it would raise the word
+        if (ma > 0.f && ma < 3.0e38f) {
+            const unsigned ba = __builtin_bit_cast(unsigned, ma), bd = __builtin_bit_cast(unsigned, fminf(md, 3.0e38f));
+            if (ba > __atomic_load_n(&words[GUARD_W_ABSMAX], __ATOMIC_RELAXED)) atomicMax(&words[GUARD_W_ABSMAX], ba);
+            if (bd > __atomic_load_n(&words[GUARD_W_DOTMAX], __ATOMIC_RELAXED)) atomicMax(&words[GUARD_W_DOTMAX], bd);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void guard_poison_kernel(const unsigned* words, float* out, int64_t n) {
-    if (words[GUARD_W_STATUS] == 0u) return;
+__global__ __launch_bounds__(256) void guard_poison_kernel(const unsigned* words, float* out, int64_t n, unsigned bits) {
+    if ((words[GUARD_W_STATUS] & bits) == 0u) return;
     const float nan = __builtin_nanf("");
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = nan;
 }
@@ -193,7 +244,11 @@ int guard_scan(const GuardArgs& g, hipStream_t st) {
         if (sg.kind == 1 && (reinterpret_cast<uintptr_t>(sg.p) & 15)) return fail(CTI_E_ALIGN, "guard_scan: fp32 segment %d is not 16-B aligned", s);
     }
     hipLaunchKernelGGL(guard_scan_kernel, dim3(1024), dim3(256), 0, st, g);
-    if (g.final) hipLaunchKernelGGL(guard_verdict_kernel, dim3(1), dim3(64), 0, st, g);
+    if (g.final) {
+        GuardArgs gv = g;
+        gv.rho_bf16x3 = tuning_guard_rho(0); gv.rho_fp32 = tuning_guard_rho(1);
+        hipLaunchKernelGGL(guard_verdict_kernel, dim3(1), dim3(64), 0, st, gv);
+    }
     return launch_status("guard_scan");
 }
 
@@ -208,13 +263,14 @@ int guard_cancel(const F6Planes& M, int64_t mrows, const F6Planes& A, int64_t ar
         if (e != hipSuccess) return fail((int)e, "guard_cancel: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(guard_cancel_kernel, dim3((unsigned)nb), dim3(256), lds, st, reinterpret_cast<const char*>(M.H), M.rows_alloc, nb > 1 ? M.rstride : 0, (int)mrows,
-                       reinterpret_cast<const char*>(A.H), A.rows_alloc, nb > 1 ? A.rstride : 0, (int)arows, M.Kb, words);
+    hipLaunchKernelGGL(guard_cancel_kernel, dim3((unsigned)nb), dim3(256), lds, st, reinterpret_cast<const char*>(M.H), reinterpret_cast<const char*>(M.S), M.rows_alloc,
+                       M.rows_allocS, nb > 1 ? M.rstride : 0, (int)mrows, reinterpret_cast<const char*>(A.H), reinterpret_cast<const char*>(A.S), A.rows_alloc, A.rows_allocS,
+                       nb > 1 ? A.rstride : 0, (int)arows, M.Kb, words, tuning_guard_strata());
     return launch_status("guard_cancel");
 }
 
 int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(guard_poison_kernel, dim3(2048), dim3(256), 0, st, words, out, n);
+    hipLaunchKernelGGL(guard_poison_kernel, dim3(2048), dim3(256), 0, st, words, out, n, tuning_guard_poison_bits());
     return launch_status("guard_poison");
 }
 

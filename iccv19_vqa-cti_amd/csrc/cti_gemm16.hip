@@ -376,7 +376,10 @@ int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
     // is built and under test but measured no faster where its rounds are fewer (126.0 vs 128.5 us at 9216 x 3072 x 2048) and 20 % slower where they are equal
     // (539 vs 451 us at 9216 x 11264 x 2048): its COMPUTE interval is 27 MFMAs = 432 cycles against a LOAD interval of ~480 (12 fragment reads, 3-4 DMA
     // pieces at ~50 cycles of issue each, the LDS round trip): the square tile's 512-cycle COMPUTE interval is what just covers the LOAD interval.
-    static const bool wide = [] { const char* e = getenv("CTI_GEMM16_TILE"); return e && atoi(e) == 1; }();
+    static const bool wide_env = [] { const char* e = getenv("CTI_GEMM16_TILE"); return e && atoi(e) == 1; }();
+    //  the planes form of the A operand reads up to BM - 1 rows past M and the planes carry PLANE_SLACK_ROWS = 256 of slack: the 288-row tile is
+    // for the row-major A operand only, whose DMA clamps its row index
+    const bool wide = wide_env && a.Abf != nullptr;
 #define G16_GO(EPI, GEO) (a.Abf ? g16_launch<EPI, GEO, true>(p, nb, ncols, st) : g16_launch<EPI, GEO, false>(p, nb, ncols, st))
     if (a.epi == 5) return wide ? G16_GO(G16_EPI_BF16, G16Wide) : G16_GO(G16_EPI_BF16, G16Sq);
     return wide ? G16_GO(G16_EPI_F32, G16Wide) : G16_GO(G16_EPI_F32, G16Sq);

@@ -89,6 +89,23 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     if (lo) *reinterpret_cast<uint4*>(lo + o) = pack8(l);           // lo == NULL: the plain-bf16 mode's operands (one product per pair reads the hi plane only)
 }
 
+// bf16 rows -> chunk-major planes (round 5: a producer's bf16 output as the next product's planes operand): the hi plane takes the bits as they are, the lo
+// plane (three-product callers) zeros.  Same thread map as split_kernel; K % 8 == 0, 16-B aligned rows.
+__global__ __launch_bounds__(256) void split16_kernel(const unsigned short* __restrict__ x, int64_t ld, int64_t rows, int K, unsigned short* __restrict__ hi,
+                                                      unsigned short* __restrict__ lo, int64_t pitch) {
+    const int64_t idx = ((int64_t)blockIdx.y * gridDim.z + blockIdx.z) * 256 + threadIdx.x;
+    const int kg = blockIdx.x;
+    const int c = (int)(idx & 3);
+    const int64_t row = idx >> 2;
+    if (row >= rows) return;
+    const int k0 = kg * 32 + c * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 + 8 <= K) v = *reinterpret_cast<const uint4*>(x + row * ld + k0);
+    const int64_t o = (int64_t)(k0 >> 4) * pitch + row * 16 + (k0 & 15);
+    *reinterpret_cast<uint4*>(hi + o) = v;
+    if (lo) *reinterpret_cast<uint4*>(lo + o) = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Transposing split: x is (M x n) row-major; the planes hold x^T, i.e. rows = the n columns of x, depth = M (zero-filled up to Mp).
 // A thread owns one column: its 16 loads (one per row of the chunk) are coalesced across the workgroup, and its 16 values are one
 // contiguous 32-B run of each plane.  This is the weight-gradient operand layout (dW = dz^T x contracts over the ROW axis) without
@@ -731,6 +748,16 @@ int split_planes(const float* x, int64_t ld, int64_t rows, int K, unsigned short
                        rows_alloc * 16);
 #endif
     return launch_status("split_planes");
+}
+
+int split_planes16(const unsigned short* x, int64_t ld, int64_t rows, int K, unsigned short* hi, unsigned short* lo, int64_t rows_alloc, hipStream_t st) {
+    if (rows <= 0 || K <= 0 || (K & 7) || (ld & 7) || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(CTI_E_ALIGN, "split_planes16: rows=%lld K=%d ld=%lld (K, ld multiples of 8; 16-B aligned)", (long long)rows, K, (long long)ld);
+    const int Kp = planes_kp(K);
+    const int64_t blocks = (rows * 4 + 255) / 256;
+    const unsigned gz = (unsigned)((blocks + 65534) / 65535);
+    const unsigned gy = (unsigned)((blocks + gz - 1) / gz);
+    hipLaunchKernelGGL(split16_kernel, dim3((unsigned)(Kp >> 5), gy, gz), dim3(256), 0, st, x, ld, rows, K, hi, lo, rows_alloc * 16);
+    return launch_status("split_planes16");
 }
 
 int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, unsigned short* hi, unsigned short* lo, int64_t rows_alloc,

@@ -178,11 +178,18 @@ struct GeoF6T {
     static_assert(OFF_AS == OFF_BFL + PBF * 1024 + 512, "the shared piece is contiguous in LDS");
     static_assert(NST >= 2 && LDS <= 160 * 1024, "ring exceeds the CU's LDS");
 };
-using GeoF6 = GeoF6T<4, 2, 2, 3>;                    // 8 waves of 64 x 96, two per SIMD
+#ifndef CTI_F6_TN
+#define CTI_F6_TN 3          // column tiles per wave.  -DCTI_F6_TN=1 (timing experiments only): 256 x 64 tiles -- the K loops of a Tucker -> rank chain that keeps a 64-token a~
+#endif                       // tile on chip and re-streams both weight matrices per tile (VERDICT r4 #1 iv; profiles/r05_aside_chain_ablation.txt)
+using GeoF6 = GeoF6T<4, 2, 2, CTI_F6_TN>;            // 8 waves of 64 x 96, two per SIMD
 // Round 3 experiment (d): 128 x 192 tiles, FOUR waves of 64 x 96 (the same wave tile, so the same fragment reads / conversions / MFMAs per wave
 // and K block), a 2-slot ring of 31 KiB -- TWO independent workgroups per CU, each with its own barriers: one workgroup's epilogue (and every
 // other phase) overlaps the other's K loop instead of idling the matrix pipe.  Price: 43 % more DMA bytes per flop and one block in flight.
+// Round 5: compiled only with -DCTI_F6_WITH_HALF_GEO (tools/ab_f6_geo.sh builds that variant): its transposed-planes instantiation spills two registers to
+// SCRATCH, and round 4 saw a scratch row corrupted beside another stream's kernel -- no kernel of the product library may own a private segment.
+#ifdef CTI_F6_WITH_HALF_GEO
 using GeoF6Half = GeoF6T<2, 2, 2, 3, 2>;
+#endif
 
 
 #ifndef CTI_F6_PHASE
@@ -651,7 +658,9 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
 #endif
 // CTI_F6_GEO=half selects the two-workgroups-per-CU geometry (GeoF6Half) for the plain mode-3 product and the transposed a-side products
 // (experiment (d) of round 3; the softmax-partials variant keeps the layout of its partials and stays on GeoF6).
+#ifdef CTI_F6_WITH_HALF_GEO
 static int f6_geo() { static const int g = [] { const char* e = getenv("CTI_F6_GEO"); return (e && e[0] == 'h') ? 1 : 0; }(); return g; }
+#endif
 
 template <int EPI, class G>
 int launch_f6g(const F6P& p0, long long nb, int ncols, hipStream_t st) {
@@ -684,7 +693,9 @@ int launch_f6g(const F6P& p0, long long nb, int ncols, hipStream_t st) {
 
 template <int EPI>
 int launch_f6(const F6P& p0, long long nb, int ncols, hipStream_t st) {
+#ifdef CTI_F6_WITH_HALF_GEO
     if ((EPI == F6_EPI_INTERLEAVE2 || EPI == F6_EPI_PLANES_T) && f6_geo() == 1) return launch_f6g<EPI == F6_EPI_INTERLEAVE2 ? F6_EPI_INTERLEAVE2 : F6_EPI_PLANES_T, GeoF6Half>(p0, nb, ncols, st);
+#endif
     return launch_f6g<EPI, GeoF6>(p0, nb, ncols, st);
 }
 
@@ -765,6 +776,16 @@ extern "C" int cti_quantize_f16f6(const float* x, int64_t ld, int64_t rows, int 
     CTI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 255) == 0, CTI_E_ALIGN, "cti_quantize_f16f6: the plane block must be 256-B aligned");
     hipError_t e = hipMemsetAsync(planes, 0, f6_planes_bytes(rows, K, batch_rows), as_stream(stream));       // slack / padding rows: defined scales, zero codes
     if (e != hipSuccess) return fail((int)e, "cti_quantize_f16f6: hipMemsetAsync: %s", hipGetErrorString(e));
+    return quantize_f16f6(x, ld, rows, K, f6_carve(planes, rows, K, batch_rows), as_stream(stream));
+}
+
+// The encoder alone, as cti_tcnet_forward launches it (round 5, VERDICT r4 #8: bench.py's stand-alone record of this pass timed the memset above with it):
+// `planes` is a block cti_quantize_f16f6 has filled before, or one the caller zero-filled -- slack and padding rows are left as they are.
+extern "C" int cti_quantize_f16f6_into(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, void* planes, size_t planes_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(planes);
+    CTI_REQUIRE(rows > 0 && K > 0 && ld >= K && batch_rows >= 0, CTI_E_SHAPE, "cti_quantize_f16f6_into: rows=%lld K=%d ld=%lld batch_rows=%lld", (long long)rows, K, (long long)ld, (long long)batch_rows);
+    CTI_REQUIRE(planes_bytes >= f6_planes_bytes(rows, K, batch_rows), CTI_E_WORKSPACE, "cti_quantize_f16f6_into: block %zu < %zu", planes_bytes, f6_planes_bytes(rows, K, batch_rows));
+    CTI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 255) == 0, CTI_E_ALIGN, "cti_quantize_f16f6_into: the plane block must be 256-B aligned");
     return quantize_f16f6(x, ld, rows, K, f6_carve(planes, rows, K, batch_rows), as_stream(stream));
 }
 

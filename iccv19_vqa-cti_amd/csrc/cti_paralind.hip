@@ -72,24 +72,24 @@ __global__ __launch_bounds__(64) void wn_final_kernel(WnBatch d, const float* __
 
 // ---- mask[r] = every element of row r is +-0 ---------------------------------------------------------------------
 // One wave per row; OR of the magnitude bits, so -0.0 counts as zero and NaN / inf / subnormals do not.
-__global__ __launch_bounds__(256) void zero_row_mask_kernel(const float* __restrict__ v, int64_t ldv,
-                                                            uint8_t* __restrict__ mask, int64_t rows, int dim) {
+// `v` as 32-bit words: a row is `dimw` words (fp32: one element each, magmask 0x7fffffff; bf16 (round 5): two elements each, magmask 0x7fff7fff).
+__global__ __launch_bounds__(256) void zero_row_mask_kernel(const unsigned* __restrict__ v, int64_t ldw,
+                                                            uint8_t* __restrict__ mask, int64_t rows, int dimw, unsigned magmask) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* p = v + row * ldv;
+    const unsigned* p = v + row * ldw;
     unsigned bits = 0u;
-    if (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((dim & 3) == 0)) {
+    if (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((dimw & 3) == 0)) {
         const uint4* p4 = reinterpret_cast<const uint4*>(p);
-        for (int j = lane; j < (dim >> 2); j += 64) {
+        for (int j = lane; j < (dimw >> 2); j += 64) {
             const uint4 x = p4[j];
             bits |= (x.x | x.y | x.z | x.w);
         }
     } else {
-        const unsigned* pu = reinterpret_cast<const unsigned*>(p);
-        for (int j = lane; j < dim; j += 64) bits |= pu[j];
+        for (int j = lane; j < dimw; j += 64) bits |= p[j];
     }
-    const bool nz = (bits & 0x7fffffffu) != 0u;
+    const bool nz = (bits & magmask) != 0u;
     const bool any_nz = __any(nz);
     if (lane == 0) mask[row] = any_nz ? 0 : 1;
 }
@@ -238,9 +238,19 @@ extern "C" int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(mask);
     CTI_REQUIRE(rows > 0 && dim > 0 && ldv >= dim, CTI_E_SHAPE, "cti_zero_row_mask: rows=%lld dim=%d ldv=%lld",
                 (long long)rows, dim, (long long)ldv);
-    hipLaunchKernelGGL(zero_row_mask_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), v, ldv,
-                       mask, rows, dim);
+    hipLaunchKernelGGL(zero_row_mask_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned*>(v), ldv,
+                       mask, rows, dim, 0x7fffffffu);
     return launch_status("cti_zero_row_mask");
+}
+
+// The same mask of a bf16 matrix (round 5: BASELINE configs[2] / [3] name bf16 tensors): row r is masked iff every element is +-0.  dim and ldv even.
+extern "C" int cti_zero_row_mask_bf16(const void* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream) {
+    CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(mask);
+    CTI_REQUIRE(rows > 0 && dim > 0 && ldv >= dim, CTI_E_SHAPE, "cti_zero_row_mask_bf16: rows=%lld dim=%d ldv=%lld", (long long)rows, dim, (long long)ldv);
+    CTI_REQUIRE((dim & 1) == 0 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(v) & 3) == 0, CTI_E_ALIGN, "cti_zero_row_mask_bf16: dim, ldv must be even and v 4-B aligned");
+    hipLaunchKernelGGL(zero_row_mask_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), static_cast<const unsigned*>(v), ldv / 2,
+                       mask, rows, dim / 2, 0x7fff7fffu);
+    return launch_status("cti_zero_row_mask_bf16");
 }
 
 extern "C" int cti_teff_scramble(const float* src, float* dst, int R, int I, int J, int K, int G, int inverse, void* stream) {

@@ -273,7 +273,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                               void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused = nullptr,
-                              const float* v_tucked = nullptr, int64_t ld_vt = 0, int v_rep = 1);
+                              const float* v_tucked = nullptr, int64_t ld_vt = 0, int v_rep = 1, int v16 = 0);
 
 extern "C" int cti_tcnet_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
@@ -305,7 +305,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
                               uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                               int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                               void* ev_core_end, void* aux_stream, void* stream, float* sm_part, float* p_fused,
-                              const float* v_tucked, int64_t ld_vt, int v_rep) {
+                              const float* v_tucked, int64_t ld_vt, int v_rep, int v16) {
+    // v16 (round 5; cti_triattention_forward_vt16): `v` AND `v_tucked` are bf16 rows -- v is then read for the zero-row mask only (the hoisted projection replaces
+    // its Tucker layer), v_tucked enters the rank nets' product as a planes operand with a zero lo plane
+    CTI_REQUIRE(!v16 || (v_tucked != nullptr && zero_mask != nullptr), CTI_E_UNSUPPORTED, "cti_triattention_forward_vt16: bf16 inputs need the hoisted v projection and the mask output");
     CTI_REQUIRE_PTR(v); CTI_REQUIRE_PTR(q); CTI_REQUIRE_PTR(a); CTI_REQUIRE_PTR(tucker_wv); CTI_REQUIRE_PTR(tucker_g);
     CTI_REQUIRE_PTR(tucker_b); CTI_REQUIRE_PTR(rank_wv); CTI_REQUIRE_PTR(rank_g); CTI_REQUIRE_PTR(rank_b); CTI_REQUIRE_PTR(T_g);
     CTI_REQUIRE_PTR(out); CTI_REQUIRE_PTR(workspace);
@@ -330,7 +333,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     const int relu = act == CTI_ACT_RELU;
 
     if (p.guard) { rc = guard_reset(p.guard, st); if (rc) return rc; }
-    if (zero_mask) { rc = cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream); if (rc) return rc; }
+    if (zero_mask) {
+        rc = v16 ? cti_zero_row_mask_bf16(v, v_dim, zero_mask, rows[0], v_dim, stream) : cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream);
+        if (rc) return rc;
+    }
     if (!prepared) { rc = run_prepare(d, prec, p, tucker_wv, tucker_g, rank_wv, rank_g, T_g, false, stream); if (rc) return rc; }
     const int64_t mrows_per_b = (int64_t)V * Q * G;
 
@@ -352,7 +358,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
 
     const bool f6 = prec == CTI_PREC_F16F6;
     const bool fused_core = small_a(d);                        // A <= 6: mbuild_core_small replaces M build + planes + mode-3 GEMM
-    CTI_REQUIRE(v_tucked == nullptr || (fused_core && v_rep >= 1 && B % v_rep == 0 && ld_vt >= h && h % 4 == 0 && (ld_vt & 3) == 0 &&
+    CTI_REQUIRE(v_tucked == nullptr || (fused_core && v_rep >= 1 && B % v_rep == 0 && ld_vt >= h && h % 4 == 0 && (ld_vt & (v16 ? 7 : 3)) == 0 && (!v16 || h % 8 == 0) &&
                                         (reinterpret_cast<uintptr_t>(v_tucked) & 15) == 0),
                 CTI_E_UNSUPPORTED, "cti_triattention_forward: a hoisted v projection needs the few-answer path, B %% v_rep == 0 and 16-B aligned rows (A=%d v_rep=%d)", A, v_rep);
     CTI_REQUIRE(!(fused_core && sm_part), CTI_E_UNSUPPORTED, "cti_tcnet_forward_sm: no softmax partials on the few-answer path (A=%d)", A);
@@ -386,7 +392,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (s == 0 && hoisted_v) {
             PlaneGemmArgs r{};
             r.Bh = p.wr[0].hi; r.Bl = p.wr[0].lo;
-            if (terms == 3) { r.Af = v_tucked; r.ldaf = ld_vt; r.Kreal = h; r.rows_allocA = rows[0] / v_rep + PLANE_SLACK_ROWS; }   // (the fp32-A operand path exists for the 3-term mode)
+            if (v16) {                                           // bf16 rows: the hi plane as it stands, a zero lo plane for the three-product form
+                int r1 = split_planes16(reinterpret_cast<const unsigned short*>(v_tucked), ld_vt, rows[0] / v_rep, h, p.tp[0].hi, terms == 3 ? p.tp[0].lo : nullptr, p.tp[0].rows_alloc, ss); if (r1) return r1;
+                r.Ah = p.tp[0].hi; r.Al = p.tp[0].lo; r.rows_allocA = p.tp[0].rows_alloc;
+            } else if (terms == 3) { r.Af = v_tucked; r.ldaf = ld_vt; r.Kreal = h; r.rows_allocA = rows[0] / v_rep + PLANE_SLACK_ROWS; }   // (the fp32-A operand path exists for the 3-term mode)
             else {
                 int r1 = split_planes(v_tucked, ld_vt, rows[0] / v_rep, h, p.tp[0].hi, p.tp[0].lo, p.tp[0].rows_alloc, ss); if (r1) return r1;
                 r.Ah = p.tp[0].hi; r.Al = p.tp[0].lo; r.rows_allocA = p.tp[0].rows_alloc;
@@ -603,12 +612,45 @@ extern "C" size_t cti_triattention_workspace_bytes(int B, int V, int Q, int A, i
     return a256(t) + a256(cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, prec)) + a256(cti_softmax_tri_workspace_bytes(B, V, (int64_t)Q * A, G));
 }
 
+static int triattention_impl(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                             const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                             const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                             uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                             int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                             void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep, int v16);
+
 extern "C" int cti_triattention_forward(const float* v, const float* q, const float* a, const float* const* tucker_wv,
                                         const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
                                         const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
                                         uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
                                         int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                                         void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep) {
+    return triattention_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, p_out, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, act, prec,
+                             prepared, workspace, workspace_bytes, ev_core_begin, ev_core_end, aux_stream, stream, v_tucker_out, ld_vt, v_rep, 0);
+}
+
+// Round 5 (BASELINE configs[2] / [3] name bf16 tensors): the same call with `v` (B, V, v_dim) AND the hoisted projection `v_tucker_out` as bf16 rows (ld_vt in
+// elements, a multiple of 8).  v is read for the zero-row mask only; the few-answer path (cti_triattention_hoist_ok) and a hoisted projection are required --
+// CTI_E_UNSUPPORTED otherwise (the caller widens v and takes cti_triattention_forward).
+extern "C" int cti_triattention_forward_vt16(const void* v_bf16, const float* q, const float* a, const float* const* tucker_wv,
+                                             const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                                             const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                                             uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                             int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                             void* ev_core_end, void* aux_stream, void* stream, const void* v_tucker_out_bf16, int64_t ld_vt, int v_rep) {
+    CTI_REQUIRE_PTR(v_tucker_out_bf16);
+    CTI_REQUIRE(cti_triattention_hoist_ok(B, V, Q, A, h, R, G, prec), CTI_E_UNSUPPORTED, "cti_triattention_forward_vt16: the few-answer path only (A=%d)", A);
+    return triattention_impl(static_cast<const float*>(v_bf16), q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, p_out, zero_mask, B, V, Q, A, v_dim, q_dim,
+                             a_dim, h, R, G, act, prec, prepared, workspace, workspace_bytes, ev_core_begin, ev_core_end, aux_stream, stream,
+                             static_cast<const float*>(v_tucker_out_bf16), ld_vt, v_rep, 1);
+}
+
+static int triattention_impl(const float* v, const float* q, const float* a, const float* const* tucker_wv,
+                             const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                             const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                             uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                             int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                             void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep, int v16) {
     CTI_REQUIRE_PTR(p_out); CTI_REQUIRE_PTR(zero_mask); CTI_REQUIRE_PTR(workspace);
     CTI_REQUIRE(G >= 2, CTI_E_UNSUPPORTED, "cti_triattention_forward: glimpse must be >= 2 (the reference's mask expand fails for 1, src/attention.py:55)");
     const size_t need = cti_triattention_workspace_bytes(B, V, Q, A, v_dim, q_dim, a_dim, h, R, G, prec);
@@ -625,7 +667,7 @@ extern "C" int cti_triattention_forward(const float* v, const float* q, const fl
     const bool planes_mode = prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16 || (prec == CTI_PREC_F16F6 && h % 32 == 0);
     if (planes_mode && small_a(d))                             // logits + p out of the fused kernel's registers
         return tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,
-                                  G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, nullptr, p_out, v_tucker_out, ld_vt, v_rep > 0 ? v_rep : 1);
+                                  G, act, prec, prepared, workspace, wt, ev_core_begin, ev_core_end, aux_stream, stream, nullptr, p_out, v_tucker_out, ld_vt, v_rep > 0 ? v_rep : 1, v16);
     CTI_REQUIRE(v_tucker_out == nullptr, CTI_E_UNSUPPORTED, "cti_triattention_forward: a hoisted v projection is taken on the few-answer path only (cti_triattention_hoist_ok)");
     const bool partials = pb != 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && ((int64_t)V * Q * A) % 2 == 0;
     rc = tcnet_forward_impl(v, q, a, tucker_wv, tucker_g, tucker_b, rank_wv, rank_g, rank_b, T_g, logits, zero_mask, B, V, Q, A, v_dim, q_dim, a_dim, h, R,

@@ -79,9 +79,25 @@ class WNLinear(nn.Module):
         return self._planes_val
 
     def forward(self, x, relu=False):
+        if x.dtype == torch.bfloat16:
+            # (round 5) bf16 activations of the plain-bf16 mode: the row-major bf16 matrix IS the product's A operand (no split pass), the output leaves as bf16
+            # rows = the next consumer's operand (cti_gemm_bf16_rows).  Anything else widens first.
+            if (_bf16_rows_ok(x, self.in_features) and not (torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad
+                                                                                            or self.weight_g.requires_grad or self.bias.requires_grad))):
+                x2 = x.reshape(-1, x.shape[-1])
+                y = ops.gemm_bf16_rows(x2, self.planes(), self.out_features, out_dtype=torch.bfloat16, scale=self.scale(), scale_div=self.out_features, bias=self.bias,
+                                       relu=bool(relu))
+                return y.view(x.shape[:-1] + (self.out_features,))
+            x = ops.widen_bf16(x)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad or self.weight_g.requires_grad or self.bias.requires_grad):
             return AG.WNLinearFn.apply(x, self.weight_v, self.weight_g, self.bias, relu, 1, self.scale())
         return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu, w_planes=self.planes())
+
+
+def _bf16_rows_ok(x, in_features):
+    """The bf16-rows GEMM takes this input: plain-bf16 mode, K a multiple of 32, at least a few 256-row tiles' worth of rows (its 256 x 256 tile), 16-B aligned rows."""
+    return (ops.get_precision() == "bf16" and x.is_cuda and in_features % 32 == 0 and x.numel() // max(1, x.shape[-1]) >= 1024
+            and x.stride(-1) == 1)
 
 
 class FCNet(nn.Module):
@@ -185,6 +201,15 @@ class HoistedProjection:
             self._key = key
         n, out_dim = len(layers), layers[0].out_features
         x2 = x.reshape(-1, x.shape[-1])
+        if x.dtype == torch.bfloat16:
+            if _bf16_rows_ok(x2, layers[0].in_features):
+                # (round 5) bf16 rows in -> bf16 rows out: no split pass over x, half the bytes written here and read by the pools / the attention
+                y = ops.gemm_bf16_rows(x2, self._wp, n * out_dim, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, out_dtype=torch.bfloat16, scale=self._s,
+                                       scale_div=out_dim, scale_bs=1, bias=self._b, bias_bs=out_dim, relu=bool(relu))
+                outs = [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]
+                self.last_padded = outs[len(self.nets):]
+                return outs[:len(self.nets)]
+            x2 = ops.widen_bf16(x2)
         y = ops.gemm_nt(x2, self._w, nb1=n, rA1=0, rB1=out_dim, M=x2.shape[0], N=out_dim, scale=self._s, scale_div=out_dim, scale_bs=1,
                         bias=self._b, bias_bs=out_dim, relu=bool(relu), B_planes=self._wp)
         outs = [y[i].view(x.shape[:-1] + (out_dim,)) for i in range(n)]

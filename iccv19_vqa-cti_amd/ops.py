@@ -25,9 +25,11 @@ def set_precision(name):
         f16f6                                       ~2^-17 sum_k |M_k A^_k|   (each cross term rounded to the 4 bits of e2m3; 2^-15 worst case)
     so the error NORMALISED by the largest output grows with rho = sum_k |M_k A^_k| / max |out|.  Measured on the whole forward at the configs[1]
     widths (tests/test_accuracy_envelope_gpu.py; the operands M and A^ carry their own rounding, which a cancelling sum amplifies just the same):
-    ~1e-5 rho as f16f6 (2.7e-5 on the synthetic tensors, rho 2-4), ~4e-6 rho as bf16x3, ~5e-8 rho in fp32.  The guard estimates rho on the device
-    from 1 024 sampled (row, answer) pairs per sample and re-runs the call as bf16x3 when it exceeds 10, as exact fp32 when it exceeds 20
-    (include/cti_hip.h: CTI_GUARD_CANCEL / _HEAVY)."""
+    at most ~1.8e-5 rho as f16f6 (2.7e-5 on the synthetic tensors, rho 1.4-1.8), ~0.9e-5 rho as bf16x3, ~3e-7 rho in fp32.  The guard estimates rho
+    on the device from 1 024 (row, answer) pairs per sample -- per operand 16 evenly spaced rows and the largest row of each of 16 strata, so a few
+    outsized answer tokens cannot hide; numerator and denominator are maxima over the whole call, as the tolerance is -- and re-runs the call as
+    bf16x3 when it exceeds 2.75, as exact fp32 when it exceeds 5.5 (set_cancel_thresholds; include/cti_hip.h: CTI_GUARD_CANCEL / _HEAVY): a factor
+    two under 1e-4 on either law.  The estimate is a sample, not a bound."""
     global _default_prec
     if name not in _PREC:
         raise ValueError("precision must be one of %s" % sorted(_PREC))
@@ -51,10 +53,53 @@ _guard_res = {}
 
 
 def set_range_check(mode):
+    """'sync' (default): the wrapper waits for the guard's verdict and re-runs an out-of-domain call (the caller always gets fp32-grade numbers).
+    'poison' (also what hipGraph capture forces, whatever this is set to): no host wait -- a call whose operands leave the f16f6 format's RANGE
+    (status bits 1, 2, 4: saturation / non-finite, underflow) returns all-NaN output, never clamped numbers.  The two CANCELLATION bits (8, 16) come
+    from a sampled heuristic whose worst consequence is an error of a few 1e-4 of the largest output: without a host to re-run the call they leave the
+    f16f6 result in place (ADVICE r4: trained weights may well exceed the threshold, and an all-NaN batch under a replayed graph has no remedy);
+    f16f6_device_status() reads the status word of the last guarded call -- e.g. after a replay -- so that a caller can re-run eagerly.
+    set_poison_bits(31) restores NaN on every bit."""
     global _range_check
     if mode not in ("sync", "poison"):
         raise ValueError("range check must be 'sync' or 'poison'")
     _range_check = mode
+
+
+_poison_bits_nohost = 7
+
+
+def set_poison_bits(bits):
+    """Status bits that NaN-fill the output of a guarded call nobody waits for ('poison' mode / hipGraph capture).  Default 7 = the range bits."""
+    global _poison_bits_nohost
+    bits = int(bits)
+    if not 0 <= bits <= 31:
+        raise ValueError("poison bits: a mask of the five status bits")
+    _poison_bits_nohost = bits
+
+
+def set_cancel_thresholds(bf16x3=2.75, fp32=5.5):
+    """Cancellation estimate rho beyond which a guarded f16f6 call is re-run as bf16x3 / as exact fp32 (this host thread's calls; the library's
+    defaults are 2.75 / 5.5: a factor two under 1e-4 on the measured error laws ~1.8e-5 rho and ~0.9e-5 rho)."""
+    lib = L.lib()
+    L.check(lib.cti_set_tuning(L.TUNE_GUARD_RHO_BF16X3, int(round(float(bf16x3) * 1000))), "cti_set_tuning")
+    L.check(lib.cti_set_tuning(L.TUNE_GUARD_RHO_FP32, int(round(float(fp32) * 1000))), "cti_set_tuning")
+
+
+_last_guard_ws = [None]
+
+
+def f16f6_device_status():
+    """Status word (and rho) of the LAST guarded f16f6 call of this process, read from its guard block on the device after a synchronise --
+    the way to learn what a replayed hipGraph's forward found (the block belongs to the graph's memory pool and is rewritten by every replay).
+    None when no guarded call has run."""
+    ws = _last_guard_ws[0]
+    if ws is None:
+        return None
+    torch.cuda.synchronize(ws.device)
+    w = ws[:128].clone().cpu().view(torch.int32)
+    f = lambda i: float(w[i:i + 1].view(torch.float32)[0])
+    return {"status": int(w[0]) & 0xffffffff, "rho": f(2), "abs_max": f(16), "dot_max": f(17)}
 
 
 def f16f6_range_status():
@@ -361,10 +406,13 @@ def wn_linear(x, weight_v, scale, scale_div, bias, relu, prec=None, w_planes=Non
 
 def zero_row_mask(v):
     """(B, V, d) -> uint8 (B, V): 1 where the row is all zeros (reference `0 == v.abs().sum(2)`)."""
-    _req(v, "v")
+    _req(v, "v", v.dtype if isinstance(v, torch.Tensor) and v.dtype == torch.bfloat16 else torch.float32)
     x2, ld = _rows2d(v)
     mask = torch.empty(v.shape[:-1], device=v.device, dtype=torch.uint8)
     if mask.numel() == 0:
+        return mask
+    if v.dtype == torch.bfloat16:                                    # (round 5: bf16 inputs of the plain-bf16 mode; same bit-exact rule: every element +-0)
+        L.check(L.lib().cti_zero_row_mask_bf16(x2.data_ptr(), ld, mask.data_ptr(), x2.shape[0], v.shape[-1], _stream()), "cti_zero_row_mask_bf16")
         return mask
     L.check(L.lib().cti_zero_row_mask(x2.data_ptr(), ld, mask.data_ptr(), x2.shape[0], v.shape[-1], _stream()), "cti_zero_row_mask")
     return mask
@@ -524,7 +572,15 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     these weights (optional).  Returns out (B,V,Q,A,G) [, mask (B,V)] [, partials]: with want_sm_partials (needs want_mask) the third
     value is the Tri softmax's partial pass left by the mode-3 GEMM (masked_softmax_tri_from_partials_), or None where the library has no
     fused form for this precision / glimpse.  _tri (triattention_forward): cti_triattention_forward instead -- returns (p, logits)."""
-    for t, n in ((v, "v"), (q, "q"), (a, "a"), (T_g, "T_g")):
+    # (round 5) bf16 `v` + bf16 hoisted projection: TriAttention's few-answer path takes them as they are (cti_triattention_forward_vt16: v is read for the
+    # zero-row mask only); every other path widens them first
+    v16 = isinstance(v, torch.Tensor) and v.dtype == torch.bfloat16
+    if v16 and not (_tri and _v_tucked is not None and _v_tucked.dtype == torch.bfloat16):
+        v, v16 = widen_bf16(v), False
+    if not v16 and _v_tucked is not None and _v_tucked.dtype == torch.bfloat16:
+        _v_tucked = widen_bf16(_v_tucked)
+    _req(v, "v", torch.bfloat16 if v16 else torch.float32)
+    for t, n in ((q, "q"), (a, "a"), (T_g, "T_g")):
         _req(t, n)
     v, q, a = v.contiguous(), q.contiguous(), a.contiguous()
     B, V, vd = v.shape
@@ -585,6 +641,11 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         if pb and out.data_ptr() % 16 == 0 and (V * Q * A) % 2 == 0:
             part = torch.empty(pb, device=v.device, dtype=torch.uint8)
     act = L.ACT_RELU if relu else L.ACT_NONE
+    if guarded:
+        # a call whose verdict the host reads is re-run on ANY bit (the NaN fill is belt and braces); one nobody waits for keeps its f16f6 result on the
+        # cancellation bits (set_range_check)
+        lib.cti_set_tuning(L.TUNE_GUARD_POISON_BITS, 31 if wait_guard else _poison_bits_nohost)
+        _last_guard_ws[0] = ws
     with _timed("triattention_forward" if _tri else "tcnet_forward"):
         if _tri:
             p_att = torch.empty_like(out)
@@ -592,10 +653,19 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
             if _v_tucked is not None and lib.cti_triattention_hoist_ok(B, V, Q, A, h, R, G, pr) and B % int(_v_rep) == 0:
                 # relu(v_tucker(v)) from the caller's batched projection (one block per image when _v_rep > 1): rows (B / rep * V, >= h), 16-B aligned
                 vt2 = _v_tucked.reshape(-1, _v_tucked.shape[-1])
-                if (vt2.stride(1) == 1 and vt2.shape[0] == (B // int(_v_rep)) * V and vt2.shape[1] >= h and vt2.stride(0) % 4 == 0
-                        and vt2.data_ptr() % 16 == 0 and vt2.dtype == torch.float32):
+                if (vt2.stride(1) == 1 and vt2.shape[0] == (B // int(_v_rep)) * V and vt2.shape[1] >= h and vt2.stride(0) % (8 if v16 else 4) == 0
+                        and vt2.data_ptr() % 16 == 0 and vt2.dtype == (torch.bfloat16 if v16 else torch.float32) and (not v16 or (h % 8 == 0 and vd % 2 == 0))):
                     vt_ptr, vt_ld, vt_rep = vt2.data_ptr(), vt2.stride(0), int(_v_rep)
-            L.check(lib.cti_triattention_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+            if v16 and vt_ptr == 0:                                   # the bf16 form needs the hoisted projection: widen and take the fp32 call
+                v, v16 = widen_bf16(v), False
+                if _v_tucked is not None:
+                    return tcnet_forward(v, q, a, tucker, rank, T_g, relu, want_mask, prec, prepared, want_sm_partials, _tri, widen_bf16(_v_tucked), _v_rep)
+            if v16:
+                L.check(lib.cti_triattention_forward_vt16(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
+                                                          p_att.data_ptr(), mask.data_ptr(), B, V, Q, A, vd, qd, ad, h, R, G, act, pr, prep_ptr, ws.data_ptr(), wsb,
+                                                          ev0, ev1, _aux_stream(v.device), _stream(), vt_ptr, vt_ld, vt_rep), "cti_triattention_forward_vt16")
+            else:
+              L.check(lib.cti_triattention_forward(v.data_ptr(), q.data_ptr(), a.data_ptr(), twv, tg, tb, rwv, rg, rb, Tg.data_ptr(), out.data_ptr(),
                                                  p_att.data_ptr(), mask.data_ptr(), B, V, Q, A, vd, qd, ad, h, R, G, act, pr, prep_ptr, ws.data_ptr(), wsb,
                                                  ev0, ev1, _aux_stream(v.device), _stream(), vt_ptr, vt_ld, vt_rep), "cti_triattention_forward")
         elif part is not None:
@@ -707,7 +777,9 @@ def masked_softmax_bi_(logits, mask):
 def tri_pool(vt, qt, at, w, v_rep=1):
     """out[b,d] = sum_vqa vt[b,v,d] w[b,v,q,a] qt[b,q,d] at[b,a,d]; w may be any strided (B,V,Q,A) view.  v_rep > 1: vt is (B / v_rep, V, D),
     one block per image shared by v_rep consecutive batch rows (the kernel that takes it reads it in place; otherwise it is expanded here)."""
-    for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
+    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32)
+    for t, n in ((qt, "qt"), (at, "at"), (w, "w")):
         _req(t, n)
     v_rep = int(v_rep)
     B, (V, D) = qt.shape[0], vt.shape[1:]
@@ -763,7 +835,8 @@ def bi_pool(vt, qt, w, k=1):
 def bi_pool_shift(vt, qt, qadd, w):
     """out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + qadd[b,d])  (k = 1; qadd (B,D) or None = 0), or None when no kernel forms the shifted
     operand on load at this shape (the caller materialises it).  Inference only."""
-    _req(vt, "vt"); _req(qt, "qt"); _req(w, "w")
+    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16          # (round 5) bf16 rows from the hoisted projection: half the bytes of the streamed operand
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32); _req(qt, "qt"); _req(w, "w")
     B, V, D = vt.shape
     Q = qt.shape[1]
     vt, qt = vt.contiguous(), qt.contiguous()
@@ -774,11 +847,23 @@ def bi_pool_shift(vt, qt, qadd, w):
         qadd = qadd.contiguous()
     sb, sv, sq = w.stride()
     out = torch.empty((B, D), device=vt.device, dtype=torch.float32)
-    rc = L.lib().cti_bi_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(qadd), w.data_ptr(), sb, sv, sq, out.data_ptr(), B, V, Q, D, _stream())
+    lib = L.lib()
+    if vt16:
+        rc = lib.cti_bi_pool_shift_vt16_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(qadd), w.data_ptr(), sb, sv, sq, out.data_ptr(), B, V, Q, D, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_bi_pool_shift_vt16_fwd")
+            return out
+        vt = widen_bf16(vt)                                            # no bf16-reading kernel at this shape
+    rc = lib.cti_bi_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), _ptr(qadd), w.data_ptr(), sb, sv, sq, out.data_ptr(), B, V, Q, D, _stream())
     if rc == L.E_UNSUPPORTED:
         return None
     L.check(rc, "cti_bi_pool_shift_fwd")
     return out
+
+
+def widen_bf16(x):
+    """bf16 -> fp32 copy (off the fast path: a consumer without a bf16-reading kernel at its shape)."""
+    return x.float()
 
 
 def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
@@ -798,6 +883,13 @@ def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
     sb, sv, sq, sa = w.stride()
     lib = L.lib()
     use_mfma = 0 if (get_precision() == "fp32" or _os.environ.get("CTI_NO_TRI_POOL_MFMA", "0") == "1") else (2 if get_precision() == "bf16" else 1)
+    if vt16:
+        rc = lib.cti_tri_pool_shift_vt16_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), _ptr(qadd), _ptr(aadd), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
+                                             B, V, Q, A, D, v_rep, use_mfma, _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_tri_pool_shift_vt16_fwd")
+            return out
+        vt = widen_bf16(vt)
     rc = lib.cti_tri_pool_shift_fwd(vt.data_ptr(), qt.data_ptr(), at.data_ptr(), _ptr(qadd), _ptr(aadd), w.data_ptr(), sb, sv, sq, sa, out.data_ptr(),
                                     B, V, Q, A, D, v_rep, use_mfma, _stream())
     if rc == L.E_UNSUPPORTED and v_rep > 1:
@@ -825,12 +917,14 @@ def rows_equal_prev(x):
 
 
 def replication_of(eq):
-    """Largest r dividing the batch such that every row b with b % r != 0 equals its predecessor (HOST side: reads eq back -- one synchronisation)."""
+    """Largest r dividing the batch such that every row b with b % r != 0 equals its predecessor (HOST side: reads eq back -- one synchronisation
+    of the stream that computed it)."""
+    import numpy as np
     e = eq.cpu().numpy().astype(bool)
     B = e.shape[0]
+    idx = np.arange(B)
     for r in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
-        idx = [b for b in range(B) if b % r]
-        if all(e[idx]):
+        if e[idx % r != 0].all():
             return r
     return 1
 
@@ -867,7 +961,8 @@ def axpby(x, a, y, b, out=None):
 
 def bi_logits(vt, qt, h, h_scale, h_bias):
     """logits[b,g,v,q] = h_scale * sum_d vt[b,v,d] h[g,d] qt[b,q,d] + h_bias[g]."""
-    _req(vt, "vt"); _req(qt, "qt"); _req(h, "h")
+    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32); _req(qt, "qt"); _req(h, "h")
     B, V, D = vt.shape
     Q = qt.shape[1]
     G = h.shape[0]
@@ -877,6 +972,12 @@ def bi_logits(vt, qt, h, h_scale, h_bias):
     if out.numel() == 0:
         return out
     lib = L.lib()
+    if vt16:
+        rc = lib.cti_bi_logits_prec_vt16_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D, _prec(None), _stream())
+        if rc != L.E_UNSUPPORTED:
+            L.check(rc, "cti_bi_logits_prec_vt16_fwd")
+            return out
+        vt = widen_bf16(vt)
     if get_precision() != "fp32":                       # MFMA form (fp32-grade: three bf16 products; plain-bf16 mode: one); the exact-fp32 mode keeps the fp32 VALU kernel
         rc = lib.cti_bi_logits_prec_fwd(vt.data_ptr(), qt.data_ptr(), h.data_ptr(), _ptr(h_scale), _ptr(hb), out.data_ptr(), B, G, V, Q, D,
                                         _prec(None), _stream())
@@ -894,7 +995,10 @@ _bi_counters = {}
 def biattention_forward(vt, qt, h, h_scale, h_bias, mask):
     """(p, logits) of BiAttention.forward_all from the projections: bilinear logits, -inf on the rows of `mask` ((B, V) uint8 or None) and the softmax over (V, Q)
     per glimpse, in ONE launch (cti_biattention_fwd).  Shapes outside that kernel: the separate calls."""
-    _req(vt, "vt"); _req(qt, "qt"); _req(h, "h")
+    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32); _req(qt, "qt"); _req(h, "h")
+    if vt16 and _os.environ.get("CTI_BIATT_FUSED", "0") == "1":
+        vt = widen_bf16(vt)                                            # (the one-launch form reads fp32 rows)
     B, V, D = vt.shape
     Q = qt.shape[1]
     G = h.shape[0]
@@ -941,7 +1045,7 @@ def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None,
     pr = _prec(prec)
     lib = L.lib()
     if B_planes is not None and pr != L.PREC_F32 and ldc_n == 1:
-        wsb = lib.cti_gemm_nt_pb_workspace_bytes(A2.shape[0], B2.shape[0], K, pr)
+        wsb = lib.cti_gemm_nt_pb_workspace_bytes2(A2.shape[0], B2.shape[0], K, pr, int(nb1), int(M), int(N))
         ws = torch.empty(wsb, device=A.device, dtype=torch.uint8)
         L.check(lib.cti_gemm_nt_pb(A2.data_ptr(), lda, A2.shape[0], rA1, B_planes.data_ptr(), B2.shape[0], rB1, out.data_ptr(), ldc_m, sC1, nb1, M, N, K,
                                    _ptr(scale), int(scale_div), int(scale_bs), _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, pr,

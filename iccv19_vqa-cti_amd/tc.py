@@ -159,6 +159,8 @@ class TCNet(nn.Module):
         q_ = self.q_tucker(q)
         a_ = self.a_tucker(a)
         w = w.float()
+        if v_.dtype == torch.bfloat16:
+            v_ = ops.widen_bf16(v_)
         if _needs_grad(v_, q_, a_, w):
             return AG.TriPoolFn.apply(v_.repeat_interleave(v_rep, 0) if v_rep > 1 else v_, q_, a_, w)
         return ops.tri_pool(v_, q_, a_, w, v_rep=v_rep)

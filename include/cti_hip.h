@@ -57,7 +57,15 @@ const char* cti_last_error_string(void);
  * 0 = 128x128, 1 = 256x128, 2 = 256x256).  CTI_TUNE_TRI_CHUNK: positions per chunk of the two-level Tri softmax, forward and backward
  * (0 = 32768; a multiple of 4 otherwise) -- lets a small tensor run the multi-chunk combine that BASELINE configs[1] needs
  * (1.58 M positions per sample = 49 chunks).  cti_get_tuning returns INT64_MIN for an unknown key. */
-enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2 };
+/* Guard policy of the CTI_PREC_F16F6 forward (round 5; production settings, thread-local like the rest; see "Range guard" below):
+ * CTI_TUNE_GUARD_RHO_BF16X3 / CTI_TUNE_GUARD_RHO_FP32: the cancellation estimate rho, x 1000, beyond which the verdict asks for a re-run as bf16x3 /
+ * as exact fp32 (defaults 2750 / 5500: the measured error laws ~1.8e-5 rho and ~0.9e-5 rho then stay a factor two under 1e-4);
+ * CTI_TUNE_GUARD_POISON_BITS: which status bits NaN-fill `out` (default 31 = all; a caller that cannot re-run -- hipGraph replay -- may keep the f16f6
+ * result of a call that only trips the cancellation ESTIMATE by passing 7: the status word still tells);
+ * CTI_TUNE_F6_CORE_FREE_CUS: compute units the persistent mode-3 product leaves to the guard's last kernels, which run beside it on aux_stream
+ * (-1 = the library's default). */
+enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2, CTI_TUNE_GUARD_RHO_BF16X3 = 3, CTI_TUNE_GUARD_RHO_FP32 = 4, CTI_TUNE_GUARD_POISON_BITS = 5,
+       CTI_TUNE_F6_CORE_FREE_CUS = 6, CTI_TUNE_GUARD_STRATA = 7 /* tests: 0 = sample evenly spaced rows only */ };
 int cti_set_tuning(int key, int64_t value);
 int64_t cti_get_tuning(int key);
 
@@ -95,6 +103,8 @@ size_t cti_wn_linear_workspace_bytes(int64_t rows, int in_dim, int out_dim, int 
 /* ---- zero-row mask  (src/attention.py:36,55: `0 == v.abs().sum(2)`) ------------------------------------------- */
 /* mask[r] = 1 iff every element of row r is +-0 (bit-exact statement of the reference's test for finite input). */
 int cti_zero_row_mask(const float* v, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream);
+/* The same mask of a bf16 matrix (round 5: BASELINE configs[2] / [3] name bf16 tensors): every element +-0.  dim, ldv even. */
+int cti_zero_row_mask_bf16(const void* v_bf16, int64_t ldv, uint8_t* mask, int64_t rows, int dim, void* stream);
 
 /* ---- PARALIND core  (src/tc.py:46-52 -> src/Tensor.py:3-20) ---------------------------------------------------- */
 
@@ -169,24 +179,29 @@ size_t cti_tcnet_softmax_partials_bytes(int B, int V, int Q, int A, int h, int G
  * fp32-grade only for magnitudes inside f16's normal range (csrc/cti_f16f6.h: 6.1e-5 <= |x| <= 65504).  Whenever cti_tcnet_forward /
  * cti_tcnet_forward_sm run their f16f6 kernels -- cti_tcnet_forward_guard_bytes(...) != 0 -- the first that many bytes of `workspace` are
  * the guard block: a scan of every encoded operand (`a`, its Tucker projection, A^, M, the a-side weights: the per-block scale bytes the
- * encoders wrote) and of V^ / Q^ / T_eff for non-finite values runs on `stream` BEFORE ev_core_begin is recorded and leaves a status word
+ * encoders wrote) and of V^ / Q^ / T_eff for non-finite values leaves a status word -- without an aux_stream on `stream` BEFORE ev_core_begin is
+ * recorded; with one (round 5) its last kernels run on aux_stream BESIDE the mode-3 product (which leaves them a few compute units) and are the LAST
+ * work the call enqueues there: an event the caller records on aux_stream after the call returns marks the verdict --
  * (uint32 at offset 0):  0 = every operand is inside the format's domain;  CTI_GUARD_SATURATED = a block reaches beyond +-61440 (incl.
  * inf / NaN in an encoded tensor);  CTI_GUARD_UNDERFLOW = a tensor that is not all zero has no block above 2^-12 (its f16 hi parts are
  * subnormal);  CTI_GUARD_NONFINITE = inf / NaN in V^, Q^ or T_eff.  With a non-zero status the call still completes, but `out` is then
  * OVERWRITTEN WITH NaN (stream-ordered, no host involvement: valid under hipGraph capture) -- a caller never receives clamped numbers.
- * cti_guard_read waits on the HOST for ev_core_begin (i.e. while the mode-3 product is still running), copies the status word through
- * `stream` (any stream of the caller that is idle by then, e.g. the call's aux_stream) and returns it: a non-zero value means "re-run
- * this call with CTI_PREC_BF16X3" (what the shipped Python wrapper does).  It is the only entry point of the library that synchronises. */
+ * cti_guard_read waits on the HOST for the event it is given -- ev_core_begin of a call without aux_stream, else an event recorded on aux_stream
+ * after the call (either way the mode-3 product is still running) --, copies the status word through `stream` (a stream of the caller's that is
+ * idle by then) and returns it: a non-zero value means "re-run this call with CTI_PREC_BF16X3" (what the shipped Python wrapper does).  It is the
+ * only entry point of the library that synchronises. */
 /* Accuracy (round 4): inside the range the f16f6 product's error is ~2^-17 sum_k |M_k A^_k| per output (2^-15 worst case) against fp32's 2^-24: it
  * is 1e-4 of the LARGEST output only while the contraction does not cancel too heavily.  The guard therefore also samples 32 x 32 (M row, A^ row)
- * pairs per batch from the f16 planes and forms  rho = max sum_k |m_k a_k| / max |sum_k m_k a_k|  (2-4 on the synthetic BASELINE tensors; the
- * measured error of the whole forward is ~1e-5 rho as f16f6, ~4e-6 rho as bf16x3, ~5e-8 rho in fp32);
- * CTI_GUARD_CANCEL: rho > 10 -- re-run with CTI_PREC_BF16X3;  CTI_GUARD_CANCEL_HEAVY: rho > 20 -- re-run with CTI_PREC_F32.
+ * pairs per batch from the f16 planes -- per operand 16 evenly spaced rows and the LARGEST row (by its blocks' scale bytes) of each of 16 strata, so
+ * that a few outsized answer tokens cannot hide (round 5) -- and forms  rho = max sum_k |m_k a_k| / max |sum_k m_k a_k|  (the measured error of the
+ * whole forward is at most ~1.8e-5 rho as f16f6, ~0.9e-5 rho as bf16x3, ~3e-7 rho in fp32; 1.4-1.8 on the synthetic BASELINE tensors);
+ * CTI_GUARD_CANCEL: rho > 2.75 -- re-run with CTI_PREC_BF16X3;  CTI_GUARD_CANCEL_HEAVY: rho > 5.5 -- re-run with CTI_PREC_F32 (CTI_TUNE_GUARD_RHO_*).
+ * Numerator and denominator are maxima over ALL batches of the call, as the tolerance is (1e-4 of the tensor's largest output).
  * cti_guard_read_ratio copies rho (diagnostics / tests; it synchronises `stream`). */
 enum { CTI_GUARD_SATURATED = 1, CTI_GUARD_UNDERFLOW = 2, CTI_GUARD_NONFINITE = 4, CTI_GUARD_CANCEL = 8, CTI_GUARD_CANCEL_HEAVY = 16 };
 int cti_guard_read_ratio(const void* workspace, void* stream, float* ratio_host);
 size_t cti_tcnet_forward_guard_bytes(int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R, int G, int prec);
-int cti_guard_read(const void* workspace, void* ev_core_begin, void* stream, uint32_t* status_host);
+int cti_guard_read(const void* workspace, void* event, void* stream, uint32_t* status_host);
 /* The batch-independent part of cti_tcnet_forward, computed once per parameter update: the six weight-norm scales, T_eff (and its
  * [r][(j,k,g)][i] copy), and in the bf16 modes the hi/lo operand planes of the six weight matrices.  `prepared`: a device block of
  * cti_tcnet_prepared_bytes(...) owned by the caller; valid until a weight, T_g or the precision changes. */
@@ -213,6 +228,15 @@ int cti_triattention_forward(const float* v, const float* q, const float* a, con
                              int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
                              void* ev_core_end, void* aux_stream, void* stream, const float* v_tucker_out, int64_t ld_vt, int v_rep);
 int cti_triattention_hoist_ok(int B, int V, int Q, int A, int h, int R, int G, int prec);
+/* Round 5 -- bf16 activations (BASELINE configs[2] / [3] name bf16 tensors): the same call with `v` (B, V, v_dim) AND the hoisted projection v_tucker_out as
+ * bf16 rows (ld_vt in elements, a multiple of 8; what cti_gemm_bf16_rows writes with c_bf16 = 1).  v is read for the zero-row mask only; requires
+ * cti_triattention_hoist_ok(...) and a hoisted projection -- CTI_E_UNSUPPORTED otherwise (widen v, call cti_triattention_forward). */
+int cti_triattention_forward_vt16(const void* v_bf16, const float* q, const float* a, const float* const* tucker_wv,
+                                  const float* const* tucker_g, const float* const* tucker_b, const float* const* rank_wv,
+                                  const float* const* rank_g, const float* const* rank_b, const float* T_g, float* logits, float* p_out,
+                                  uint8_t* zero_mask, int B, int V, int Q, int A, int v_dim, int q_dim, int a_dim, int h, int R,
+                                  int G, int act, int prec, const void* prepared, void* workspace, size_t workspace_bytes, void* ev_core_begin,
+                                  void* ev_core_end, void* aux_stream, void* stream, const void* v_tucker_out_bf16, int64_t ld_vt, int v_rep);
 
 /* ---- masked softmax  (src/attention.py:55-58 Tri, :35-39 Bi) --------------------------------------------------- */
 
@@ -255,6 +279,14 @@ int cti_tri_pool_shift_fwd(const float* vt, const float* qt, const float* at, co
                            int use_mfma, void* stream);
 int cti_bi_pool_shift_fwd(const float* vt, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
                           float* out, int B, int V, int Q, int D, void* stream);
+/* Round 5: the shifted pools with `vt` -- the tensor these kernels exist to stream: (B, V, D) per glimpse -- as bf16 ROWS, what the plain-bf16 mode's hoisted
+ * v projection writes (cti_gemm_bf16_rows, c_bf16 = 1): half the bytes.  qt / at / w / out stay fp32.  The tri form exists on the MFMA kernel only (use_mfma != 0,
+ * A = 3 or 6); CTI_E_UNSUPPORTED (nothing launched, no message) otherwise. */
+int cti_tri_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
+                                int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
+                                int use_mfma, void* stream);
+int cti_bi_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
+                               float* out, int B, int V, int Q, int D, void* stream);
 
 /* out[b,n] = sum_{t<k} sum_{v,q} vt[b,v,n*k+t] * w[b,v,q] * qt[b,q,n*k+t],  n < D/k.  w == NULL means w = 1
  * (that is BCNet.forward with h_out=None, src/bc.py:42-47: out is then (B,1,D) with k = 1). */
@@ -276,6 +308,9 @@ int cti_bi_logits_mfma_fwd(const float* vt, const float* qt, const float* h, con
  * splitting, a third of the MFMAs), any other value the fp32-grade three-product form.  Same shapes, same CTI_E_UNSUPPORTED rule. */
 int cti_bi_logits_prec_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,
                            float* logits, int B, int G, int V, int Q, int D, int prec, void* stream);
+/* ... with `vt` as bf16 rows (round 5): the LDS-staged kernel's shapes only (V <= 64, G*Q <= 128, D % 32 == 0); CTI_E_UNSUPPORTED otherwise. */
+int cti_bi_logits_prec_vt16_fwd(const void* vt_bf16, const float* qt, const float* h, const float* h_scale, const float* h_bias,
+                                float* logits, int B, int G, int V, int Q, int D, int prec, void* stream);
 
 /* BiAttention.forward_all's logits + mask + softmax in ONE launch (round 3; reference src/attention.py:29-40 on the projections of src/bc.py:52-57): the
  * bilinear logits as cti_bi_logits_mfma_fwd, then the last workgroup to add into a sample's logits fills the rows of `mask` ((B, V) bytes, 1 = all-zero object
@@ -307,7 +342,9 @@ int cti_split_operand(const float* x, int64_t ld, int64_t rows, int K, void* pla
 int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
                    float* C, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div, int64_t scale_bs,
                    const float* bias, int64_t bias_bs, int act, int prec, void* workspace, size_t workspace_bytes, void* stream);
-size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);
+size_t cti_gemm_nt_pb_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec);    /* an upper bound for any (nb1, M, N) on these rows */
+/* ... and what ONE call needs exactly: the A planes + the fp32 partials of the split-K plan cti_gemm_nt_pb makes for (nb1, M, N) (round 5) */
+size_t cti_gemm_nt_pb_workspace_bytes2(int64_t rowsA_total, int64_t rowsB_total, int K, int prec, int nb1, int M, int N);
 /* The same product in the plain-bf16 arithmetic with A given as a row-major bf16 matrix (row stride lda elements, a multiple of 8; 16-B aligned; K % 32
  * == 0): read as it stands -- no split pass, no workspace -- by the round-4 kernel (csrc/cti_gemm16.hip: 256 x 256 / 288 x 192 tiles, two wave groups one
  * interval apart).  C: fp32 rows (c_bf16 = 0; 16-B aligned, ldc_m % 4 == 0) or bf16 rows (c_bf16 = 1; 8-B aligned): the output of one layer of reference
@@ -326,6 +363,9 @@ int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA_total, int
  * GEMM rows (row m' = m*gdiv + g -> C[z*sC + m*ldc_m + g + n*ldc_n]), the mode-3 product of src/Tensor.py:16-20 with G = gdiv. */
 size_t cti_f16f6_planes_bytes(int64_t rows, int K, int64_t batch_rows);
 int cti_quantize_f16f6(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, void* planes, size_t planes_bytes, void* stream);
+/* The same encoding pass WITHOUT the zero fill of the block's slack / padding rows that cti_quantize_f16f6 issues first: for a block that call has filled
+ * before (or the caller zeroed) -- the pass exactly as cti_tcnet_forward runs it on `a` (src/tc.py:43's input), which is what a benchmark of it should time. */
+int cti_quantize_f16f6_into(const float* x, int64_t ld, int64_t rows, int K, int64_t batch_rows, void* planes, size_t planes_bytes, void* stream);
 int cti_gemm_nt_f16f6(const void* A_planes, int64_t rowsA_total, int64_t batch_rowsA, const void* B_planes, int64_t rowsB_total, int64_t batch_rowsB,
                       float* C, int64_t ldc_m, int64_t ldc_n, int64_t sC, int gdiv, int nb, int M, int N, int K, const float* scale, int scale_div,
                       const float* bias, int act, void* stream);

@@ -213,9 +213,10 @@ def test_hoisted_glimpse_loops_equal_the_literal_loops():
 
 
 def test_mc_model_detects_replicated_images_by_itself():
-    """TanModel.v_replication = 'auto' (the default; src/MC/train.py:75-79 repeats every image per candidate answer and tells the model nothing): the factor is
-    detected on the first forward, the logits equal those of the explicit hint bit for bit and those of the literal all-rows forward to rounding; a later batch
-    that is NOT replicated gives NaN logits (the per-forward device check), never a plausible wrong answer; a model whose first batch has no repeats runs as before."""
+    """TanModel.v_replication = 'auto' (the default; src/MC/train.py:75-79 repeats every image per candidate answer and tells the model nothing): every EAGER
+    forward detects the factor of its own batch, the logits equal those of the explicit hint bit for bit and those of the literal all-rows forward to rounding;
+    a later batch that is replicated differently -- or not at all -- is simply detected as such and still gives the oracle's logits (round 5, ADVICE r4: the
+    factor used to be frozen from the first batch and every batch that broke it was NaN-filled)."""
     torch.manual_seed(35)
     m = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
     assert m.v_replication == "auto"
@@ -238,9 +239,10 @@ def test_mc_model_detects_replicated_images_by_itself():
         assert O.norm_max_err(out_auto.cpu().numpy(), out_off.cpu().numpy()) < 2e-5
         assert O.norm_max_err(out_auto.cpu().numpy(), OM.mc_tan_forward(v, q, a, sd(m), 2, dtype=np.float64)[0]) < TOL
         v_bad = v.copy()
-        v_bad[5, 2, 7] += 1.0                                                  # one element of one repeated row
+        v_bad[5, 2, 7] += 1.0                                                  # one element of one repeated row: this batch has no replication at all
         out_bad, _ = m(T(v_bad), None, T(q), T(a))
-        assert bool(torch.isnan(out_bad).all())
+        assert bool(torch.isfinite(out_bad).all())
+        assert O.norm_max_err(out_bad.cpu().numpy(), OM.mc_tan_forward(v_bad, q, a, sd(m), 2, dtype=np.float64)[0]) < TOL
         out_again, _ = m(T(v), None, T(q), T(a))
         assert torch.equal(out_again, out_auto)
         m2 = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
@@ -248,6 +250,59 @@ def test_mc_model_detects_replicated_images_by_itself():
         out_plain, _ = m2(T(v_plain), None, T(q), T(a))
         assert m2._v_rep_auto == 1 and bool(torch.isfinite(out_plain).all())
         assert O.norm_max_err(out_plain.cpu().numpy(), OM.mc_tan_forward(v_plain, q, a, sd(m2), 2, dtype=np.float64)[0]) < TOL
+
+
+def test_mc_model_auto_replication_first_batch_one_image_then_mixed():
+    """The reference's eval loader is unshuffled and sorted by question id (consecutive Visual7W questions share an image): a first batch made of ONE image
+    (r = 8 detected where the pipeline's factor is 4), then a batch that crosses an image boundary.  Both give the oracle's logits; what a captured graph would use
+    afterwards is the gcd of what was seen (4)."""
+    torch.manual_seed(36)
+    m = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
+    rs = np.random.RandomState(12)
+    img = np.abs(rs.standard_normal((3, 9, 48))).astype(np.float32)
+    v1 = np.repeat(img[:1], 8, axis=0)                                         # two questions about image 0, four candidates each
+    v2 = np.concatenate([np.repeat(img[1:2], 4, axis=0), np.repeat(img[2:3], 4, axis=0)])    # one question each about images 1 and 2
+    q = np.repeat(rs.randint(0, 50, size=(2, 7)), 4, axis=0).astype(np.int64)
+    a = rs.randint(0, 50, size=(8, 6)).astype(np.int64)
+    with torch.no_grad():
+        o1, _ = m(T(v1), None, T(q), T(a))
+        assert m._v_rep_auto == 8
+        o2, _ = m(T(v2), None, T(q), T(a))
+        assert m._v_rep_auto == 4
+    for o, v in ((o1, v1), (o2, v2)):
+        assert bool(torch.isfinite(o).all())
+        assert O.norm_max_err(o.cpu().numpy(), OM.mc_tan_forward(v, q, a, sd(m), 2, dtype=np.float64)[0]) < TOL
+
+
+def test_mc_model_auto_replication_under_graph_capture_checks_every_replay_on_the_device():
+    """Under hipGraph capture the host cannot detect anything: the captured forward uses the factor the eager forwards have seen (their gcd), re-checks every
+    replayed batch on the device and NaN-fills the logits of a batch that breaks it -- never a plausible wrong answer."""
+    torch.manual_seed(37)
+    m = cti_amd.build_mc_cti(_args(2), _ds(50, 48, 2)).to(DEV).eval()
+    rs = np.random.RandomState(13)
+    vu = np.abs(rs.standard_normal((3, 9, 48))).astype(np.float32)
+    v = np.repeat(vu, 4, axis=0)
+    q = np.repeat(rs.randint(0, 50, size=(3, 7)), 4, axis=0).astype(np.int64)
+    a = rs.randint(0, 50, size=(12, 6)).astype(np.int64)
+    vs, qs, as_ = T(v), T(q), T(a)
+    with torch.no_grad():
+        eager, _ = m(vs, None, qs, as_)
+        assert m._v_rep_auto == 4
+        gr = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(gr, stream=side):
+                out, _ = m(vs, None, qs, as_)
+        torch.cuda.current_stream().wait_stream(side)
+        gr.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        vs[5, 2, 7] += 1.0                                                     # the replayed batch no longer consists of groups of four identical images
+        gr.replay(); torch.cuda.synchronize()
+        assert bool(torch.isnan(out).all())
+        vs.copy_(T(v))
+        gr.replay(); torch.cuda.synchronize()
+        assert torch.equal(out, eager)
 
 
 @pytest.mark.parametrize("B,G,V,Q,D", [(4, 8, 36, 14, 3072), (3, 2, 9, 7, 96), (2, 4, 50, 16, 128)])

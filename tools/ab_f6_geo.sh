@@ -1,3 +1,4 @@
+# needs a library built with -DCTI_F6_WITH_HALF_GEO (CTI_HIP_LIB=<that .so>): the product build has no half geometry since round 5
 cd $GRAFT_REPO_ROOT
 for g in default half; do
   if [ $g = half ]; then export CTI_F6_GEO=half; else unset CTI_F6_GEO; fi

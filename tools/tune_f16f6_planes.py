@@ -46,7 +46,7 @@ def run(rounds=5):
             fn.restype, fn.argtypes = L.SIGNATURES[name]
         libs[os.path.basename(f)[len("libf6p_"):-3]] = l
     dev = "cuda"
-    rows, K, M, A = 256 * 3129, 512, 512, 3129
+    rows, K, M, A = 256 * 3129, int(os.environ.get("CTI_TUNE_K", "512")), 512, 3129      # CTI_TUNE_K=300: the Tucker projection's shape
     x = torch.relu(torch.randn(rows, K, device=dev))
     w = torch.randn(M, K, device=dev) * 0.05
     sc = torch.rand(32, device=dev) + 0.5
