@@ -126,6 +126,10 @@ SIGNATURES = {
     "cti_pool_dw_mfma": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_fwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _vp]),
     "cti_bi_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
+    "cti_bi_pool_shift_multi_fwd": (_int, [_vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _i64, _i64, _vp, _i64, _int, _int, _int, _int, _vp]),
+    "cti_gemm_pb_partials_count": (_int, [_int, _int, _int]),
+    "cti_gemm_pb_partials_workspace_bytes": (_sz, [_int, _int, _int]),
+    "cti_gemm_pb_partials": (_int, [_vp, _i64, _vp, _int, _int, _int, _int, _vp, _sz, _vp, _sz, _vp]),
     "cti_bi_pool_shift_vt16_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp]),
     "cti_tri_pool_shift_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "cti_tri_pool_shift_vt16_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),

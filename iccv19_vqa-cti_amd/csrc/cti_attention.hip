@@ -430,6 +430,11 @@ __global__ __launch_bounds__(256) void bi_pool_kernel(const float* __restrict__ 
 // row = the hoisted pre-activation projection of the INITIAL sequence, add = the projection of the accumulated residual (one (B, D) vector per sample): the
 // glimpse loops of src/FFOE/base_model.py:53-61,129-132 then need no (B*L, D) projection GEMM between two glimpses (base_model.py here, _HoistedLoop).
 struct PoolShift { const float* qadd; const float* aadd; int relu; };
+// Round 5 (the unrolled BAN glimpse loop, base_model.py `_ban_forward_unrolled`): the q operand's shift as a SUM of up to POOL_MAX_ADDS addends -- the raw split-K partials of
+// the products that feed it, each (B, ld) fp32 with its own row stride (0 = one row broadcast over the batch) -- added up as the pool loads them: the reduce pass that
+// stood between a product and the pool it feeds is gone.  n == 0: the single-addend form of PoolShift.
+constexpr int POOL_MAX_ADDS = 32;
+struct PoolAdds { const float* p[POOL_MAX_ADDS]; int ld[POOL_MAX_ADDS]; int n; int ldo; };      // ldo: row stride of `out` (0 = D): the pooled vectors of all glimpses side by side
 __device__ __forceinline__ float shift1(float x, float a, int relu) { x += a; return relu ? fmaxf(x, 0.f) : x; }
 // `c ? *p : z` with two lvalues is an lvalue conditional: the constant would live in private memory (scratch) and be loaded from there -- select VALUES instead
 __device__ __forceinline__ float2 ld2_or_zero(bool c, const float* p) { float2 r = make_float2(0.f, 0.f); if (c) r = *reinterpret_cast<const float2*>(p); return r; }
@@ -456,7 +461,7 @@ template <bool TRI, int AP, int NG, int QX>
 __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                           const float* __restrict__ at, const float* __restrict__ w,
                                                           int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                          float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh, int vt16) {
+                                                          float* __restrict__ out, int V, int Q, int A, int D, PoolShift sh, int vt16, PoolAdds qa) {
 #ifndef CTI_POOL_VC
 #define CTI_POOL_VC 9
 #endif
@@ -496,8 +501,21 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
 #pragma unroll
         for (int a = 0; a < AP; ++a) ar[a] = ld4_or_zero(a < A, at + ((int64_t)b * A + a) * D + dd);
     }
-    if (sh.relu || sh.qadd || sh.aadd) {                             // shifted form: the real rows only (padding rows stay 0)
-        const float4 dq = ld4_or_zero(sh.qadd != nullptr, sh.qadd + (int64_t)b * D + dd);
+    if (sh.relu || sh.qadd || sh.aadd || qa.n) {                     // shifted form: the real rows only (padding rows stay 0)
+        float4 dq = ld4_or_zero(sh.qadd != nullptr, sh.qadd + (int64_t)b * D + dd);
+        // several addends: the partial slabs of the products behind this shift, summed here.  Eight INDEPENDENT loads per round (the first form walked up to 31
+        // addends one dependent load at a time: the pool took 26 us instead of 16.5, profiles/r05_model_c4_kernel_stats_unrolled_v1.txt)
+        for (int i0 = 0; i0 < qa.n; i0 += 8) {
+            float4 t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < qa.n ? i0 + u : i0;           // (a short last round re-reads its first addend; its value is not added)
+                t8[u] = *reinterpret_cast<const float4*>(qa.p[i] + (int64_t)b * qa.ld[i] + dd);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < qa.n) { dq.x += t8[u].x; dq.y += t8[u].y; dq.z += t8[u].z; dq.w += t8[u].w; }
+        }
 #pragma unroll
         for (int q = 0; q < QM; ++q)
             if (q < QL && q < Qn) { qr[q].x = shift1(qr[q].x, dq.x, sh.relu); qr[q].y = shift1(qr[q].y, dq.y, sh.relu); qr[q].z = shift1(qr[q].z, dq.z, sh.relu); qr[q].w = shift1(qr[q].w, dq.w, sh.relu); }
@@ -572,7 +590,7 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
             for (int g = 1; g < NG; ++g) { const float4 o = red[(g - 1) * 128 + t]; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
         }
     }
-    if (live && grp == 0) *reinterpret_cast<float4*>(out + (int64_t)b * D + d) = acc;
+    if (live && grp == 0) *reinterpret_cast<float4*>(out + (int64_t)b * (qa.ldo ? qa.ldo : D) + d) = acc;
 }
 
 // Tri pool, product-table form (exact Q*A known at compile time: 36, 42 -- the A = 3 answer tokens of the FFOE model).  The arithmetic of the tri pool is V*Q*A FMAs per
@@ -1548,7 +1566,7 @@ static int tri_pool_impl(const float* vt, const float* qt, const float* at, cons
         if (lds_p < sizeof(float4) * 128 * (NG - 1)) lds_p = sizeof(float4) * 128 * (NG - 1);
         if (lds_p <= 64 * 1024) {
             const dim3 grid((D / 4 + 127) / 128, B);
-#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh, 0)
+#define CTI_TP(APv, QXv) hipLaunchKernelGGL((pool_stream_kernel<true, APv, NG, QXv>), grid, dim3(128 * NG), lds_p, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, A, D, sh, 0, PoolAdds{})
             if (AP == 4) { if (Q == 14) CTI_TP(4, 14); else if (Q == 12) CTI_TP(4, 12); else CTI_TP(4, 0); }
             else         { if (Q == 14) CTI_TP(8, 14); else if (Q == 12) CTI_TP(8, 12); else CTI_TP(8, 0); }
 #undef CTI_TP
@@ -1580,8 +1598,8 @@ extern "C" int cti_tri_pool_fwd(const float* vt, const float* qt, const float* a
 }
 
 static int bi_pool_impl(const float* vt, const float* qt, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
-                        float* out, int B, int V, int Q, int D, int k, PoolShift sh, void* stream, int vt16 = 0) {
-    const bool shifted = sh.relu || sh.qadd;
+                        float* out, int B, int V, int Q, int D, int k, PoolShift sh, void* stream, int vt16 = 0, const PoolAdds* qa = nullptr) {
+    const bool shifted = sh.relu || sh.qadd || qa;
     CTI_REQUIRE_PTR(vt); CTI_REQUIRE_PTR(qt); CTI_REQUIRE_PTR(out);
     if (shifted && sh.qadd && !aligned16(sh.qadd)) return CTI_E_UNSUPPORTED;
     CTI_REQUIRE(B > 0 && V > 0 && Q > 0 && D > 0 && k > 0 && B <= 65535, CTI_E_SHAPE, "cti_bi_pool_fwd: B=%d V=%d Q=%d D=%d k=%d", B, V, Q, D, k);
@@ -1594,7 +1612,7 @@ static int bi_pool_impl(const float* vt, const float* qt, const float* w, int64_
         size_t lds_b = sizeof(float) * (size_t)V * 16;
         if (lds_b < sizeof(float4) * 128 * (NGB - 1)) lds_b = sizeof(float4) * 128 * (NGB - 1);
 #define CTI_BP(QXv) hipLaunchKernelGGL((pool_stream_kernel<false, 4, NGB, QXv>), dim3((D / 4 + 127) / 128, B), dim3(128 * NGB), lds_b, as_stream(stream), \
-                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D, sh, vt16)
+                           vt, qt, nullptr, w, w_sb, w_sv, w_sq, (int64_t)0, out, V, Q, 0, D, sh, vt16, qa ? *qa : PoolAdds{})
         if (Q == 14) CTI_BP(14); else if (Q == 12) CTI_BP(12); else CTI_BP(0);
 #undef CTI_BP
         return launch_status("cti_bi_pool_fwd");
@@ -1634,6 +1652,26 @@ extern "C" int cti_bi_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, 
                                           float* out, int B, int V, int Q, int D, void* stream) {
     CTI_REQUIRE_PTR(w);
     return bi_pool_impl(static_cast<const float*>(vt_bf16), qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, 1, PoolShift{qadd, nullptr, 1}, stream, 1);
+}
+
+// The shifted bi pool whose shift is a SUM of n_qadd addends, qadds[i] a (B, qadd_ld[i]) fp32 matrix read at columns [0, D) -- row stride 0 = one row for the whole
+// batch --: out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + sum_i qadds[i][b * ld_i + d]).  qadds / qadd_ld are HOST arrays (consumed before the call returns);
+// every addend 16-B aligned with ld % 4 == 0.  vt_bf16 != 0: vt as bf16 rows.  CTI_E_UNSUPPORTED (nothing launched) outside the streaming kernel's shapes or for more than 32 addends.
+extern "C" int cti_bi_pool_shift_multi_fwd(const void* vt, int vt_bf16, const float* qt, const float* const* qadds, const int64_t* qadd_ld, int n_qadd, const float* w,
+                                           int64_t w_sb, int64_t w_sv, int64_t w_sq, float* out, int64_t ldo, int B, int V, int Q, int D, void* stream) {
+    CTI_REQUIRE_PTR(w);
+    CTI_REQUIRE(ldo >= D && (ldo & 3) == 0 && ldo < (1ll << 31), CTI_E_SHAPE, "cti_bi_pool_shift_multi_fwd: ldo=%lld (>= D, a multiple of 4)", (long long)ldo);
+    CTI_REQUIRE(n_qadd >= 0 && (n_qadd == 0 || (qadds && qadd_ld)), CTI_E_NULL, "cti_bi_pool_shift_multi_fwd: n_qadd=%d without the arrays", n_qadd);
+    if (n_qadd > POOL_MAX_ADDS) return CTI_E_UNSUPPORTED;
+    PoolAdds qa{};
+    qa.n = n_qadd;
+    for (int i = 0; i < n_qadd; ++i) {
+        CTI_REQUIRE(qadds[i] != nullptr && qadd_ld[i] >= 0 && qadd_ld[i] < (1ll << 31), CTI_E_SHAPE, "cti_bi_pool_shift_multi_fwd: addend %d", i);
+        if (!aligned16(qadds[i]) || (qadd_ld[i] & 3)) return CTI_E_UNSUPPORTED;
+        qa.p[i] = qadds[i]; qa.ld[i] = (int)qadd_ld[i];
+    }
+    qa.ldo = (int)ldo;
+    return bi_pool_impl(static_cast<const float*>(vt), qt, w, w_sb, w_sv, w_sq, out, B, V, Q, D, 1, PoolShift{nullptr, nullptr, 1}, stream, vt_bf16 ? 1 : 0, &qa);
 }
 
 extern "C" int cti_bi_logits_fwd(const float* vt, const float* qt, const float* h, const float* h_scale, const float* h_bias,

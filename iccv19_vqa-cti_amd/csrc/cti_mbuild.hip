@@ -440,6 +440,20 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_kernel(const float* __restri
 #ifndef CTI_MBF6_PREFETCH_EARLY
 #define CTI_MBF6_PREFETCH_EARLY 1
 #endif
+#ifndef CTI_MBF6_ABL      // timing-only ablations of mbuild_mfma_f6_kernel (wrong results; tools/tune_mbuild_f6.py): 1 the step-1 operand splits (V^, Q^, T) become four
+#define CTI_MBF6_ABL 0    // byte permutes each, 2 the same for the step-2 X fragment, 4 no encoder (the odd rank's items are not encoded or stored), 8 no MFMAs
+#endif
+// (ablation helper) 8 floats -> the upper halves of their bit patterns as "hi" (truncation: 4 v_perm_b32), lo = hi: what a split would cost if it were free
+__device__ __forceinline__ void mb_trunc8(const float4 a, const float4 b, mb_bf16x8& hi, mb_bf16x8& lo) {
+    const unsigned x[8] = {__builtin_bit_cast(unsigned, a.x), __builtin_bit_cast(unsigned, a.y), __builtin_bit_cast(unsigned, a.z), __builtin_bit_cast(unsigned, a.w),
+                           __builtin_bit_cast(unsigned, b.x), __builtin_bit_cast(unsigned, b.y), __builtin_bit_cast(unsigned, b.z), __builtin_bit_cast(unsigned, b.w)};
+    typedef unsigned mb_u32x4 __attribute__((ext_vector_type(4)));
+    mb_u32x4 p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = (x[2 * i] >> 16) | (x[2 * i + 1] & 0xffff0000u);
+    hi = __builtin_bit_cast(mb_bf16x8, p);
+    lo = hi;
+}
 __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr, const float* __restrict__ Tt,
                                                               F6Planes P, int V, int Q, int R) {
     constexpr int HR = 16, G = 2, INNER = HR * HR * G;
@@ -476,20 +490,25 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
     CTI_MM_LOAD(0)
     for (int r = 0; r < R; ++r) {
         mb_bf16x8 ah0, al0, ah1, al1, th, tl, qh, ql;
+        if (CTI_MBF6_ABL & 1) { mb_trunc8(a00, a01, ah0, al0); mb_trunc8(a10, a11, ah1, al1); mb_trunc8(t0, t1, th, tl); mb_trunc8(q0, q1, qh, ql); }
+        else {
         mb_split8(a00, a01, ah0, al0);
         mb_split8(a10, a11, ah1, al1);
         mb_split8(t0, t1, th, tl);
         mb_split8(q0, q1, qh, ql);
+        }
 #if CTI_MBF6_PREFETCH_EARLY
         if (r + 1 < R) CTI_MM_LOAD(r + 1)
 #endif
         mb_f32x16 x0, x1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { x0[e] = 0.f; x1[e] = 0.f; }
+        if (!(CTI_MBF6_ABL & 8) || R < 0) {
         x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, th, x0, 0, 0, 0);
         x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, tl, x0, 0, 0, 0);
         x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, th, x0, 0, 0, 0);
-        if (V > 32) {
+        } else { x0[0] = static_cast<float>(ah0[0]) + static_cast<float>(th[1]) + static_cast<float>(al0[2]) + static_cast<float>(tl[3]); x1[0] = static_cast<float>(ah1[0]) + static_cast<float>(al1[1]); }
+        if (V > 32 && (!(CTI_MBF6_ABL & 8) || R < 0)) {
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, th, x1, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, tl, x1, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, th, x1, 0, 0, 0);
@@ -505,13 +524,19 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
         for (int v = wid; v < V; v += 16) {
             const float* xr = X2 + ((v * G + sg) * HR + sk) * MB_XP + kg * 8;
             mb_bf16x8 xh, xl;
-            mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
+            if (CTI_MBF6_ABL & 2) mb_trunc8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
+            else mb_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), xh, xl);
             mb_f32x16 m;
 #pragma unroll
             for (int e = 0; e < 16; ++e) m[e] = 0.f;
+            if (!(CTI_MBF6_ABL & 8) || R < 0) {
             m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, qh, m, 0, 0, 0);
             m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ql, m, 0, 0, 0);
             m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, qh, m, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { m[e] = static_cast<float>(xh[e]) * static_cast<float>(qh[e]); m[8 + e] = static_cast<float>(xl[e]) + static_cast<float>(ql[e]); }
+            }
             // register 4 eg + t of lane (q, kg) is rho = 8 eg + 4 kg + t = (g = eg >> 1, k = 8 (eg & 1) + 4 kg + t): the swaps of (eg 0, eg 2) and
             // (eg 1, eg 3) leave lane half g with y[k], k = 0 .. 15, of output row (v, q, g)
             float y[16];
@@ -538,6 +563,7 @@ __global__ __launch_bounds__(1024) void mbuild_mfma_f6_kernel(const float* __res
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[16 + k] = y[k];
+            if ((CTI_MBF6_ABL & 4) && x[0] != 12345.f) continue;
             const int64_t prow = f6_prow(P, rows_b + ((int64_t)v * Q + l31) * G + kg);
             const int kb = r >> 1;
             const int64_t o = (int64_t)kb * P.rows_alloc + prow;

@@ -441,6 +441,54 @@ int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, co
     return launch_status("cti_linear_residual_pb");
 }
 
+// The raw fp32 partial slabs of x (M, K) @ W^T (W (N, K) as resident planes): partials[s][m][n], s < cti_gemm_pb_partials_count(M, N, K) -- no reduce pass, no
+// scale / bias: the consumer adds the slabs up as it loads them (cti_bi_pool_shift_multi_fwd).  Round 5: the unrolled BAN glimpse loop.
+int cti_gemm_pb_partials_count(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // Its own planner (the slabs are consumed raw, so a K split costs the consumer one more addend, not a reduce launch): the largest power of two with about one
+    // 128 x 128 workgroup per CU and K ranges of at least 128.  plan_ksplit() leaves products of more than 96 tiles unsplit: 256 x 7 168 x 1 024, the unrolled
+    // BAN loop's first product, then ran on 112 workgroups for 27 us.
+    const int Kp = planes_kp(K);
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    int best = 1;
+    for (int s = 2; s <= 16; s *= 2) {
+        if (Kp % (s * 32) != 0 || Kp / s < 128 || tiles * s > 256) break;
+        best = s;
+    }
+    return best;
+}
+size_t cti_gemm_pb_partials_workspace_bytes(int M, int K, int prec) {
+    if (M <= 0 || K <= 0 || (prec != CTI_PREC_BF16X3 && prec != CTI_PREC_BF16)) return 0;
+    return (planes_bytes((int64_t)M + PLANE_SLACK_ROWS, K) + 255) & ~(size_t)255;
+}
+int cti_gemm_pb_partials(const float* x, int64_t ldx, const void* W_planes, int M, int N, int K, int prec, float* partials, size_t partials_bytes, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(W_planes); CTI_REQUIRE_PTR(partials); CTI_REQUIRE_PTR(workspace);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && ldx >= K, CTI_E_SHAPE, "cti_gemm_pb_partials: M=%d N=%d K=%d ldx=%lld", M, N, K, (long long)ldx);
+    CTI_REQUIRE(prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gemm_pb_partials: prec=%d (resident planes exist in the bf16 modes only)", prec);
+    const int S = cti_gemm_pb_partials_count(M, N, K);
+    CTI_REQUIRE(partials_bytes >= sizeof(float) * (size_t)S * (size_t)M * (size_t)N, CTI_E_WORKSPACE, "cti_gemm_pb_partials: %zu bytes for %d slabs of %d x %d", partials_bytes, S, M, N);
+    CTI_REQUIRE(workspace_bytes >= cti_gemm_pb_partials_workspace_bytes(M, K, prec), CTI_E_WORKSPACE, "cti_gemm_pb_partials: workspace too small");
+    CTI_REQUIRE((reinterpret_cast<uintptr_t>(partials) & 15) == 0, CTI_E_ALIGN, "cti_gemm_pb_partials: the slabs must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    const int Kp = planes_kp(K);
+    const int64_t ra = (int64_t)M + PLANE_SLACK_ROWS, rb = (int64_t)N + PLANE_SLACK_ROWS;
+    unsigned short* ah = static_cast<unsigned short*>(workspace);
+    unsigned short* al_ = ah + (size_t)ra * Kp;
+    const unsigned short* bh = static_cast<const unsigned short*>(W_planes);
+    const unsigned short* bl = bh + (size_t)rb * Kp;
+    const bool af32 = M <= 256 && (K & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;      // batch-sized: the product reads its fp32 rows itself
+    int rc = CTI_OK;
+    if (!af32) { rc = split_planes(x, ldx, M, K, ah, prec == CTI_PREC_BF16 ? nullptr : al_, ra, st); if (rc) return rc; }
+    PlaneGemmArgs g{};
+    if (af32) { g.Af = x; g.ldaf = ldx; g.Kreal = K; }
+    g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
+    g.M = M; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
+    g.C = partials; g.ldc_m = N; g.ldc_n = 1;
+    if (S > 1) { g.ksplit = S; g.partial = partials; g.partials_only = 1; }       // (the plane GEMM takes the split it is given)
+    return gemm_nt_planes(g, st);
+}
+
 int cti_seq_bcast_add(const float* x, const float* y, float* out, int B, int L, int H, void* stream) {
     CTI_REQUIRE_PTR(y); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B >= 0 && L >= 0 && H > 0, CTI_E_SHAPE, "cti_seq_bcast_add: B=%d L=%d H=%d", B, L, H);

@@ -777,9 +777,9 @@ def masked_softmax_bi_(logits, mask):
 def tri_pool(vt, qt, at, w, v_rep=1):
     """out[b,d] = sum_vqa vt[b,v,d] w[b,v,q,a] qt[b,q,d] at[b,a,d]; w may be any strided (B,V,Q,A) view.  v_rep > 1: vt is (B / v_rep, V, D),
     one block per image shared by v_rep consecutive batch rows (the kernel that takes it reads it in place; otherwise it is expanded here)."""
-    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16
-    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32)
-    for t, n in ((qt, "qt"), (at, "at"), (w, "w")):
+    if isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16:
+        vt = widen_bf16(vt)                                            # (the unshifted pools read fp32 rows)
+    for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
         _req(t, n)
     v_rep = int(v_rep)
     B, (V, D) = qt.shape[0], vt.shape[1:]
@@ -861,6 +861,48 @@ def bi_pool_shift(vt, qt, qadd, w):
     return out
 
 
+def bi_pool_shift_multi(vt, qt, adds, w, out):
+    """out[b, :D] = sum_vq vt[b,v,:] w[b,v,q] relu(qt[b,q,:] + sum_i add_i[b,:])  with adds = [(device address, row stride in floats), ...] -- row stride 0 = one
+    row for the whole batch -- summed as the pool loads them (cti_bi_pool_shift_multi_fwd: the raw split-K slabs of the products that feed the shift, no reduce
+    launch in between).  out: a (B, D) view whose row stride may exceed D.  vt fp32 or bf16 rows.  False when no kernel takes the shape.  Inference only."""
+    import ctypes as _C
+    vt16 = vt.dtype == torch.bfloat16
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32); _req(qt, "qt"); _req(w, "w"); _req(out, "out")
+    B, V, D = vt.shape
+    Q = qt.shape[1]
+    vt, qt = vt.contiguous(), qt.contiguous()
+    if tuple(w.shape) != (B, V, Q) or tuple(out.shape) != (B, D) or out.stride(1) != 1 or B == 0 or V * Q == 0 or len(adds) > 32:
+        return False
+    n = len(adds)
+    ptrs = (_C.c_void_p * max(1, n))(*[int(a) for a, _ in adds])
+    lds = (_C.c_int64 * max(1, n))(*[int(l) for _, l in adds])
+    sb, sv, sq = w.stride()
+    rc = L.lib().cti_bi_pool_shift_multi_fwd(vt.data_ptr(), 1 if vt16 else 0, qt.data_ptr(), ptrs, lds, n, w.data_ptr(), sb, sv, sq, out.data_ptr(), out.stride(0),
+                                             B, V, Q, D, _stream())
+    if rc == L.E_UNSUPPORTED:
+        return False
+    L.check(rc, "cti_bi_pool_shift_multi_fwd")
+    return True
+
+
+def gemm_pb_partials(x, w_planes, N, prec=None):
+    """The raw fp32 split-K slabs (S, M, N) of x (M, K; any row stride) @ W^T against resident planes of an (N, K) weight -- no reduce pass, scale or bias
+    (cti_gemm_pb_partials); bf16 modes only."""
+    _req(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.reshape(-1, x.shape[-1]).contiguous()
+    M, K = x.shape
+    pr = _prec(prec)
+    lib = L.lib()
+    S = lib.cti_gemm_pb_partials_count(M, int(N), K)
+    out = torch.empty((S, M, int(N)), device=x.device, dtype=torch.float32)
+    wsb = lib.cti_gemm_pb_partials_workspace_bytes(M, K, pr)
+    ws = torch.empty(max(wsb, 16), device=x.device, dtype=torch.uint8)
+    L.check(lib.cti_gemm_pb_partials(x.data_ptr(), x.stride(0), w_planes.data_ptr(), M, int(N), K, pr, out.data_ptr(), out.numel() * 4, ws.data_ptr(), wsb, _stream()),
+            "cti_gemm_pb_partials")
+    return out
+
+
 def widen_bf16(x):
     """bf16 -> fp32 copy (off the fast path: a consumer without a bf16-reading kernel at its shape)."""
     return x.float()
@@ -869,7 +911,9 @@ def widen_bf16(x):
 def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
     """out[b,d] = sum_vqa vt[b / v_rep, v, d] w[b,v,q,a] relu(qt[b,q,d] + qadd[b,d]) relu(at[b,a,d] + aadd[b,d])  (qadd / aadd (B,D) or None = 0), or
     None when no kernel forms the shifted operands on load at this shape.  Inference only."""
-    for t, n in ((vt, "vt"), (qt, "qt"), (at, "at"), (w, "w")):
+    vt16 = isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16          # (round 5) bf16 rows from the hoisted projection
+    _req(vt, "vt", torch.bfloat16 if vt16 else torch.float32)
+    for t, n in ((qt, "qt"), (at, "at"), (w, "w")):
         _req(t, n)
     v_rep = int(v_rep)
     B, (V, D) = qt.shape[0], vt.shape[1:]
@@ -902,8 +946,8 @@ def tri_pool_shift(vt, qt, at, qadd, aadd, w, v_rep=1):
 
 
 def rows_equal_prev(x):
-    """(B,) uint8: row b of x (B, ...) holds the same bits as row b - 1 (element 0 is 0), or None when the rows are not 16-B multiples."""
-    _req(x, "x")
+    """(B,) uint8: row b of x (B, ...) holds the same bits as row b - 1 (element 0 is 0), or None when the rows are not 16-B multiples.  Any dtype (a byte compare)."""
+    _req(x, "x", x.dtype if isinstance(x, torch.Tensor) else torch.float32)
     xc = x.contiguous()
     B = xc.shape[0]
     eq = torch.empty(B, device=x.device, dtype=torch.uint8)

@@ -285,6 +285,21 @@ int cti_bi_pool_shift_fwd(const float* vt, const float* qt, const float* qadd, c
 int cti_tri_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* at, const float* qadd, const float* aadd, const float* w,
                                 int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa, float* out, int B, int V, int Q, int A, int D, int v_rep,
                                 int use_mfma, void* stream);
+/* Round 5 -- the unrolled BAN glimpse loop (base_model.py `_ban_forward_unrolled`; reference src/FFOE/base_model.py:53-61): the pool's shift as a SUM of n_qadd
+ * addends, qadds[i] a (B, qadd_ld[i]) fp32 matrix read at columns [0, D) (row stride 0 = one row for the whole batch), summed as the pool loads them:
+ *   out[b,d] = sum_vq vt[b,v,d] w[b,v,q] relu(qt[b,q,d] + sum_i qadds[i][b * qadd_ld[i] + d]).
+ * The addends are the raw split-K slabs of the products that feed the shift (cti_gemm_pb_partials): no reduce launch between a product and the pool.
+ * qadds / qadd_ld: HOST arrays, consumed before the call returns; addends 16-B aligned, ld % 4 == 0, at most 32.  vt_bf16 != 0: vt as bf16 rows.
+ * out: row stride ldo >= D (the pooled vectors of all glimpses side by side = the K-concatenated operand of the loop's last product).
+ * CTI_E_UNSUPPORTED (nothing launched, no message) outside the streaming kernel's shapes (Q <= 16, D % 4 == 0). */
+int cti_bi_pool_shift_multi_fwd(const void* vt, int vt_bf16, const float* qt, const float* const* qadds, const int64_t* qadd_ld, int n_qadd, const float* w,
+                                int64_t w_sb, int64_t w_sv, int64_t w_sq, float* out, int64_t ldo, int B, int V, int Q, int D, void* stream);
+/* partials[s][m][n] = the s-th K range's share of x (M, K; row stride ldx) @ W^T, W (N, K) as cti_split_operand planes: the RAW fp32 slabs of the split-K plan,
+ * s < cti_gemm_pb_partials_count(M, N, K) (>= 1) -- no reduce pass, no scale, no bias.  workspace: cti_gemm_pb_partials_workspace_bytes(M, K, prec). */
+int cti_gemm_pb_partials_count(int M, int N, int K);
+size_t cti_gemm_pb_partials_workspace_bytes(int M, int K, int prec);
+int cti_gemm_pb_partials(const float* x, int64_t ldx, const void* W_planes, int M, int N, int K, int prec, float* partials, size_t partials_bytes, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int cti_bi_pool_shift_vt16_fwd(const void* vt_bf16, const float* qt, const float* qadd, const float* w, int64_t w_sb, int64_t w_sv, int64_t w_sq,
                                float* out, int B, int V, int Q, int D, void* stream);
 

@@ -193,23 +193,70 @@ def test_hoisted_glimpse_loops_equal_the_literal_loops():
     v[1, 6:] = 0
     q = rs.randint(0, 50, size=(6, 8)).astype(np.int64)
     a = rs.randint(0, 50, size=(6, 3)).astype(np.int64)
-    calls = {"tri": 0, "bi": 0}
-    tps, bps = ops.tri_pool_shift, ops.bi_pool_shift
+    calls = {"tri": 0, "bi": 0, "multi": 0}
+    tps, bps, mps = ops.tri_pool_shift, ops.bi_pool_shift, ops.bi_pool_shift_multi
     ops.tri_pool_shift = lambda *x, **k: (calls.__setitem__("tri", calls["tri"] + 1), tps(*x, **k))[1]
     ops.bi_pool_shift = lambda *x, **k: (calls.__setitem__("bi", calls["bi"] + 1), bps(*x, **k))[1]
+    ops.bi_pool_shift_multi = lambda *x, **k: (calls.__setitem__("multi", calls["multi"] + 1), mps(*x, **k))[1]
     try:
         with torch.no_grad():
             lc, (lb, ab) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
-            assert calls == {"tri": 3, "bi": 4}, calls                     # the hoisted form is what ran
+            assert calls == {"tri": 3, "bi": 0, "multi": 4}, calls         # BAN: the UNROLLED loop (round 5: two launches per glimpse on the dependent chain) is what ran
+            bm._UNROLL = False
+            lb1, ab1 = ban(T(v), None, T(q), None)
+            assert calls == {"tri": 3, "bi": 4, "multi": 4}, calls         # ... and with its knob off the hoisted form of round 4
             bm._HOIST_LOOP = False
             lc0, (lb0, ab0) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
-            assert calls == {"tri": 3, "bi": 4}
+            assert calls == {"tri": 3, "bi": 4, "multi": 4}
     finally:
         bm._HOIST_LOOP = True
-        ops.tri_pool_shift, ops.bi_pool_shift = tps, bps
+        bm._UNROLL = True
+        ops.tri_pool_shift, ops.bi_pool_shift, ops.bi_pool_shift_multi = tps, bps, mps
     assert O.norm_max_err(lc.cpu().numpy(), lc0.cpu().numpy()) < 2e-5 and O.norm_max_err(lb.cpu().numpy(), lb0.cpu().numpy()) < 2e-5
+    assert O.norm_max_err(lb1.cpu().numpy(), lb0.cpu().numpy()) < 2e-5 and torch.equal(ab, ab0) and torch.equal(ab1, ab0)
     assert O.norm_max_err(lc.cpu().numpy(), OM.ffoe_cti_forward(v, q, a, sd(cti), 3, dtype=np.float64)) < TOL
     assert O.norm_max_err(lb.cpu().numpy(), OM.ffoe_ban_forward(v, q, sd(ban), 4, dtype=np.float64)[0]) < 1.5e-4
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 6e-3), ("f16f6", 3e-5)])
+def test_unrolled_ban_loop_at_full_widths_on_every_row(prec, tol):
+    """The unrolled glimpse loop of BanModel (8 glimpses, 1 024 wide, B = 256: up to 30 split-K slabs summed inside a pool) against the hoisted loop it replaces and
+    the literal loop of src/FFOE/base_model.py:53-61, every row of the logits; the weight-only products C[g][j] follow a parameter change (cache key)."""
+    import types
+    bm = cti_amd.base_model
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(prec)
+    try:
+        torch.manual_seed(41)
+        ds = types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=2000), v_dim=2048, num_ans_candidates=3129)
+        margs = types.SimpleNamespace(op="c", num_hid=1024, gamma=8, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+        ban = cti_amd.build_ban(margs, ds).to(DEV).eval()
+        g = torch.Generator().manual_seed(42)
+        v = torch.randn(256, 36, 2048, generator=g).abs()
+        nv = torch.randint(10, 37, (256,), generator=g)
+        v[torch.arange(36)[None, :] >= nv[:, None]] = 0
+        v = v.to(DEV)
+        q = torch.randint(0, 2000, (256, 14), generator=g).to(DEV)
+        rel = lambda a, b: float(((a - b).abs().flatten(1).amax(1) / b.abs().max()).max())
+        with torch.no_grad():
+            lu = ban(v, None, q, None)[0]
+            bm._UNROLL = False
+            lh = ban(v, None, q, None)[0]
+            bm._HOIST_LOOP = False
+            ll = ban(v, None, q, None)[0]
+            bm._HOIST_LOOP, bm._UNROLL = True, True
+            print(prec, "unrolled vs hoisted %.2e, vs literal %.2e" % (rel(lu, lh), rel(lu, ll)))
+            assert rel(lu, lh) < tol and rel(lu, ll) < tol
+            # a parameter update must rebuild the weight-only products
+            ban.q_prj[3].main[1].weight_g.data.mul_(1.5)
+            cti_amd.ops.invalidate_caches()
+            lu2 = ban(v, None, q, None)[0]
+            bm._UNROLL = False
+            lh2 = ban(v, None, q, None)[0]
+            assert rel(lu2, lh2) < tol and rel(lu2, lu) > 3 * tol
+    finally:
+        bm._HOIST_LOOP, bm._UNROLL = True, True
+        cti_amd.set_precision(old)
 
 
 def test_mc_model_detects_replicated_images_by_itself():

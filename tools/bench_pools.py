@@ -59,8 +59,32 @@ def main(reps=20):
     cti_amd.set_precision("bf16")
     report("bi_logits G=8, plain-bf16 mode (one product per pair)", timeit(lambda: ops.bi_logits(vt3, qt3, h, hs, hb), reps),
            f * (B * (V * D3 + Q * D3 + 8 * V * Q) + 8 * D3), Q=Q, D=D3, G=8)
+    # round 5: the plain-bf16 mode's consumers reading the projected v as bf16 ROWS (what the hoisted projection GEMMs write): bytes = what each form really moves
+    vt3h = vt3.to(torch.bfloat16)
+    report("bi_logits G=8, plain-bf16 mode, bf16 vt rows (round 5)", timeit(lambda: ops.bi_logits(vt3h, qt3, h, hs, hb), reps),
+           B * (2 * V * D3 + f * Q * D3 + f * 8 * V * Q) + f * 8 * D3, Q=Q, D=D3, G=8)
+    vth = vt.to(torch.bfloat16)
+    qadd = torch.randn(B, D, device=DEV) * 0.1
+    report("bi_pool_shift (hoisted BAN loop), fp32 vt", timeit(lambda: ops.bi_pool_shift(vt, qt, qadd, att[:, 0]), reps), f * B * (V * D + Q * D + V * Q + 2 * D), Q=Q, D=D)
+    report("bi_pool_shift, bf16 vt rows (round 5)", timeit(lambda: ops.bi_pool_shift(vth, qt, qadd, att[:, 0]), reps), B * (2 * V * D + f * (Q * D + V * Q + 2 * D)), Q=Q, D=D)
+    slab = torch.randn(31, B, D, device=DEV) * 0.01
+    adds = [(slab[i].data_ptr(), D) for i in range(31)]
+    outm = torch.empty(B, 8 * D, device=DEV)
+    report("bi_pool_shift_multi, bf16 vt rows + 31 addends (unrolled BAN loop, last glimpse)",
+           timeit(lambda: ops.bi_pool_shift_multi(vth, qt, adds, att[:, 0], outm[:, :D]), reps), B * (2 * V * D + f * (Q * D + V * Q + 32 * D)), Q=Q, D=D)
+    for (Qt, At) in ((14, 3), (12, 6)):
+        qtt = torch.randn(B, Qt, D, device=DEV); att_ = torch.randn(B, At, D, device=DEV)
+        wt = torch.softmax(torch.randn(B, V * Qt * At, device=DEV), 1).view(B, V, Qt, At)
+        aadd = torch.randn(B, D, device=DEV) * 0.1
+        report("tri_pool_shift (hoisted CTI loop), fp32 vt", timeit(lambda: ops.tri_pool_shift(vt, qtt, att_, qadd, aadd, wt), reps),
+               f * B * (V * D + Qt * D + At * D + V * Qt * At + 3 * D), Q=Qt, A=At, D=D)
+        report("tri_pool_shift, bf16 vt rows (round 5)", timeit(lambda: ops.tri_pool_shift(vth, qtt, att_, qadd, aadd, wt), reps),
+               B * (2 * V * D + f * (Qt * D + At * D + V * Qt * At + 3 * D)), Q=Qt, A=At, D=D)
     cti_amd.set_precision("bf16x3")
     v = torch.randn(B, V, 2048, device=DEV).abs(); v[:, 30:] = 0
+    vh = v.to(torch.bfloat16)
+    report("zero_row_mask, bf16 rows (round 5)", timeit(lambda: ops.zero_row_mask(vh), reps), 2 * B * V * 2048 + B * V)
+    report("rows_equal_prev (repeated-image detection, fp32 v)", timeit(lambda: ops.rows_equal_prev(v), reps), f * B * V * 2048 + B)
     report("zero_row_mask", timeit(lambda: ops.zero_row_mask(v), reps), f * B * V * 2048 + B * V)
     mask = ops.zero_row_mask(v)
     lg = torch.randn(B, 8, V, Q, device=DEV)
