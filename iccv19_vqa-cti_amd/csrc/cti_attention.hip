@@ -440,22 +440,8 @@ __device__ __forceinline__ float shift1(float x, float a, int relu) { x += a; re
 __device__ __forceinline__ float2 ld2_or_zero(bool c, const float* p) { float2 r = make_float2(0.f, 0.f); if (c) r = *reinterpret_cast<const float2*>(p); return r; }
 __device__ __forceinline__ float4 ld4_or_zero(bool c, const float* p) { float4 r = make_float4(0.f, 0.f, 0.f, 0.f); if (c) r = *reinterpret_cast<const float4*>(p); return r; }
 // Round 5: the projected `vt` rows may be bf16 (vt16 != 0: the plain-bf16 mode's hoisted projections write the pools' operand as bf16 rows -- half the bytes of
-// the tensor these kernels exist to stream).  Four consecutive channels at BYTE address p: one 16-B fp32 load or one 8-B bf16 load widened in registers.
+// the tensor these kernels exist to stream).  Four consecutive channels are one 16-B fp32 load or one 8-B bf16 load widened in registers.
 typedef unsigned pl_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 ldv4_or_zero(bool c, const char* p, int vt16) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c) {
-        if (vt16) {
-            const pl_u32x2 u = *reinterpret_cast<const pl_u32x2*>(p);
-            r.x = __builtin_bit_cast(float, u[0] << 16); r.y = __builtin_bit_cast(float, u[0] & 0xffff0000u);
-            r.z = __builtin_bit_cast(float, u[1] << 16); r.w = __builtin_bit_cast(float, u[1] & 0xffff0000u);
-        } else r = *reinterpret_cast<const float4*>(p);
-    }
-    return r;
-}
-__device__ __forceinline__ float ldv1(const char* p, int vt16) {
-    return vt16 ? __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(p) << 16) : *reinterpret_cast<const float*>(p);
-}
 
 template <bool TRI, int AP, int NG, int QX>
 __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
@@ -534,7 +520,20 @@ __global__ __launch_bounds__(128 * NG) void pool_stream_kernel(const float* __re
     for (int v0 = v_lo; v0 < v_hi; v0 += VC) {
         float4 vr[VC];
 #pragma unroll
-        for (int u = 0; u < VC; ++u) vr[u] = ldv4_or_zero(v0 + u < v_hi, vb + (int64_t)(v0 + u) * D * vsz, vt16);
+        for (int u = 0; u < VC; ++u) vr[u] = z4;
+        // the row format is decided ONCE around the whole round of loads (a per-load choice keeps the compiler from issuing them back to back)
+        if (vt16) {
+            pl_u32x2 raw[VC];
+#pragma unroll
+            for (int u = 0; u < VC; ++u) { raw[u] = pl_u32x2{0u, 0u}; if (v0 + u < v_hi) raw[u] = *reinterpret_cast<const pl_u32x2*>(vb + (int64_t)(v0 + u) * D * 2); }
+#pragma unroll
+            for (int u = 0; u < VC; ++u)
+                vr[u] = make_float4(__builtin_bit_cast(float, raw[u][0] << 16), __builtin_bit_cast(float, raw[u][0] & 0xffff0000u),
+                                    __builtin_bit_cast(float, raw[u][1] << 16), __builtin_bit_cast(float, raw[u][1] & 0xffff0000u));
+        } else {
+#pragma unroll
+            for (int u = 0; u < VC; ++u) if (v0 + u < v_hi) vr[u] = *reinterpret_cast<const float4*>(vb + (int64_t)(v0 + u) * D * 4);
+        }
 #pragma unroll
         for (int u = 0; u < VC; ++u) {
             const int v = v0 + u;
@@ -1107,12 +1106,12 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
 // N = d: lane = channel, so qt / at / vt are read as coalesced 128-B rows and P is formed per lane; with rows = v in the
 // accumulator the Hadamard with vt and the sum over v are in-lane (+ one exchange between the two k-halves).
 // =====================================================================================================
-template <int A_, int KS, int TERMS>
+template <int A_, int KS, int TERMS, int VT16>
 __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restrict__ vt, const float* __restrict__ qt,
                                                             const float* __restrict__ at, const float* __restrict__ w,
                                                             int64_t w_sb, int64_t w_sv, int64_t w_sq, int64_t w_sa,
-                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh, int vt16) {
-    const int vsz = vt16 ? 2 : 4;                                   // (round 5) bytes per element of vt: fp32 or bf16 rows
+                                                            float* __restrict__ out, int V, int Q, int D, int tiles_per_wave, int v_rep, PoolShift sh) {
+    constexpr int vsz = VT16 ? 2 : 4;                               // (round 5) bytes per element of vt: fp32 or bf16 rows
     // Round 4: the sample's compacted attention slice is split into bf16 hi / lo ONCE per workgroup, into LDS, and the MFMA fragments are read from there at
     // every use (20 ds_read_b128 per tile) instead of living in 80 registers per wave: eight waves fit the register file (two per SIMD), ONE workgroup per sample
     // covers its 32 channel tiles, and the set-up -- what this kernel's time is made of -- is paid once per sample.
@@ -1142,10 +1141,18 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
             _Pragma("unroll") for (int a = 0; a < A_; ++a) ar_[a] = shift1(ar_[a], da_, sh.relu);                \
         }                                                                                                        \
         const char* vb_ = reinterpret_cast<const char*>(vt) + ((int64_t)(b / v_rep) * V * D + d_) * vsz;      /* v_rep > 1: one vt block per image, v_rep batch rows share it */ \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                         \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {               /* VT16 is a template argument: no per-load choice of the row format */ \
             const int v = (e & 3) + 8 * (e >> 2) + 4 * kg;                                                       \
-            v0_[e] = v < V ? ldv1(vb_ + (int64_t)v * D * vsz, vt16) : 0.f;                                       \
-            v1_[e] = (two && v + 32 < V) ? ldv1(vb_ + (int64_t)(v + 32) * D * vsz, vt16) : 0.f;                  \
+            if (VT16) {          /* bf16 rows: a lane PAIR loads the dword that holds both its channels and each lane keeps its half (2-B loads measured 1.7x slower) */ \
+                const char* vp_ = vb_ - (l31 & 1) * 2;                                                           \
+                const unsigned x0_ = v < V ? *reinterpret_cast<const unsigned*>(vp_ + (int64_t)v * D * 2) : 0u;  \
+                const unsigned x1_ = (two && v + 32 < V) ? *reinterpret_cast<const unsigned*>(vp_ + (int64_t)(v + 32) * D * 2) : 0u; \
+                v0_[e] = __builtin_bit_cast(float, (x0_ << ((l31 & 1) ? 0 : 16)) & 0xffff0000u);                 \
+                v1_[e] = __builtin_bit_cast(float, (x1_ << ((l31 & 1) ? 0 : 16)) & 0xffff0000u);                 \
+            } else {                                                                                             \
+                v0_[e] = v < V ? *reinterpret_cast<const float*>(vb_ + (int64_t)v * D * 4) : 0.f;                \
+                v1_[e] = (two && v + 32 < V) ? *reinterpret_cast<const float*>(vb_ + (int64_t)(v + 32) * D * 4) : 0.f; \
+            }                                                                                                    \
         }                                                                                                        \
     }
     if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)              // (in flight while the attention slice is compacted and split below)
@@ -1783,8 +1790,9 @@ static int tri_pool_mfma_impl(const float* vt, const float* qt, const float* at,
     const int tpw = tpw_env > 0 ? tpw_env : (tiles >= 32 ? (tiles + nw - 1) / nw : 1);
     const dim3 grid((tiles + nw * tpw - 1) / (nw * tpw), B);
     const size_t lds = sizeof(unsigned short) * 2 * 64 * (size_t)(KS * 16 + 8);
-#define CTI_TM(Av, KSv) { if (terms == 1) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 1>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh, vt16); \
-                          else hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, 3>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh, vt16); }
+#define CTI_TM1(Av, KSv, Tv, Hv) hipLaunchKernelGGL((tri_pool_mfma_kernel<Av, KSv, Tv, Hv>), grid, dim3(64 * nw), lds, as_stream(stream), vt, qt, at, w, w_sb, w_sv, w_sq, w_sa, out, V, Q, D, tpw, v_rep, sh)
+#define CTI_TM(Av, KSv) { if (terms == 1) { if (vt16) CTI_TM1(Av, KSv, 1, 1); else CTI_TM1(Av, KSv, 1, 0); } \
+                          else            { if (vt16) CTI_TM1(Av, KSv, 3, 1); else CTI_TM1(Av, KSv, 3, 0); } }
     if (A == 3) { if (KS <= 2) CTI_TM(3, 2) else CTI_TM(3, 3) }
     else        { if (KS <= 4) CTI_TM(6, 4) else if (KS == 5) CTI_TM(6, 5) else CTI_TM(6, 6) }
 #undef CTI_TM

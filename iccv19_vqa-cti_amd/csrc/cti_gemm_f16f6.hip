@@ -159,8 +159,8 @@ enum { F6_EPI_F32 = 0, F6_EPI_INTERLEAVE2 = 2, F6_EPI_INTERLEAVE = 3, F6_EPI_INT
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 256 x 192 tile, 8 waves.  One ring slot = one 32-deep K block of both operands:
-//   A_H 256 rows x 64 B | B_H 192 x 64 B | A_FL 256 x 24 B | B_FL 192 x 24 B | A_S 256 x 2 B | B_S 192 x 2 B (+ 640 B the last piece over-writes)
-// = exactly 40 pieces of 1 KiB (one LDS-DMA wave-instruction each), five per wave; four slots fill the CU's 160 KiB.
+//   A_H 256 rows x 64 B | B_H 192 x 64 B | A_FL 256 x 24 B | B_FL 192 x 24 B | A_S 256 x 2 B | B_S 192 x 2 B
+// = 40 pieces (one LDS-DMA wave-instruction each; the last one 384 B), five per wave; four slots + the bias KiB fill the CU's 160 KiB.
 template <int WM_, int WN_, int TM_, int TN_, int NST_ = 4>
 struct GeoF6T {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NST = NST_;
@@ -168,13 +168,19 @@ struct GeoF6T {
     static constexpr int PAH = BM / 16, PBH = BN / 16, PAF = BM * 24 / 1024, PBF = BN * 24 / 1024;      // whole pieces; B_FL leaves a 512-B tail
     static constexpr int OFF_AH = 0, OFF_BH = OFF_AH + BM * 64, OFF_AFL = OFF_BH + BN * 64, OFF_BFL = OFF_AFL + BM * 24;
     static constexpr int OFF_AS = OFF_BFL + BN * 24, OFF_BS = OFF_AS + 512;                            // (the A scales' half piece always moves 512 B = 256 rows)
-    static constexpr int SLOT = OFF_BS + 1024;
+    // Round 5: the B scales' piece moves its BN * 2 real bytes only (lanes >= BS_LANES sit the instruction out; the first form moved a whole KiB and the slot
+    // ended in 640 B of slack): 2.5 KiB of the CU's LDS come free -- 1 KiB of it holds the transposed products' BIAS (the accumulators' initial value), which
+    // was 32 registers per lane of a kernel at its 256-register ceiling.
+    static constexpr int BS_LANES = BN * 2 / 16;
+    static constexpr int SLOT = OFF_BS + BN * 2;
+    static constexpr int BIAS_BYTES = BM * 4;
     static constexpr int NREAL = PAH + PBH + PAF + PBF + 2;          // pieces a slot needs
     static constexpr int CNT = (NREAL + NW - 1) / NW;                // pieces per wave and slot
     static constexpr int NPIECE = CNT * NW;                          // issued: the NPIECE - NREAL extra ones repeat the first pieces (same bytes, same place)
-    static constexpr int LDS = NST * SLOT;
+    static constexpr int LDS = NST * SLOT + BIAS_BYTES;
     static constexpr int MINW = 160 * 1024 / LDS >= 2 ? 2 * NW / 4 : NW / 4;     // waves per SIMD the launch bounds promise (two co-resident workgroups when the LDS allows)
     static_assert(BM * 24 % 1024 == 0 && BN * 24 % 1024 == 512 && BM * 2 <= 512, "the B_FL tail and the A scales share one piece");
+    static_assert(BN * 2 % 16 == 0 && SLOT % 16 == 0, "slots stay 16-B aligned");
     static_assert(OFF_AS == OFF_BFL + PBF * 1024 + 512, "the shared piece is contiguous in LDS");
     static_assert(NST >= 2 && LDS <= 160 * 1024, "ring exceeds the CU's LDS");
 };
@@ -240,6 +246,8 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
         const bool mok = mblk < p.M;                                // M % 32 == 0: a block is all real or all padding
         const float lo_bound = p.relu ? 0.f : -__builtin_huge_valf();
         unsigned nq = 0, nr = 0;
+        // (Round 5: the H stores -- 16 B per lane into 32 cache lines per lane half -- were also staged through the ring slot the tile's last K block frees and stored as
+        // 512-B runs: 4-5 % faster per product on its own, nothing in the step; tools/experiments/f16f6_staged_h_stores.patch, profiles/r05_aside_hstage_ab.txt.)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             __builtin_amdgcn_sched_barrier(0);
@@ -255,7 +263,8 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
                 x[k] = lo_; x[k + 4] = hi_;
             }
             const int n = cn0 + (wn * TN + j) * 32 + r;
-            if (n >= p.N || !mok || ((CTI_F6_ABL & 8) && x[0] != 12345.f)) continue;
+            const bool valid = !(n >= p.N || !mok || ((CTI_F6_ABL & 8) && x[0] != 12345.f));
+            if (!valid) continue;
             // plane row of n: batches of o_rdiv rows start at multiples of o_rstride.  One division per tile (column tile 0); the wave's other column
             // tiles are 32 rows further on -- at most one batch boundary when a batch has 32 rows or more
             if (j == 0 || o_rdiv < 32) {
@@ -266,7 +275,11 @@ __device__ __forceinline__ void f6_epilogue(const f32x16 (&acc)[G::TM][G::TN], c
             }
             const int64_t prow = (int64_t)nq * o_rstride + nr;
             const int64_t o = (int64_t)kb * o_ra + prow;
+#if CTI_F6_ABL & 4096     // timing-only: the four H pieces of the wave's 32 rows as four fully coalesced 512-B runs per lane half (WRONG placement): what staging the H rows through LDS could buy at most
+            f6_encode_row32_regs(x, lo_bound, oH + ((int64_t)kb * o_ra + ((int64_t)nq * o_rstride + nr - r)) * 64 + r * 16, oFL + o * 24, oS + ((int64_t)kb * o_ras + prow) * 2, 32);
+#else
             f6_encode_row32_regs(x, lo_bound, oH + o * 64, oFL + o * 24, oS + ((int64_t)kb * o_ras + prow) * 2);
+#endif
         }
         return;
     }
@@ -401,6 +414,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
     // walks the K blocks of the tile being issued: one VALU add per piece and block, no scalar address arithmetic in the loop.
     const char* vp[CNT]; int64_t kstride[CNT]; int ldsoff[CNT];
     bool piece_is_a[CNT];                                           // (ablation 1024 only)
+    bool piece_is_bs[CNT];                                          // the B scales: BS_LANES lanes take part
     const bool shared_piece_wave = (G::NREAL - 2) % NW == wid;
     constexpr int U_SHARED = (G::NREAL - 2) / NW;                   // which of that wave's pieces is the shared one
 #pragma unroll
@@ -413,6 +427,7 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
         else if ((g -= G::PBH) < G::PAF)  { kstride[u] = p.pA * 24; ldsoff[u] = G::OFF_AFL + g * 1024; }
         else if ((g -= G::PAF) <= G::PBF) { kstride[u] = p.pB * 24; ldsoff[u] = G::OFF_BFL + g * 1024; }   // g == PBF: the tail
         else                              { kstride[u] = p.pBS * 2; ldsoff[u] = G::OFF_BS; }
+        piece_is_bs[u] = ldsoff[u] == G::OFF_BS;
     }
     const int64_t vks_shared = (shared_piece_wave && h) ? p.pAS * 2 : kstride[U_SHARED];    // per lane: the shared piece's halves walk different planes
     int iss_tile = blockIdx.x, iss_kb = 0, issued = 0;
@@ -444,7 +459,8 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
         char* slot = smem + pos * SLOT;
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-            if (!((CTI_F6_ABL & 1024) && piece_is_a[u])) dma16(vp[u], slot + ldsoff[u]);
+            if (piece_is_bs[u]) { if (lane < G::BS_LANES) dma16(vp[u], slot + ldsoff[u]); }      // (wave-uniform branch; the piece's upper lanes would write past the slot)
+            else if (!((CTI_F6_ABL & 1024) && piece_is_a[u])) dma16(vp[u], slot + ldsoff[u]);
             vp[u] += u == U_SHARED ? vks_shared : kstride[u];
         }
         ++issued;
@@ -489,41 +505,52 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
     };
     compute_tile_setup();
     f32x16 acc[TM][TN];
-    // F6_EPI_PLANES_T: the accumulators start from the bias of their GEMM row (register e of row tile i: row 8 (e >> 2) + 4 h + (e & 3)), held in
-    // registers for as long as the workgroup's row tile stays the same -- with a power-of-two number of row tiles <= 32 it never changes.
-    f32x16 bv[EPI == F6_EPI_PLANES_T ? TM : 1];
+    // F6_EPI_PLANES_T: the accumulators start from the bias of their GEMM row (register e of row tile i: row 8 (e >> 2) + 4 h + (e & 3)).  Round 5: the workgroup's
+    // BM bias values live in the KiB behind the ring (written once: with a power-of-two number of row tiles <= 32 a workgroup's row tile never changes) and every tile
+    // reads its 32 values per lane from there (eight ds_read_b128) -- they were 32 registers per lane for the whole kernel.
+    float* const bias_lds = reinterpret_cast<float*>(smem + NST * SLOT);
     int bv_m0 = -1;
     auto load_bias = [&]() {
         if (EPI != F6_EPI_PLANES_T || bv_m0 == m0) return;
         const bool first = bv_m0 < 0;
         bv_m0 = m0;
-#pragma unroll
-        for (int i = 0; i < (EPI == F6_EPI_PLANES_T ? TM : 1); ++i)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                const int m = m0 + (wm * TM + i) * 32 + 8 * g4 + 4 * h;
-                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && m < p.M) {
-                    const float* src = p.bias + m;
-                    if (first) { b4[0] = src[0]; b4[1] = src[1]; b4[2] = src[2]; b4[3] = src[3]; }
-                    else       // mid-stream: opaque loads with their own wait, so that the compiler's vmcnt bookkeeping of the tile loop stays as it is
-                        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
-                                     "global_load_dword %3, %4, off offset:12\n\ts_waitcnt vmcnt(0)"
-                                     : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3]) : "v"(src) : "memory");
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bv[i][4 * g4 + u] = b4[u];
+        if (!first) __builtin_amdgcn_s_barrier();                   // (mid-stream: every wave has read the old row tile's values)
+        if (t < BM) {
+            const int m = m0 + t;
+            float b1 = 0.f;
+            if (p.bias && m < p.M) {
+                const float* src = p.bias + m;
+                if (first) b1 = src[0];
+                else       // mid-stream: an opaque load with its own wait, so that the compiler's vmcnt bookkeeping of the tile loop stays as it is
+                    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(b1) : "v"(src) : "memory");
             }
+            bias_lds[t] = b1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
     auto zero_acc = [&]() {
         load_bias();
+        if (EPI == F6_EPI_PLANES_T) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + (wm * TM + i) * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[i][j][4 * g4 + u] = b4[u];
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = EPI == F6_EPI_PLANES_T ? bv[i][e] : 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     };
     zero_acc();
 
