@@ -417,6 +417,10 @@ class _TriModel(nn.Module):
         qn, an = [n.q_tucker for n in self.t_net], [n.a_tucker for n in self.t_net]
         B, Lq, H = q_emb.shape
         La = ans_emb.shape[1]
+        if _tri_unroll_ok(self):
+            joint = _tri_loop_unrolled(self, vp, q_emb, ans_emb, att, rep, Hq, Ha)
+            if joint is not None:
+                return joint
         if not hasattr(self, "_prj_pairs"):
             # the two sequences' products of a glimpse as ONE batched launch each: the residual projections (q_prj[g], a_prj[g]) of the pooled vector, and the
             # shift projections (q_tucker[g], a_tucker[g] without bias / activation) of the two accumulated residuals
@@ -431,6 +435,81 @@ class _TriModel(nn.Module):
             y = self._prj_pairs[g].shared(b_emb)
             D = y if g == 0 else ops.axpby(D, 1.0, y, 1.0, out=y)
         return ops.joint_sums(q_emb, 1.0, ans_emb, 1.0, D[0], float(Lq), D[1], float(La))
+
+
+def _tri_unroll_ok(self):
+    """Preconditions of the unrolled tri loop beyond the hoisted loop's: inference in a bf16 mode, 2 to 8 glimpses, every residual projection a single WNLinear."""
+    return (_UNROLL and not torch.is_grad_enabled() and ops.get_precision() != "fp32" and 2 <= self.glimpse <= 8
+            and all(_single_linear(p) is not None for p in list(self.q_prj) + list(self.a_prj))
+            and all(HoistedProjection._layer_of(n) is not None for t in self.t_net for n in (t.q_tucker, t.a_tucker)))
+
+
+def _tri_unrolled_prep(self):
+    """Weights of the unrolled tri glimpse loop, rebuilt when a parameter or the precision changes (the BAN form of _ban_unrolled_prep for two sequences s = q, a):
+        Ws_g = scale W of s_tucker[g] (D, H);  Ps_j = scale W of s_prj[j] (H, D) and its bias cs_j
+        shift[g] = [[Wq_g Pq_0 | ... | Wq_g Pq_{g-1}]; [Wa_g Pa_0 | ... | Wa_g Pa_{g-1}]]  (2 D, g D), resident planes, with k[g] = [Wq_g sum_{j<g} cq_j; Wa_g sum_{j<g} ca_j]
+        fin = [[Pq_0 | ... | Pq_{G-1}]; [Pa_0 | ...]]  (2 H, G D) with e = [sum_j cq_j; sum_j ca_j]: the two accumulated residuals in one product.
+    The products of weight matrices are taken once per parameter update in the exact-fp32 kernels.  None when the two sequences' shapes differ."""
+    G = self.glimpse
+    tq = [HoistedProjection._layer_of(n.q_tucker) for n in self.t_net]
+    ta = [HoistedProjection._layer_of(n.a_tucker) for n in self.t_net]
+    pq = [_single_linear(p) for p in self.q_prj]
+    pa = [_single_linear(p) for p in self.a_prj]
+    key = (ops._param_epoch[0], ops.get_precision()) + tuple((p.data_ptr(), p._version) for l in tq + ta + pq + pa for p in (l.weight_v, l.weight_g, l.bias))
+    if getattr(self, "_unroll_key", None) == key:
+        return self._unroll_val
+    val = None
+    shapes = {tuple(l.weight_v.shape) for l in tq + ta}
+    pshapes = {tuple(l.weight_v.shape) for l in pq + pa}
+    if len(shapes) == 1 and len(pshapes) == 1 and next(iter(pshapes)) == next(iter(shapes))[::-1]:
+        with torch.no_grad():
+            W = [[(l.weight_v.detach() * l.scale()).contiguous() for l in ls] for ls in (tq, ta)]                   # [s][g] (D, H)
+            P = [[(l.weight_v.detach() * l.scale()).contiguous() for l in ls] for ls in (pq, pa)]                   # [s][j] (H, D)
+            c = [[l.bias.detach() for l in ls] for ls in (pq, pa)]
+            D, H = W[0][0].shape
+            shift, kvec = [None], [None]
+            for g in range(1, G):
+                rows, ks = [], []
+                for s_ in range(2):
+                    rows.append(torch.cat([ops.gemm_nt(W[s_][g], P[s_][j].t().contiguous(), prec="fp32") for j in range(g)], 1))       # (D, g D)
+                    ks.append(ops.gemm_nt(sum(c[s_][:g]).view(1, H).contiguous(), W[s_][g], prec="fp32").view(D))
+                shift.append(torch.cat(rows, 0).contiguous())
+                kvec.append(torch.cat(ks, 0).contiguous())
+            fin = torch.cat([torch.cat(P[s_], 1) for s_ in range(2)], 0).contiguous()                               # (2 H, G D)
+            e = torch.cat([sum(c[s_]) for s_ in range(2)], 0).contiguous()
+            val = dict(shift=shift, shift_planes=[None if t is None else ops.split_operand(t) for t in shift], kvec=kvec, fin=fin, fin_planes=ops.split_operand(fin),
+                       e=e, D=D, H=H)
+    object.__setattr__(self, "_unroll_key", key)
+    object.__setattr__(self, "_unroll_val", val)
+    return val
+
+
+def _tri_loop_unrolled(self, vp, q_emb, ans_emb, att, rep, Hq, Ha):
+    """_TriModel._loop_hoisted with ONE product between two pools instead of two (round 5, the tri form of _ban_forward_unrolled).  There D_{g+1} = D_g + P_g b_g + c_g
+    for both sequences and the next pool's shifts are W_{g+1} D_{g+1}: the residual projection, then the shift projection, each a split / product / reduce triple
+    between consecutive pools.  Both are linear in the pooled vectors, so shift_g = [b_0 | ... | b_{g-1}] shift[g]^T + k[g] (weights-only products precomputed,
+    _tri_unrolled_prep) is one product of the pooled vectors so far, for both sequences at once; the accumulated residuals themselves are only needed by the
+    classifier input: one K-concatenated product behind the last pool.  Returns q_emb_G.sum(1) + ans_emb_G.sum(1), or None when the form does not apply."""
+    P = _tri_unrolled_prep(self)
+    B, Lq, H = q_emb.shape
+    La = ans_emb.shape[1]
+    if P is None or P["H"] != H or ans_emb.shape[2] != H:
+        return None
+    D, G = P["D"], self.glimpse
+    bs, cat = [], None
+    for g in range(G):
+        sh = None
+        if g > 0:
+            cat = bs[0] if g == 1 else torch.cat(bs, 1)
+            sh = ops.gemm_nt(cat, P["shift"][g], nb1=2, rA1=0, rB1=D, M=B, N=D, bias=P["kvec"][g], bias_bs=D, B_planes=P["shift_planes"][g])        # (2, B, D)
+        b_emb = ops.tri_pool_shift(vp[g], Hq[g], Ha[g], sh[0] if g > 0 else None, sh[1] if g > 0 else None, att[:, :, :, :, g].float(), v_rep=rep)
+        if b_emb is None:
+            if g == 0:
+                return None
+            _unrolled_bail(g)
+        bs.append(b_emb)
+    Dfin = ops.gemm_nt(torch.cat(bs, 1), P["fin"], nb1=2, rA1=0, rB1=H, M=B, N=H, bias=P["e"], bias_bs=H, B_planes=P["fin_planes"])                   # (2, B, H)
+    return ops.joint_sums(q_emb, 1.0, ans_emb, 1.0, Dfin[0], float(Lq), Dfin[1], float(La))
 
 
 class CTIModel(_TriModel):

@@ -202,18 +202,20 @@ def test_hoisted_glimpse_loops_equal_the_literal_loops():
         with torch.no_grad():
             lc, (lb, ab) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
             assert calls == {"tri": 3, "bi": 0, "multi": 4}, calls         # BAN: the UNROLLED loop (round 5: two launches per glimpse on the dependent chain) is what ran
+            assert getattr(cti, "_unroll_val", None) is not None           # ... and the CTI model's unrolled form (one product between two pools)
             bm._UNROLL = False
-            lb1, ab1 = ban(T(v), None, T(q), None)
-            assert calls == {"tri": 3, "bi": 4, "multi": 4}, calls         # ... and with its knob off the hoisted form of round 4
+            lc1, (lb1, ab1) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
+            assert calls == {"tri": 6, "bi": 4, "multi": 4}, calls         # ... and with the knob off the hoisted forms of round 4
             bm._HOIST_LOOP = False
             lc0, (lb0, ab0) = cti(T(v), T(q), T(a)), ban(T(v), None, T(q), None)
-            assert calls == {"tri": 3, "bi": 4, "multi": 4}
+            assert calls == {"tri": 6, "bi": 4, "multi": 4}
     finally:
         bm._HOIST_LOOP = True
         bm._UNROLL = True
         ops.tri_pool_shift, ops.bi_pool_shift, ops.bi_pool_shift_multi = tps, bps, mps
     assert O.norm_max_err(lc.cpu().numpy(), lc0.cpu().numpy()) < 2e-5 and O.norm_max_err(lb.cpu().numpy(), lb0.cpu().numpy()) < 2e-5
     assert O.norm_max_err(lb1.cpu().numpy(), lb0.cpu().numpy()) < 2e-5 and torch.equal(ab, ab0) and torch.equal(ab1, ab0)
+    assert O.norm_max_err(lc1.cpu().numpy(), lc0.cpu().numpy()) < 2e-5
     assert O.norm_max_err(lc.cpu().numpy(), OM.ffoe_cti_forward(v, q, a, sd(cti), 3, dtype=np.float64)) < TOL
     assert O.norm_max_err(lb.cpu().numpy(), OM.ffoe_ban_forward(v, q, sd(ban), 4, dtype=np.float64)[0]) < 1.5e-4
 
@@ -254,6 +256,54 @@ def test_unrolled_ban_loop_at_full_widths_on_every_row(prec, tol):
             bm._UNROLL = False
             lh2 = ban(v, None, q, None)[0]
             assert rel(lu2, lh2) < tol and rel(lu2, lu) > 3 * tol
+    finally:
+        bm._HOIST_LOOP, bm._UNROLL = True, True
+        cti_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 6e-3), ("f16f6", 3e-5)])
+@pytest.mark.parametrize("glimpse", [2, 3])
+def test_unrolled_tri_loop_at_full_widths_on_every_row(prec, tol, glimpse):
+    """The unrolled glimpse loop of the CTI models (base_model._tri_loop_unrolled: ONE product between two pools, the accumulated residuals in one K-concatenated
+    product behind the last pool) against the hoisted loop it replaces and the literal loop of src/MC/base_model.py:145-150, at the Visual7W shapes of
+    BASELINE configs[2] (B = 256 rows = 64 images x 4 candidates, 1 024 wide), every row of the logits; a parameter update rebuilds the weight-only products."""
+    import types
+    bm = cti_amd.base_model
+    old = cti_amd.get_precision()
+    cti_amd.set_precision(prec)
+    try:
+        torch.manual_seed(43)
+        ds = types.SimpleNamespace(dictionary=types.SimpleNamespace(ntoken=2000), v_dim=2048, num_ans_candidates=2)
+        margs = types.SimpleNamespace(op="c", num_hid=1024, gamma=glimpse, h_mm=512, rank=32, k=1, h_out=1, activation="relu", dropout=0.5, use_counter=False)
+        m = cti_amd.build_mc_cti(margs, ds).to(DEV).eval()
+        g = torch.Generator().manual_seed(44)
+        vi = torch.randn(64, 36, 2048, generator=g).abs()
+        nv = torch.randint(10, 37, (64,), generator=g)
+        vi[torch.arange(36)[None, :] >= nv[:, None]] = 0
+        v = vi.unsqueeze(1).expand(-1, 4, -1, -1).contiguous().view(256, 36, 2048).to(DEV)
+        q = torch.randint(0, 2000, (64, 12), generator=g).unsqueeze(1).expand(-1, 4, -1).contiguous().view(256, 12).to(DEV)
+        a = torch.randint(0, 2000, (256, 6), generator=g).to(DEV)
+        rel = lambda x, y: float(((x - y).abs().flatten(1).amax(1) / y.abs().max()).max())
+        with torch.no_grad():
+            lu = m(v, None, q, a)[0]
+            assert getattr(m, "_unroll_val", None) is not None             # the unrolled form is what ran
+            bm._UNROLL = False
+            lh = m(v, None, q, a)[0]
+            bm._HOIST_LOOP = False
+            ll = m(v, None, q, a)[0]
+            bm._HOIST_LOOP, bm._UNROLL = True, True
+            print(prec, glimpse, "unrolled vs hoisted %.2e, vs literal %.2e" % (rel(lu, lh), rel(lu, ll)))
+            assert rel(lu, lh) < tol and rel(lu, ll) < tol
+            # a parameter update must rebuild the weight-only products: the updated unrolled loop follows the updated hoisted loop far more closely than the
+            # update moved the logits (with stale products it would sit at the old logits)
+            m.a_prj[0].main[1].weight_g.data.mul_(3.0)
+            m.q_prj[0].main[1].weight_g.data.mul_(3.0)
+            cti_amd.ops.invalidate_caches()
+            lu2 = m(v, None, q, a)[0]
+            bm._UNROLL = False
+            lh2 = m(v, None, q, a)[0]
+            print(prec, glimpse, "after the update: unrolled vs hoisted %.2e, moved by %.2e" % (rel(lu2, lh2), rel(lu2, lu)))
+            assert rel(lu2, lh2) < tol and rel(lu2, lu) > 4 * rel(lu2, lh2)
     finally:
         bm._HOIST_LOOP, bm._UNROLL = True, True
         cti_amd.set_precision(old)
