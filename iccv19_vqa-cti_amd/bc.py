@@ -83,8 +83,18 @@ class BCNet(nn.Module):
         q_ = self.q_net(q)
         G, D = (h.shape[-3] if h.dim() == 4 else h.shape[0]), h.shape[-1]
         h2 = h.reshape(G, D)
-        scale = ops.wn_scale(h2.reshape(1, -1), h_g.reshape(1)) if h_g is not None else None
-        return ops.biattention_forward(v_, q_, h2, scale, h_bias, mask)
+        return ops.biattention_forward(v_, q_, h2, self._h_scale(h, h_g), h_bias, mask)
+
+    def _h_scale(self, h, h_g):
+        """g / ||h||_F of the weight-normed bilinear map (src/attention.py:19-20), cached like WNLinear.scale() until a parameter changes: on this inference-only
+        path the two-launch norm stood on the dependent chain between the q projection and the logits of EVERY forward (23 us of BanModel's 1.09 ms)."""
+        if h_g is None:
+            return None
+        key = (h.data_ptr(), h._version, h_g.data_ptr(), h_g._version, ops._param_epoch[0])
+        if getattr(self, "_h_scale_key", None) != key:
+            object.__setattr__(self, "_h_scale_val", ops.wn_scale(h.detach().reshape(1, -1), h_g.detach().reshape(1)))
+            object.__setattr__(self, "_h_scale_key", key)
+        return self._h_scale_val
 
     def forward_with_weights(self, v, q, w):
         return self._pool_projected(self.v_net(v), q, w)

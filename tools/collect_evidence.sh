@@ -48,6 +48,8 @@ timeout 300 python tools/f16f6_ksweep.py > $E/f16f6_ksweep.txt 2>/dev/null
 timeout 300 python tools/bench_f16f6_aside.py 2>/dev/null | grep '^{' > $E/aside_f16f6.jsonl
 bash tools/prof_models.sh > $E/prof_models.log 2>&1; cp gpurun_out/pc_c3/summary.txt $E/model_c3_kernel_stats.txt; cp gpurun_out/pc_c4/summary.txt $E/model_c4_kernel_stats.txt
 fi
+bash tools/trace_step.sh > $E/trace_step.log 2>&1; cp gpurun_out/step_trace/timeline.txt $E/step_timeline.txt        # kernel timeline of one configs[1] step
+python -m pytest tests/test_accuracy_envelope_gpu.py -q -m gpu -s > $E/accuracy_envelope.txt 2>&1                      # the guard's calibration: error and estimate per case
 # summaries on the box; the raw traces (100+ MB) stay there: gpurun merges at most 64 MiB back
 python tools/pmc_summary.py $E/pmc_summary.json $E $E/stats/fwd_kernel_stats.csv > $E/pmc_summary.log 2>&1
 find $E -name "*kernel_trace.csv" -delete; find $E -name "*counter_collection.csv" -delete; find gpurun_out/pc_c3 gpurun_out/pc_c4 -name "*kernel_trace.csv" -delete 2>/dev/null

@@ -2,12 +2,12 @@
 # Copy the summaries of gpurun_out/evidence (written by tools/collect_evidence.sh on the GPU box) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
-E=gpurun_out/evidence; R=${1:-r04}
+E=gpurun_out/evidence; R=${1:-r05}
 cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
 for f in f16f6 bf16x3 fp32 bf16 train train_rccl_world1 c3 c4 c4_serial rccl_world1; do [ -s $E/bench_$f.log ] && tail -1 $E/bench_$f.log > profiles/${R}_bench_$f.json; done
 cp $E/stats/fwd_kernel_stats.csv profiles/${R}_rocprof_kernel_stats_f16f6.csv
 cat $E/model_fwd.jsonl $E/model_train.jsonl $E/model_fwd_bf16.jsonl > profiles/${R}_model_bench.jsonl 2>/dev/null || true
-for f in graph_train.jsonl hbm_kernels.jsonl mode3_f16f6_vs_bf16x3.json mb_f16f6.txt mb_issue.txt f16f6_ksweep.txt aside_f16f6.jsonl model_c3_kernel_stats.txt model_c4_kernel_stats.txt model_c3_timeline.txt model_c4_timeline.txt gemm16_vs_vendor.json; do [ -s $E/$f ] && cp $E/$f profiles/${R}_$f; done
+for f in graph_train.jsonl hbm_kernels.jsonl mode3_f16f6_vs_bf16x3.json mb_f16f6.txt mb_issue.txt f16f6_ksweep.txt aside_f16f6.jsonl model_c3_kernel_stats.txt model_c4_kernel_stats.txt model_c3_timeline.txt model_c4_timeline.txt gemm16_vs_vendor.json step_timeline.txt accuracy_envelope.txt; do [ -s $E/$f ] && cp $E/$f profiles/${R}_$f; done
 cp $E/pmc_summary.json profiles/${R}_pmc_summary.json
 cp $E/g16/pmc_summary_gemm16.json profiles/${R}_pmc_summary_gemm16.json 2>/dev/null || true
 cp $E/g16stats/g_kernel_stats.csv profiles/${R}_rocprof_kernel_stats_gemm16.csv 2>/dev/null || true

@@ -35,6 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef MB_STAGGER
 #define MB_STAGGER 1
 #endif
+#ifndef MB_DMAC          // round 5 experiment: the wave's 4 LDS-DMA pieces of a stage are issued inside the COMPUTE interval, one per 8 MFMAs, instead of in the LOAD interval
+#define MB_DMAC 0
+#endif
 
 struct P {
     const char* A; const char* B; float* C;
@@ -93,19 +96,27 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
         voA0 = (unsigned)(ra0 * p.lda) + dch * 16; voA1 = (unsigned)(ra1 * p.lda) + dch * 16;
         voB0 = (unsigned)(rb0 * p.ldb) + dch * 16; voB1 = (unsigned)(rb1 * p.ldb) + dch * 16;
     };
-    auto issue_next = [&](int slot) {
+    auto issue_piece = [&](int slot, int q) {                    // piece q of the wave's four (A rows, A rows + 128, B rows, B rows + 128)
         if (issued >= total || (MB_ABL & 1)) return;
         char* sb = smem + slot * STAGE + wid * 1024;
-        glds16(Ab + voA0, sb);
-        glds16(Ab + voA1, sb + 8192);
-        glds16(Bb + voB0, sb + 16384);
-        glds16(Bb + voB1, sb + 24576);
+        if (q == 0) glds16(Ab + voA0, sb);
+        else if (q == 1) glds16(Ab + voA1, sb + 8192);
+        else if (q == 2) glds16(Bb + voB0, sb + 16384);
+        else glds16(Bb + voB1, sb + 24576);
+    };
+    auto issue_advance = [&]() {
+        if (issued >= total || (MB_ABL & 1)) return;
         Ab += BKB; Bb += BKB;
         ++issued;
         if (++iss_kb == nk) {
             iss_kb = 0; iss_tile += (int)gridDim.x;
             if (iss_tile < p.total_tiles) issue_tile_setup();
         }
+    };
+    auto issue_next = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(slot, q);
+        issue_advance();
     };
 
     issue_tile_setup();
@@ -164,17 +175,27 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
                 for (int u = 0; u < 4; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(s + b_off + u * 1024);
             }
         }
-        issue_next(slot == 0 ? NS - 1 : slot - 1);
+        const int rslot = slot == 0 ? NS - 1 : slot - 1;           // the slot stage i - 1 was read from: refilled with stage i + NS - 1
+#if !MB_DMAC
+        issue_next(rslot);
+#endif
         if (ep_pending) {
             epilogue(ep_tm, ep_tn, ep_full);
             ep_pending = false; ep_age = 0;
         }
         {
             const int rem = total - 2 - i;                       // stages beyond i + 1 that exist; min(NS - 2, rem) of them may stay in flight
-            const bool st = ep_full && ep_age <= NS - 2 && nk > NS - 2;
+            const bool st = ep_full && ep_age <= NS - 2 - MB_DMAC && nk > NS - 2;      // (MB_DMAC: the stores are OLDER than the stage issued in the same iteration's COMPUTE interval: one interval less)
+#if MB_DMAC
+            // stage i + NS - 1 is issued in THIS iteration's COMPUTE interval: at this wait the stages i + 1 .. i + NS - 2 are in flight; i + 1 must have landed
+            static_assert(!MB_DMAC || NS == 4, "MB_DMAC: counted waits written for NS = 4");
+            if (rem >= 1) { if (st) wait_vm_lgkm0<4 + NSTORE>(); else wait_vm_lgkm0<4>(); }
+            else { if (st) wait_vm_lgkm0<NSTORE>(); else wait_vm_lgkm0<0>(); }
+#else
             if (NS >= 4 && rem >= 2) { if (st) wait_vm_lgkm0<8 + NSTORE>(); else wait_vm_lgkm0<(NS >= 4 ? 8 : 0)>(); }
             else if (NS >= 3 && rem == 1) { if (st) wait_vm_lgkm0<4 + NSTORE>(); else wait_vm_lgkm0<4>(); }
             else { if (st) wait_vm_lgkm0<NSTORE>(); else wait_vm_lgkm0<0>(); }
+#endif
             ++ep_age;
         }
         BARRIER();
@@ -201,10 +222,21 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
                 for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
+#if MB_DMAC
+                if (u & 1) { __builtin_amdgcn_sched_barrier(0); issue_piece(rslot, u >> 1); __builtin_amdgcn_sched_barrier(0); }     // one piece behind every 8 MFMAs
+#endif
+            }
         }
+#endif
+#if MB_DMAC
+        if (kb == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_piece(rslot, q);      // (a tile's first stage takes the other MFMA branch above: its pieces here)
+        }
+        issue_advance();
 #endif
 #if MB_SETPRIO
         __builtin_amdgcn_s_setprio(0);
