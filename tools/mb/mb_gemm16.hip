@@ -95,6 +95,13 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
         const int rb0 = min(wid * 16 + drow, p.N - 1 - n0), rb1 = min(128 + wid * 16 + drow, p.N - 1 - n0);
         voA0 = (unsigned)(ra0 * p.lda) + dch * 16; voA1 = (unsigned)(ra1 * p.lda) + dch * 16;
         voB0 = (unsigned)(rb0 * p.ldb) + dch * 16; voB1 = (unsigned)(rb1 * p.ldb) + dch * 16;
+#if MB_ABL & 16     // timing-only (WRONG data): every 1-KiB piece reads 8 rows x 128 B -- whole cache lines -- instead of 16 rows x 64 B: what line-granular DMA requests would buy
+        {
+            const int r8 = lane >> 3, c8 = lane & 7;
+            voA0 = (unsigned)(min(wid * 16 + r8, p.M - 1 - m0) * p.lda) + c8 * 16; voA1 = (unsigned)(min(128 + wid * 16 + r8, p.M - 1 - m0) * p.lda) + c8 * 16;
+            voB0 = (unsigned)(min(wid * 16 + r8, p.N - 1 - n0) * p.ldb) + c8 * 16; voB1 = (unsigned)(min(128 + wid * 16 + r8, p.N - 1 - n0) * p.ldb) + c8 * 16;
+        }
+#endif
     };
     auto issue_piece = [&](int slot, int q) {                    // piece q of the wave's four (A rows, A rows + 128, B rows, B rows + 128)
         if (issued >= total || (MB_ABL & 1)) return;
@@ -178,6 +185,8 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
         const int rslot = slot == 0 ? NS - 1 : slot - 1;           // the slot stage i - 1 was read from: refilled with stage i + NS - 1
 #if !MB_DMAC
         issue_next(rslot);
+#elif MB_DMAC == 2          // two pieces here, two at the head of the COMPUTE interval (in front of its first MFMA: the matrix pipe is not running yet)
+        issue_piece(rslot, 0); issue_piece(rslot, 1);
 #endif
         if (ep_pending) {
             epilogue(ep_tm, ep_tn, ep_full);
@@ -185,8 +194,14 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
         }
         {
             const int rem = total - 2 - i;                       // stages beyond i + 1 that exist; min(NS - 2, rem) of them may stay in flight
-            const bool st = ep_full && ep_age <= NS - 2 - MB_DMAC && nk > NS - 2;      // (MB_DMAC: the stores are OLDER than the stage issued in the same iteration's COMPUTE interval: one interval less)
-#if MB_DMAC
+            const bool st = ep_full && ep_age <= NS - 2 - (MB_DMAC ? 1 : 0) && nk > NS - 2;      // (MB_DMAC: the stores are OLDER than the stage issued in the same iteration's COMPUTE interval: one interval less)
+#if MB_DMAC == 2
+            // in flight at this wait: stage i + 1, stage i + 2, the first two pieces of stage i + 3 (where they exist); i + 1 must have landed
+            static_assert(NS == 4, "MB_DMAC: counted waits written for NS = 4");
+            if (rem >= 2) { if (st) wait_vm_lgkm0<6 + NSTORE>(); else wait_vm_lgkm0<6>(); }
+            else if (rem == 1) { if (st) wait_vm_lgkm0<4 + NSTORE>(); else wait_vm_lgkm0<4>(); }
+            else { if (st) wait_vm_lgkm0<NSTORE>(); else wait_vm_lgkm0<0>(); }
+#elif MB_DMAC
             // stage i + NS - 1 is issued in THIS iteration's COMPUTE interval: at this wait the stages i + 1 .. i + NS - 2 are in flight; i + 1 must have landed
             static_assert(!MB_DMAC || NS == 4, "MB_DMAC: counted waits written for NS = 4");
             if (rem >= 1) { if (st) wait_vm_lgkm0<4 + NSTORE>(); else wait_vm_lgkm0<4>(); }
@@ -200,6 +215,13 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
         }
         BARRIER();
         // ================= COMPUTE interval =================
+#if MB_DMAC >= 2
+#if MB_DMAC == 3
+        issue_piece(rslot, 0); issue_piece(rslot, 1);
+#endif
+        issue_piece(rslot, 2); issue_piece(rslot, 3);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #if MB_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -225,17 +247,19 @@ __global__ __launch_bounds__(512) void gemm16_kernel(P p) {
             for (int u = 0; u < 8; ++u) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
-#if MB_DMAC
+#if MB_DMAC == 1
                 if (u & 1) { __builtin_amdgcn_sched_barrier(0); issue_piece(rslot, u >> 1); __builtin_amdgcn_sched_barrier(0); }     // one piece behind every 8 MFMAs
 #endif
             }
         }
 #endif
-#if MB_DMAC
+#if MB_DMAC == 1
         if (kb == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) issue_piece(rslot, q);      // (a tile's first stage takes the other MFMA branch above: its pieces here)
         }
+#endif
+#if MB_DMAC
         issue_advance();
 #endif
 #if MB_SETPRIO
