@@ -103,6 +103,15 @@ constexpr int GF_KPB = CTI_GF_KPB;                                   // 32-deep 
 #define CTI_GF_NST 4
 #endif
 constexpr int GF_NST = CTI_GF_NST, GF_SLOT = 16384;                         // slot: A [plane][chunk][64 rows][32 B] = 8 KiB, B likewise (48 of 64 rows used)
+// -DCTI_GF_COMPACT=1 (round-5 experiment): the plain-bf16 mode stages the hi planes only -- 8 KiB of a slot -- in a ring of THREE such slots = 24 KiB, small enough to be
+// co-resident with a workgroup of the 288 x 192 projection GEMM (128 KiB of LDS, 2 x 224 registers per SIMD lane): see DESIGN.md, round 5, VERDICT r4 #6.
+#ifndef CTI_GF_COMPACT
+#define CTI_GF_COMPACT 0
+#endif
+template <int TERMS> struct GfRing {
+    static constexpr bool compact = CTI_GF_COMPACT && TERMS == 1;
+    static constexpr int NST = compact ? 3 : GF_NST, SLOT = compact ? 8192 : GF_SLOT, OFF_B = compact ? 4096 : 8192;
+};
 template <int N> __device__ __forceinline__ void gf_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // KPB (round 3 experiment): 32-deep K sub-steps per barrier (a slot holds KPB sub-slots of the same layout).  Measured on the MC model forward (16 GRU steps
@@ -122,6 +131,8 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u0 = blockIdx.x * 16, row0 = blockIdx.y * 64;
     constexpr int NPL = TERMS == 3 ? 2 : 1;
+    using R = GfRing<TERMS>;
+    constexpr int NST = R::NST;
     // this wave's 4 DMA pieces per slot (2 with one plane): piece q of 16 = (operand, plane, chunk, half); a piece = 32 rows x 32 B of one plane-chunk.
     // A rows are contiguous in the plane; B rows are the three gates' 16-row groups: half 0 = gates r, z, half 1 = gate n (+ gate r again: unused)
     const unsigned short* src[4]; int ldso[4];
@@ -136,10 +147,10 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
             base = plane ? Wl : Wh; row = (int64_t)gate * H + u0 + (r32 & 15); base += (int64_t)chunk * pitchW;
         }
         src[u] = base + row * 16 + c16 * 8;
-        ldso[u] = opnd * 8192 + plane * 4096 + chunk * 2048 + half * 1024;
+        ldso[u] = opnd * R::OFF_B + plane * 4096 + chunk * 2048 + half * 1024;       // (compact ring: plane 0 only)
     }
     const int64_t kstepH = 2 * pitchH, kstepW = 2 * pitchW;       // elements per 32-deep K step
-    constexpr int SLOT = KPB * GF_SLOT;
+    constexpr int SLOT = KPB * R::SLOT;
     auto issue = [&](int pos, int kg) {                            // kg: group of KPB sub-steps
 #pragma unroll
         for (int sub = 0; sub < KPB; ++sub)
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
             if ((NPL == 1 || (CTI_GF_DBG & 1)) && ((q >> 2) & 1)) continue;              // plain bf16: the lo planes are not staged
             const unsigned short* s_ = src[u] + (int64_t)(kg * KPB + sub) * ((q >> 3) ? kstepW : kstepH);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
-                                             (__attribute__((address_space(3))) void*)(gsm + pos * SLOT + sub * GF_SLOT + ldso[u]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(gsm + pos * SLOT + sub * R::SLOT + ldso[u]), 16, 0, 0);
         }
     };
     constexpr int PER = 4 * KPB;                                   // DMA instructions per wave and slot (plain bf16: waves 0 and 2 issue them, waves 1 and 3 -- the lo planes -- none)
@@ -163,19 +174,19 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < GF_NST - 1; ++i) if (i < nsteps) issue(i, i);
+    for (int i = 0; i < NST - 1; ++i) if (i < nsteps) issue(i, i);
     // fragment addresses: lane l -> row (l & 15), k = 8 (l >> 4) .. + 7 of the 32-deep step = chunk (l >> 5), 16-B half (l >> 4) & 1
     const int fa = (lane >> 5) * 2048 + (wid * 16 + (lane & 15)) * 32 + ((lane >> 4) & 1) * 16;
-    const int fb = 8192 + (lane >> 5) * 2048 + (lane & 15) * 32 + ((lane >> 4) & 1) * 16;
+    const int fb = R::OFF_B + (lane >> 5) * 2048 + (lane & 15) * 32 + ((lane >> 4) & 1) * 16;
     int pos = 0;
     for (int ks = 0; ks < nsteps; ++ks) {
         const int rem = nsteps - 1 - ks;
-        if (rem >= GF_NST - 2) gf_wait<(GF_NST - 2) * PER>(); else if (rem == 1) gf_wait<PER>(); else gf_wait<0>();
+        if (rem >= NST - 2) gf_wait<(NST - 2) * PER>(); else if (rem == 1) gf_wait<PER>(); else gf_wait<0>();
         __builtin_amdgcn_s_barrier();
-        if (ks + GF_NST - 1 < nsteps) issue(pos == 0 ? GF_NST - 1 : pos - 1, ks + GF_NST - 1);
+        if (ks + NST - 1 < nsteps) issue(pos == 0 ? NST - 1 : pos - 1, ks + NST - 1);
 #pragma unroll
         for (int sub = 0; sub < KPB; ++sub) {
-        const char* s = gsm + pos * SLOT + sub * GF_SLOT;
+        const char* s = gsm + pos * SLOT + sub * R::SLOT;
         const g_bf16x8 ah = *reinterpret_cast<const g_bf16x8*>(s + fa);
         g_bf16x8 al = ah;
         if (TERMS == 3) al = *reinterpret_cast<const g_bf16x8*>(s + fa + 4096);
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[g], 0, 0, 0);
         }
         }
-        pos = pos == GF_NST - 1 ? 0 : pos + 1;
+        pos = pos == NST - 1 ? 0 : pos + 1;
     }
     // epilogue: C/D map of the 16x16 MFMA: column = lane & 15 (unit), row = 4 (lane >> 4) + reg
     const int j = u0 + (lane & 15);
@@ -335,9 +346,9 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         (void)hipGetDevice(&dev);
         if (attr_dev != dev) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, GfRing<1>::NST * GfRing<1>::SLOT);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<3, GF_KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_KPB * GF_NST * GF_SLOT);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, GF_KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_KPB * GF_NST * GF_SLOT);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fused_kernel<1, GF_KPB>), hipFuncAttributeMaxDynamicSharedMemorySize, GF_KPB * GfRing<1>::NST * GfRing<1>::SLOT);
             if (e != hipSuccess) return fail((int)e, "cti_gru_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_dev = dev;
         }
@@ -347,7 +358,7 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         if (fused && t) {
             const dim3 grid((H + 15) / 16, (B + 63) / 64);
 #define CTI_GF(TR) CTI_GF2(TR, 1)
-#define CTI_GF2(TR, KP) hipLaunchKernelGGL((gru_step_fused_kernel<TR, KP>), grid, dim3(256), KP * GF_NST * GF_SLOT, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, \
+#define CTI_GF2(TR, KP) hipLaunchKernelGGL((gru_step_fused_kernel<TR, KP>), grid, dim3(256), KP * GfRing<TR>::NST * GfRing<TR>::SLOT, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, \
                                       gi + (size_t)t * H3, (int64_t)T * H3, b_hh, h_tm + (size_t)(t - 1) * B * H, out + (size_t)t * H, (int64_t)T * H,                     \
                                       h_tm + (size_t)t * B * H, save ? save + (size_t)t * B * 5 * H : nullptr, hp_[cur], hl_[cur], rh * 16, B, H)
             if ((KpH / 32) % GF_KPB == 0 && KpH / 32 >= 2 * GF_KPB) { if (terms == 3) CTI_GF2(3, GF_KPB); else CTI_GF2(1, GF_KPB); }
