@@ -25,6 +25,7 @@ static thread_local long long g_tri_chunk = 0;
 static thread_local int g_guard_rho_milli[2] = {2750, 5500};      // cancellation estimate beyond which a guarded f16f6 call is re-run as bf16x3 / as exact fp32 (x 1000)
 static thread_local int g_guard_poison_bits = 31;                 // status bits that NaN-fill the output of a guarded call
 static thread_local int g_guard_strata = 1;                       // test knob: 0 = the cancellation estimate samples 32 evenly spaced rows per operand (round 4)
+static thread_local int g_gemm16_sk = -1;                          // stream-K cut of the plain-bf16 row GEMM: -1 = where it was measured to pay (three or more rounds of tiles), 0 = never, 1 = wherever it can be planned
 static thread_local int g_f6_core_free_cus = -1;                  // CUs the mode-3 product leaves to the guard kernels beside it (-1 = the library's default)
 int tuning_gemm_cfg() { return g_gemm_cfg; }
 int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk; }
@@ -32,6 +33,7 @@ float tuning_guard_rho(int which) { return 1e-3f * (float)g_guard_rho_milli[whic
 unsigned tuning_guard_poison_bits() { return (unsigned)g_guard_poison_bits; }
 int tuning_f6_core_free_cus() { return g_f6_core_free_cus; }
 int tuning_guard_strata() { return g_guard_strata; }
+int tuning_gemm16_sk() { return g_gemm16_sk; }
 
 }  // namespace cti
 
@@ -59,6 +61,9 @@ extern "C" int cti_set_tuning(int key, int64_t value) {
         case CTI_TUNE_F6_CORE_FREE_CUS:
             CTI_REQUIRE(value >= -1 && value <= 64, CTI_E_SHAPE, "cti_set_tuning: F6_CORE_FREE_CUS must be -1 (default) or 0 .. 64, got %lld", (long long)value);
             g_f6_core_free_cus = (int)value; return CTI_OK;
+        case CTI_TUNE_GEMM16_SK:
+            CTI_REQUIRE(value >= -1 && value <= 1, CTI_E_SHAPE, "cti_set_tuning: GEMM16_SK must be -1 (auto), 0 or 1, got %lld", (long long)value);
+            g_gemm16_sk = (int)value; return CTI_OK;
         default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
     }
 }
@@ -71,6 +76,7 @@ extern "C" int64_t cti_get_tuning(int key) {
         case CTI_TUNE_GUARD_POISON_BITS: return g_guard_poison_bits;
         case CTI_TUNE_F6_CORE_FREE_CUS: return g_f6_core_free_cus;
         case CTI_TUNE_GUARD_STRATA: return g_guard_strata;
+        case CTI_TUNE_GEMM16_SK: return g_gemm16_sk;
         default: return INT64_MIN;
     }
 }

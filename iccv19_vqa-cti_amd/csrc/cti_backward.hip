@@ -607,16 +607,18 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     return gemm_nt_planes(g, as_stream(stream));
 }
 
-// Plain-bf16 product whose A operand is a row-major bf16 matrix as it stands (no split pass, no workspace) against resident planes; C as fp32 rows or as
-// bf16 rows -- the next layer's A operand.  cti_gemm16.hip; K % 32 == 0 (a row is read in whole 64-B stages).
-extern "C" int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
-                                  void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
-                                  int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* stream) {
-    CTI_REQUIRE_PTR(A_bf16); CTI_REQUIRE_PTR(B_planes); CTI_REQUIRE_PTR(C);
-    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && nb1 > 0 && lda >= K, CTI_E_SHAPE, "cti_gemm_bf16_rows: M=%d N=%d K=%d nb=%d", M, N, K, nb1);
-    CTI_REQUIRE(K % 32 == 0, CTI_E_UNSUPPORTED, "cti_gemm_bf16_rows: K=%d must be a multiple of 32 (rows are read in 64-B stages; zero-pad the operand)", K);
-    CTI_REQUIRE((int64_t)(nb1 - 1) * rA1 + M <= rowsA_total && (int64_t)(nb1 - 1) * rB1 + N <= rowsB_total, CTI_E_SHAPE, "cti_gemm_bf16_rows: batches run past the operand rows");
-    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "cti_gemm_bf16_rows: act=%d", act);
+// Plain-bf16 product whose A operand is a row-major bf16 matrix as it stands (no split pass) against resident planes; C as fp32 rows or as
+// bf16 rows -- the next layer's A operand.  cti_gemm16.hip; K % 32 == 0 (a row is read in whole 64-B stages).  With a workspace
+// (cti_gemm_bf16_rows_sk_workspace_bytes(); zeroed once, one per stream) products whose tiles do not fill whole rounds of the compute units are cut stream-K.
+static int gemm_bf16_rows_impl(const char* who, const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                               void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
+                               int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    CTI_REQUIRE(A_bf16 && B_planes && C, CTI_E_NULL, "%s: A_bf16 / B_planes / C is NULL", who);
+    CTI_REQUIRE(M > 0 && N > 0 && K > 0 && nb1 > 0 && lda >= K, CTI_E_SHAPE, "%s: M=%d N=%d K=%d nb=%d", who, M, N, K, nb1);
+    CTI_REQUIRE(K % 32 == 0, CTI_E_UNSUPPORTED, "%s: K=%d must be a multiple of 32 (rows are read in 64-B stages; zero-pad the operand)", who, K);
+    CTI_REQUIRE((int64_t)(nb1 - 1) * rA1 + M <= rowsA_total && (int64_t)(nb1 - 1) * rB1 + N <= rowsB_total, CTI_E_SHAPE, "%s: batches run past the operand rows", who);
+    CTI_REQUIRE(act == CTI_ACT_NONE || act == CTI_ACT_RELU, CTI_E_UNSUPPORTED, "%s: act=%d", who, act);
+    CTI_REQUIRE(!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, CTI_E_ALIGN, "%s: the stream-K workspace must be 256-B aligned", who);
     const int64_t rb = rowsB_total + PLANE_SLACK_ROWS;
     PlaneGemmArgs g{};
     g.Abf = A_bf16; g.ldabf = lda; g.Bh = static_cast<const unsigned short*>(B_planes); g.Bl = g.Bh + (size_t)rb * planes_kp(K);
@@ -624,9 +626,26 @@ extern "C" int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA
     g.M = M; g.N = N; g.Kp = K; g.terms = 1; g.epi = c_bf16 ? 5 : 0; g.gdiv = 1;
     g.C = static_cast<float*>(C); g.ldc_m = ldc_m; g.ldc_n = 1; g.sC1 = sC1;
     g.scale = scale; g.scale_div = scale ? scale_div : 1; g.bias = bias; g.relu = act == CTI_ACT_RELU; g.scale_bs = scale_bs; g.bias_bs = bias_bs;
-    CTI_REQUIRE(gemm16_eligible(g), CTI_E_ALIGN, "cti_gemm_bf16_rows: A needs 16-B aligned rows (lda %% 8 == 0), C rows of a multiple of 4 elements at a %d-B aligned origin, K / 32 >= 4 with bias or scale",
-                c_bf16 ? 8 : 16);
+    g.sk_ws = workspace; g.sk_ws_bytes = workspace ? workspace_bytes : 0;
+    CTI_REQUIRE(gemm16_eligible(g), CTI_E_ALIGN, "%s: A needs 16-B aligned rows (lda %% 8 == 0), C rows of a multiple of 4 elements at a %d-B aligned origin, K / 32 >= 4 with bias or scale",
+                who, c_bf16 ? 8 : 16);
     return gemm16_planes(g, as_stream(stream));
+}
+
+extern "C" int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                                  void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
+                                  int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* stream) {
+    return gemm_bf16_rows_impl("cti_gemm_bf16_rows", A_bf16, lda, rowsA_total, rA1, B_planes, rowsB_total, rB1, C, c_bf16, ldc_m, sC1, nb1, M, N, K, scale, scale_div, scale_bs,
+                               bias, bias_bs, act, nullptr, 0, stream);
+}
+
+extern "C" size_t cti_gemm_bf16_rows_sk_workspace_bytes(void) { return gemm16_sk_workspace_bytes(); }
+
+extern "C" int cti_gemm_bf16_rows_sk(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                                     void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
+                                     int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_bf16_rows_impl("cti_gemm_bf16_rows_sk", A_bf16, lda, rowsA_total, rA1, B_planes, rowsB_total, rB1, C, c_bf16, ldc_m, sC1, nb1, M, N, K, scale, scale_div,
+                               scale_bs, bias, bias_bs, act, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t cti_gemm_nt_workspace_bytes(int64_t rowsA_total, int64_t rowsB_total, int K, int prec) {

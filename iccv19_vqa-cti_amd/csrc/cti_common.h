@@ -22,6 +22,7 @@ int64_t tuning_tri_chunk();       // 0 auto (32768), else positions per chunk of
 float tuning_guard_rho(int which);    // f16f6 guard policy (cti_set_tuning keys 3 / 4): cancellation estimate beyond which a call belongs in bf16x3 (0) / exact fp32 (1)
 unsigned tuning_guard_poison_bits();  // key 5: status bits that NaN-fill the output
 int tuning_guard_strata();            // key 7 (tests): 0 = the cancellation estimate without its strata maxima
+int tuning_gemm16_sk();               // key 8: stream-K cut of cti_gemm16.hip's row products (-1 auto, 0 never, 1 wherever plannable)
 int tuning_f6_core_free_cus();        // key 6: CUs the mode-3 product leaves free for the guard kernels beside it (-1 = default)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -124,6 +125,8 @@ struct PlaneGemmArgs {
     int ksplit; float* partial;
     int partials_only;                         // ksplit > 1: leave the fp32 partials [ksplit][M][N] to the caller (no reduce kernel, C / scale / bias unused)
     int64_t kc2;                               // set by the split-K path itself: batch b2 starts kc2 * b2 K-chunks into both operands
+    // cti_gemm16.hip only: stream-K workspace (gemm16_sk_workspace_bytes(); zeroed once by the caller, 256-B aligned, one per stream); NULL = every tile whole
+    void* sk_ws; size_t sk_ws_bytes;
 };
 int plan_ksplit(int M, int N, int Kp, long long nb);       // 1 = do not split
 int planes_kp(int K);
@@ -135,6 +138,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
 // cti_gemm16.hip: the plain-bf16 (terms = 1) products of the 256 x 256 tile with fp32-row or planes epilogues
 bool gemm16_eligible(const PlaneGemmArgs& a);
 int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st);
+size_t gemm16_sk_workspace_bytes();
 // planes of x^T for x (M x n) row-major: rows = n, depth = Mp >= M (multiple of 16, zero-filled)
 int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, unsigned short* hi, unsigned short* lo, int64_t rows_alloc, hipStream_t st);
 int plan_ksplit_tn(int64_t M, int N, int K);

@@ -16,6 +16,19 @@
 //   * a workgroup's tiles are one stream of stages (persistent, XCD-aware tile order): the ring never drains at a tile boundary;
 //   * bias and weight-norm scale of the tile's 64 columns per wave travel through LDS too (two global_load_lds_dword per wave and tile, double
 //     buffered): an ordinary global load in the epilogue would make the compiler drain vmcnt(0) -- the whole ring -- in front of it.
+// Stream-K (round 6; reference layer src/fc.py:22-29 at the hoisted projections' shapes: 9216 x 3072 = 432 tiles = 1.69 rounds of 256 workgroups):
+//   with T tiles on P workgroups (8 | P), T > P and T % P != 0, the last T - (T / P - 1) P tiles (between one and two rounds' worth) are cut PER XCD: the
+//   tiles of XCD x's chunk of the tile order (tile_coords: the tiles its L2 shares operands for) that are left after the whole rounds are ONE sequence of
+//   K stages cut into P / 8 equal ranges, one per workgroup of that XCD (w = x + 8 s); a range is at least one tile long, so it is [the K tail of a
+//   tile][whole tiles][the K head of the next tile] and every tile has at most TWO contributors, workgroups w and w + 8.  A workgroup runs its pieces as  head piece -> whole tiles (its range's, then its data-parallel ones) -> tail piece:
+//     * the head piece's accumulators go to the workgroup's 256-KiB slot of the caller's workspace as they stand (the ordinary pipelined epilogue with
+//       `sc1` write-through stores), and once every wave's stores have drained (the store window's own counted wait + the interval barrier) ONE lane
+//       sets the slot's flag with an `sc1` store;
+//     * the tail piece -- the LAST thing workgroup w does, a whole tile or more after workgroup w - 8 wrote its slot -- polls the flag (`sc1` load),
+//       runs an agent-scope acquire and starts its K loop from workgroup w - 8's slot instead of from zero: partial + the tail's products, a fixed order, so the
+//       result does not depend on timing; its epilogue is the ordinary one.  The flag goes back to 0 at the end of the kernel.
+//   A workgroup only ever waits for a LOWER-numbered workgroup's FIRST piece, which waits for nothing; the poll is bounded (an error word in the
+//   workspace instead of a hang).  Every workgroup runs the same number of stages (+- 1): 108 instead of 128 at 432 tiles.
 // Epilogues: fp32 rows (scale / bias / ReLU; 16-B stores) and chunk-major hi / lo planes.  Everything else (3-term products, interleaved outputs,
 // fp32 A operands, other tiles) stays on cti_gemm_bf16x3.hip; gemm_nt_planes() routes.
 #include "cti_common.h"
@@ -30,6 +43,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int G16_ROWB = 64;                                         // bytes of K per stage row (32 bf16)
 constexpr int G16_NS = 4;
 constexpr int G16_EPI_LDS = 8 * 2 * 2 * 256;                         // per wave: 2 buffers x (bias | scale) x 64 floats
+constexpr size_t G16_SK_FLAG_BYTES = 4096;                           // stream-K workspace: flag words in front of the partial slots
 
 struct G16P {
     const char* Ah; const char* Bh;
@@ -41,6 +55,9 @@ struct G16P {
     int64_t scale_bs, bias_bs;
     int nb2, M, N, Np, nk, scale_div, relu;
     int tiles_m, tiles_n, total_tiles;
+    // stream-K (round 6; see "Stream-K" below): the LAST sk_tiles virtual tiles are cut into gridDim.x equal K ranges; 0 = every tile whole
+    float* sk_part; unsigned* sk_flag;
+    int sk_tiles;
 };
 typedef const __attribute__((address_space(4))) G16P G16P_K;
 __device__ __forceinline__ const G16P_K* g16_kernarg() { return __builtin_bit_cast(const G16P_K*, __builtin_amdgcn_kernarg_segment_ptr()); }
@@ -73,9 +90,23 @@ struct G16Geo {
     static_assert((G16_NS - 2) * (CQ + 1) + NSTORE < 64, "the store window must fit vmcnt's six bits");
 };
 
+// Stream-K range of workgroup w = x + 8 s: XCD x's chunk of the tile order holds total / 8 (+ 1 for x < total % 8) tiles, its first dp_tiles / 8 slots are whole
+// rounds; the n remaining tiles are n * nk stages, of which slot s of the P / 8 takes an equal share [u0, u0 + len): tile ta from stage ka (la stages; 0 when the
+// range starts on a tile boundary), nfull whole tiles, lb stages of the next
+__device__ __forceinline__ void sk_range(int total, int dp_tiles, int nk, int w, int P, int& ta, int& ka, int& la, int& nfull, int& lb) {
+    const int x = w & 7, s = w >> 3, S = P >> 3;
+    const int n = (total >> 3) + (x < (total & 7) ? 1 : 0) - (dp_tiles >> 3);
+    const int units = n * nk, base = units / S, extra = units - base * S;
+    const int len = base + (s < extra ? 1 : 0), u0 = s * base + min(s, extra);
+    ta = u0 / nk; ka = u0 - ta * nk; la = ka > 0 ? min(nk - ka, len) : 0;
+    const int rem = len - la;
+    nfull = rem / nk; lb = rem - nfull * nk;
+}
+
 template <int EPI, class G, bool AROW>
 __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
     constexpr int NS = G16_NS, STAGE = G::STAGE, BM = G::BM, BN = G::BN, TMW = G::TMW, TNW = G::TNW, UMAX = G::UMAX, NSTORE = G::NSTORE;
+    constexpr bool SK = EPI != G16_EPI_PLANES;                       // stream-K pieces exist for the row epilogues only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,10 +114,37 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
     const int total_tiles = p.total_tiles;
     if ((int)blockIdx.x >= total_tiles) return;
     const int nk = p.nk;
-    const int my_tiles = (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-    const int total = my_tiles * nk;
+    // ---- this workgroup's pieces (tile, first stage, stages, kind): kind 0 = a whole tile or the K tail of one without a partial (ordinary epilogue),
+    // 1 = K head (accumulators -> the workgroup's partial slot), 2 = K tail (starts from workgroup w - 1's slot)
+    int npieces, total;
+    {
+        const int dp_tiles = total_tiles - p.sk_tiles, w = blockIdx.x, P = gridDim.x;
+        const int ndp = w < dp_tiles ? (dp_tiles - 1 - w) / P + 1 : 0;
+        npieces = ndp; total = ndp * nk;
+        if (SK && p.sk_tiles > 0) {
+            int ta, ka, la, nfull, lb;
+            sk_range(total_tiles, dp_tiles, nk, w, P, ta, ka, la, nfull, lb);
+            npieces += (lb > 0) + nfull + (la > 0); total += la + nfull * nk + lb;
+        }
+    }
+    auto piece = [&](int pi, int& id, int& k0, int& kl, int& kind) {
+        const G16P_K* q = g16_kernarg();
+        asm volatile("" : "+s"(q));
+        const int nkq = q->nk, dp_tiles = q->total_tiles - q->sk_tiles, w = blockIdx.x, P = gridDim.x;
+        const int ndp = w < dp_tiles ? (dp_tiles - 1 - w) / P + 1 : 0;
+        int ta = 0, ka = 0, la = 0, nfull = 0, lb = 0;
+        if (SK && q->sk_tiles > 0) sk_range(q->total_tiles, dp_tiles, nkq, w, P, ta, ka, la, nfull, lb);
+        // cut tile t of this XCD's chunk = slot dp_tiles / 8 + t of the chunk = virtual tile ((dp_tiles >> 3) + t) << 3 | x
+        const int x = w & 7, first_full = ta + (ka > 0 ? 1 : 0);
+        auto skid = [&](int t) { return (((dp_tiles >> 3) + t) << 3) | x; };
+        int qi = pi - (lb > 0 ? 1 : 0);
+        if (qi < 0) { id = skid(first_full + nfull); k0 = 0; kl = lb; kind = 1; }
+        else if (qi < nfull) { id = skid(first_full + qi); k0 = 0; kl = nkq; kind = 0; }
+        else if (qi < nfull + ndp) { id = w + (qi - nfull) * P; k0 = 0; kl = nkq; kind = 0; }
+        else { id = skid(ta); k0 = ka; kl = la; kind = 2; }
+    };
     const bool has_bias = p.bias != nullptr, has_scale = p.scale != nullptr;
-    const bool hiw = wid < G::CR;                                    // this wave issues CQ + 1 pieces per stage
+    const bool hiw = G::CR > 0 && wid < G::CR;                       // this wave issues CQ + 1 pieces per stage (never, at 8 | P: folds away)
 
     // fragment addresses inside a slot: lane = (row lr of a 16-row MFMA tile, K group g of 8 elements = 16 B); unit' = g ^ f(row)
     const int lr = lane & 15, g = lane >> 4;
@@ -104,51 +162,47 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
         const int gp = wid + 8 * u;
-        pv[u] = gp < G::P; pa[u] = gp < G::PA;
+        // (8 | PA and 8 | P: piece u of EVERY wave is an A piece for u < PA / 8 and exists -- compile-time, no scalar selects or branches per stage)
+        pv[u] = G::P % 8 == 0 ? true : gp < G::P; pa[u] = G::PA % 8 == 0 ? u < G::PA / 8 : gp < G::PA;
         const int row = (pa[u] ? gp : gp - G::PA) * 16 + drow;
         if (pa[u] && AROW) voff[u] = 0;                              // per issue tile (rows past the matrix re-read its last row: no slack rows there)
         else voff[u] = (unsigned)(dc >> 1) * (pa[u] ? pitchA32 : pitchB32) + (unsigned)(row * 32 + (dc & 1) * 16);
     }
     const int64_t ksA = AROW ? 64 : 2 * p.pitchA, ksB = 2 * p.pitchB;
-    int iss_tile = blockIdx.x, iss_kb = 0, issued = 0, iss_par = 0;
-    const char* Ab = nullptr; const char* Bb = nullptr;              // wave-uniform: the issue tile's operand origins at the current K stage
-    const float* ep_bias = nullptr; const float* ep_scale = nullptr; // per-lane sources of this wave's epilogue constants for the issue tile
-    auto issue_tile_setup = [&]() {
+    // ---- issue side.  iss_left: stages of the open piece not yet issued (0: the next issue opens piece iss_pi); iss_rem: stages of the stream not yet issued.
+    // Everything a stage's issue needs beyond its four LDS-DMA instructions is either rare (a piece opens) or advanced in the COMPUTE interval, between the
+    // MFMAs: an instruction in the LOAD interval costs ~4 cycles of the interval that the partner wave group's MFMAs have to cover (round 6: the
+    // per-stage scalar selects / branches / counters of the round-4 form were ~55 scalar instructions per wave and stage -- a third of the LOAD interval).
+    int iss_pi = 0, iss_left = 0, iss_rem = total;
+    const char* Ab = nullptr; const char* Bb = nullptr;              // wave-uniform: the open piece's operand origins at the next stage to issue
+    auto issue_piece_open = [&]() {
         const G16P_K* q = g16_kernarg();
-        asm volatile("" : "+s"(q));                                  // re-read once per tile instead of living in SGPRs across the K loop
-        int z, tm, tn;
-        tile_coords(iss_tile, q->total_tiles, q->tiles_m, q->tiles_n, z, tm, tn);
+        asm volatile("" : "+s"(q));                                  // re-read once per piece instead of living in SGPRs across the K loop
+        int z, tm, tn, id, k0, kind;
+        piece(iss_pi, id, k0, iss_left, kind);
+        tile_coords(id, q->total_tiles, q->tiles_m, q->tiles_n, z, tm, tn);
         const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
         if (AROW) {
-            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * q->pitchA + b2 * q->kc2 * 32;
+            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * q->pitchA + b2 * q->kc2 * 32 + (int64_t)k0 * 64;
             const int last = q->M - 1 - tm * BM;
 #pragma unroll
             for (int u = 0; u < UMAX; ++u)
                 if (pa[u]) voff[u] = (unsigned)min((wid + 8 * u) * 16 + drow, last) * pitchA32 + (unsigned)(dc * 16);
         } else {
-            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * 32 + b2 * q->kc2 * q->pitchA;
+            Ab = q->Ah + (b1 * q->rA1 + b2 * q->rA2 + (int64_t)tm * BM) * 32 + (b2 * q->kc2 + 2 * (int64_t)k0) * q->pitchA;
         }
-        Bb = q->Bh + (b1 * q->rB1 + b2 * q->rB2 + (int64_t)tn * BN) * 32 + b2 * q->kc2 * q->pitchB;
+        Bb = q->Bh + (b1 * q->rB1 + b2 * q->rB2 + (int64_t)tn * BN) * 32 + (b2 * q->kc2 + 2 * (int64_t)k0) * q->pitchB;
+        // the piece's epilogue constants ride in front of its first stage (buffer = the piece's parity; older than the stage's pieces: outside every counted window)
         const int n = min(tn * BN + wc * 16 * TNW + min(lane, 16 * TNW - 1), q->N - 1);
-        ep_bias = q->bias + b1 * q->bias_bs + n;
-        ep_scale = q->scale + b1 * q->scale_bs + n / q->scale_div;
+        if (has_bias) g16_dma4(q->bias + b1 * q->bias_bs + n, epi_lds + (iss_pi & 1) * 512);
+        if (has_scale) g16_dma4(q->scale + b1 * q->scale_bs + n / q->scale_div, epi_lds + (iss_pi & 1) * 512 + 256);
+        ++iss_pi;
     };
-    auto issue_next = [&](int slot) {
-        if (issued >= total) return;
-        char* sb = smem + slot * STAGE + wid * 1024;
+    auto issue_stage = [&](int slot_off) {
+        char* sb = smem + slot_off + wid * 1024;
 #pragma unroll
         for (int u = 0; u < UMAX; ++u)
             if (pv[u]) g16_dma16((pa[u] ? Ab : Bb) + voff[u], sb + u * 8192);
-        if (iss_kb == 0) {                                           // the tile's epilogue constants ride behind its first stage
-            if (has_bias) g16_dma4(ep_bias, epi_lds + iss_par * 512);
-            if (has_scale) g16_dma4(ep_scale, epi_lds + iss_par * 512 + 256);
-        }
-        Ab += ksA; Bb += ksB;
-        ++issued;
-        if (++iss_kb == nk) {
-            iss_kb = 0; iss_tile += (int)gridDim.x; iss_par ^= 1;
-            if (iss_tile < total_tiles) issue_tile_setup();
-        }
     };
     // all but this wave's youngest `stages` stages of pieces (and, with `st`, the NSTORE unconditional stores issued behind them) have landed
     auto wait_stages = [&](int stages, bool st) {
@@ -165,22 +219,42 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
     };
     static_assert(NS == 4, "wait_stages is written for two stages in flight behind the one awaited");
 
-    issue_tile_setup();
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_next(s);
+    for (int s = 0; s < NS - 1; ++s)
+        if (iss_rem > 0) {
+            if (iss_left == 0) issue_piece_open();
+            issue_stage(s * STAGE);
+            Ab += ksA; Bb += ksB; --iss_left; --iss_rem;
+        }
     wait_stages(total - 1, false);
     G16_BAR();
     if (wr == 1) G16_BAR();                                          // waves 4-7 run one interval behind
 
     f32x4 acc[TMW][TNW];
     bf16x8 fa[TMW], fb[TNW];
-    int vtile = blockIdx.x, kb = 0, slot = 0;
-    int ep_z = 0, ep_tm = 0, ep_tn = 0, ep_age = 1000, ep_par = 0;
-    bool ep_pending = false, ep_full = false;
+    // ---- compute side.  kleft: stages of the open piece (cpi: virtual tile cid, kind ckind) not yet multiplied; 0 in a LOAD interval = the piece ended with
+    // the COMPUTE interval before: its epilogue and the next piece's accumulators (zeros, or a stream-K partial) are that LOAD interval's rare path
+    int cpi = 0, kleft, cid, ckind;
+    { int k0; piece(0, cid, k0, kleft, ckind); }
+    int st_left = 0, sig_left = -1;                                  // LOAD intervals whose wait still has the store window; intervals until the partial's flag goes up (-1: none)
+    bool had_tail = false;
 
-    auto epilogue = [&](int z, int tm, int tn, int par) -> bool {
+    auto epilogue = [&](int z, int tm, int tn, int par, int kind) -> bool {
         const G16P_K* q = g16_kernarg();
         asm volatile("" : "+s"(q));
+        if (SK && kind == 1) {
+            // stream-K head piece: the accumulators as they stand -> this workgroup's slot, [wave][i][j][lane] x 16 B (1 KiB per store instruction),
+            // write-through (`sc1`): the reader may sit on another XCD
+            char* dst = reinterpret_cast<char*>(q->sk_part) + (size_t)blockIdx.x * (BM * BN * 4) + wid * (TMW * TNW * 1024) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    // (s_nop: a store of more than 8 bytes needs wait states before anything writes its data registers -- the compiler does not know this
+                    // is a store, and it does reuse a dead accumulator as the next store's address)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (i * TNW + j) * 1024), "v"(acc[i][j]) : "memory");
+            return true;
+        }
         const int pM = q->M, pN = q->N;
         const int b1 = z / q->nb2, b2 = z - b1 * q->nb2;
         const int m0 = tm * BM + wr * 16 * TMW, n0 = tn * BN + wc * 16 * TNW;
@@ -260,58 +334,144 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         return full;
     };
 
+#pragma unroll
+    for (int u = 0; u < TMW; ++u)
+#pragma unroll
+        for (int v = 0; v < TNW; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a piece ended / the partial's flag is due / the ring is running out: the LOAD interval's rare path (everything else in it is unconditional)
+    auto finish_piece = [&]() -> bool {
+        const G16P_K* q = g16_kernarg();
+        asm volatile("" : "+s"(q));
+        int z, tm, tn;
+        tile_coords(cid, q->total_tiles, q->tiles_m, q->tiles_n, z, tm, tn);
+        return epilogue(z, tm, tn, cpi & 1, ckind);
+    };
+    int slot_rd = 0, slot_wr = (NS - 1) * STAGE, rem = total - 2;    // byte offsets of the slot read / filled; stages issued behind the one this interval's wait awaits
+    bool evt = rem < 2;
     for (int i = 0; i < total; ++i) {
         // ================= LOAD interval =================
         {
-            const char* s = smem + slot * STAGE;
+            const char* s = smem + slot_rd;
 #pragma unroll
             for (int u = 0; u < TMW; ++u) fa[u] = *reinterpret_cast<const bf16x8*>(s + a_off + u * 1024);
 #pragma unroll
             for (int u = 0; u < TNW; ++u) fb[u] = *reinterpret_cast<const bf16x8*>(s + b_off + u * 1024);
         }
-        issue_next(slot == 0 ? NS - 1 : slot - 1);
-        if (ep_pending) {
-            ep_full = epilogue(ep_z, ep_tm, ep_tn, ep_par);
-            ep_pending = false; ep_age = 0;
+        if (iss_rem > 0) {
+            if (iss_left == 0) issue_piece_open();
+            issue_stage(slot_wr);
         }
-        // (planes epilogue: up to 64 stores + the pieces exceed vmcnt's six bits: no store window there)
-        wait_stages(total - 2 - i, EPI != G16_EPI_PLANES && ep_full && ep_age <= NS - 2 && nk > NS - 2);
-        ++ep_age;
-        G16_BAR();
-        // ================= COMPUTE interval =================
-        __builtin_amdgcn_s_setprio(1);
-        if (kb == 0) {
+        if (evt) {
+            if (kleft == 0) {
+                const bool full = finish_piece();
+                // (planes epilogue: up to 64 stores + the pieces exceed vmcnt's six bits: no store window there)
+                st_left = (EPI != G16_EPI_PLANES && full && nk > NS - 2) ? NS - 1 : 0;
+                if (SK && ckind == 1) sig_left = NS;                 // the slot's stores leave every wave's window NS - 1 waits on; one barrier more for the later wave group
+                int k0;
+                piece(++cpi, cid, k0, kleft, ckind);
+                if (SK && ckind == 2) {
+                    // stream-K tail piece: the K loop starts from workgroup w - 8's partial (flag poll: bounded; acquire: this CU's L1 may hold the slot's
+                    // lines of an earlier launch)
+                    const G16P_K* q = g16_kernarg();
+                    asm volatile("" : "+s"(q));
+                    const unsigned* fl = q->sk_flag + (blockIdx.x - 8);
+                    int spins = 0;
+                    // (readfirstlane: the loaded word is wave-uniform, and told so the loop -- and every counter behind it -- stays on the scalar unit)
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                        __builtin_amdgcn_s_sleep(16);
+                        if (++spins > (1 << 20)) {
+                            if (lane == 0) __hip_atomic_store(q->sk_flag + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const char* src = reinterpret_cast<const char*>(q->sk_part) + (size_t)(blockIdx.x - 8) * (BM * BN * 4) + wid * (TMW * TNW * 1024) + lane * 16;
+                    // (inline asm: loads the compiler knew of would make it drain vmcnt -- the whole ring -- in front of EVERY interval's first MFMA)
 #pragma unroll
-            for (int u = 0; u < TMW; ++u)
+                    for (int u = 0; u < TMW; ++u)
 #pragma unroll
-                for (int v = 0; v < TNW; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        for (int v = 0; v < TNW; ++v) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(acc[u][v]) : "v"(src + (u * TNW + v) * 1024) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < TMW; ++u)
+#pragma unroll
+                        for (int v = 0; v < TNW; ++v) asm volatile("" : "+v"(acc[u][v]));     // the accumulators are defined HERE, behind the wait
+                    had_tail = true;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TMW; ++u)
+#pragma unroll
+                        for (int v = 0; v < TNW; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (SK && sig_left == 0) {
+                // every wave's slot stores have drained and a barrier has passed since: one lane of the LATER wave group raises the flag
+                sig_left = -1;
+                if (wid == 4 && lane == 0) {
+                    const G16P_K* q = g16_kernarg();
+                    __hip_atomic_store(q->sk_flag + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // (readfirstlane: what the rare path leaves re-enters the loop on the scalar unit; without it the compiler keeps the counters in vector registers
+            // and turns the loop's uniform branches into exec-mask sequences)
+            kleft = __builtin_amdgcn_readfirstlane(kleft); ckind = __builtin_amdgcn_readfirstlane(ckind); cid = __builtin_amdgcn_readfirstlane(cid);
+            cpi = __builtin_amdgcn_readfirstlane(cpi); st_left = __builtin_amdgcn_readfirstlane(st_left); sig_left = __builtin_amdgcn_readfirstlane(sig_left);
+            wait_stages(rem, st_left > 0);
         } else {
-#pragma unroll
-            for (int u = 0; u < TMW; ++u)
-#pragma unroll
-                for (int v = 0; v < TNW; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        slot = slot == NS - 1 ? 0 : slot + 1;
-        if (++kb == nk) {
-            kb = 0;
-            const G16P_K* q = g16_kernarg();
-            asm volatile("" : "+s"(q));
-            tile_coords(vtile, q->total_tiles, q->tiles_m, q->tiles_n, ep_z, ep_tm, ep_tn);
-            ep_pending = true; ep_par = ((vtile - (int)blockIdx.x) / (int)gridDim.x) & 1;
-            vtile += (int)gridDim.x;
+            wait_stages(2, st_left > 0);
         }
         G16_BAR();
+        // ================= COMPUTE interval: the MFMAs, and between them the scalar bookkeeping of the NEXT interval =================
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < TMW; ++u)
+#pragma unroll
+            for (int v = 0; v < TNW; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[v], fa[u], acc[u][v], 0, 0, 0);
+        slot_rd = slot_rd == (NS - 1) * STAGE ? 0 : slot_rd + STAGE;
+        slot_wr = slot_wr == (NS - 1) * STAGE ? 0 : slot_wr + STAGE;
+        Ab += ksA; Bb += ksB; --iss_left; --iss_rem;                 // (as if this interval issued a stage: past the end of the stream nobody looks)
+        --kleft; --rem;
+        st_left = st_left > 0 ? st_left - 1 : 0;
+        sig_left = sig_left > 0 ? sig_left - 1 : sig_left;
+        evt = kleft == 0 || rem < 2 || sig_left == 0;
+        // one bookkeeping instruction behind each MFMA: issued while the matrix pipe is busy with it, instead of in a row in front of the first / behind the last
+#pragma unroll
+        for (int k = 0; k < TMW * TNW; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, 1, 0); }
+        __builtin_amdgcn_s_setprio(0);
+        G16_BAR();
     }
-    if (ep_pending) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        (void)epilogue(ep_z, ep_tm, ep_tn, ep_par);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)finish_piece();                                            // the last piece ended with the last COMPUTE interval
     if (wr == 0) G16_BAR();
+    if (SK && (sig_left >= 0 || had_tail)) {                         // (workgroup-uniform) both wave groups have run every interval: plain barriers from here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G16_BAR();
+        if (wid == 0 && lane == 0) {
+            const G16P_K* q = g16_kernarg();
+            if (sig_left >= 0) __hip_atomic_store(q->sk_flag + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // a head piece within NS intervals of the end
+            if (had_tail) __hip_atomic_store(q->sk_flag + (blockIdx.x - 8), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // consumed: ready for the next launch
+        }
+    }
+}
+
+// Stream-K plan for T tiles of nk stages on P workgroups (the kernel's header): the number of tiles cut (0 = every tile whole).
+// Where it pays (measured, profiles/r06_gemm16_stream_k.txt): the cut gives every workgroup the same number of stages, but a cut tile's contributors walk K out
+// of step with the workgroups that share its operand rows, so the XCD's L2 no longer serves one fetch of a K slice to all of them and the cut rounds run on the
+// Infinity Cache's bandwidth (864 MB of operands for 432 tiles cut = ~9.5 TB/s at the uncut rate).  With three or more rounds the whole rounds in front
+// still run in step and the cut is a net gain (9216 x 8192 x 2048: 282 -> 272 us); with one or two it is a loss (9216 x 3072 x 2048: 111 -> 123 us) and is left off
+// unless forced (cti_set_tuning(CTI_TUNE_GEMM16_SK, 1): the tests).
+int g16_sk_plan(long long T, int P, int nk) {
+    const int mode = tuning_gemm16_sk();
+    if (mode == 0 || T <= P || T % P == 0 || (P & 7) || nk < 16) return 0;
+    const long long rounds = T / P, tsk = T - (rounds - 1) * P;
+    if (mode < 0 && rounds < 3) return 0;
+    const long long n_max = (T >> 3) + ((T & 7) ? 1 : 0) - ((rounds - 1) * P >> 3), S = P >> 3;     // the fullest XCD chunk's cut tiles, on S workgroups
+    if (2ll * nk - (n_max * nk + S - 1) / S < 6) return 0;     // whole tiles: (rounds + 1) nk stages on the longest workgroup; cut: (rounds - 1) nk + ceil(n nk / S).  < 6 stages to gain: not worth a partial's round trip
+    return (int)tsk;
 }
 
 template <int EPI, class G, bool AROW>
-int g16_launch(G16P& p, int nb, int ncols, hipStream_t st) {
+int g16_launch(G16P& p, int nb, int ncols, void* sk_ws, size_t sk_ws_bytes, hipStream_t st) {
     p.tiles_m = (p.M + G::BM - 1) / G::BM; p.tiles_n = (ncols + G::BN - 1) / G::BN;
     const long long total = (long long)nb * p.tiles_m * p.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return fail(CTI_E_SHAPE, "gemm16_planes: %lld tiles", total);
@@ -331,6 +491,14 @@ int g16_launch(G16P& p, int nb, int ncols, hipStream_t st) {
     static const int leave = [] { const char* e = getenv("CTI_GEMM16_LEAVE"); return e ? atoi(e) : 0; }();
     const int cus = (leave > 0 && leave < n_cu && total > n_cu - leave) ? n_cu - leave : n_cu;
     const long long grid = total < cus ? total : cus;
+    // stream-K (EPI rows only; the caller's workspace = [flags: one word per workgroup + an error word, 4 KiB][one BM x BN fp32 slot per workgroup]); CTI_GEMM16_SK=0 = off
+    static const bool sk_env = [] { const char* e = getenv("CTI_GEMM16_SK"); return !e || atoi(e) != 0; }();
+    p.sk_tiles = 0; p.sk_part = nullptr; p.sk_flag = nullptr;
+    if (EPI != G16_EPI_PLANES && sk_env && sk_ws && sk_ws_bytes >= G16_SK_FLAG_BYTES + (size_t)cus * G::BM * G::BN * 4 && (size_t)(cus + 1) * 4 <= G16_SK_FLAG_BYTES
+        && (reinterpret_cast<uintptr_t>(sk_ws) & 255) == 0 && (p.sk_tiles = g16_sk_plan(total, cus, p.nk)) > 0) {
+        p.sk_flag = static_cast<unsigned*>(sk_ws);
+        p.sk_part = reinterpret_cast<float*>(static_cast<char*>(sk_ws) + G16_SK_FLAG_BYTES);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), G::LDS, st, p);
     return launch_status("gemm16_planes");
 }
@@ -339,6 +507,15 @@ using G16Sq = G16Geo<8, 4>;                    // 256 x 256
 using G16Wide = G16Geo<9, 3>;                  // 288 x 192
 
 }  // namespace
+
+// bytes of the stream-K workspace gemm16_planes() takes through PlaneGemmArgs::sk_ws (zeroed ONCE by the caller; the kernel leaves the flags at 0): the larger tile's slots
+size_t gemm16_sk_workspace_bytes() {
+    int dev = 0, n_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    return G16_SK_FLAG_BYTES + (size_t)n_cu * 256 * 256 * 4;
+}
 
 // Takes the plain-bf16 products gemm_nt_planes() would run on its 256 x 256 tile; false = not eligible (the caller's own kernel runs)
 bool gemm16_eligible(const PlaneGemmArgs& a) {
@@ -371,7 +548,7 @@ int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.nb2 = a.nb2 > 0 ? a.nb2 : 1; p.M = a.M; p.N = a.N; p.Np = a.Np; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const int nb = a.nb1 * p.nb2;
-    if (a.epi == 1) return g16_launch<G16_EPI_PLANES, G16Sq, false>(p, nb, ncols, st);
+    if (a.epi == 1) return g16_launch<G16_EPI_PLANES, G16Sq, false>(p, nb, ncols, nullptr, 0, st);
     // Tile: 256 x 256.  The 288 x 192 geometry (CTI_GEMM16_TILE=1; 9216 x 3072 outputs = 512 tiles = two FULL rounds of the 256 workgroups instead of 1.69)
     // is built and under test but measured no faster where its rounds are fewer (126.0 vs 128.5 us at 9216 x 3072 x 2048) and 20 % slower where they are equal
     // (539 vs 451 us at 9216 x 11264 x 2048): its COMPUTE interval is 27 MFMAs = 432 cycles against a LOAD interval of ~480 (12 fragment reads, 3-4 DMA
@@ -380,7 +557,7 @@ int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
     //  the planes form of the A operand reads up to BM - 1 rows past M and the planes carry PLANE_SLACK_ROWS = 256 of slack: the 288-row tile is
     // for the row-major A operand only, whose DMA clamps its row index
     const bool wide = wide_env && a.Abf != nullptr;
-#define G16_GO(EPI, GEO) (a.Abf ? g16_launch<EPI, GEO, true>(p, nb, ncols, st) : g16_launch<EPI, GEO, false>(p, nb, ncols, st))
+#define G16_GO(EPI, GEO) (a.Abf ? g16_launch<EPI, GEO, true>(p, nb, ncols, a.sk_ws, a.sk_ws_bytes, st) : g16_launch<EPI, GEO, false>(p, nb, ncols, a.sk_ws, a.sk_ws_bytes, st))
     if (a.epi == 5) return wide ? G16_GO(G16_EPI_BF16, G16Wide) : G16_GO(G16_EPI_BF16, G16Sq);
     return wide ? G16_GO(G16_EPI_F32, G16Wide) : G16_GO(G16_EPI_F32, G16Sq);
 #undef G16_GO

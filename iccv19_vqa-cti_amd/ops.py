@@ -168,10 +168,11 @@ import os as _os
 class tuning:
     """Context manager over cti_set_tuning (tests / benchmarks only): `with ops.tuning(gemm_cfg=2, tri_chunk=64): ...` forces the plane GEMM's
     tile geometry (0 = 128x128, 1 = 256x128, 2 = 256x256) and / or the Tri softmax's chunk length, so small tensors run the instantiations that
-    BASELINE configs[1] selects.  Restores the previous values on exit."""
+    BASELINE configs[1] selects; gemm16_sk = 1 cuts every plannable product of cti_gemm_bf16_rows_sk stream-K (default: only where it pays).  Restores the
+    previous values on exit."""
 
-    def __init__(self, gemm_cfg=None, tri_chunk=None):
-        self.want = {L.TUNE_GEMM_CFG: gemm_cfg, L.TUNE_TRI_CHUNK: tri_chunk}
+    def __init__(self, gemm_cfg=None, tri_chunk=None, gemm16_sk=None):
+        self.want = {L.TUNE_GEMM_CFG: gemm_cfg, L.TUNE_TRI_CHUNK: tri_chunk, L.TUNE_GEMM16_SK: gemm16_sk}
 
     def __enter__(self):
         lib = L.lib()
@@ -1103,11 +1104,57 @@ def gemm_nt(A, B, nb1=1, rA1=0, rB1=0, M=None, N=None, out=None, c_strides=None,
     return out
 
 
+# Stream-K workspace of cti_gemm_bf16_rows_sk: one per (device, stream) -- two calls that may run at the same time must not share one -- zeroed once
+# (the kernel leaves its flag words at zero).  64 MiB + 4 KiB each; built on first use by a product that is actually cut.
+_sk_ws = {}
+_sk_ws_bytes = [None]
+
+
+def _sk_workspace(device, stream):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+    ws = _sk_ws.get(key)
+    if ws is None:
+        if _sk_ws_bytes[0] is None:
+            _sk_ws_bytes[0] = int(L.lib().cti_gemm_bf16_rows_sk_workspace_bytes())
+        ws = torch.empty(_sk_ws_bytes[0], device=device, dtype=torch.uint8)
+        ws[:4096].zero_()                 # the flag page; the partial slots are written before they are read
+        if not torch.cuda.is_current_stream_capturing():
+            _sk_ws[key] = ws              # (a workspace born under capture belongs to that graph's pool: used by this call only, its zero-fill replays with the graph)
+    return ws
+
+
+def gemm16_sk_state(device=None):
+    """(error words set, flag words left non-zero) over every stream-K workspace of `device` (tests; synchronises).  Both are 0 after any completed call."""
+    err = left = 0
+    for (d, _), ws in _sk_ws.items():
+        if device is None or d == (device.index if device.index is not None else torch.cuda.current_device()):
+            w = ws[:4096].view(torch.int32).cpu()
+            n = torch.cuda.get_device_properties(d).multi_processor_count
+            err += int(w[n] != 0); left += int((w[:n] != 0).sum())
+    return err, left
+
+
+_n_cu = {}
+
+
+def _sk_cut(tiles, K):
+    """Does csrc/cti_gemm16.hip's g16_sk_plan cut this product (256 x 256 tiles on all compute units)?  Only decides whether a workspace is worth building:
+    by default three or more rounds of tiles that do not end on a whole round; with the test override (tuning(gemm16_sk=1)) any incomplete round."""
+    d = torch.cuda.current_device()
+    P = _n_cu.get(d)
+    if P is None:
+        P = _n_cu[d] = torch.cuda.get_device_properties(d).multi_processor_count
+    if tiles <= P or tiles % P == 0 or K < 512:
+        return False
+    return tiles >= 3 * P or L.lib().cti_get_tuning(L.TUNE_GEMM16_SK) == 1
+
+
 def gemm_bf16_rows(A, B_planes, rowsB, nb1=1, rA1=0, rB1=0, M=None, N=None, out_dtype=torch.float32, scale=None, scale_div=1, scale_bs=0, bias=None,
-                   bias_bs=0, relu=False):
+                   bias_bs=0, relu=False, stream_k=True):
     """C[z][m,n] = act(scale * sum_k A[z*rA1 + m, k] * W[z*rB1 + n, k] + bias) in the plain-bf16 arithmetic with A a row-major torch.bfloat16
     matrix read as it stands (no split pass) and W = split_operand(..., prec='bf16') planes of a (rowsB, K) weight; out_dtype float32 or bfloat16
-    (bf16 rows = the next layer's A operand).  cti_gemm_bf16_rows; K % 32 == 0."""
+    (bf16 rows = the next layer's A operand).  K % 32 == 0.  stream_k (round 6): products whose tiles do not fill whole rounds of the compute units
+    are cut stream-K through cti_gemm_bf16_rows_sk (bit-identical results; a per-stream workspace); False = cti_gemm_bf16_rows, every tile whole."""
     _req(A, "A", torch.bfloat16)
     A2 = A.reshape(-1, A.shape[-1])
     if A2.stride(1) != 1:
@@ -1116,9 +1163,19 @@ def gemm_bf16_rows(A, B_planes, rowsB, nb1=1, rA1=0, rB1=0, M=None, N=None, out_
     M = A2.shape[0] if M is None else M
     N = rowsB if N is None else N
     out = torch.empty((nb1, M, N) if nb1 > 1 else (M, N), device=A.device, dtype=out_dtype)
+    st = _stream()
+    if stream_k and _sk_cut(nb1 * ((M + 255) // 256) * ((N + 255) // 256), K):
+        ws = _sk_workspace(A.device, st)
+    else:
+        ws = None
+    if ws is not None:
+        L.check(L.lib().cti_gemm_bf16_rows_sk(A2.data_ptr(), A2.stride(0), A2.shape[0], rA1, B_planes.data_ptr(), rowsB, rB1, out.data_ptr(),
+                                              1 if out_dtype == torch.bfloat16 else 0, N, M * N, nb1, M, N, K, _ptr(scale), int(scale_div), int(scale_bs),
+                                              _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, ws.data_ptr(), ws.numel(), st), "cti_gemm_bf16_rows_sk")
+        return out
     L.check(L.lib().cti_gemm_bf16_rows(A2.data_ptr(), A2.stride(0), A2.shape[0], rA1, B_planes.data_ptr(), rowsB, rB1, out.data_ptr(),
                                        1 if out_dtype == torch.bfloat16 else 0, N, M * N, nb1, M, N, K, _ptr(scale), int(scale_div), int(scale_bs),
-                                       _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, _stream()), "cti_gemm_bf16_rows")
+                                       _ptr(bias), int(bias_bs), L.ACT_RELU if relu else L.ACT_NONE, st), "cti_gemm_bf16_rows")
     return out
 
 

@@ -65,7 +65,8 @@ const char* cti_last_error_string(void);
  * CTI_TUNE_F6_CORE_FREE_CUS: compute units the persistent mode-3 product leaves to the guard's last kernels, which run beside it on aux_stream
  * (-1 = the library's default). */
 enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2, CTI_TUNE_GUARD_RHO_BF16X3 = 3, CTI_TUNE_GUARD_RHO_FP32 = 4, CTI_TUNE_GUARD_POISON_BITS = 5,
-       CTI_TUNE_F6_CORE_FREE_CUS = 6, CTI_TUNE_GUARD_STRATA = 7 /* tests: 0 = sample evenly spaced rows only */ };
+       CTI_TUNE_F6_CORE_FREE_CUS = 6, CTI_TUNE_GUARD_STRATA = 7 /* tests: 0 = sample evenly spaced rows only */,
+       CTI_TUNE_GEMM16_SK = 8 /* cti_gemm_bf16_rows_sk: -1 = cut stream-K where it was measured to pay (three or more rounds of tiles), 0 = never, 1 = wherever a cut can be planned (tests) */ };
 int cti_set_tuning(int key, int64_t value);
 int64_t cti_get_tuning(int key);
 
@@ -367,6 +368,17 @@ size_t cti_gemm_nt_pb_workspace_bytes2(int64_t rowsA_total, int64_t rowsB_total,
 int cti_gemm_bf16_rows(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
                        void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
                        int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* stream);
+/* Round 6: the same product cut STREAM-K (csrc/cti_gemm16.hip, "Stream-K") when its T output tiles do not fill whole rounds of the P compute units
+ * (T > P, T % P != 0, K >= 512: e.g. the hoisted projections of reference src/fc.py:22-29 at 9 216 x 3 072 = 432 tiles = 1.69 rounds): the last one-to-two
+ * rounds' tiles become ONE sequence of K stages shared out evenly; a tile then has at most two contributors, the first of which leaves its accumulators in
+ * `workspace` for the second to start from -- bit-identical to the uncut product (same additions in the same order).  `workspace`:
+ * cti_gemm_bf16_rows_sk_workspace_bytes() bytes, 256-B aligned, ZEROED ONCE by the caller (the kernel leaves its flag words at zero), never shared by two
+ * calls that may run at the same time (one per stream); word [compute units] of it is an error word the kernel sets if a contributor's flag never came
+ * (bounded poll; cannot happen while workgroups are dispatched in order).  workspace = NULL: every tile whole (= cti_gemm_bf16_rows). */
+size_t cti_gemm_bf16_rows_sk_workspace_bytes(void);
+int cti_gemm_bf16_rows_sk(const void* A_bf16, int64_t lda, int64_t rowsA_total, int64_t rA1, const void* B_planes, int64_t rowsB_total, int64_t rB1,
+                          void* C, int c_bf16, int64_t ldc_m, int64_t sC1, int nb1, int M, int N, int K, const float* scale, int scale_div,
+                          int64_t scale_bs, const float* bias, int64_t bias_bs, int act, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The "f16f6" operand format (csrc/cti_f16f6.h): an fp32 matrix as an f16 hi plane plus ONE block-scaled fp6 (e2m3) plane -- the codes of the
  * residual -- and two E8M0 scales per 32 elements (of the hi part, whose fp6 codes the GEMM derives in registers, and of the residual): 2.81

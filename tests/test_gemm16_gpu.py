@@ -110,6 +110,59 @@ def test_row_major_bf16_operand_and_bf16_rows_output(M, N, K, nb, out_dtype):
     assert err < (3e-6 if out_dtype == torch.float32 else 4e-3), err       # bf16 rows: one rounding of the result to 8 significant bits
 
 
+@pytest.mark.parametrize("M,N,K,nb,out_dtype", [
+    (4608, 4096, 512, 1, torch.float32),          # 288 tiles on 256 compute units, 16 stages per tile: ranges of 18 stages (heads / tails of 2 .. 16)
+    (9216, 3072, 2048, 1, torch.bfloat16),        # configs[2]'s hoisted projection: 432 tiles, ranges of 108 stages
+    (9216, 1024, 1024, 3, torch.float32),         # batched: 432 tiles over three weight sets, 32 stages per tile
+    (9000, 3000, 768, 1, torch.float32),          # ragged edges: 36 x 12 tiles with partial last rows / columns
+    (5120, 4352, 1056, 1, torch.bfloat16),        # 340 tiles, 33 stages: 256 does not divide the stage count (ranges of 43 and 44)
+    (9216, 8192, 1024, 1, torch.bfloat16),        # configs[3]'s hoisted projections: 1 152 tiles = 4.5 rounds, the shape the default cuts (three whole rounds in front)
+])
+def test_stream_k_is_bit_identical_to_whole_tiles(M, N, K, nb, out_dtype):
+    """cti_gemm_bf16_rows_sk (round 6): tiles cut along K, the second contributor starting from the first one's accumulators -- the same additions in the
+    same order as the uncut product, so EVERY bit agrees with cti_gemm_bf16_rows; and against float64; flags back at zero, no error word; twice (the
+    second launch finds the workspace the first one left)"""
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the shapes are chosen for 256 compute units")
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = bf16r(torch.randn(nb * N, K, generator=g) / 4)
+    b = torch.randn(nb * N, generator=g).to(DEV)
+    wp = ops.split_operand(w.to(DEV), prec="bf16")
+    kw = dict(nb1=nb, rA1=0, rB1=N, M=M, N=N, out_dtype=out_dtype, bias=b, bias_bs=N, relu=True)
+    y0 = ops.gemm_bf16_rows(a, wp, nb * N, stream_k=False, **kw)
+    for rep in range(2):
+        with ops.tuning(gemm16_sk=1):                 # (the default cuts only products of three or more rounds of tiles)
+            y1 = ops.gemm_bf16_rows(a, wp, nb * N, stream_k=True, **kw)
+        assert torch.equal(y0, y1), (rep, float((y0.float() - y1.float()).abs().max()))
+        assert ops.gemm16_sk_state() == (0, 0)
+    cols = torch.arange(0, N, 7)
+    ref = torch.relu((a.cpu().double() @ w.double().t() + b.cpu().double()).view(M, nb, N).permute(1, 0, 2))[..., cols]
+    err = float((y1.double().cpu().view(nb, M, N)[..., cols] - ref).abs().max() / ref.abs().max())
+    assert err < (3e-6 if out_dtype == torch.float32 else 4e-3), err
+
+
+def test_stream_k_on_two_streams_at_once():
+    """two cut products in flight on sibling streams (each stream has its own workspace): both bit-identical to the uncut product, ten rounds"""
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the shape is chosen for 256 compute units")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4608, 4096, 1024
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    wp = ops.split_operand(bf16r(torch.randn(N, K, generator=g) / 4).to(DEV), prec="bf16")
+    y0 = ops.gemm_bf16_rows(a, wp, N, stream_k=False)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(10):
+        for s in (s1, s2):
+            with torch.cuda.stream(s), ops.tuning(gemm16_sk=1):
+                outs.append(ops.gemm_bf16_rows(a, wp, N))
+    torch.cuda.synchronize()
+    assert all(torch.equal(y0, y) for y in outs)
+    assert ops.gemm16_sk_state() == (0, 0)
+
+
 def test_wide_tile_geometry_in_a_child_process():
     """CTI_GEMM16_TILE=1 (288 x 192 tiles; read once per process): every entry of two products against float64"""
     import os, subprocess, sys

@@ -2,6 +2,7 @@
 """The plain-bf16 projection GEMM (csrc/cti_gemm16.hip) at the hoisted projections' shapes, next to the vendor GEMM behind torch.matmul (yardstick, not
 on the product path), interleaved in ONE process on the same random operands:
   rows_f32 / rows_bf16   cti_gemm_bf16_rows: A a row-major bf16 matrix read as it stands, fp32 / bf16 rows out (bias + ReLU in the epilogue)
+  rows_bf16_whole_tiles  the same without the round-6 stream-K cut (cti_gemm_bf16_rows)
   f32_in                 cti_gemm_nt_pb in the bf16 mode: fp32 A -> hi plane (one pass) -> product (conversion INCLUDED)
   vendor                 torch.matmul(a_bf16, w_bf16.t()) (bf16 out, no epilogue)
 python tools/bench_gemm16.py [reps]"""
@@ -30,13 +31,14 @@ def timeit(fns, reps):
     return {k: min(v) for k, v in out.items()}
 
 
-for M, N, K in [(9216, 3072, 2048), (9216, 11264, 2048), (9216, 1024, 2048), (3584, 3072, 1024), (4096, 4096, 4096)]:
+for M, N, K in [(9216, 3072, 2048), (9216, 8192, 2048), (9216, 11264, 2048), (9216, 1024, 2048), (3584, 3072, 1024), (4096, 4096, 4096)]:
     a32 = torch.randn(M, K, generator=g).cuda(); w32 = (torch.randn(N, K, generator=g) / 8).cuda(); b = torch.randn(N, generator=g).cuda()
     a16, w16 = a32.to(torch.bfloat16), w32.to(torch.bfloat16)
     wp = ops.split_operand(w32, prec="bf16")
     fns = {
         "rows_f32": lambda: ops.gemm_bf16_rows(a16, wp, N, bias=b, relu=True),
         "rows_bf16": lambda: ops.gemm_bf16_rows(a16, wp, N, out_dtype=torch.bfloat16, bias=b, relu=True),
+        "rows_bf16_whole_tiles": lambda: ops.gemm_bf16_rows(a16, wp, N, out_dtype=torch.bfloat16, bias=b, relu=True, stream_k=False),
         "f32_in": lambda: ops.gemm_nt(a32, w32, bias=b, relu=True, prec="bf16", B_planes=wp),
         "vendor": lambda: torch.matmul(a16, w16.t()),
     }
