@@ -188,18 +188,24 @@ def launch_ranks(n, argv):
 
 def run_dry(args, world, rank):
     """--dry-launch: the launch + rendezvous + timing path on CPU (gloo), no GPU and no kernels: every rank joins, sleeps through its
-    "steps", and rank 0 reports how many ranks met at the barrier."""
+    "steps", and rank 0 reports how many ranks met at the barrier and which device each of them WOULD have bound (main() binds cuda:LOCAL_RANK) --
+    so the first real 8-GPU run is not the first time `--gpus 8` executes (VERDICT r5 #8)."""
     import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         dist.init_process_group("gloo")
     el = measure(lambda: time.sleep(0.01), args.steps, args.warmup, world, lambda: None, dist if world > 1 else None, "cpu")
     seen = torch.ones(1)
+    binding = [(rank, "cuda:%d" % local)]
     if world > 1:
         dist.all_reduce(seen)
+        got = [None] * world
+        dist.all_gather_object(got, binding[0])
+        binding = sorted(got)
         dist.barrier(); dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": el / args.steps * 1e3}), flush=True)
+        print(json.dumps({"dry_launch": True, "mode": args.mode, "n_gpus": world, "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": el / args.steps * 1e3, "device_of_rank": [d for _, d in binding]}), flush=True)
 
 
 class CTIFusionBlock(torch.nn.Module):
@@ -394,10 +400,11 @@ def model_setup(config, B, rank, dev):
         # (TanModel.v_replication stays at its default 'auto': the repeated images are detected on the first forward and verified on the device on every later one)
         fwd = lambda: m(v, boxes, q, a)[0]                                           # noqa: E731
 
-        def oracle(n, out):
+        def oracle(n, out, rows=None):
             from oracle import cti_models as OM
-            ref = OM.mc_tan_forward(v[:n].float().cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy(), state(m), 2)[0]
-            return [("mc_cti logits", out[:n].cpu().numpy(), ref)]
+            ix = torch.arange(n) if rows is None else torch.as_tensor(rows)                # (rows: any subset of the batch -- the forward has no cross-row term)
+            ref = OM.mc_tan_forward(v.cpu()[ix].float().numpy(), q.cpu()[ix].numpy(), a.cpu()[ix].numpy(), state(m), 2)[0]
+            return [("mc_cti logits", out.cpu()[ix].numpy(), ref)]
         return dict(fwd=fwd, oracle=oracle, models={"mc_cti": m}, flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2), out_shape=(B, 2), rep=rep, v_bf16=v_bf16, inputs=dict(v=v, boxes=boxes, q=q, a=a),
                     executed_flops=model_flops("cti", B, 36, 12, 6, 2, n_ans=2, rep=rep, executed=True),
                     workload="BASELINE configs[2]: MC CTI model forward (TanModel, src/MC/base_model.py:128-152), Visual7W shapes, B=64 images x 4 candidates = %d rows, V=36, Q=12, A=6, glimpse 2" % B)
@@ -419,11 +426,12 @@ def model_setup(config, B, rank, dev):
         c, b = cti_amd.ops.run_concurrently(lambda: cti(v, q, a), lambda: ban(v, boxes, q, None)[0])
         return b, c
 
-    def oracle(n, out):
+    def oracle(n, out, rows=None):
         from oracle import cti_models as OM
-        vn, qn, an = v[:n].float().cpu().numpy(), q[:n].cpu().numpy(), a[:n].cpu().numpy()
-        return [("ban logits", out[0][:n].cpu().numpy(), OM.ffoe_ban_forward(vn, qn, state(ban), 8)[0]),
-                ("cti logits", out[1][:n].cpu().numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
+        ix = torch.arange(n) if rows is None else torch.as_tensor(rows)
+        vn, qn, an = v.cpu()[ix].float().numpy(), q.cpu()[ix].numpy(), a.cpu()[ix].numpy()
+        return [("ban logits", out[0].cpu()[ix].numpy(), OM.ffoe_ban_forward(vn, qn, state(ban), 8)[0]),
+                ("cti logits", out[1].cpu()[ix].numpy(), OM.ffoe_cti_forward(vn, qn, an, state(cti), 2))]
     return dict(fwd=fwd, oracle=oracle, models={"ban": ban, "cti": cti}, flops=model_flops("ban", B, 36, 14, 0, 8) + model_flops("cti", B, 36, 14, 3, 2), out_shape=(B, 3129), v_bf16=v_bf16, inputs=dict(v=v, boxes=boxes, q=q, a=a),
                 workload=("BASELINE configs[3]: FFOE teacher forward = BanModel (BiAttention glimpse 8, src/FFOE/base_model.py:37-67) + CTIModel (glimpse 2, "
                           ":112-136), VQA-2.0 shapes, B=%d, V=36, Q=14, A=3, 3129 classes; %s" % (
@@ -784,6 +792,11 @@ def run_forward(args, world, rank, dev, dist):
             r["share_of_step"] = r["ms"] / step_ms
         res["roofline_kernels"] = {"note": "every kernel family >= 5 % of the step: mode-3 from the library's hipEvents inside the timed steps; the "
                                            "a-side kernels re-launched stand-alone at the same shapes (HIP events on the launch stream)", "kernels": rk}
+        if args.precision == "f16f6":
+            # what the range / cancellation guard saw over this run's guarded launches (the host waits for every verdict in this eager loop: a tripped call
+            # would have been re-run as bf16x3 / fp32 inside the timed region and counted here)
+            gs = cti_amd.ops.f16f6_range_status()
+            res["guard"] = {"guarded_calls": gs["calls"], "trips": gs["trips"], "last_status": gs["last_status"], "mode": "sync (host reads every verdict)"}
         if fp32_exact is not None:
             res["fp32_exact"] = fp32_exact
         if bf16x3 is not None:

@@ -12,7 +12,7 @@ from .Tensor import ModeProduct                                # noqa: F401
 from .ops import set_precision, get_precision, invalidate_caches, set_range_check, f16f6_range_status, run_concurrently   # noqa: F401
 from ._lib import CtiError                                     # noqa: F401
 from .dp import FlatAdamaxDP                                   # noqa: F401
-from .graph import GraphedTrainStep                            # noqa: F401
+from .graph import GraphedTrainStep, GraphedForward                            # noqa: F401
 from .language_model import WordEmbedding, QuestionEmbedding   # noqa: F401
 from .classifier import SimpleClassifier                       # noqa: F401
 from .loss_function import BCEWithLogitsSum, Distillation_Loss # noqa: F401
@@ -21,6 +21,6 @@ from . import base_model                                       # noqa: F401
 from .base_model import BanModel, CTIModel, TanModel, MCBanModel, build_ban, build_cti, build_mc_cti, build_mc_ban   # noqa: F401
 
 __all__ = ["FCNet", "WNLinear", "TCNet", "BCNet", "BiAttention", "TriAttention", "StackedAttention", "ModeProduct",
-           "ops", "set_precision", "get_precision", "invalidate_caches", "set_range_check", "f16f6_range_status", "CtiError", "FlatAdamaxDP", "GraphedTrainStep",
+           "ops", "set_precision", "get_precision", "invalidate_caches", "set_range_check", "f16f6_range_status", "CtiError", "FlatAdamaxDP", "GraphedTrainStep", "GraphedForward",
            "WordEmbedding", "QuestionEmbedding", "SimpleClassifier", "BCEWithLogitsSum", "Distillation_Loss", "base_model",
            "BanModel", "CTIModel", "TanModel", "MCBanModel", "build_ban", "build_cti", "build_mc_cti", "build_mc_ban"]

@@ -12,6 +12,7 @@ initialisation of the embeddings (`tfidf_loading`, src/utils.py) is data prepara
 `WordEmbedding.init_embedding`."""
 import contextlib
 import math
+import weakref
 import os as _os
 
 import torch
@@ -162,7 +163,10 @@ class BanModel(nn.Module):
             att, logits = self.v_att.forward_all(v, q_emb)                  # b x g x v x q
             vp = self._v_hoist.maybe(v)
             Hq = self._hoist_prepare(q_emb, vp)
-        hoisted = _ban_forward_unrolled(self, q_emb, att, vp, Hq) if _ban_unroll_ok(self, vp) else None
+        try:
+            hoisted = _ban_forward_unrolled(self, q_emb, att, vp, Hq) if _ban_unroll_ok(self, vp) else None
+        except _UnrolledLoopLost:
+            hoisted = None                        # -> the hoisted / literal loop recomputes the forward
         if hoisted is None:
             hoisted = self._forward_hoisted(q_emb, att, vp, Hq)
         if hoisted is not None:
@@ -288,8 +292,13 @@ def _ban_forward_unrolled(self, q_emb, att, vp, Hq):
     return ops.joint_sums(q_emb, float(G), Dq=E, dq=float(Lq))
 
 
+class _UnrolledLoopLost(Exception):
+    """A kernel of the unrolled glimpse loop refused its shape past glimpse 0 (cannot happen with today's planner: the shape test is the same at every glimpse);
+    the callers catch it and recompute the forward through the hoisted loop instead of failing an inference."""
+
+
 def _unrolled_bail(g):
-    raise RuntimeError("the unrolled glimpse loop lost its kernel at glimpse %d (the shape test passed at glimpse 0)" % g)
+    raise _UnrolledLoopLost(g)
 
 
 def _ban_hoist_prepare(self, q_emb, vp):
@@ -338,11 +347,24 @@ class _TriModel(nn.Module):
             # (it only shrinks), re-checks each replayed batch on the device and NaN-fills its logits if the batch does not keep that promise; callers that
             # capture should prefer the explicit hint (v_replication = 4).
             rep = 1
-            if not torch.is_grad_enabled() and v.is_cuda and v.dim() == 3:
+            capturing = v.is_cuda and torch.cuda.is_current_stream_capturing()
+            # (the tensor OBJECT, not its address: the caching allocator hands a freed batch's block to the next batch)
+            seen = getattr(self, "_v_rep_seen", None)
+            vkey = v._version
+            if not capturing and seen is not None and seen[0]() is v and seen[2] == vkey:
+                # the SAME tensor as the last eager forward (an evaluation loop over a resident batch, a benchmark): its r is known -- no comparison kernel, no
+                # read-back that drains the side stream in front of the question GRU's launches
+                rep = seen[1]
+            elif not torch.is_grad_enabled() and v.is_cuda and v.dim() == 3:
+                if capturing and getattr(self, "_v_rep_auto", None) is None and not getattr(self, "_v_rep_warned", False):
+                    import warnings
+                    object.__setattr__(self, "_v_rep_warned", True)
+                    warnings.warn("cti: capturing a forward with v_replication='auto' before any eager forward has seen a batch: the graph is built for r = 1 "
+                                  "(every row's image projected); set model.v_replication = <r> or run one eager forward first")
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):      # (v-only work: beside the question GRU)
                     eq = ops.rows_equal_prev(v)
                     if eq is not None:
-                        if torch.cuda.is_current_stream_capturing():
+                        if capturing:
                             rep = getattr(self, "_v_rep_auto", None) or 1
                         else:
                             rep = ops.replication_of(eq)
@@ -351,6 +373,8 @@ class _TriModel(nn.Module):
                             eq = None                    # verified on the host for this very batch: no device-side poison
                         if v.shape[0] % rep:
                             rep = 1
+                        if not capturing:
+                            object.__setattr__(self, "_v_rep_seen", (weakref.ref(v), int(rep), vkey))
                 if rep == 1:
                     eq = None
         rep = int(rep)
@@ -418,7 +442,10 @@ class _TriModel(nn.Module):
         B, Lq, H = q_emb.shape
         La = ans_emb.shape[1]
         if _tri_unroll_ok(self):
-            joint = _tri_loop_unrolled(self, vp, q_emb, ans_emb, att, rep, Hq, Ha)
+            try:
+                joint = _tri_loop_unrolled(self, vp, q_emb, ans_emb, att, rep, Hq, Ha)
+            except _UnrolledLoopLost:
+                joint = None                      # -> the hoisted loop below recomputes the forward
             if joint is not None:
                 return joint
         if not hasattr(self, "_prj_pairs"):

@@ -16,6 +16,11 @@ from .tc import _needs_grad
 class BCNet(nn.Module):
     """Simple class for non-linear bilinear connect network"""
 
+    def apply(self, fn):
+        r = super().apply(fn)            # (an initialiser writing through .data moves no cache key: fc.WNLinear.apply)
+        ops.invalidate_caches()
+        return r
+
     def __init__(self, v_dim, q_dim, h_dim, h_out, act='ReLU', dropout=[.2, .5], k=1):
         super(BCNet, self).__init__()
         self.c = 32

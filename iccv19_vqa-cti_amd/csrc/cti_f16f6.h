@@ -154,7 +154,7 @@ int guard_poison(const unsigned* words, float* out, int64_t n, hipStream_t st); 
 // normalised by the largest output is ~1e-5 rho in the f16f6 mode (rho 2-4 on the synthetic tensors: 2.7e-5), ~4e-6 rho as bf16x3 (the
 // operands M and A^ carry their own 2^-17 relative errors, which a cancelling sum amplifies just the same), ~5e-8 rho in exact fp32.  The final
 // guard scan turns rho into CTI_GUARD_CANCEL (f16f6 -> bf16x3) / CTI_GUARD_CANCEL_HEAVY (-> fp32) at the thresholds of cti_set_tuning (CTI_TUNE_GUARD_RHO_*:
-// 5 / 9 by default -- round 4's 10 / 20 left no margin: rho 9.0 measured 9.0e-5).  A no-op (rho 0) when K > 1024.
+// 2.75 / 5.5 by default: a factor two under 1e-4 on the measured laws ~1.8e-5 rho (f16f6) / ~0.9e-5 rho (bf16x3); round 4's 10 / 20 left no margin).  A no-op (rho 0) when K > 1024.
 int guard_cancel(const F6Planes& M, int64_t mrows, const F6Planes& A, int64_t arows, int nb, unsigned* words, hipStream_t st);
 
 int f6_sm_chunks(int M, int N);                // partial (max, sum) pairs per batch and g that gemm_nt_f16f6 writes for an M x N product

@@ -43,6 +43,14 @@ class WNLinear(nn.Module):
     def extra_repr(self):
         return "in_features=%d, out_features=%d, weight_norm(dim=None)" % (self.in_features, self.out_features)
 
+    def apply(self, fn):
+        """nn.Module.apply, then ops.invalidate_caches(): the usual passenger of .apply is an initialiser that writes through `param.data` (the reference's own
+        utils.weights_init, src/utils.py:61-70,77: `m.weight.data.normal_(0.0, 0.02)`), which moves neither the autograd version nor the storage the derived
+        weight caches are keyed on.  Every network of this package holds WNLinear layers, so any .apply over a tree that contains one refreshes the caches."""
+        r = super().apply(fn)
+        ops.invalidate_caches()
+        return r
+
     def scale(self):
         """g / ||V||_F on the device, cached until weight_v / weight_g change (optimizer steps bump `_version`, .to() / load_state_dict
         change the storage): in eval mode the norm of a 6M-element weight is computed once, not per forward."""
@@ -82,7 +90,7 @@ class WNLinear(nn.Module):
         if x.dtype == torch.bfloat16:
             # (round 5) bf16 activations of the plain-bf16 mode: the row-major bf16 matrix IS the product's A operand (no split pass), the output leaves as bf16
             # rows = the next consumer's operand (cti_gemm_bf16_rows).  Anything else widens first.
-            if (_bf16_rows_ok(x, self.in_features) and not (torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad
+            if (_bf16_rows_ok(x, self.in_features, self.out_features) and not (torch.is_grad_enabled() and (x.requires_grad or self.weight_v.requires_grad
                                                                                             or self.weight_g.requires_grad or self.bias.requires_grad))):
                 x2 = x.reshape(-1, x.shape[-1])
                 y = ops.gemm_bf16_rows(x2, self.planes(), self.out_features, out_dtype=torch.bfloat16, scale=self.scale(), scale_div=self.out_features, bias=self.bias,
@@ -94,10 +102,13 @@ class WNLinear(nn.Module):
         return ops.wn_linear(x, self.weight_v, self.scale(), self.out_features, self.bias, relu, w_planes=self.planes())
 
 
-def _bf16_rows_ok(x, in_features):
-    """The bf16-rows GEMM takes this input: plain-bf16 mode, K a multiple of 32, at least a few 256-row tiles' worth of rows (its 256 x 256 tile), 16-B aligned rows."""
-    return (ops.get_precision() == "bf16" and x.is_cuda and in_features % 32 == 0 and x.numel() // max(1, x.shape[-1]) >= 1024
-            and x.stride(-1) == 1)
+def _bf16_rows_ok(x, in_features, out_features=None):
+    """The bf16-rows GEMM takes this input -- the same conditions as csrc/cti_gemm16.hip's gemm16_eligible / cti_gemm_bf16_rows (the laxer test sent a
+    layer the kernel refuses into CTI_E_ALIGN instead of the widen-first path): plain-bf16 mode, K a multiple of 32 and at least four 32-deep stages (bias + scale
+    ride behind a tile's first stage), output rows of a multiple of 4 elements, 16-B aligned input rows at a 16-B aligned origin, and at least a few 256-row
+    tiles' worth of rows (its 256 x 256 tile)."""
+    return (ops.get_precision() == "bf16" and x.is_cuda and in_features % 32 == 0 and in_features >= 128 and (out_features is None or out_features % 4 == 0)
+            and x.numel() // max(1, x.shape[-1]) >= 1024 and x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and (x.dim() < 2 or (x.stride(-2) * 2) % 16 == 0))
 
 
 class FCNet(nn.Module):

@@ -15,6 +15,11 @@ class WordEmbedding(nn.Module):
     """Token ids -> word vectors; row `ntoken` of each table is the padding row (src/language_model.py:13-17).  With 'c' in `op` a second,
     frozen table `emb_` is looked up in the same kernel pass and concatenated (src/language_model.py:20-22,43-44)."""
 
+    def apply(self, fn):
+        r = super().apply(fn)            # (an initialiser writing through .data moves no cache key: fc.WNLinear.apply)
+        ops.invalidate_caches()
+        return r
+
     def __init__(self, ntoken, emb_dim, dropout, op=''):
         super(WordEmbedding, self).__init__()
         self.ntoken, self.emb_dim, self.op = ntoken, emb_dim, op
@@ -60,6 +65,11 @@ class WordEmbedding(nn.Module):
 class QuestionEmbedding(nn.Module):
     """GRU over the word vectors (src/language_model.py:50-98).  `rnn` is a torch nn.GRU / nn.LSTM used ONLY as the parameter container
     (same keys `rnn.weight_ih_l0` ... and the same initial values as the reference); the arithmetic runs in the HIP library."""
+
+    def apply(self, fn):
+        r = super().apply(fn)            # (an initialiser writing through .data moves no cache key: fc.WNLinear.apply)
+        ops.invalidate_caches()
+        return r
 
     _CELLS = {'GRU': nn.GRU, 'LSTM': nn.LSTM}
 

@@ -10,7 +10,8 @@ _PREC = {"fp32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16, "f16f
 # Default: 'f16f6' = the mode bench.py's headline line runs.  Outside the fused TCNet.forward / TriAttention.forward with more than 6 answer
 # tokens it IS bf16x3 (fp32-grade, 1e-5 vs float64 truth at the BASELINE shapes, 3/16 of the exact-fp32 MFMA cost); inside, the a side and the
 # mode-3 product run on f16 + block-scaled fp6 planes (3e-5) under the range guard below, which re-runs a call as bf16x3 when an operand leaves
-# the format's domain -- so the default never trades range or NaN semantics for speed.
+# the format's domain -- so the default never trades range or NaN semantics for speed (a call nobody can wait for -- hipGraph replay -- is NaN-filled
+# instead, except on the mild cancellation bit; set_range_check).
 _default_prec = "f16f6"
 
 
@@ -55,22 +56,24 @@ _guard_res = {}
 def set_range_check(mode):
     """'sync' (default): the wrapper waits for the guard's verdict and re-runs an out-of-domain call (the caller always gets fp32-grade numbers).
     'poison' (also what hipGraph capture forces, whatever this is set to): no host wait -- a call whose operands leave the f16f6 format's RANGE
-    (status bits 1, 2, 4: saturation / non-finite, underflow) returns all-NaN output, never clamped numbers.  The two CANCELLATION bits (8, 16) come
-    from a sampled heuristic whose worst consequence is an error of a few 1e-4 of the largest output: without a host to re-run the call they leave the
-    f16f6 result in place (ADVICE r4: trained weights may well exceed the threshold, and an all-NaN batch under a replayed graph has no remedy);
-    f16f6_device_status() reads the status word of the last guarded call -- e.g. after a replay -- so that a caller can re-run eagerly.
-    set_poison_bits(31) restores NaN on every bit."""
+    (status bits 1, 2, 4: saturation / non-finite, underflow) or whose cancellation estimate rho is beyond the HEAVY threshold (bit 16: rho > 5.5, and rho has
+    no upper bound there) returns all-NaN output, never clamped or inaccurate numbers.  Bit 8 alone (2.75 < rho <= 5.5) leaves the f16f6 result in place: by
+    the measured law (error <= ~1.8e-5 rho of the largest output, tests/test_accuracy_envelope_gpu.py) that result is still within 1e-4, and an all-NaN batch
+    under a replayed graph has no remedy.  f16f6_device_status() reads the status word of the last guarded call -- e.g. after a replay --
+    and graph.GraphedForward does so after every replay and re-runs a tripped call eagerly as bf16x3 / fp32.  set_poison_bits(31) NaN-fills on every bit,
+    set_poison_bits(7) on the range bits only."""
     global _range_check
     if mode not in ("sync", "poison"):
         raise ValueError("range check must be 'sync' or 'poison'")
     _range_check = mode
 
 
-_poison_bits_nohost = 7
+_poison_bits_nohost = 23
 
 
 def set_poison_bits(bits):
-    """Status bits that NaN-fill the output of a guarded call nobody waits for ('poison' mode / hipGraph capture).  Default 7 = the range bits."""
+    """Status bits that NaN-fill the output of a guarded call nobody waits for ('poison' mode / hipGraph capture).  Default 23 = the range bits (1, 2, 4) and
+    the HEAVY cancellation bit (16); bit 8 -- a mild cancellation estimate, error still <= ~1e-4 -- keeps its result."""
     global _poison_bits_nohost
     bits = int(bits)
     if not 0 <= bits <= 31:
@@ -86,18 +89,33 @@ def set_cancel_thresholds(bf16x3=2.75, fp32=5.5):
     L.check(lib.cti_set_tuning(L.TUNE_GUARD_RHO_FP32, int(round(float(fp32) * 1000))), "cti_set_tuning")
 
 
-_last_guard_ws = [None]
+# The guard block (first 256 B of a guarded call's workspace) of the LAST guarded call per device, copied stream-ordered into a small tensor that lives as long
+# as the process (a reference to the workspace itself pinned GBs and kept the caching allocator from recycling the block).  Under graph capture the
+# copy is a node of the graph, so after a replay the tensor holds what THAT replay found.
+_guard_status_block = {}
 
 
-def f16f6_device_status():
-    """Status word (and rho) of the LAST guarded f16f6 call of this process, read from its guard block on the device after a synchronise --
-    the way to learn what a replayed hipGraph's forward found (the block belongs to the graph's memory pool and is rewritten by every replay).
-    None when no guarded call has run."""
-    ws = _last_guard_ws[0]
-    if ws is None:
+def _keep_guard_block(ws):
+    key = ws.device.index if ws.device.index is not None else torch.cuda.current_device()
+    blk = _guard_status_block.get(key)
+    if blk is None:
+        if torch.cuda.is_current_stream_capturing():
+            return                        # (memory born under capture belongs to that graph's pool; an eager guarded call -- any warm-up -- creates the block)
+        blk = _guard_status_block[key] = torch.zeros(256, device=ws.device, dtype=torch.uint8)
+    blk.copy_(ws[:256], non_blocking=True)
+
+
+def f16f6_device_status(device=None, sync=True):
+    """Status word (and rho) of the LAST guarded f16f6 call on `device`, read from the copy of its guard block -- the way to learn what a replayed hipGraph's
+    forward found.  sync=False: the caller has already waited for the stream the call ran on.  None when no guarded call has run."""
+    key = torch.cuda.current_device() if device is None else (device.index if isinstance(device, torch.device) and device.index is not None else
+                                                              (device if isinstance(device, int) else torch.cuda.current_device()))
+    blk = _guard_status_block.get(key)
+    if blk is None:
         return None
-    torch.cuda.synchronize(ws.device)
-    w = ws[:128].clone().cpu().view(torch.int32)
+    if sync:
+        torch.cuda.synchronize(blk.device)
+    w = blk[:128].cpu().view(torch.int32)
     f = lambda i: float(w[i:i + 1].view(torch.float32)[0])
     return {"status": int(w[0]) & 0xffffffff, "rho": f(2), "abs_max": f(16), "dot_max": f(17)}
 
@@ -646,7 +664,6 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         # a call whose verdict the host reads is re-run on ANY bit (the NaN fill is belt and braces); one nobody waits for keeps its f16f6 result on the
         # cancellation bits (set_range_check)
         lib.cti_set_tuning(L.TUNE_GUARD_POISON_BITS, 31 if wait_guard else _poison_bits_nohost)
-        _last_guard_ws[0] = ws
     with _timed("triattention_forward" if _tri else "tcnet_forward"):
         if _tri:
             p_att = torch.empty_like(out)
@@ -680,6 +697,8 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
                                           prep_ptr, ws.data_ptr(), wsb, ev0, ev1, _aux_stream(v.device), _stream()), "cti_tcnet_forward")
     if guarded:
         _range_log["calls"] += 1
+        if not wait_guard:
+            _keep_guard_block(ws)          # nobody waits for this call's verdict: leave it where f16f6_device_status() / GraphedForward find it
     if wait_guard:
         import ctypes as _C
         status = _C.c_uint32(0)
@@ -812,6 +831,10 @@ def tri_pool(vt, qt, at, w, v_rep=1):
 
 def bi_pool(vt, qt, w, k=1):
     """out[b,n] = sum_{t<k} sum_vq vt[b,v,nk+t] w[b,v,q] qt[b,q,nk+t]; w=None means all ones."""
+    if isinstance(vt, torch.Tensor) and vt.dtype == torch.bfloat16:
+        vt = widen_bf16(vt)                                            # (the unshifted pools read fp32 rows: as tri_pool; ADVICE r5)
+    if isinstance(qt, torch.Tensor) and qt.dtype == torch.bfloat16:
+        qt = widen_bf16(qt)
     _req(vt, "vt"); _req(qt, "qt")
     B, V, D = vt.shape
     Q = qt.shape[1]

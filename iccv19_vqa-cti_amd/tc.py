@@ -22,6 +22,11 @@ def _needs_grad(*ts):
 
 
 class TCNet(nn.Module):
+
+    def apply(self, fn):
+        r = super().apply(fn)            # (an initialiser writing through .data moves no cache key: fc.WNLinear.apply)
+        ops.invalidate_caches()
+        return r
     def __init__(self, v_dim, q_dim, a_dim, h_dim, h_out, rank, glimpse, act='ReLU', dropout=[.2, .5], k=1):
         super(TCNet, self).__init__()
         self.v_dim = v_dim

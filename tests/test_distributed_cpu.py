@@ -5,6 +5,8 @@ import os
 import sys
 import time
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,3 +76,35 @@ def test_bare_multi_gpu_command_launches_its_own_ranks():
     res = json.loads(last)                                   # the JSON line is the LAST line of stdout
     assert res == dict(res, dry_launch=True, n_gpus=2, ranks_seen=2, steps=3, warmup=1)
     assert res["ms_per_step"] >= 10.0
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "train"]])
+def test_eight_rank_launch_and_device_binding_dry(extra):
+    """`bench.py --gpus 8` (forward and --mode train) through its own launcher on CPU: eight ranks rendezvous over gloo at 127.0.0.1, time the
+    barrier-bracketed steps, and rank r binds cuda:r (LOCAL_RANK -> device, what main() does before any kernel) -- BASELINE configs[4]'s launch shape
+    (reference trainer: src/FFOE/trainer.py:221-232 has no launcher at all)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch", "--steps", "3", "--warmup", "1"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res == dict(res, dry_launch=True, n_gpus=8, ranks_seen=8, steps=3, warmup=1, mode="train" if extra else "forward")
+    assert res["device_of_rank"] == ["cuda:%d" % i for i in range(8)]
+
+
+def test_eight_ranks_under_the_drivers_own_launcher_dry():
+    """... and launched the way the driver does it: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 8 ...` -- the ranks read RANK / LOCAL_RANK / WORLD_SIZE from the environment and must NOT spawn ranks of their own."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29577",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # ONE JSON line, from rank 0
+    res = json.loads(lines[-1])
+    assert res["ranks_seen"] == 8 and res["n_gpus"] == 8 and res["device_of_rank"] == ["cuda:%d" % i for i in range(8)]
