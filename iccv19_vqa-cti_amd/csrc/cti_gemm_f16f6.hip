@@ -459,7 +459,9 @@ __global__ __launch_bounds__(G::NTHR, G::MINW) void gemm_f16f6_kernel(F6P p) {
         char* slot = smem + pos * SLOT;
 #pragma unroll
         for (int u = 0; u < CNT; ++u) {
-            if (piece_is_bs[u]) { if (lane < G::BS_LANES) dma16(vp[u], slot + ldsoff[u]); }      // (wave-uniform branch; the piece's upper lanes would write past the slot)
+            // (round 6: only piece NREAL - 1 = (wave (NREAL - 1) % NW, u = (NREAL - 1) / NW) can be the B scales: the other u issue unconditionally -- the test was a
+            // run-time exec-mask sequence in front of EVERY piece of every K block)
+            if (u == (G::NREAL - 1) / NW && piece_is_bs[u]) { if (lane < G::BS_LANES) dma16(vp[u], slot + ldsoff[u]); }      // (wave-uniform branch; the piece's upper lanes would write past the slot)
             else if (!((CTI_F6_ABL & 1024) && piece_is_a[u])) dma16(vp[u], slot + ldsoff[u]);
             vp[u] += u == U_SHARED ? vks_shared : kstride[u];
         }

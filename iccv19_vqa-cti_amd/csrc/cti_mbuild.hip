@@ -797,6 +797,245 @@ __global__ __launch_bounds__(1024) void mbuild_core_small_kernel(const float* __
     }
 }
 
+
+// =====================================================================================================
+// Round 6: the few-answer core with the contraction order turned round (reference src/Tensor.py:9-20 + src/tc.py:46-50 for A <= 6).
+//   out[v, (q, a, g)] = sum_{r, i} V^[v, (r, i)] W[(r, i), (q, a, g)],      W[(r, i), (q, a, g)] = sum_j Q^[q, (r, j)] sum_k T[r, i, j, k, g] A^[a, (r, k)]
+// The kernel above multiplies the image side in first (X = V^ T_r: 36 x 16 x 512 per rank), which makes every rank a workgroup-wide LDS exchange of X
+// between two barriers: 64 barriers and ~520 instructions per wave AND RANK, of which 14 are MFMAs (142 us per 256 samples: instruction issue, not
+// arithmetic).  With the few answers and the question contracted first the ranks are INDEPENDENT until one final GEMM:
+//   phase A (a wave per rank, no barrier between ranks): for every (i, g) the 16 x 16 block T[r, i, g][j][k] (k contiguous in the derived layout Tk: one
+//       16-B load per lane) x A^_r -> D[j, a] on the 16x16x16 MFMA, whose accumulator layout IS the B-operand layout of the next product
+//       W_t[q, a] = sum_j Q^_r[q, j] D[j, a]; four consecutive i are packed per lane into one 8-B LDS store of W in the final GEMM's B-operand order;
+//   phase B (one barrier): out tiles (16 v x 16 n) over K = 512, A operand = V^ rows from global memory, B operand = W from LDS.
+// 5.4 M multiply-adds per sample instead of 19 M, ~1 000 instructions per wave for the WHOLE sample instead of ~16 000, 2 barriers per chunk of ranks
+// (one chunk when W fits the LDS: 128 x NP x 8 B per bf16 plane, NP = G Q A rounded up to 16).
+// =====================================================================================================
+__global__ void tk_layout_kernel(const float* __restrict__ Teff, unsigned short* __restrict__ Tk, int64_t n) {
+    // Teff[(r, i)][(j, k, g)] fp32 -> Tk: two bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of [(r, i)][g][j][k]   (hr = 16, G = 2: 512 values per (r, i))
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t ri = t >> 9;
+    const int c = (int)(t & 511), g = c >> 8, j = (c >> 4) & 15, k = c & 15;
+    const float x = Teff[ri * 512 + ((j * 16 + k) << 1) + g];
+    const unsigned short h = bf16_bits(x);
+    Tk[t] = h;
+    Tk[n + t] = bf16_bits(x - bf16_to_f32(h));
+}
+
+#ifndef CTI_AQ_ABL
+#define CTI_AQ_ABL 0      // timing-only ablation mask: 1 no phase B, 2 no output stores, 4 no T loads, 8 no W stores, 16 no phase A at all
+#endif
+constexpr int AQ_NW = 8;                         // waves per workgroup: two per SIMD, 256 registers each (sixteen waves of 128 registers spilled the fragment buffers)
+template <int TERMS, int MAXT>
+__global__ __launch_bounds__(64 * AQ_NW) void core_small_aq_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr, const unsigned short* __restrict__ Tk,
+                                                             const float* __restrict__ Ar, float* __restrict__ out, int V, int Q, int A, int R, int NCH,
+                                                             const uint8_t* __restrict__ sm_mask, float* __restrict__ sm_p, int v_rep) {
+    constexpr int G = 2, NPL = TERMS == 3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long Wimg[];   // [plane][K4 = (rank in chunk) * 4 + i / 4][n] x 8 B = four consecutive i of one (rank, n) as bf16; then 64 trash slots
+    const int b = blockIdx.x;
+    constexpr int NW = AQ_NW;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, s4 = lane >> 4;                                     // 16x16x16 roles: row / column c, 4-deep K slice s4
+    const int K = R * 16, N = G * Q * A, NP = (N + 15) & ~15, NT = NP >> 4, VTL = (V + 15) >> 4;
+    const int RC = R / NCH, K4C = RC * 4;                                        // ranks / 8-B K rows per chunk
+    const int plane = K4C * NP;                                                  // (8-byte units; the whole image is < 2^15 of them)
+    const int trash = NPL * plane + lane;                                     // where the lanes without a (q, a) of their own put their 8 bytes
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vb = Vr + (int64_t)(b / v_rep) * V * K;                         // v_rep > 1: rows b*v_rep .. +v_rep-1 share one image (V^ holds one block per image)
+    const bool aok = c < A, qok = c < Q;
+    const int64_t tplane = (int64_t)R * 16 * 512;                                // elements per bf16 plane of Tk
+    // phase-B tiles of this wave: ONE row tile vt (so that a K step's V^ fragment serves all of them), column tiles nt0, nt0 + ngrp, ...
+    const int vt = wid % VTL, nt0 = wid / VTL, ngrp = (NW - vt + VTL - 1) / VTL;
+    mb_f32x4 acc[MAXT];                                                          // out[v = 16 vt + 4 s4 + e, n = 16 (nt0 + u ngrp) + c]
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) acc[u] = mb_f32x4{0.f, 0.f, 0.f, 0.f};
+    // W slots of this lane for phase A: (g, e) -> n = (g Q + 4 s4 + e) A + c, or the trash slot
+    int wo[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wo[g][e] = (aok && 4 * s4 + e < Q) ? (g * Q + 4 * s4 + e) * A + c : -1;
+    typedef unsigned long long u64;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        // ---------------- phase A: W of this chunk's ranks, a wave per rank ----------------
+        for (int rc = wid; rc < ((CTI_AQ_ABL & 16) ? 0 : RC); rc += NW) {
+            const int r = ch * RC + rc;
+            mb_s16x4 ah, al, qh, ql;
+            // (columns / rows beyond A / Q read row 0: what they produce is never stored -- an exec-masked load could not be hoisted)
+            mb_split4t<TERMS>(*reinterpret_cast<const float4*>(Ar + ((int64_t)b * A + (aok ? c : 0)) * K + r * 16 + s4 * 4), ah, al);   // B operand: A^[a = c][k = 4 s4 ..]
+            mb_split4t<TERMS>(*reinterpret_cast<const float4*>(Qr + ((int64_t)b * Q + (qok ? c : 0)) * K + r * 16 + s4 * 4), qh, ql);   // A operand: Q^[q = c][j = 4 s4 ..]
+            const u64* tr = reinterpret_cast<const u64*>(Tk + (int64_t)r * 16 * 512 + c * 16 + s4 * 4);                               // + (i * 512 + g * 256) / 4: T[r, i, g][j = c][k = 4 s4 ..]
+            u64 th_[2][4][G], tl_[2][4][G];                                      // two sets: the loads of i group ig + 1 fly under the products of ig
+#define CTI_AQ_LOADT(set, ig_)                                                                                       \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                             \
+                _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                          \
+                    th_[set][ii][g] = (CTI_AQ_ABL & 4) ? (u64)(lane + ii) : tr[(((ig_) * 4 + ii) * 512 + g * 256) >> 2];       \
+                    if (TERMS == 3) tl_[set][ii][g] = tr[(tplane + ((ig_) * 4 + ii) * 512 + g * 256) >> 2];              \
+                }
+            // i groups in pairs: group 2 p on set 0 while set 1 loads group 2 p + 1, then the other way round (a fully unrolled loop let the scheduler hoist
+            // every load of the rank and spill)
+#define CTI_AQ_GROUP(set, ig_)                                                                                                 \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                                        \
+                float w[4][4];                                                                                                     \
+                _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                                 \
+                    const mb_s16x4 th = __builtin_bit_cast(mb_s16x4, th_[set][ii][g]);                                             \
+                    const mb_s16x4 tl = TERMS == 3 ? __builtin_bit_cast(mb_s16x4, tl_[set][ii][g]) : th;                           \
+                    mb_s16x4 dh, dl;                                                                                               \
+                    const mb_f32x4 d = mb_mfma3<TERMS>(th, tl, ah, al, mb_f32x4{0.f, 0.f, 0.f, 0.f});     /* D[j = 4 s4 + e][a = c] */ \
+                    mb_split4t<TERMS>(make_float4(d[0], d[1], d[2], d[3]), dh, dl);                       /* ... already in B-operand position (K = j) */ \
+                    const mb_f32x4 wt = mb_mfma3<TERMS>(qh, ql, dh, dl, mb_f32x4{0.f, 0.f, 0.f, 0.f});    /* W_t[q = 4 s4 + e][a = c] */ \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) w[ii][e] = wt[e];                                                \
+                }                                                                                                                  \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                    \
+                    mb_s16x4 hi, lo;                                                                                               \
+                    mb_split4t<TERMS>(make_float4(w[0][e], w[1][e], w[2][e], w[3][e]), hi, lo);                                    \
+                    const int o = wo[g][e] < 0 ? trash : (rc * 4 + (ig_)) * NP + wo[g][e];                                         \
+                    if (!(CTI_AQ_ABL & 8) || hi[0] == 12345) Wimg[o] = __builtin_bit_cast(u64, hi);                                \
+                    if (TERMS == 3) Wimg[wo[g][e] < 0 ? trash : plane + o] = __builtin_bit_cast(u64, lo);                          \
+                }                                                                                                                  \
+            }
+            CTI_AQ_LOADT(0, 0)
+#pragma unroll 1
+            for (int igp = 0; igp < 2; ++igp) {
+                CTI_AQ_LOADT(1, 2 * igp + 1)
+                CTI_AQ_GROUP(0, 2 * igp)
+                __builtin_amdgcn_sched_barrier(0);
+                if (igp == 0) CTI_AQ_LOADT(0, 2)
+                CTI_AQ_GROUP(1, 2 * igp + 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef CTI_AQ_GROUP
+#undef CTI_AQ_LOADT
+        }
+        if (ch == 0 && NP > N) {                                                 // the padding columns of the last n tile: zeros, once (no rank writes them)
+            for (int t = threadIdx.x; t < K4C * (NP - N) * NPL; t += 64 * NW) {
+                const int pl = t / (K4C * (NP - N)), rem = t - pl * (K4C * (NP - N));
+                Wimg[pl * plane + (rem / (NP - N)) * NP + N + rem % (NP - N)] = 0ull;
+            }
+        }
+        // ---------------- phase B: out tiles (16 v x 16 n) += V^[:, chunk] W[chunk, :] ----------------
+        // The V^ fragments of the first sixteen K steps are in flight BEFORE the barrier (rows beyond V read row 0: their output rows are never stored), and
+        // every group of eight is re-filled two groups ahead: the first form loaded one fragment per step behind an exec-masked branch -- 32 dependent L2
+        // round trips, 43 of the kernel's 67 us.
+        constexpr int GB = 8 / ((TERMS == 3 ? 2 : 1) * (MAXT > 3 ? 2 : 1));             // fragments per refill group (two groups in flight): what 256 registers hold beside the accumulators
+        const int v = vt * 16 + c;
+        const float* vrow = vb + (int64_t)(v < V ? v : 0) * K + ch * RC * 16 + s4 * 4;
+        float4 vbuf[2][GB];
+#define CTI_AQ_LOADV(set, k0_) _Pragma("unroll") for (int j_ = 0; j_ < GB; ++j_) vbuf[set][j_] = *reinterpret_cast<const float4*>(vrow + ((k0_) + j_) * 16);
+#define CTI_AQ_STEPS(set, k0_)                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < GB; ++j_) {                                                                            \
+            mb_s16x4 vh, vl;                                                                                                           \
+            mb_split4t<TERMS>(vbuf[set][j_], vh, vl);                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < MAXT; ++u) {                                                                         \
+                const int nt = nt0 + u * ngrp;                                                                                         \
+                if (nt < NT) {                                               /* (wave-uniform) */                                      \
+                    const mb_s16x4 bh = __builtin_bit_cast(mb_s16x4, wb_[((k0_) + j_) * 4 * NP + nt * 16]);                    \
+                    const mb_s16x4 bl = TERMS == 3 ? __builtin_bit_cast(mb_s16x4, wb_[plane + ((k0_) + j_) * 4 * NP + nt * 16]) : bh; \
+                    acc[u] = mb_mfma3<TERMS>(vh, vl, bh, bl, acc[u]);                                                                  \
+                }                                                                                                                      \
+            }                                                                                                                          \
+            if ((j_ & 1) == 1) __builtin_amdgcn_sched_barrier(0);    /* (two steps' W reads in flight at most: hoisting a whole group's spills) */ \
+        }
+        CTI_AQ_LOADV(0, 0)
+        if (RC > GB) CTI_AQ_LOADV(1, GB)
+        __syncthreads();
+        {
+            const u64* wb_ = Wimg + s4 * NP + c;
+#pragma unroll 1
+            for (int k0 = 0; k0 < ((CTI_AQ_ABL & 1) ? 0 : RC); k0 += 2 * GB) {    // RC is a multiple of 8 (launcher): an even number of groups
+                CTI_AQ_STEPS(0, k0)
+                if (k0 + 2 * GB < RC) CTI_AQ_LOADV(0, k0 + 2 * GB)
+                if (k0 + GB < RC) {
+                    CTI_AQ_STEPS(1, k0 + GB)
+                    if (k0 + 3 * GB < RC) CTI_AQ_LOADV(1, k0 + 3 * GB)
+                }
+            }
+        }
+#undef CTI_AQ_LOADV
+#undef CTI_AQ_STEPS
+        if (ch + 1 < NCH) __syncthreads();                                       // the next chunk's ranks overwrite W
+    }
+    // lane (c, s4) of tile (vt, nt): out[b, v = 16 vt + 4 s4 + e, q, a, g] with n = 16 nt + c = (g Q + q) A + a
+    int og[MAXT]; int64_t ooff[MAXT]; bool nok[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int nt = nt0 + u * ngrp, n = nt * 16 + c;
+        nok[u] = nt < NT && n < N;
+        const int g = n / (Q * A), rem = n - g * (Q * A), q = rem / A, a = rem - q * A;
+        og[u] = g;
+        ooff[u] = (((int64_t)b * V + vt * 16 + 4 * s4) * Q + q) * A * G + a * G + g;          // + e * Q * A * G
+    }
+    const int64_t vstride = (int64_t)Q * A * G;
+    if (sm_p == nullptr) {
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            if (nok[u]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (vt * 16 + 4 * s4 + e < V) out[ooff[u] + e * vstride] = acc[u][e];
+            }
+        }
+        return;
+    }
+    // TriAttention's masked softmax (reference src/attention.py:55-58) in the same kernel, as in mbuild_core_small_kernel: the workgroup holds ALL of the
+    // sample's logits, so the per-glimpse maximum and sum are two workgroup reductions; an all-masked sample keeps the reference's NaN row.
+    constexpr float L2E = 1.4426950408889634f;
+    const float ninf = -__builtin_huge_valf();
+    __syncthreads();                                                             // every wave is done with W: the reductions reuse the LDS
+    float* red = reinterpret_cast<float*>(Wimg);                                 // [NW waves][2]
+    bool rowok[MAXT][4];
+    float mx[G] = {ninf, ninf};
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = vt * 16 + 4 * s4 + e;
+            rowok[u][e] = nt0 + u * ngrp < NT && v < V && sm_mask[(int64_t)b * V + (v < V ? v : 0)] == 0;
+            if (rowok[u][e] && nok[u]) { if (og[u] == 0) mx[0] = fmaxf(mx[0], acc[u][e]); else mx[1] = fmaxf(mx[1], acc[u][e]); }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float w = wave_max(mx[g]); if (lane == 0) red[wid * 2 + g] = w; }
+    __syncthreads();
+    float gm[G] = {ninf, ninf};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { gm[0] = fmaxf(gm[0], red[w * 2]); gm[1] = fmaxf(gm[1], red[w * 2 + 1]); }
+    __syncthreads();
+    float ex[MAXT][4];
+    float sum[G] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const float m = og[u] == 0 ? gm[0] : gm[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // exp(x - m) = exp2(x log2e - m log2e); masked rows contribute exp(-inf) = 0; m = -inf (every row masked) gives NaN like the reference
+            ex[u][e] = rowok[u][e] ? __builtin_amdgcn_exp2f(fmaf(acc[u][e], L2E, -m * L2E)) : (m == ninf ? __builtin_nanf("") : 0.f);
+            if (nok[u] && vt * 16 + 4 * s4 + e < V) { if (og[u] == 0) sum[0] += ex[u][e]; else sum[1] += ex[u][e]; }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { const float w = wave_sum(sum[g]); if (lane == 0) red[wid * 2 + g] = w; }
+    __syncthreads();
+    float tot[G] = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { tot[0] += red[w * 2]; tot[1] += red[w * 2 + 1]; }
+    const float inv[G] = {1.f / tot[0], 1.f / tot[1]};
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        if (nok[u]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (vt * 16 + 4 * s4 + e < V) {
+                    out[ooff[u] + e * vstride] = rowok[u][e] ? acc[u][e] : ninf;
+                    sm_p[ooff[u] + e * vstride] = ex[u][e] * (og[u] == 0 ? inv[0] : inv[1]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool mbuild_mfma_fits(int B, int V, int Q, int R, int hr, int G) {
@@ -870,13 +1109,48 @@ int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Pl
 // Modes 1 + 2 + 3 for few answer tokens, out (B,V,Q,A,G) fp32.  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2, V <= 64, Q <= 16, A <= 6:
 // the caller takes the M build + GEMM pair.  sm_p != NULL (with sm_mask = the zero-row mask of v): TriAttention's masked softmax in the same
 // kernel -- `out` gets -inf on masked rows, sm_p the attention map.
+// Tk != NULL: the round-6 kernel (answers and question contracted first, core_small_aq_kernel; Tk = T_eff as [(r, i)][g][j][k], core_small_tk_layout) where its W
+// image fits the LDS in at most 8 chunks of ranks and R is a multiple of the chunk count; CTI_CORE_SMALL_OLD=1 keeps the round-3 kernel (A/B).
+int core_small_tk_layout(const float* Teff, float* Tk, int R, int hr, int G, hipStream_t st) {          // Tk: R * 16 * 512 * 4 bytes = two bf16 planes
+    if (hr != 16 || G != 2) return CTI_OK;                       // (the fused few-answer kernels exist for hr = 16, G = 2 only: nothing reads Tk otherwise)
+    const int64_t n = (int64_t)R * 16 * 512;
+    hipLaunchKernelGGL(tk_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Teff, reinterpret_cast<unsigned short*>(Tk), n);
+    return launch_status("core_small_tk_layout");
+}
+
+static int core_small_aq_chunks(int V, int Q, int A, int R, int terms) {
+    const size_t NP = (size_t)((2 * Q * A + 15) & ~15), npl = terms == 3 ? 2 : 1;
+    for (int nch = 1; nch <= 4; nch *= 2)
+        if (R % (8 * nch) == 0 && npl * (size_t)(R / nch) * 4 * NP * 8 + 512 <= 160 * 1024) return nch;     // (a chunk's K steps go in groups of eight)
+    return 0;
+}
+
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask, float* sm_p, int v_rep, int terms) {
+                      hipStream_t st, const uint8_t* sm_mask, float* sm_p, int v_rep, int terms, const float* Tk) {
 #ifdef CTI_NO_MBUILD_CORE_SMALL
     return CTI_E_UNSUPPORTED;
 #endif
     if (!mbuild_core_small_fits(B, V, Q, A, R, hr, G) || !Tt) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt) | reinterpret_cast<uintptr_t>(Ar)) & 15) return CTI_E_UNSUPPORTED;
+    static const bool old_env = [] { const char* e = getenv("CTI_CORE_SMALL_OLD"); return e && e[0] == '1'; }();
+    const int nch = (Tk && !old_env && !(reinterpret_cast<uintptr_t>(Tk) & 15)) ? core_small_aq_chunks(V, Q, A, R, terms) : 0;
+    if (nch > 0) {
+        const int NP = (2 * Q * A + 15) & ~15, vtl = (V + 15) / 16, maxt = (NP / 16 + AQ_NW / vtl - 1) / (AQ_NW / vtl);     // a row tile's column tiles over its 8 / vtl (or more) waves
+        const size_t lds_aq = (size_t)(terms == 3 ? 2 : 1) * (R / nch) * 4 * NP * 8 + 512;
+#define CTI_AQ_LAUNCH(TRM, MT)                                                                                                              \
+        {                                                                                                                                   \
+            auto kern = core_small_aq_kernel<TRM, MT>;                                                                                      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                   \
+            hipLaunchKernelGGL(kern, dim3(B), dim3(64 * AQ_NW), lds_aq, st, Vr, Qr, reinterpret_cast<const unsigned short*>(Tk), Ar, out, V, Q, A, R, nch, sm_mask, sm_p, v_rep > 0 ? v_rep : 1); \
+        }
+        if (maxt <= 6) {
+            if (terms == 1) { if (maxt <= 3) CTI_AQ_LAUNCH(1, 3) else CTI_AQ_LAUNCH(1, 6) }
+            else            { if (maxt <= 3) CTI_AQ_LAUNCH(3, 3) else CTI_AQ_LAUNCH(3, 6) }
+            return launch_status("core_small_aq");
+        }
+#undef CTI_AQ_LAUNCH
+    }
     const size_t lds = mbuild_core_small_lds(V, A, R, hr, G);
     const int VT = (V + 15) / 16;
 #define CTI_MC_LAUNCH(VTv, TRM)                                                                                                             \

@@ -11,8 +11,9 @@ namespace cti {
 int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
 int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
+int core_small_tk_layout(const float* Teff, float* Tk, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
-                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1, int terms = 3);
+                      hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1, int terms = 3, const float* Tk = nullptr);
 int mbuild_fast(const float* Vr, const float* Qr, const float* Teff, float* Mf, unsigned short* Mh, unsigned short* Ml, int B,
                 int V, int Q, int R, int hr, int G, int64_t ldm_or_pitch, hipStream_t st);
 bool mbuild_mfma_f6_fits(int B, int V, int Q, int R, int hr, int G);              // the launchers' own shape tests (cti_mbuild.hip), by sizes only
@@ -73,7 +74,7 @@ static bool m_needs_scratch(const Dims& d) {
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
-    float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* wn_partial;
+    float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* Tk; float* wn_partial;
     // fp32 mode
     float* t32[3]; float* r32[3]; float* M32;
     // planes mode
@@ -103,6 +104,7 @@ void carve_prep(const Dims& d, int prec, Bump& w, Plan& p) {
     for (int s = 0; s < 3; ++s) { p.scale_t[s] = static_cast<float*>(w.take(sizeof(float))); p.scale_r[s] = static_cast<float*>(w.take(sizeof(float) * d.R)); }
     p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
     p.Tt = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [r][c][i]: the MFMA M build's B operand
+    p.Tk = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [(r, i)][g][j][k]: the round-6 few-answer core's A operand (k contiguous)
     {
         size_t chunks = 0;
         for (int s = 0; s < 3; ++s) chunks += (size_t)(((int64_t)d.h * in[s] + WN_CHUNK - 1) / WN_CHUNK) + (size_t)d.R * (((int64_t)hr * d.h + WN_CHUNK - 1) / WN_CHUNK);
@@ -196,6 +198,7 @@ int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tuck
     if (prec != CTI_PREC_F32) {                                 // T_eff[r] (i x c) -> Tt[r] (c x i): contraction axis contiguous
         rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * d.G, (int64_t)hr * hr * hr * d.G, p.Tt, hr, (int64_t)hr * hr * hr * d.G, hr, hr * hr * d.G, d.R, stream);
         if (rc) return rc;
+        rc = core_small_tk_layout(p.Teff, p.Tk, d.R, hr, d.G, st); if (rc) return rc;
         if (weight_planes) {
             for (int s = 0; s < 3; ++s) {
                 rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
@@ -455,16 +458,63 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         else       { r.epi = 1; r.Ph = p.Arp.hi; r.Pl = p.Arp.lo; r.rows_allocP = p.Arp.rows_alloc; r.Np = Kh; }
         return gemm_nt_planes(r, ss);
     };
+    // CTI_F6_ORDER=1 (round 6 experiment; f16f6 with an auxiliary stream and the direct-encoding M build): the v / q sides run FIRST, alone, on the main stream
+    // (~0.1 ms), then the M build -- MFMA / vector-ALU bound, 256 workgroups -- runs on the auxiliary stream BESIDE the encoding pass of `a` (HBM bound) instead of
+    // behind the a side's last product, where nothing overlaps it (0.27 ms + the scans in front of the mode-3 product: profiles/r05_step_timeline.txt)
+    static const bool order1_env = [] { const char* e = getenv("CTI_F6_ORDER"); return e && e[0] == '1'; }();
+    const bool order1 = order1_env && f6 && aux_stream && !fused_core && !guard_late() && !p.Mf32;
     // chain B on the auxiliary stream (or first, on the main stream)
-    rc = side(0, sb); if (rc) return finish(rc);
-    rc = side(1, sb); if (rc) return finish(rc);
+    rc = side(0, order1 ? st : sb); if (rc) return finish(rc);
+    rc = side(1, order1 ? st : sb); if (rc) return finish(rc);
+    if (order1) {
+        hipEvent_t ev_vq = nullptr;
+        if (hipEventCreateWithFlags(&ev_vq, hipEventDisableTiming) != hipSuccess) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed"));
+        (void)hipEventRecord(ev_vq, st);
+        (void)hipStreamWaitEvent(sb, ev_vq, 0);
+        (void)hipEventDestroy(ev_vq);
+        {   // auxiliary stream: the fp32 sweeps of V^ / Q^ / T_eff, the M build
+            GuardArgs gb{};
+            gb.words = p.guard;
+            gb.seg[gb.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
+            gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
+            gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
+            if (!guard_ablate()) { rc = guard_scan(gb, sb); if (rc) return finish(rc); }
+            rc = mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb); if (rc) return finish(rc);
+            (void)hipEventRecord(ev_join, sb);
+        }
+        // main stream: the whole a side, its scans, the join, the cancellation estimate + verdict, the mode-3 product
+        a_phase = 0;
+        rc = side(2, st); if (rc) return finish(rc);
+        GuardArgs ga{};
+        ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h, 1);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h, 2);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
+        ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
+        if (!guard_ablate()) {
+            rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, st); if (rc) return finish(rc);
+            rc = guard_scan(ga, st); if (rc) return finish(rc);
+        }
+        F6GemmArgs c{};
+        c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
+        c.epi = 3; c.gdiv = G; c.C = out; c.ldc_m = (int64_t)A * G; c.ldc_n = G; c.sC = (int64_t)V * Q * A * G;
+        if (sm_part) { c.sm_part = sm_part; c.sm_mask = zero_mask; c.sm_rows_per_obj = Q * G; c.sm_objs = V; }
+        if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
+        rc = gemm_nt_f16f6(c, st);
+        if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
+        if (rc) return finish(rc);
+        return finish(guard_ablate() ? CTI_OK : guard_poison(p.guard, out, (int64_t)B * V * Q * A * G, st));
+    }
     if (fused_core) {
         // few answer tokens: chain B ends with the rank nets; modes 1 + 2 + 3 are one kernel behind the join, M is never written
         if (aux_stream) (void)hipEventRecord(ev_join, sb);
         rc = side(2, st); if (rc) return finish(rc);
         if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
-        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1, terms);   // p_fused: + the masked softmax
+        rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1, terms, p.Tk);   // p_fused: + the masked softmax
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         return finish(rc);
     }
