@@ -1036,6 +1036,82 @@ __global__ __launch_bounds__(64 * AQ_NW) void core_small_aq_kernel(const float* 
     }
 }
 
+
+// =====================================================================================================
+// Round 6: the direct-encoding M build without LDS and without barriers (the M build runs alone between the a side's last product and the
+// mode-3 product, 0.27 ms of the headline step; reference src/Tensor.py:6-13).  mbuild_mfma_f6_kernel above exchanges X = V^ T_r through the LDS between two
+// workgroup barriers for every rank and encodes on a fraction of its lanes.  Here both contractions of a (rank, k, g) are 16x16x16 MFMAs chained through
+// registers, with the image side multiplied in TRANSPOSED:
+//   D[j, v]   = sum_i T[r, i, j, k, g] V^[v, (r, i)]      A operand T (rows j, i contiguous in the derived layout Tj: 8-B loads), B operand V^ from global memory
+//   M^t[q, v] = sum_j Q^[q, (r, j)] D[j, v]               D's accumulator layout (rows j = 4 s + e, column v) IS this product's B-operand layout
+// A wave owns a (rank pair, 16 objects, glimpse) item at a time: after 2 x 16 (r, k) steps lane (v, s) holds the 32 K values of a scale block for its four
+// rows (v, q = 4 s + e, g) and encodes them in registers (f6_encode_row32_regs) -- every lane with a real (v, q) encodes, nothing waits for anything else.
+// =====================================================================================================
+__global__ void tj_layout_kernel(const float* __restrict__ Teff, unsigned short* __restrict__ Tj, int64_t n) {
+    // Teff[(r, i)][(j, k, g)] fp32 -> Tj: two bf16 planes (hi, lo) of [(r, k)][g][j][i]
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = (int)(t & 15), j = (int)(t >> 4) & 15, g = (int)(t >> 8) & 1, k = (int)(t >> 9) & 15;
+    const int64_t r = t >> 13;
+    const float x = Teff[(r * 16 + i) * 512 + ((j * 16 + k) << 1) + g];
+    const unsigned short h = bf16_bits(x);
+    Tj[t] = h;
+    Tj[n + t] = bf16_bits(x - bf16_to_f32(h));
+}
+
+constexpr int KQ_NW = 8;
+__global__ __launch_bounds__(64 * KQ_NW) void mbuild_f6_kq_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr, const unsigned short* __restrict__ Tj,
+                                                                  F6Planes P, int V, int Q, int R) {
+    constexpr int G = 2;
+    typedef unsigned long long u64;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, s4 = lane >> 4;
+    const int K = R * 16, VTL = (V + 15) >> 4, items = (R >> 1) * G * VTL;
+    const int64_t tplane = (int64_t)R * 16 * 512, rows_b = (int64_t)b * V * Q * G;
+    const float* qrow = Qr + ((int64_t)b * Q + (c < Q ? c : 0)) * K + s4 * 4;                // A operand of the second product: Q^[q = c][(r, j = 4 s4 ..)]
+    // items ((kb, g), vt): the waves that run together share a (rank pair, g) slice of T
+    for (int item = wid; item < items; item += KQ_NW) {
+        const int vt = item % VTL, kg_ = item / VTL, g = kg_ & 1, kb = kg_ >> 1;
+        const int v = vt * 16 + c;
+        const float* vrow = Vr + ((int64_t)b * V + (v < V ? v : 0)) * K + s4 * 4;            // B operand of the first product: V^[v = c][(r, i = 4 s4 ..)]
+        float x[4][32];                                                                     // row (v, q = 4 s4 + e, g): K = 32 kb .. + 31
+#pragma unroll
+        for (int rl = 0; rl < 2; ++rl) {
+            const int r = 2 * kb + rl;
+            mb_s16x4 vh, vl, qh, ql;
+            mb_split4(*reinterpret_cast<const float4*>(vrow + r * 16), vh, vl);
+            mb_split4(*reinterpret_cast<const float4*>(qrow + r * 16), qh, ql);
+            const u64* tr = reinterpret_cast<const u64*>(Tj + ((int64_t)r * 16 * 2 + g) * 256 + c * 16 + s4 * 4);      // + k * 512 / 4: T[r, :, j = c, k, g] as [i]
+            u64 th_[16], tl_[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { th_[k] = tr[k * 128]; tl_[k] = tr[(tplane >> 2) + k * 128]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const mb_s16x4 th = __builtin_bit_cast(mb_s16x4, th_[k]), tl = __builtin_bit_cast(mb_s16x4, tl_[k]);
+                mb_s16x4 dh, dl;
+                const mb_f32x4 d = mb_mfma3<3>(th, tl, vh, vl, mb_f32x4{0.f, 0.f, 0.f, 0.f});          // D[j = 4 s4 + e][v = c]
+                mb_split4(make_float4(d[0], d[1], d[2], d[3]), dh, dl);
+                const mb_f32x4 mt = mb_mfma3<3>(qh, ql, dh, dl, mb_f32x4{0.f, 0.f, 0.f, 0.f});         // M^t[q = 4 s4 + e][v = c]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e][rl * 16 + k] = mt[e];
+            }
+        }
+        if (v < V) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = 4 * s4 + e;
+                if (q < Q) {
+                    const int64_t prow = f6_prow(P, rows_b + ((int64_t)v * Q + q) * G + g);
+                    const int64_t o = (int64_t)kb * P.rows_alloc + prow;
+                    f6_encode_row32_regs<false>(x[e], -__builtin_huge_valf(), reinterpret_cast<char*>(P.H) + o * 64, reinterpret_cast<char*>(P.FL) + o * 24,
+                                                reinterpret_cast<char*>(P.S) + ((int64_t)kb * P.rows_allocS + prow) * 2);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool mbuild_mfma_fits(int B, int V, int Q, int R, int hr, int G) {
@@ -1087,12 +1163,25 @@ bool mbuild_core_small_fits(int B, int V, int Q, int A, int R, int hr, int G) {
 
 // M straight into the f16f6 planes P of the mode-3 product (rows (b, v, q, g), K = R * 16).  CTI_E_UNSUPPORTED (no message) outside hr = 16, G = 2,
 // even R and the LDS budget: the caller takes mbuild_mfma -> fp32 rows -> quantize_f16f6.
-int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st) {
+// Tj: T_eff as two bf16 planes of [(r, k)][g][j][i] for the round-6 kernel (mbuild_f6_kq_kernel); R * 16 * 512 * 4 bytes
+int mbuild_f6_tj_layout(const float* Teff, float* Tj, int R, int hr, int G, hipStream_t st) {
+    if (hr != 16 || G != 2) return CTI_OK;
+    const int64_t n = (int64_t)R * 16 * 512;
+    hipLaunchKernelGGL(tj_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Teff, reinterpret_cast<unsigned short*>(Tj), n);
+    return launch_status("mbuild_f6_tj_layout");
+}
+
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st, const float* Tj) {
 #if defined(CTI_NO_MBUILD_MFMA) || defined(CTI_NO_MBUILD_F6)
     return CTI_E_UNSUPPORTED;
 #endif
     if (!mbuild_mfma_f6_fits(B, V, Q, R, hr, G) || !Tt || P.Kb * 32 != R * hr) return CTI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
+    static const bool old_env = [] { const char* e = getenv("CTI_MBF6_OLD"); return e && e[0] == '1'; }();
+    if (Tj && !old_env && !(reinterpret_cast<uintptr_t>(Tj) & 15)) {        // round 6: no LDS, no barriers (CTI_MBF6_OLD=1: the round-2 kernel, A/B)
+        hipLaunchKernelGGL(mbuild_f6_kq_kernel, dim3(B), dim3(64 * KQ_NW), 0, st, Vr, Qr, reinterpret_cast<const unsigned short*>(Tj), P, V, Q, R);
+        return launch_status("mbuild_f6_kq");
+    }
     const size_t lds = mbuild_mfma_f6_lds(V, Q, G);
     static thread_local int attr_dev = -1;
     int dev = 0;

@@ -281,7 +281,7 @@ extern "C" int cti_paralind_mbuild_planes_fwd(const float* Vr, const float* Qr, 
 }
 
 namespace cti {
-int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st, const float* Tj = nullptr);
 }
 
 extern "C" int cti_paralind_mbuild_f16f6_fwd(const float* Vr, const float* Qr, const float* Teff_t, void* planes, size_t planes_bytes, int B, int V, int Q,

@@ -10,7 +10,8 @@
 namespace cti {
 int mbuild_mfma(const float* Vr, const float* Qr, const float* Tt, unsigned short* Mh, unsigned short* Ml, float* Mf, int B, int V, int Q, int R,
                 int hr, int G, int64_t pitchM, hipStream_t st);
-int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st);
+int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Planes& P, int B, int V, int Q, int R, int hr, int G, hipStream_t st, const float* Tj = nullptr);
+int mbuild_f6_tj_layout(const float* Teff, float* Tj, int R, int hr, int G, hipStream_t st);
 int core_small_tk_layout(const float* Teff, float* Tk, int R, int hr, int G, hipStream_t st);
 int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const float* Ar, float* out, int B, int V, int Q, int A, int R, int hr, int G,
                       hipStream_t st, const uint8_t* sm_mask = nullptr, float* sm_p = nullptr, int v_rep = 1, int terms = 3, const float* Tk = nullptr);
@@ -74,7 +75,7 @@ static bool m_needs_scratch(const Dims& d) {
 
 // One pass over the carve plan: with base == nullptr it only measures.
 struct Plan {
-    float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* Tk; float* wn_partial;
+    float* scale_t[3]; float* scale_r[3]; float* Teff; float* Tt; float* Tk; float* Tj; float* wn_partial;
     // fp32 mode
     float* t32[3]; float* r32[3]; float* M32;
     // planes mode
@@ -105,6 +106,7 @@ void carve_prep(const Dims& d, int prec, Bump& w, Plan& p) {
     p.Teff = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));
     p.Tt = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [r][c][i]: the MFMA M build's B operand
     p.Tk = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [(r, i)][g][j][k]: the round-6 few-answer core's A operand (k contiguous)
+    p.Tj = static_cast<float*>(w.take(sizeof(float) * (size_t)d.R * hr * hr * hr * d.G));      // [(r, k)][g][j][i]: the round-6 direct-encoding M build's A operand (i contiguous)
     {
         size_t chunks = 0;
         for (int s = 0; s < 3; ++s) chunks += (size_t)(((int64_t)d.h * in[s] + WN_CHUNK - 1) / WN_CHUNK) + (size_t)d.R * (((int64_t)hr * d.h + WN_CHUNK - 1) / WN_CHUNK);
@@ -199,6 +201,7 @@ int run_prepare(const Dims& d, int prec, const Plan& p, const float* const* tuck
         rc = cti_transpose_f32(p.Teff, (int64_t)hr * hr * d.G, (int64_t)hr * hr * hr * d.G, p.Tt, hr, (int64_t)hr * hr * hr * d.G, hr, hr * hr * d.G, d.R, stream);
         if (rc) return rc;
         rc = core_small_tk_layout(p.Teff, p.Tk, d.R, hr, d.G, st); if (rc) return rc;
+        rc = mbuild_f6_tj_layout(p.Teff, p.Tj, d.R, hr, d.G, st); if (rc) return rc;
         if (weight_planes) {
             for (int s = 0; s < 3; ++s) {
                 rc = split_planes(tucker_wv[s], in[s], d.h, in[s], p.wt[s].hi, p.wt[s].lo, p.wt[s].rows_alloc, st); if (rc) return rc;
@@ -479,7 +482,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
             gb.seg[gb.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
             gb.seg[gb.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
             if (!guard_ablate()) { rc = guard_scan(gb, sb); if (rc) return finish(rc); }
-            rc = mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb); if (rc) return finish(rc);
+            rc = mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb, p.Tj); if (rc) return finish(rc);
             (void)hipEventRecord(ev_join, sb);
         }
         // main stream: the whole a side, its scans, the join, the cancellation estimate + verdict, the mode-3 product
@@ -557,7 +560,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     if (f6) {
         // M as fp32 rows (MFMA M build, or the VALU forms for other shapes), then one encoding pass into planes whose batches of V*Q*G rows
         // start at multiples of 8 rows
-        rc = p.Mf32 ? CTI_E_UNSUPPORTED : mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb);       // the planes directly (hr = 16, glimpse 2, X + hold buffer fit the LDS)
+        rc = p.Mf32 ? CTI_E_UNSUPPORTED : mbuild_mfma_f6(p.Vr, p.Qr, p.Tt, p.f_Mp, B, V, Q, R, hr, G, sb, p.Tj);       // the planes directly (hr = 16, glimpse 2, X + hold buffer fit the LDS)
         if (rc == CTI_E_UNSUPPORTED && !p.Mf32) return finish(fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: the direct-encoding M build refused a shape its plan accepted"));
         if (rc == CTI_E_UNSUPPORTED) {
             rc = mbuild_mfma(p.Vr, p.Qr, p.Tt, nullptr, nullptr, p.Mf32, B, V, Q, R, hr, G, h, sb);
