@@ -2,7 +2,7 @@
 # Copy the summaries of gpurun_out/evidence (written by tools/collect_evidence.sh on the GPU box) into profiles/ (tracked).
 set -eu
 cd "$(dirname "$0")/.."
-E=gpurun_out/evidence; R=${1:-r05}
+E=gpurun_out/evidence; R=${1:-r06}
 cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
 for f in f16f6 bf16x3 fp32 bf16 train train_rccl_world1 c3 c4 c4_serial rccl_world1; do [ -s $E/bench_$f.log ] && tail -1 $E/bench_$f.log > profiles/${R}_bench_$f.json; done
 cp $E/stats/fwd_kernel_stats.csv profiles/${R}_rocprof_kernel_stats_f16f6.csv
