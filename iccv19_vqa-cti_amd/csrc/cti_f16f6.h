@@ -223,8 +223,11 @@ typedef unsigned short f6_u16x2 __attribute__((ext_vector_type(2)));
 #endif
 // SAT_EXCESS = false drops that branch (a saturated value then decodes to +-65504): for callers at their register ceiling -- the branch keeps
 // all 32 inputs and the 16 packed hi words alive to the end.
+typedef __attribute__((address_space(3))) f6_u32x4 f6_lds_u32x4;
+// h_lds != NULL (round 6, the M build): the row's four H pieces go to that LDS address (consecutive 16-B units) instead of Hrow -- the caller re-reads them so that four
+// lanes store one row's 64 B (a lane storing its own row's pieces makes every store instruction touch 64 cache lines)
 template <bool SAT_EXCESS = true>
-__device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float lo_bound, char* Hrow, char* FLrow, char* Srow, int hstep = 1) {      // hstep: 16-B units between the row's four H pieces (1 = the row as it lies in the plane; timing experiments only otherwise)
+__device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float lo_bound, char* Hrow, char* FLrow, char* Srow, int hstep = 1, f6_lds_u32x4* h_lds = nullptr) {      // hstep: 16-B units between the row's four H pieces (1 = the row as it lies in the plane; timing experiments only otherwise)
     if ((CTI_F6_ABL & 16) && x[31] != 12345.f) { Hrow = FLrow = Srow = nullptr; }      // timing-only ablation: the arithmetic without the stores
     const float lo_sat = fmaxf(lo_bound, -65504.f);
     float ml = 0.f, mx = 0.f;                                       // mx: max |hi part|
@@ -241,7 +244,8 @@ __device__ __forceinline__ void f6_encode_row32_regs(const float (&x)[32], float
         if (SAT_EXCESS) mx = fmaxf(fmaxf(mx, fabsf(hf[0])), fabsf(hf[1]));
         else            mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));   // (of the inputs: rounding is monotone; frees the converted pair earlier -- the M build's ceiling)
         hw[u] = __builtin_bit_cast(unsigned, h);
-        if ((u & 3) == 3 && (!(CTI_F6_ABL & 16) || Hrow)) reinterpret_cast<f6_u32x4*>(Hrow)[(u >> 2) * hstep] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
+        if ((u & 3) == 3 && h_lds) h_lds[u >> 2] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
+        else if ((u & 3) == 3 && (!(CTI_F6_ABL & 16) || Hrow)) reinterpret_cast<f6_u32x4*>(Hrow)[(u >> 2) * hstep] = f6_u32x4{hw[u - 3], hw[u - 2], hw[u - 1], hw[u]};
     }
     const float mh = SAT_EXCESS ? mx : static_cast<float>(static_cast<_Float16>(mx));
     if (SAT_EXCESS && mh >= 65504.f) {                                          // a saturated value: its residual carries the excess (as the LDS encoder has it)

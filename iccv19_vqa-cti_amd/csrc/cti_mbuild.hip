@@ -1060,6 +1060,9 @@ __global__ void tj_layout_kernel(const float* __restrict__ Teff, unsigned short*
 }
 
 constexpr int KQ_NW = 8;
+#ifndef CTI_KQ_ABL
+#define CTI_KQ_ABL 0       // timing-only ablation mask: 1 no encoder / stores, 2 no MFMA chain, 4 no T loads
+#endif
 __global__ __launch_bounds__(64 * KQ_NW) void mbuild_f6_kq_kernel(const float* __restrict__ Vr, const float* __restrict__ Qr, const unsigned short* __restrict__ Tj,
                                                                   F6Planes P, int V, int Q, int R) {
     constexpr int G = 2;
@@ -1068,7 +1071,9 @@ __global__ __launch_bounds__(64 * KQ_NW) void mbuild_f6_kq_kernel(const float* _
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, s4 = lane >> 4;
     const int K = R * 16, VTL = (V + 15) >> 4, items = (R >> 1) * G * VTL;
-    const int64_t tplane = (int64_t)R * 16 * 512, rows_b = (int64_t)b * V * Q * G;
+    extern __shared__ __attribute__((aligned(16))) char kq_lds[];                        // [wave][lane][64 B]: the H pieces on their way out
+    const int64_t tplane = (int64_t)R * 16 * 512;
+    const int64_t prow_b = f6_prow(P, (int64_t)b * V * Q * G);                              // the sample's first plane row (its rows are consecutive from there)
     const float* qrow = Qr + ((int64_t)b * Q + (c < Q ? c : 0)) * K + s4 * 4;                // A operand of the second product: Q^[q = c][(r, j = 4 s4 ..)]
     // items ((kb, g), vt): the waves that run together share a (rank pair, g) slice of T
     for (int item = wid; item < items; item += KQ_NW) {
@@ -1076,38 +1081,58 @@ __global__ __launch_bounds__(64 * KQ_NW) void mbuild_f6_kq_kernel(const float* _
         const int v = vt * 16 + c;
         const float* vrow = Vr + ((int64_t)b * V + (v < V ? v : 0)) * K + s4 * 4;            // B operand of the first product: V^[v = c][(r, i = 4 s4 ..)]
         float x[4][32];                                                                     // row (v, q = 4 s4 + e, g): K = 32 kb .. + 31
+        // the item's 2 x 16 (rank, k) steps as ONE stream of T fragments through a rolling window of eight (hi + lo: 32 registers): the loads of step t + 8 fly
+        // under the products of step t (the first form loaded a rank's sixteen at once and waited: ~58 of the kernel's 223 us)
+        const u64* tr0 = reinterpret_cast<const u64*>(Tj + ((int64_t)(2 * kb) * 16 * 2 + g) * 256 + c * 16 + s4 * 4);       // step t = 16 rl + k: + t * 512 / 4
+        mb_s16x4 vh[2], vl[2], qh[2], ql[2];
 #pragma unroll
         for (int rl = 0; rl < 2; ++rl) {
-            const int r = 2 * kb + rl;
-            mb_s16x4 vh, vl, qh, ql;
-            mb_split4(*reinterpret_cast<const float4*>(vrow + r * 16), vh, vl);
-            mb_split4(*reinterpret_cast<const float4*>(qrow + r * 16), qh, ql);
-            const u64* tr = reinterpret_cast<const u64*>(Tj + ((int64_t)r * 16 * 2 + g) * 256 + c * 16 + s4 * 4);      // + k * 512 / 4: T[r, :, j = c, k, g] as [i]
-            u64 th_[16], tl_[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { th_[k] = tr[k * 128]; tl_[k] = tr[(tplane >> 2) + k * 128]; }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const mb_s16x4 th = __builtin_bit_cast(mb_s16x4, th_[k]), tl = __builtin_bit_cast(mb_s16x4, tl_[k]);
-                mb_s16x4 dh, dl;
-                const mb_f32x4 d = mb_mfma3<3>(th, tl, vh, vl, mb_f32x4{0.f, 0.f, 0.f, 0.f});          // D[j = 4 s4 + e][v = c]
-                mb_split4(make_float4(d[0], d[1], d[2], d[3]), dh, dl);
-                const mb_f32x4 mt = mb_mfma3<3>(qh, ql, dh, dl, mb_f32x4{0.f, 0.f, 0.f, 0.f});         // M^t[q = 4 s4 + e][v = c]
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e][rl * 16 + k] = mt[e];
-            }
+            mb_split4(*reinterpret_cast<const float4*>(vrow + (2 * kb + rl) * 16), vh[rl], vl[rl]);
+            mb_split4(*reinterpret_cast<const float4*>(qrow + (2 * kb + rl) * 16), qh[rl], ql[rl]);
         }
-        if (v < V) {
+        u64 th_[8], tl_[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int q = 4 * s4 + e;
-                if (q < Q) {
-                    const int64_t prow = f6_prow(P, rows_b + ((int64_t)v * Q + q) * G + g);
-                    const int64_t o = (int64_t)kb * P.rows_alloc + prow;
-                    f6_encode_row32_regs<false>(x[e], -__builtin_huge_valf(), reinterpret_cast<char*>(P.H) + o * 64, reinterpret_cast<char*>(P.FL) + o * 24,
-                                                reinterpret_cast<char*>(P.S) + ((int64_t)kb * P.rows_allocS + prow) * 2);
+        for (int t = 0; t < 8; ++t) { th_[t] = (CTI_KQ_ABL & 4) ? (u64)(lane + t) : tr0[t * 128]; tl_[t] = (CTI_KQ_ABL & 4) ? (u64)(lane * 3 + t) : tr0[(tplane >> 2) + t * 128]; }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int rl = t >> 4;
+            const mb_s16x4 th = __builtin_bit_cast(mb_s16x4, th_[t & 7]), tl = __builtin_bit_cast(mb_s16x4, tl_[t & 7]);
+            if (t + 8 < 32) { th_[t & 7] = (CTI_KQ_ABL & 4) ? (u64)(lane + t) : tr0[(t + 8) * 128]; tl_[t & 7] = (CTI_KQ_ABL & 4) ? (u64)(lane * 3 + t) : tr0[(tplane >> 2) + (t + 8) * 128]; }
+            mb_s16x4 dh, dl;
+            if (CTI_KQ_ABL & 2) { x[0][t] = (float)th[0] + (float)tl[1]; x[1][t] = (float)vh[rl][0]; x[2][t] = (float)qh[rl][1]; x[3][t] = (float)ql[rl][2] + (float)vl[rl][3]; continue; }
+            const mb_f32x4 d = mb_mfma3<3>(th, tl, vh[rl], vl[rl], mb_f32x4{0.f, 0.f, 0.f, 0.f});          // D[j = 4 s4 + e][v = c]
+            mb_split4(make_float4(d[0], d[1], d[2], d[3]), dh, dl);
+            const mb_f32x4 mt = mb_mfma3<3>(qh[rl], ql[rl], dh, dl, mb_f32x4{0.f, 0.f, 0.f, 0.f});         // M^t[q = 4 s4 + e][v = c]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e][t] = mt[e];
+        }
+        // encode: lane (c, s4) owns rows (v, q = 4 s4 + e, g).  The H piece stores go through a wave-private LDS patch [lane][64 B] so that FOUR lanes store one
+        // row's 64 B: a lane storing its own row's four pieces makes each store instruction touch 64 cache lines (the stores were ~half of the kernel)
+        f6_lds_u32x4* const hl = (f6_lds_u32x4*)((__attribute__((address_space(3))) char*)kq_lds + wid * 4096 + lane * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = 4 * s4 + e;
+            if (v < V && q < Q && (!(CTI_KQ_ABL & 1) || x[0][0] == 12345.f)) {
+                const int64_t prow = prow_b + (v * Q + q) * G + g;
+                const int64_t o = (int64_t)kb * P.rows_alloc + prow;
+                f6_encode_row32_regs<false>(x[e], -__builtin_huge_valf(), nullptr, reinterpret_cast<char*>(P.FL) + o * 24,
+                                            reinterpret_cast<char*>(P.S) + ((int64_t)kb * P.rows_allocS + prow) * 2, 1, hl);
+            }
+            // (same wave writes and reads the patch: LDS operations of one wave complete in order; the compiler keeps the order across the clobbers)
+            asm volatile("" ::: "memory");
+            if (!(CTI_KQ_ABL & 1)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = 16 * j + (lane >> 2), piece = lane & 3;              // slot = the lane that encoded: (c' = slot & 15, s4' = slot >> 4) = (slot & 15, j)
+                    const int v2 = vt * 16 + (slot & 15), q2 = 4 * j + e;
+                    if (v2 < V && q2 < Q) {
+                        const f6_u32x4 d = *(f6_lds_u32x4*)((__attribute__((address_space(3))) char*)kq_lds + wid * 4096 + slot * 64 + piece * 16);
+                        const int64_t o2 = (int64_t)kb * P.rows_alloc + prow_b + (v2 * Q + q2) * G + g;
+                        *reinterpret_cast<f6_u32x4*>(reinterpret_cast<char*>(P.H) + o2 * 64 + piece * 16) = d;
+                    }
                 }
             }
+            asm volatile("" ::: "memory");
         }
     }
 }
@@ -1179,7 +1204,7 @@ int mbuild_mfma_f6(const float* Vr, const float* Qr, const float* Tt, const F6Pl
     if ((reinterpret_cast<uintptr_t>(Vr) | reinterpret_cast<uintptr_t>(Qr) | reinterpret_cast<uintptr_t>(Tt)) & 15) return CTI_E_UNSUPPORTED;
     static const bool old_env = [] { const char* e = getenv("CTI_MBF6_OLD"); return e && e[0] == '1'; }();
     if (Tj && !old_env && !(reinterpret_cast<uintptr_t>(Tj) & 15)) {        // round 6: no LDS, no barriers (CTI_MBF6_OLD=1: the round-2 kernel, A/B)
-        hipLaunchKernelGGL(mbuild_f6_kq_kernel, dim3(B), dim3(64 * KQ_NW), 0, st, Vr, Qr, reinterpret_cast<const unsigned short*>(Tj), P, V, Q, R);
+        hipLaunchKernelGGL(mbuild_f6_kq_kernel, dim3(B), dim3(64 * KQ_NW), KQ_NW * 4096, st, Vr, Qr, reinterpret_cast<const unsigned short*>(Tj), P, V, Q, R);
         return launch_status("mbuild_f6_kq");
     }
     const size_t lds = mbuild_mfma_f6_lds(V, Q, G);
