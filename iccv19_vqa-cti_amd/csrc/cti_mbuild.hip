@@ -1258,9 +1258,11 @@ int mbuild_core_small(const float* Vr, const float* Qr, const float* Tt, const f
             if (e != hipSuccess) return fail((int)e, "mbuild_core_small: hipFuncSetAttribute: %s", hipGetErrorString(e));                   \
             hipLaunchKernelGGL(kern, dim3(B), dim3(64 * AQ_NW), lds_aq, st, Vr, Qr, reinterpret_cast<const unsigned short*>(Tk), Ar, out, V, Q, A, R, nch, sm_mask, sm_p, v_rep > 0 ? v_rep : 1); \
         }
-        if (maxt <= 6) {
+        // (three-product mode with more than three tiles per wave -- V > 48 -- spills a register to scratch: that shape stays on the round-3 kernel;
+        // tests/test_abi.py keeps every kernel that may run beside another stream scratch-free)
+        if (maxt <= 3 || (terms == 1 && maxt <= 6)) {
             if (terms == 1) { if (maxt <= 3) CTI_AQ_LAUNCH(1, 3) else CTI_AQ_LAUNCH(1, 6) }
-            else            { if (maxt <= 3) CTI_AQ_LAUNCH(3, 3) else CTI_AQ_LAUNCH(3, 6) }
+            else            CTI_AQ_LAUNCH(3, 3)
             return launch_status("core_small_aq");
         }
 #undef CTI_AQ_LAUNCH
