@@ -373,10 +373,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // HBM-bound split of `a`, which uses no LDS) and chain B (v and q sides + M build: 0.75 ms, LDS-heavy and latency-bound).  With
     // an auxiliary stream from the caller chain B runs beside chain A's split pass: fork/join with two events, no host sync.
     hipStream_t sb = aux_stream ? as_stream(aux_stream) : st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_at = nullptr;          // ev_at: the a side's Tucker product has encoded a~ (range guard, f16f6 mode)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_at = nullptr, ev_guard = nullptr;   // ev_at: the a side has encoded a~ (early scan) / A^ (the guard beside the mode-3 product); ev_guard: the verdict
     if (aux_stream) {
         if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-            (p.guard && hipEventCreateWithFlags(&ev_at, hipEventDisableTiming) != hipSuccess))
+            (p.guard && (hipEventCreateWithFlags(&ev_at, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_guard, hipEventDisableTiming) != hipSuccess)))
             return fail(CTI_E_UNSUPPORTED, "cti_tcnet_forward: hipEventCreate failed");
         (void)hipEventRecord(ev_fork, st);                  // scales, T_eff (and the mask) precede both chains
         (void)hipStreamWaitEvent(sb, ev_fork, 0);
@@ -385,6 +385,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_at) (void)hipEventDestroy(ev_at);
+        if (ev_guard) (void)hipEventDestroy(ev_guard);
         return code;
     };
     const int Kh = planes_kp(h);
@@ -500,6 +501,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (!guard_ablate()) {
             rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, st); if (rc) return finish(rc);
             rc = guard_scan(ga, st); if (rc) return finish(rc);
+            (void)hipEventRecord(ev_guard, st); (void)hipStreamWaitEvent(sb, ev_guard, 0);      // "an event recorded on aux_stream after the call marks the verdict" (cti_hip.h)
         }
         F6GemmArgs c{};
         c.A = p.f_Mp; c.B = p.f_Arp; c.rA = p.f_Mp.rstride; c.rB = p.f_Arp.rstride; c.nb = B; c.M = (int)mrows_per_b; c.N = A;
@@ -546,11 +548,20 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         if (guard_ablate()) return CTI_OK;
         return guard_scan(gb, sb);
     };
+    // Round 6: with an auxiliary stream the guard's kernels leave the critical path altogether.  They need 35-39 registers and <= 544 B of LDS, and the mode-3
+    // product's persistent workgroups leave every SIMD 96 registers and every CU 1.5 KiB: ONE scan of everything (`a`, a~, A^, M, the a-side weights, the
+    // fp32 sweeps) + the cancellation estimate + the verdict run on the auxiliary stream BESIDE the mode-3 product, behind the M build and an event of the
+    // rank nets' product; the main stream meets them again in front of the NaN fill.  (Rounds 3-5: early / middle / final scans in front of the product,
+    // 0.10-0.15 ms of the step by the guard-off A/B, profiles/r05_guard_ab.txt; CTI_F6_GUARD_FRONT=1 restores that placement for the A/B.)
+    static const bool join_before_rank = [] { const char* e = getenv("CTI_F6_JOIN"); return e && e[0] == 'r'; }();
+    static const bool guard_front_env = [] { const char* e = getenv("CTI_F6_GUARD_FRONT"); return e && e[0] == '1'; }();
+    const bool early_join = f6 && aux_stream && join_before_rank;
+    const bool guard_beside = f6 && aux_stream && p.guard && !guard_front_env && !guard_late() && !early_join;
     if (f6 && aux_stream) {
         // host order matters: the main stream's first half (encode `a`, Tucker product, ev_at) is enqueued BEFORE chain B waits for ev_at
         a_phase = 1;
         rc = side(2, st); if (rc) return finish(rc);
-        if (!guard_late()) {
+        if (!guard_late() && !guard_beside) {
             (void)hipStreamWaitEvent(sb, ev_at, 0);
             rc = early_scan(true); if (rc) return finish(rc);
         }
@@ -589,11 +600,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // 160 KB of LDS), so its 0.34 ms are exclusive wherever they fall: launched beside the rank nets' product it crawls in that product's tail and
     // finishes ~0.3 ms AFTER it (timeline in profiles/r03_step_timeline.txt) with the mode-3 product waiting.  CTI_F6_JOIN=rank (experiment):
     // join BEFORE the rank nets' product instead -- the M build then runs alone between the two a-side products.
-    static const bool join_before_rank = [] { const char* e = getenv("CTI_F6_JOIN"); return e && e[0] == 'r'; }();
-    const bool early_join = f6 && aux_stream && join_before_rank;
     if (early_join) (void)hipStreamWaitEvent(st, ev_join, 0);
     rc = side(2, st); if (rc) return finish(rc);
-    if (f6 && aux_stream && !early_join && !guard_late()) {  // middle scan: A^, while the main stream would otherwise only wait for chain B
+    if (guard_beside) (void)hipEventRecord(ev_at, st);     // A^ is encoded: what the auxiliary stream's guard kernels wait for
+    if (f6 && aux_stream && !early_join && !guard_late() && !guard_beside) {  // middle scan: A^, while the main stream would otherwise only wait for chain B
         GuardArgs gm{};
         gm.words = p.guard;
         gm.seg[gm.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
@@ -611,26 +621,34 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         GuardArgs ga{};
         ga.words = p.guard; ga.final = 1; ga.n_slots = 9; ga.f32_slots = 7u << 6;
         ga.seg[ga.nseg++] = guard_seg_planes(p.f_Mp, (int64_t)B * mrows_per_b, 0);
-        if (!aux_stream || guard_late()) {
+        if (!aux_stream || guard_late() || guard_beside) {
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_wta, h, 1);             // written by side(2) above when the caller keeps no prepared block
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_wra, h, 2);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_Ain, rows[2], 3);
             ga.seg[ga.nseg++] = guard_seg_planes(p.f_At, rows[2], 4);
         }
-        if (!aux_stream || early_join || guard_late()) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
-        if (guard_late()) {                                  // ONE scan for everything, behind the join (see guard_late)
+        if (!aux_stream || early_join || guard_late() || guard_beside) ga.seg[ga.nseg++] = guard_seg_planes(p.f_Arp, rows[2], 5);
+        if (guard_late() || guard_beside) {                  // ONE scan for everything
             ga.seg[ga.nseg++] = guard_seg_f32(p.Vr, rows[0] * h, 6);
             ga.seg[ga.nseg++] = guard_seg_f32(p.Qr, rows[1] * h, 7);
             ga.seg[ga.nseg++] = guard_seg_f32(p.Tt, (int64_t)R * hr * hr * hr * G, 8);
         }
-        if (!guard_ablate()) {
+        const bool guard_on = p.guard && !guard_ablate();
+        if (guard_on && guard_beside) {                      // auxiliary stream, behind the M build (stream order) and A^ (ev_at): runs while the mode-3 product does
+            (void)hipStreamWaitEvent(sb, ev_at, 0);
+            rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, sb); if (rc) return finish(rc);
+            rc = guard_scan(ga, sb); if (rc) return finish(rc);
+            (void)hipEventRecord(ev_guard, sb);
+        } else if (guard_on) {
             rc = guard_cancel(p.f_Mp, mrows_per_b, p.f_Arp, A, B, p.guard, st); if (rc) return finish(rc);   // the estimate the final scan's verdict reads
             rc = guard_scan(ga, st); if (rc) return finish(rc);
+            if (aux_stream) { (void)hipEventRecord(ev_guard, st); (void)hipStreamWaitEvent(sb, ev_guard, 0); }   // the verdict is visible on the auxiliary stream too (cti_hip.h)
         }
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = gemm_nt_f16f6(c, st);
         if (ev_core_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_end), st);
         if (rc) return finish(rc);
+        if (guard_on && guard_beside) (void)hipStreamWaitEvent(st, ev_guard, 0);
         return finish(guard_ablate() ? CTI_OK : guard_poison(p.guard, out, (int64_t)B * V * Q * A * G, st));
     }
     PlaneGemmArgs c{};                                       // mode 3 + rank sum: rows (vq,g) x columns a, per sample

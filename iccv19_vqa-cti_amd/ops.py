@@ -146,7 +146,7 @@ def _guard_resources(device):
     r = _guard_res.get(key)
     if r is None:
         lib = L.lib()
-        r = _guard_res[key] = (lib.cti_event_create(), lib.cti_event_create(), torch.cuda.Stream(device=device))
+        r = _guard_res[key] = (lib.cti_event_create(), lib.cti_event_create(), torch.cuda.Stream(device=device), lib.cti_event_create())
     return r
 
 
@@ -653,7 +653,7 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
         ev0, ev1 = lib.cti_event_create(), lib.cti_event_create()
         _prof.setdefault("paralind_core", []).append(_LibEventPair(ev0, ev1))
     elif wait_guard:
-        ev0, ev1, _ = _guard_resources(v.device)
+        ev0, ev1 = _guard_resources(v.device)[:2]
     part = p_att = None
     if want_sm_partials:
         pb = lib.cti_tcnet_softmax_partials_bytes(B, V, Q, A, h, G, pr)
@@ -702,7 +702,13 @@ def tcnet_forward(v, q, a, tucker, rank, T_g, relu=True, want_mask=False, prec=N
     if wait_guard:
         import ctypes as _C
         status = _C.c_uint32(0)
-        L.check(lib.cti_guard_read(ws.data_ptr(), ev0, _guard_resources(v.device)[2].cuda_stream, _C.byref(status)), "cti_guard_read")
+        ev_verdict, aux = ev0, _aux_stream(v.device)
+        if aux is not None:
+            # with an auxiliary stream the guard's kernels run there, BESIDE the mode-3 product (round 6), and are the last work the call leaves on it:
+            # an event recorded on it now marks the verdict (include/cti_hip.h, "Range guard")
+            ev_verdict = _guard_resources(v.device)[3]
+            L.check(lib.cti_event_record(ev_verdict, aux), "cti_event_record")
+        L.check(lib.cti_guard_read(ws.data_ptr(), ev_verdict, _guard_resources(v.device)[2].cuda_stream, _C.byref(status)), "cti_guard_read")
         _range_log["last_status"] = int(status.value)
         if _range_debug:
             ratio = _C.c_float(0.0)
