@@ -151,7 +151,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16F6 = 0, 1, 2, 3
 E_UNSUPPORTED = -4                                   # CTI_E_UNSUPPORTED: shape / mode outside a specialised kernel
 ACT_NONE, ACT_RELU = 0, 1
 TUNE_GEMM_CFG, TUNE_TRI_CHUNK = 1, 2                # cti_set_tuning keys
-TUNE_GUARD_RHO_BF16X3, TUNE_GUARD_RHO_FP32, TUNE_GUARD_POISON_BITS, TUNE_F6_CORE_FREE_CUS, TUNE_GUARD_STRATA, TUNE_GEMM16_SK = 3, 4, 5, 6, 7, 8     # f16f6 guard policy (include/cti_hip.h)
+TUNE_GUARD_RHO_BF16X3, TUNE_GUARD_RHO_FP32, TUNE_GUARD_POISON_BITS, TUNE_F6_CORE_FREE_CUS, TUNE_GUARD_STRATA, TUNE_GEMM16_SK, TUNE_GRU_PERSISTENT = 3, 4, 5, 6, 7, 8, 9     # f16f6 guard policy (include/cti_hip.h)
 GUARD_SATURATED, GUARD_UNDERFLOW, GUARD_NONFINITE = 1, 2, 4     # status bits of the f16f6 range guard (cti_guard_read)
 
 _lib = None

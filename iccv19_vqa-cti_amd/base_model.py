@@ -321,7 +321,14 @@ class _TriModel(nn.Module):
     def _forward(self, t_att, v, q, ans):
         v = _v_as_taken(v, self)
         side = None if torch.is_grad_enabled() else ops.aux_stream_object(v.device)
-        if side is not None:
+        if side is not None and ops.gru_persistent_ok():
+            # persistent GRUs (one launch each, every workgroup resident): one behind the other on THIS stream, never beside each other
+            cur = torch.cuda.current_stream()
+            _refresh_scales(v.device)
+            side.wait_stream(cur)
+            ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+            q_emb = self.q_emb.forward_all(self.w_emb(q))
+        elif side is not None:
             # inference: the answer GRU (a few short, latency-bound steps) runs on the auxiliary stream beside the question GRU
             cur = torch.cuda.current_stream()
             _refresh_scales(v.device)

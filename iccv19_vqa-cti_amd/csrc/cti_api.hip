@@ -26,6 +26,7 @@ static thread_local int g_guard_rho_milli[2] = {2750, 5500};      // cancellatio
 static thread_local int g_guard_poison_bits = 31;                 // status bits that NaN-fill the output of a guarded call
 static thread_local int g_guard_strata = 1;                       // test knob: 0 = the cancellation estimate samples 32 evenly spaced rows per operand (round 4)
 static thread_local int g_gemm16_sk = -1;                          // stream-K cut of the plain-bf16 row GEMM: -1 = where it was measured to pay (three or more rounds of tiles), 0 = never, 1 = wherever it can be planned
+static thread_local int g_gru_persistent = 0;                      // 1 = cti_gru_forward may run all steps of an eligible call as ONE persistent launch (the caller keeps two of them off the chip at once)
 static thread_local int g_f6_core_free_cus = -1;                  // CUs the mode-3 product leaves to the guard kernels beside it (-1 = the library's default)
 int tuning_gemm_cfg() { return g_gemm_cfg; }
 int64_t tuning_tri_chunk() { return (int64_t)g_tri_chunk; }
@@ -34,6 +35,7 @@ unsigned tuning_guard_poison_bits() { return (unsigned)g_guard_poison_bits; }
 int tuning_f6_core_free_cus() { return g_f6_core_free_cus; }
 int tuning_guard_strata() { return g_guard_strata; }
 int tuning_gemm16_sk() { return g_gemm16_sk; }
+int tuning_gru_persistent() { return g_gru_persistent; }
 
 }  // namespace cti
 
@@ -64,6 +66,9 @@ extern "C" int cti_set_tuning(int key, int64_t value) {
         case CTI_TUNE_GEMM16_SK:
             CTI_REQUIRE(value >= -1 && value <= 1, CTI_E_SHAPE, "cti_set_tuning: GEMM16_SK must be -1 (auto), 0 or 1, got %lld", (long long)value);
             g_gemm16_sk = (int)value; return CTI_OK;
+        case CTI_TUNE_GRU_PERSISTENT:
+            CTI_REQUIRE(value == 0 || value == 1, CTI_E_SHAPE, "cti_set_tuning: GRU_PERSISTENT must be 0 or 1, got %lld", (long long)value);
+            g_gru_persistent = (int)value; return CTI_OK;
         default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
     }
 }
@@ -77,6 +82,7 @@ extern "C" int64_t cti_get_tuning(int key) {
         case CTI_TUNE_F6_CORE_FREE_CUS: return g_f6_core_free_cus;
         case CTI_TUNE_GUARD_STRATA: return g_guard_strata;
         case CTI_TUNE_GEMM16_SK: return g_gemm16_sk;
+        case CTI_TUNE_GRU_PERSISTENT: return g_gru_persistent;
         default: return INT64_MIN;
     }
 }

@@ -22,6 +22,7 @@ int64_t tuning_tri_chunk();       // 0 auto (32768), else positions per chunk of
 float tuning_guard_rho(int which);    // f16f6 guard policy (cti_set_tuning keys 3 / 4): cancellation estimate beyond which a call belongs in bf16x3 (0) / exact fp32 (1)
 unsigned tuning_guard_poison_bits();  // key 5: status bits that NaN-fill the output
 int tuning_guard_strata();            // key 7 (tests): 0 = the cancellation estimate without its strata maxima
+int tuning_gru_persistent();          // key 9: 1 = cti_gru_forward may use its persistent form (cti_gru.hip)
 int tuning_gemm16_sk();               // key 8: stream-K cut of cti_gemm16.hip's row products (-1 auto, 0 never, 1 wherever plannable)
 int tuning_f6_core_free_cus();        // key 6: CUs the mode-3 product leaves free for the guard kernels beside it (-1 = default)
 

@@ -17,6 +17,14 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x))
 __device__ __forceinline__ unsigned short bf16b(float x) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(x)); }
 __device__ __forceinline__ float bf16f(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
+// The gates of one unit (order r, z, n; g* = the recurrent side incl. b_hh, gi* = the input side incl. b_ih).  The two multiply-adds are EXPLICIT fmas so that every
+// kernel that calls this rounds alike whatever its surroundings let the compiler contract: the persistent form is tested bit for bit against the per-step form.
+__device__ __forceinline__ float gru_gates(float gir, float giz, float gin, float g0, float g1, float g2, float hp, float& r, float& z, float& n) {
+    r = sigm(gir + g0); z = sigm(giz + g1);
+    n = tanhf(__builtin_fmaf(r, g2, gin));
+    return __builtin_fmaf(z, hp, (1.f - z) * n);
+}
+
 // element (row, col) of a chunk-major plane pair: (col >> 4) * pitch + row * 16 + (col & 15)
 __device__ __forceinline__ void store_planes(unsigned short* hi, unsigned short* lo, int64_t pitch, int row, int col, float x) {
     const int64_t o = (int64_t)(col >> 4) * pitch + (int64_t)row * 16 + (col & 15);
@@ -42,9 +50,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
     }
     const float* gib = gi + (int64_t)b * ld_gi;
     const float hp = hprev ? hprev[idx] : 0.f;
-    const float r = sigm(gib[j] + g0), z = sigm(gib[H + j] + g1);
-    const float n = tanhf(gib[2 * H + j] + r * g2);
-    const float h = (1.f - z) * n + z * hp;
+    float r, z, n;
+    const float h = gru_gates(gib[j], gib[H + j], gib[2 * H + j], g0, g1, g2, hp, r, z, n);
     out[(int64_t)b * ld_out + j] = h;
     if (h_tm) h_tm[idx] = h;
     if (save) {
@@ -216,9 +223,8 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
         const float* gib = gi + (int64_t)b * ld_gi;
         const int64_t idx = (int64_t)b * H + j;
         const float hp = hprev ? hprev[idx] : 0.f;
-        const float r = sigm(gib[j] + g0), z = sigm(gib[H + j] + g1);
-        const float n = tanhf(gib[2 * H + j] + r * g2);
-        const float h = (1.f - z) * n + z * hp;
+        float r, z, n;
+        const float h = gru_gates(gib[j], gib[H + j], gib[2 * H + j], g0, g1, g2, hp, r, z, n);
         out[(int64_t)b * ld_out + j] = h;
         if (h_tm) h_tm[idx] = h;
         if (save) {
@@ -226,6 +232,121 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
             sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = g2; sv[4 * H + j] = h;
         }
         if (ph) store_planes(ph, pl, pitchP, b, j, h);
+    }
+}
+
+// ---- persistent forward (plain bf16, inference; round 6): ALL time steps in ONE launch ----------------------------------------------------------
+// The per-step kernel above re-streams its slice of W_hh (96 KiB) through LDS every step and pays a kernel boundary per step: ~12 us a step at
+// B = 256, H = 1 024 for 0.3 us of MFMA work.  Here a workgroup (64 batch rows x 16 hidden units, 4 waves) keeps its W_hh slice in LDS for the
+// whole sequence -- [K step][chunk][gate * 16 + unit][32 B], 3 KiB per 32-deep K step -- and its own h_{t-1} values in registers; what crosses
+// workgroups per step is h_t as bf16 (the chunk-major plane the step kernel also writes: 2 KiB per workgroup, 512 KiB in all), handed over by
+// the recipe of MI355X_MICROARCH.md's hand-off table (third row), with NO agent-scope fence on either side (round 4's attempt paid ~7 us a step
+// for a release + an acquire):
+//   producer: the 16 x 16 tile of a wave goes through 512 B of LDS so that ONE `global_store_dwordx4 sc1` of 32 lanes writes four whole 128-B
+//             lines; every storing wave waits vmcnt(0); workgroup barrier; ONE lane adds 1 to the row block's counter (agent-scope atomic);
+//   consumer: ONE lane polls that counter with `sc1` loads until all gridDim.x workgroups of the row block have added t times; workgroup barrier;
+//             every wave then reads its 16 rows x 1 024 k of h_{t-1} straight into MFMA A fragments with `buffer_load_dwordx4 sc1` (served by
+//             the L2 / the memory side, never by a stale L1 line).
+// Ping-pong planes: a workgroup that has passed the poll of step t knows every workgroup has finished READING h_{t-2} (they added after it), so
+// step t may overwrite that plane.  Row blocks never wait for each other.  EVERY workgroup of a row block must be resident for the others to pass:
+// the launcher refuses grids beyond the device's compute-unit count, the caller keeps two such launches from sharing the chip (ops.py: one stream
+// per device carries them), and a poll that exceeds `spin_limit` rounds sets the error word and NaN-fills this workgroup's outputs instead of hanging.
+typedef unsigned gp_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int GP_TR = 512;                                          // LDS bytes per wave for the tile transposition
+constexpr int GP_SYNC_BYTES = 4096;                                 // counters: one 128-B line per row block (<= 31), then the error word's line
+__global__ __launch_bounds__(256, 1) void gru_persistent_kernel(unsigned short* __restrict__ hp0, unsigned short* __restrict__ hp1, int64_t pitchH, size_t plane_bytes,
+                                                                const unsigned short* __restrict__ Wh, int64_t pitchW, int nsteps,
+                                                                const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ b_hh,
+                                                                float* __restrict__ out, int64_t ld_out, int T, int H, unsigned* __restrict__ sync,
+                                                                unsigned spin_limit) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];      // W_hh slice, then 4 x GP_TR
+    __shared__ int dead;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u0 = blockIdx.x * 16, row0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < nsteps * 192; i += 256) {          // 16-B units: (K step, chunk, row rr = gate * 16 + unit, half)
+        const int hf = i & 1, rr = (i >> 1) % 48, c = ((i >> 1) / 48) & 1, ks = (i >> 1) / 96;
+        const unsigned short* src = Wh + (int64_t)(2 * ks + c) * pitchW + ((int64_t)(rr >> 4) * H + u0 + (rr & 15)) * 16 + hf * 8;
+        *reinterpret_cast<uint4*>(psm + ks * 3072 + c * 1536 + rr * 32 + hf * 16) = *reinterpret_cast<const uint4*>(src);
+    }
+    if (threadIdx.x == 0) dead = 0;
+    __syncthreads();
+    char* tr = psm + nsteps * 3072 + wid * GP_TR;
+    const int fb = (lane >> 5) * 1536 + (lane & 15) * 32 + ((lane >> 4) & 1) * 16;
+    // A fragment of K step ks: row (lane & 15) of this wave's 16, k = 8 (lane >> 4) .. + 7 = chunk 2 ks + (lane >> 5), 16-B half (lane >> 4) & 1
+    const unsigned a_off = (unsigned)(((int64_t)(lane >> 5) * pitchH + (int64_t)(row0 + wid * 16 + (lane & 15)) * 16 + ((lane >> 4) & 1) * 8) * 2);
+    const unsigned a_step = (unsigned)(4 * pitchH);                  // bytes per K step (two chunks)
+    // this lane's 16 B of the wave's stored tile: row (lane >> 1), half (lane & 1) of chunk u0 / 16 (lanes < 32 store)
+    const int64_t st_off = (int64_t)(u0 >> 4) * pitchH + (int64_t)(row0 + wid * 16 + (lane >> 1)) * 16 + (lane & 1) * 8;
+    const int j = u0 + (lane & 15);
+    const float bb0 = b_hh[j], bb1 = b_hh[H + j], bb2 = b_hh[2 * H + j];
+    unsigned* ctr = sync + blockIdx.y * 32;
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+        unsigned short* hw = (t & 1) ? hp1 : hp0;                   // h_t goes here; h_{t-1} is in the other plane
+        const unsigned short* hr = (t & 1) ? hp0 : hp1;
+        float gv[12];                                               // this step's input-side pre-activations: in flight across the poll
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* gib = gi + (int64_t)(row0 + wid * 16 + (lane >> 4) * 4 + e) * ld_gi + (int64_t)t * 3 * H;
+            gv[3 * e] = gib[j]; gv[3 * e + 1] = gib[H + j]; gv[3 * e + 2] = gib[2 * H + j];
+        }
+        g_f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            if (threadIdx.x == 0) {                                 // every workgroup of this row block has stored h_{t-1}
+                const unsigned target = gridDim.x * (unsigned)t;
+                unsigned spins = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit) { __hip_atomic_fetch_or(sync + 32 * 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = 1; break; }
+                }
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(hr), 0, (int)plane_bytes, 0x00020000);
+            constexpr int NB = 32;                                  // K steps whose fragments are in flight together (all of them at H = 1 024: 128 registers)
+            for (int k0 = 0; k0 < nsteps; k0 += NB) {
+                gp_u32x4 af[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (k0 + i < nsteps) af[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_off + (unsigned)(k0 + i) * a_step, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (k0 + i >= nsteps) break;
+                    const g_bf16x8 ah = __builtin_bit_cast(g_bf16x8, af[i]);
+                    const char* wb = psm + (k0 + i) * 3072 + fb;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const g_bf16x8 bh = *reinterpret_cast<const g_bf16x8*>(wb + g * 512);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[g], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const bool poisoned = dead != 0;
+        // C/D map of the 16x16 MFMA: column = lane & 15 (unit), row = 4 (lane >> 4) + e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rl = (lane >> 4) * 4 + e;
+            const float g0 = acc[0][e] + bb0, g1 = acc[1][e] + bb1, g2 = acc[2][e] + bb2;
+            float r, z, n;
+            float h = gru_gates(gv[3 * e], gv[3 * e + 1], gv[3 * e + 2], g0, g1, g2, hprev[e], r, z, n);
+            if (poisoned) h = __builtin_nanf("");
+            hprev[e] = h;
+            out[(int64_t)(row0 + wid * 16 + rl) * ld_out + (int64_t)t * H + j] = h;
+            *reinterpret_cast<unsigned short*>(tr + rl * 32 + (lane & 15) * 2) = bf16b(h);
+        }
+        if (t + 1 < T) {
+            // the wave's own tile, transposed through its own 512 B of LDS (wave-private: no barrier), as whole lines
+            if (lane < 32) {
+                const gp_u32x4 v = *reinterpret_cast<const gp_u32x4*>(tr + lane * 16);
+                unsigned short* dst = hw + st_off;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -274,7 +395,19 @@ size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec) {
     n += al256(f * (size_t)S * B * 3 * H);
     n += al256(planes_bytes((int64_t)B * T + PLANE_SLACK_ROWS, I)) + al256(planes_bytes(3 * (int64_t)H + PLANE_SLACK_ROWS, I));
     n += al256(planes_bytes(3 * (int64_t)H + PLANE_SLACK_ROWS, H)) + 2 * al256(planes_bytes((int64_t)B + PLANE_SLACK_ROWS, H));
-    return n;
+    return n + al256(GP_SYNC_BYTES);                                                             // the persistent form's counters
+}
+
+// The persistent form (gru_persistent_kernel) takes a call when the caller has asked for it (CTI_TUNE_GRU_PERSISTENT = 1: it needs the whole chip, see the
+// kernel's header), the arithmetic is plain bf16, no per-step state is saved for a backward pass, the tile grid divides the problem and every workgroup can
+// be resident at once.
+static bool gru_persistent_fits(int B, int H, int prec, const float* save) {
+    if (tuning_gru_persistent() != 1 || prec != CTI_PREC_BF16 || save || B % 64 || H % 32 || H > 1024 || B / 64 > 31) return false;
+    static thread_local int cus_dev = -1, cus = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cus_dev != dev) { if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0; cus_dev = dev; }
+    return (H / 16) * (B / 64) <= cus;
 }
 
 int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
@@ -322,6 +455,7 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
     unsigned short* whh = ws.take<unsigned short>(planes_bytes(rw, H));  unsigned short* whl = whh + (size_t)rw * KpH;
     unsigned short* hp_[2]; unsigned short* hl_[2];
     for (int i = 0; i < 2; ++i) { hp_[i] = ws.take<unsigned short>(planes_bytes(rh, H)); hl_[i] = hp_[i] + (size_t)rh * KpH; }
+    unsigned* sync_words = ws.take<unsigned>(GP_SYNC_BYTES);
     int rc = split_planes(x, I, (int64_t)B * T, I, xh, xl, rx, st); if (rc) return rc;
     if (w_ih_planes) { wih = static_cast<unsigned short*>(const_cast<void*>(w_ih_planes)); wil = wih + (size_t)rw * KpI; }   // resident planes
     else { rc = split_planes(w_ih, I, H3, I, wih, wil, rw, st); if (rc) return rc; }
@@ -335,6 +469,22 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
         g.Ah = xh; g.Al = xl; g.Bh = wih; g.Bl = wil; g.rows_allocA = rx; g.rows_allocB = rw; g.nb1 = 1; g.nb2 = 1;
         g.M = B * T; g.N = H3; g.Kp = KpI; g.terms = terms; g.epi = 0; g.C = gi; g.ldc_m = H3; g.ldc_n = 1; g.scale_div = 1; g.bias = b_ih;
         rc = gemm_nt_planes(g, st); if (rc) return rc;
+    }
+    if (gru_persistent_fits(B, H, prec, save)) {
+        static thread_local int pattr_dev = -1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const size_t lds = (size_t)(KpH / 32) * 3072 + 4 * GP_TR;
+        if (pattr_dev != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 3072 + 4 * GP_TR);
+            if (e != hipSuccess) return fail((int)e, "cti_gru_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            pattr_dev = dev;
+        }
+        static const unsigned spin_limit = [] { const char* e = getenv("CTI_GRU_PERSISTENT_SPINS"); return e ? (unsigned)atol(e) : 400000u; }();
+        rc = zero_planes(reinterpret_cast<unsigned short*>(sync_words), GP_SYNC_BYTES, st); if (rc) return rc;
+        hipLaunchKernelGGL(gru_persistent_kernel, dim3(H / 16, B / 64), dim3(256), lds, st, hp_[0], hp_[1], rh * 16, (size_t)rh * KpH * 2, whh, rw * 16, KpH / 32,
+                           gi, (int64_t)T * H3, b_hh, out, (int64_t)T * H, T, H, sync_words, spin_limit);
+        return launch_status("cti_gru_forward/persistent");
     }
 #ifndef CTI_GRU_FUSED
 #define CTI_GRU_FUSED 1

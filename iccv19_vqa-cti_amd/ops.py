@@ -1694,6 +1694,18 @@ def col_sum(x2, alpha=1.0):
     return out
 
 
+# The GRU's persistent form (cti_gru.hip: all steps in ONE launch whose workgroups meet at counters) needs every one of its workgroups resident, so two such
+# launches must never share the device: callers that enable it keep their GRUs on ONE stream (base_model._TriModel), run_concurrently's sibling streams do not
+# get it, and a process that drives one device from several host threads should leave it off.  CTI_GRU_PERSISTENT=1 enables it (default off: see DESIGN.md,
+# round 6 -- beside the other streams' work the whole forward gains nothing from it).
+use_persistent_gru = _os.environ.get("CTI_GRU_PERSISTENT", "0") == "1"
+
+
+def gru_persistent_ok():
+    """True when gru_forward may take the persistent form for an inference call in the plain-bf16 mode (the caller then keeps its GRUs on one stream)."""
+    return use_persistent_gru and not _no_nested_fork[0] and get_precision() == "bf16" and not torch.is_grad_enabled()
+
+
 def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=None):
     """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H), in ONE library
     call (the time loop lives behind the C ABI).  want_save: also returns save (T,B,5,H) = (r, z, n, W_hn h + b_hn, h_t)."""
@@ -1708,12 +1720,19 @@ def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=
     lib = L.lib()
     wsb = lib.cti_gru_forward_workspace_bytes(B, T, I, H, pr)
     ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
-    with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
+    persistent = pr == L.PREC_BF16 and not want_save and gru_persistent_ok()
+    if persistent:
+        L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
+    try:
+      with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
         L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
                                     b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
                                     _ptr(w_planes[0]) if w_planes and pr != L.PREC_F32 else 0,
                                     _ptr(w_planes[1]) if w_planes and pr != L.PREC_F32 else 0,
                                     ws.data_ptr(), wsb, _stream()), "cti_gru_forward")
+    finally:
+        if persistent:
+            L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 0), "cti_set_tuning")
     return out, save
 
 

@@ -66,7 +66,12 @@ const char* cti_last_error_string(void);
  * (-1 = the library's default). */
 enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2, CTI_TUNE_GUARD_RHO_BF16X3 = 3, CTI_TUNE_GUARD_RHO_FP32 = 4, CTI_TUNE_GUARD_POISON_BITS = 5,
        CTI_TUNE_F6_CORE_FREE_CUS = 6, CTI_TUNE_GUARD_STRATA = 7 /* tests: 0 = sample evenly spaced rows only */,
-       CTI_TUNE_GEMM16_SK = 8 /* cti_gemm_bf16_rows_sk: -1 = cut stream-K where it was measured to pay (three or more rounds of tiles), 0 = never, 1 = wherever a cut can be planned (tests) */ };
+       CTI_TUNE_GEMM16_SK = 8 /* cti_gemm_bf16_rows_sk: -1 = cut stream-K where it was measured to pay (three or more rounds of tiles), 0 = never, 1 = wherever a cut can be planned (tests) */,
+       CTI_TUNE_GRU_PERSISTENT = 9 /* cti_gru_forward: 1 = an eligible call (CTI_PREC_BF16, save == NULL, 64 | B, 32 | H <= 1024, (H / 16) (B / 64) workgroups <= the
+                                      device's compute units) runs ALL its steps as ONE launch whose workgroups meet between steps at counters in the workspace.  Such a
+                                      launch needs every one of its workgroups resident: the caller must not let two of them share the device (same stream, or
+                                      ordered by events); a workgroup that waits beyond CTI_GRU_PERSISTENT_SPINS polls (default 400 000) NaN-fills its outputs
+                                      instead of hanging.  Default 0 (one launch per step) */ };
 int cti_set_tuning(int key, int64_t value);
 int64_t cti_get_tuning(int key);
 

@@ -1000,3 +1000,75 @@ def test_full_batch_training_mode_step_agrees_across_precisions():
             continue
         e = float((grads["bf16x3"][n].double() - g32.double()).norm()) / den
         assert e < 5e-2, (n, e)
+
+
+@pytest.mark.parametrize("B,Tn,I,H", [(256, 12, 600, 1024), (256, 6, 300, 1024), (64, 5, 300, 512), (128, 3, 64, 1024), (256, 2, 32, 64), (192, 7, 96, 160)])
+def test_persistent_gru_is_bit_identical_to_one_launch_per_step(B, Tn, I, H, precision):
+    """Round 6: the plain-bf16 GRU as ONE launch whose workgroups exchange h_t through `sc1` stores / `sc1` loads and a counter per row block
+    (cti_gru.hip, gru_persistent_kernel; opt-in: CTI_TUNE_GRU_PERSISTENT).  Same products in the same order, same gate arithmetic: every bit of every state equals
+    the per-step launches' -- a stale or torn read of another workgroup's h would show as a difference.  Checked on an idle device, 20 times back to back, and
+    while another stream streams through the L2s and takes compute units away (uneven arrival at the counters)."""
+    if precision != "bf16x3":
+        pytest.skip("mode set explicitly below; run once")
+    lib = ops.L.lib()
+    torch.manual_seed(B + Tn)
+    k = 1.0 / H ** 0.5
+    x = torch.randn(B, Tn, I, device=DEV)
+    w_ih, w_hh = (torch.rand(3 * H, I, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, H, device=DEV) * 2 - 1) * k
+    b_ih, b_hh = (torch.rand(3 * H, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, device=DEV) * 2 - 1) * k
+
+    def run():
+        return ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
+    ref = run()
+    assert lib.cti_get_tuning(ops.L.TUNE_GRU_PERSISTENT) == 0
+    ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
+    try:
+        outs = [run() for _ in range(20)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs)
+        big = torch.randn(4096, 4096, device=DEV)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                _ = big @ big                                           # other work arriving and leaving while the persistent launches run
+        outs = [run() for _ in range(20)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs)
+        assert not any(bool(torch.isnan(o).any()) for o in outs)
+    finally:
+        ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 0), "cti_set_tuning")
+
+
+def test_persistent_gru_under_graph_replay(precision):
+    """The persistent launch and the zeroing of its counters replay from a hipGraph (the counters count up from zero every replay)."""
+    if precision != "bf16x3":
+        pytest.skip("run once")
+    lib = ops.L.lib()
+    torch.manual_seed(5)
+    B, Tn, I, H = 256, 12, 600, 1024
+    k = 1.0 / H ** 0.5
+    x = torch.randn(B, Tn, I, device=DEV)
+    w_ih, w_hh = (torch.rand(3 * H, I, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, H, device=DEV) * 2 - 1) * k
+    b_ih, b_hh = (torch.rand(3 * H, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, device=DEV) * 2 - 1) * k
+    ref = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
+    ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=s):
+                out = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
+        torch.cuda.synchronize()
+        for _ in range(5):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+    finally:
+        ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 0), "cti_set_tuning")
