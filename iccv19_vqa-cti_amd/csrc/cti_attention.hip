@@ -1155,6 +1155,9 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
             }                                                                                                    \
         }                                                                                                        \
     }
+#ifndef CTI_TPM_ABL
+#define CTI_TPM_ABL 0        // timing-only ablations (wrong results): 1 = set-up only (no tile loop), 2 = no gather of the attention slice (constants into LDS), 4 = no vt loads
+#endif
     if (ntile > 0) CTI_TPM_LOAD(qA, aA, vA, wA, tile0)              // (in flight while the attention slice is compacted and split below)
     for (int it = t; it < 64 * (QAP / 8); it += nthr) {             // (row v, eight consecutive (q, a) columns)
         const int v = it / (QAP / 8), c0 = (it - v * (QAP / 8)) * 8;
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int qa = c0 + e, q = qa / A_, a = qa - q * A_;
-            x[e] = (v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f;
+            x[e] = (CTI_TPM_ABL & 2) ? 0.01f * qa : ((v < V && qa < QA) ? wb[v * w_sv + q * w_sq + a * w_sa] : 0.f);
         }
         lbf16x8 hi, lo;
         split8t<TERMS>(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), hi, lo);       // TERMS = 1 (plain-bf16 mode): hi only, one product per pair
@@ -1206,7 +1209,7 @@ __global__ __launch_bounds__(512) void tri_pool_mfma_kernel(const float* __restr
         acc += __shfl_xor(acc, 32, 64);                                                                          \
         if (kg == 0) out[(int64_t)b * D + (tile_) * 32 + l31] = acc;                                             \
     }
-    for (int ti = 0; ti < ntile; ti += 2) {
+    for (int ti = 0; ti < ((CTI_TPM_ABL & 1) ? min(ntile, 1) : ntile); ti += 2) {
         if (ti + 1 < ntile) CTI_TPM_LOAD(qB, aB, vB, wB, tile0 + ti + 1)
         CTI_TPM_COMPUTE(qA, aA, vA, wA, tile0 + ti)
         if (ti + 1 < ntile) {
