@@ -1099,6 +1099,116 @@ __global__ __launch_bounds__(256) void bi_logits_lds_kernel(const float* __restr
 }
 
 // =====================================================================================================
+// Round 6: the same contraction WITHOUT a barrier in its K loop.  The LDS form above walks K in 32-deep slices behind a workgroup
+// barrier each, with one slice of loads in flight: 48 dependent rounds of ~1.6 us = 77 us at B = 256, G = 8, D = 3 072 for 105 MB and 6 GFLOP.
+// Here ONE workgroup of eight waves takes a sample and every wave a contiguous EIGHTH of K, for which it computes the whole (3 row tiles of objects)
+// x (G column tiles) output on its own; the eight partial outputs meet in LDS at the end in a fixed order (deterministic; no atomics, no zero fill).
+// Column tile g = glimpse g's Q <= 16 question positions (two dummy columns at Q = 14), so that
+//   * the qt fragment of a K step (row q = lane & 15, eight k) is loaded ONCE and serves all G tiles,
+//   * h[g, k] is the same for the 16 lanes of a k group: the wave copies its own K range of h into its own part of LDS once (12 KiB; wave-private, no
+//     barrier) and reads 32 B per tile and K step from there (broadcast reads),
+//   * per K step a wave issues 5 (bf16 vt rows) or 8 (fp32 rows) 1-KiB global loads for 3 G MFMAs -- the LDS form issued 8 per 8 MFMAs and fetched every
+//     qt value eight times -- with the next step's operands in flight in a second register set.
+// The rows' operands are converted exactly as before (fp32 product h * qt rounded to bf16 once; fp32-grade mode: hi + lo of both sides, three products).
+template <int TERMS, int VT16>
+__global__ __launch_bounds__(512) void bi_logits_ks_kernel(const void* __restrict__ vt_, const float* __restrict__ qt, const float* __restrict__ h,
+                                                           const float* __restrict__ h_scale, const float* __restrict__ h_bias,
+                                                           float* __restrict__ logits, int G, int V, int Q, int D, int spw) {
+    extern __shared__ __attribute__((aligned(16))) float ksm[];     // [8 waves][G][spw * 32] of h, then the partial outputs
+    constexpr int MT = 3, GT = 8;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int nsteps = D / 32, s0 = wid * spw, my = max(0, min(nsteps, s0 + spw) - s0);
+    const int hw = spw * 32;                                         // floats per glimpse in a wave's slice
+    float* hl = ksm + (size_t)wid * G * hw;
+    for (int i = lane; i < G * my * 8; i += 64) {                    // (glimpse, float4 of this wave's K range)
+        const int g = i / (my * 8), c = i - g * (my * 8);
+        *reinterpret_cast<float4*>(hl + g * hw + c * 4) = *reinterpret_cast<const float4*>(h + (int64_t)g * D + s0 * 32 + c * 4);
+    }
+    constexpr int vsz = VT16 ? 2 : 4;
+    const char* ap[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ap[m] = static_cast<const char*>(vt_) + (((int64_t)b * V + min(m * 16 + l15, V - 1)) * D + s0 * 32 + kq * 8) * vsz;   // rows beyond V: a valid row, results unused
+    const float* qp = qt + ((int64_t)b * Q + min(l15, Q - 1)) * D + s0 * 32 + kq * 8;
+    lf32x4 acc[MT][GT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < GT; ++g) acc[m][g] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    float4 aA[MT][2], qA[2], aB[MT][2], qB[2];
+#define CTI_BK_LOAD(a_, q_, s_)                                                                                  \
+    {                                                                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                         \
+            a_[m][0] = *reinterpret_cast<const float4*>(ap[m] + (int64_t)(s_) * 32 * vsz);                       \
+            if (!VT16) a_[m][1] = *reinterpret_cast<const float4*>(ap[m] + (int64_t)(s_) * 32 * vsz + 16);       \
+        }                                                                                                        \
+        q_[0] = *reinterpret_cast<const float4*>(qp + (s_) * 32); q_[1] = *reinterpret_cast<const float4*>(qp + (s_) * 32 + 4); \
+    }
+#define CTI_BK_COMPUTE(a_, q_, s_)                                                                               \
+    {                                                                                                            \
+        lbf16x8 ah[MT], al[MT];                                                                                  \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                         \
+            if (VT16) { ah[m] = __builtin_bit_cast(lbf16x8, a_[m][0]); al[m] = ah[m]; }                          \
+            else split8t<TERMS>(a_[m][0], a_[m][1], ah[m], al[m]);                                               \
+        }                                                                                                        \
+        _Pragma("unroll") for (int g = 0; g < GT; ++g) {                                                         \
+            if (g < G) {                                                                                         \
+                const float4 h0 = *reinterpret_cast<const float4*>(hl + g * hw + (s_) * 32 + kq * 8);            \
+                const float4 h1 = *reinterpret_cast<const float4*>(hl + g * hw + (s_) * 32 + kq * 8 + 4);        \
+                lbf16x8 bh, bl;                                                                                  \
+                split8t<TERMS>(make_float4(h0.x * q_[0].x, h0.y * q_[0].y, h0.z * q_[0].z, h0.w * q_[0].w),      \
+                               make_float4(h1.x * q_[1].x, h1.y * q_[1].y, h1.z * q_[1].z, h1.w * q_[1].w), bh, bl); \
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                 \
+                    if (TERMS == 3) {                                                                            \
+                        if (!VT16) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][g], 0, 0, 0); \
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][g], 0, 0, 0);      \
+                    }                                                                                            \
+                    acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][g], 0, 0, 0);          \
+                }                                                                                                \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    if (my > 0) CTI_BK_LOAD(aA, qA, 0)
+    for (int s = 0; s < my; s += 2) {
+        if (s + 1 < my) CTI_BK_LOAD(aB, qB, s + 1)
+        CTI_BK_COMPUTE(aA, qA, s)
+        if (s + 1 < my) {
+            if (s + 2 < my) CTI_BK_LOAD(aA, qA, s + 2)
+            CTI_BK_COMPUTE(aB, qB, s + 1)
+        }
+    }
+#undef CTI_BK_LOAD
+#undef CTI_BK_COMPUTE
+    // the eight partial outputs, half of the glimpses at a time: part[wave][tile = m * 4 + (g & 3)][reg][lane] (64 lanes x 4 B per register: conflict-free)
+    const float hs = h_scale ? h_scale[0] : 1.f;
+    const int n = V * Q;
+    for (int ph = 0; ph < 2; ++ph) {
+        __syncthreads();                                             // (first pass: every wave is done with its h slice; second: the sums of the first are read)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const lf32x4 a0 = acc[m][gg], a1 = acc[m][4 + gg];
+                    ksm[((wid * 12 + m * 4 + gg) * 4 + e) * 64 + lane] = ph ? a1[e] : a0[e];
+                }
+        __syncthreads();
+        const int g_lo = ph * 4, g_n = min(4, G - g_lo);
+        for (int idx = t; idx < g_n * n; idx += 512) {
+            const int gg = idx / n, r = idx - gg * n, v = r / Q, q = r - v * Q;
+            const int m = v >> 4, vr = v & 15;
+            const float* pp = ksm + ((m * 4 + gg) * 4 + (vr & 3)) * 64 + (vr >> 2) * 16 + q;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += pp[w * 12 * 4 * 64];
+            const int g = g_lo + gg;
+            logits[((int64_t)b * G + g) * n + r] = sum * hs + (h_bias ? h_bias[g] : 0.f);
+        }
+    }
+}
+
+// =====================================================================================================
 // Tri pool on the MFMA (fp32-grade 3-product bf16 mode; A = 3 or 6, Q <= 16, V <= 64, D % 32 == 0).  Per sample:
 //   U[v, d] = sum_{(q,a)} w[v,(q,a)] * P[(q,a), d],  P = qt[q,d] * at[a,d];     out[d] = sum_v vt[v,d] * U[v,d]
 // The V*Q*A FMAs per channel that bound the VALU forms (27 % of the HBM roofline) become Q*A/16 MFMA steps per 32 x 32 tile.
@@ -1737,6 +1847,21 @@ static int bi_logits_mfma_impl(const float* vt, const float* qt, const float* h,
 #endif
     const bool lds_form = CTI_BL_LDS && V <= 64 && G * Q <= 128 && D % 32 == 0;
     if (sm_p && !lds_form) return CTI_E_UNSUPPORTED;                 // the fused mask + softmax lives in the LDS form only
+    // round 6: the barrier-free K-split form (bi_logits_ks_kernel) where a sample's tiles fit one workgroup: V <= 48, Q <= 16, G <= 8, K long enough to give every wave
+    // a few steps, its h slices + the partial outputs within the LDS.  CTI_BL_KS_FORM=0 restores the LDS form (A/B).
+    static const bool ks_form_env = [] { const char* e = getenv("CTI_BL_KS_FORM"); return !e || atoi(e) != 0; }();
+    if (ks_form_env && !sm_p && V <= 48 && Q <= 16 && G <= 8 && D % 32 == 0 && D >= 512) {
+        const int spw = (D / 32 + 7) / 8;
+        const size_t lds = std::max((size_t)8 * G * spw * 32 * 4, (size_t)8 * 12 * 4 * 64 * 4);
+        if (lds <= 160 * 1024) {
+            void (*kern)(const void*, const float*, const float*, const float*, const float*, float*, int, int, int, int, int) =
+                terms == 1 ? (vt16 ? bi_logits_ks_kernel<1, 1> : bi_logits_ks_kernel<1, 0>) : (vt16 ? bi_logits_ks_kernel<3, 1> : bi_logits_ks_kernel<3, 0>);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail((int)e, "cti_bi_logits_mfma_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, as_stream(stream), vt, qt, h, h_scale, h_bias, logits, G, V, Q, D, spw);
+            return launch_status("cti_bi_logits_mfma_fwd");
+        }
+    }
     if (lds_form) {                                                  // left operand split once per workgroup (see bi_logits_lds_kernel)
         static const int ks_env = [] { const char* e = getenv("CTI_BL_KS"); return e ? atoi(e) : 0; }();        // (A/B knob: K ranges per sample)
         // TWO ranges at most by default: the partial sums meet by atomicAdd on the zero-filled output, and only a + b is the same bits in either order -- three ranges measured
