@@ -67,7 +67,7 @@ extern "C" int cti_set_tuning(int key, int64_t value) {
             CTI_REQUIRE(value >= -1 && value <= 1, CTI_E_SHAPE, "cti_set_tuning: GEMM16_SK must be -1 (auto), 0 or 1, got %lld", (long long)value);
             g_gemm16_sk = (int)value; return CTI_OK;
         case CTI_TUNE_GRU_PERSISTENT:
-            CTI_REQUIRE(value == 0 || value == 1, CTI_E_SHAPE, "cti_set_tuning: GRU_PERSISTENT must be 0 or 1, got %lld", (long long)value);
+            CTI_REQUIRE(value >= 0 && value <= 2, CTI_E_SHAPE, "cti_set_tuning: GRU_PERSISTENT must be 0, 1 or 2, got %lld", (long long)value);
             g_gru_persistent = (int)value; return CTI_OK;
         default: return fail(CTI_E_UNSUPPORTED, "cti_set_tuning: unknown key %d", key);
     }

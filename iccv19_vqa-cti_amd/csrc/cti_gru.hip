@@ -235,6 +235,116 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
     }
 }
 
+// ---- fused forward step without a barrier in its K loop (round 6) ----------------------------------------------------------------------------------
+// The ring kernel above walks K = H in 32 rounds of (counted wait, barrier, 3-6 MFMAs per wave): ~6.5 us of its ~12 us are that loop, and the gate inputs are only
+// fetched behind it.  Same tile here (64 batch rows x 16 hidden units x 3 gates per workgroup), but EIGHT waves, each with a contiguous eighth of K for which it
+// computes the whole tile (4 row tiles x 3 gates = 12 accumulators): its A fragments (h_{t-1} planes) and B fragments (W_hh planes) come straight from global
+// memory as 16-B loads, all of a batch in flight at once (28 loads), no LDS staging, no barrier; the eight partial tiles meet in LDS (two halves of 48 KiB, fixed
+// order: deterministic), where thread (row, unit) finds the three gates of its output.  The gate inputs (gi, h_{t-1}, b_hh) are loaded BEFORE the K loop.
+template <int TERMS>
+__global__ __launch_bounds__(512) void gru_step_ks_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
+                                                          const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl, int64_t pitchW,
+                                                          int nsteps, const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ b_hh,
+                                                          const float* __restrict__ hprev, float* __restrict__ out, int64_t ld_out,
+                                                          float* __restrict__ h_tm, float* __restrict__ save, unsigned short* __restrict__ ph,
+                                                          unsigned short* __restrict__ pl, int64_t pitchP, int B, int H) {
+    __shared__ __attribute__((aligned(16))) float part[8 * 6 * 4 * 64];      // [wave][tile = (m & 1) * 3 + gate][reg][lane]: 48 KiB, one half of the row tiles at a time
+    const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int u0 = blockIdx.x * 16, row0 = blockIdx.y * 64;
+    // epilogue role: thread -> (row er of a half's 32, unit ej); its gate inputs are in flight while the K loop runs
+    const int er = t >> 4, ej = t & 15, j = u0 + ej;
+    float gv[2][3], hpv[2], bb[3];
+    const bool jok = j < H;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int b = row0 + p * 32 + er;
+        const bool ok = jok && b < B;
+        const float* gib = gi + (int64_t)(ok ? b : 0) * ld_gi;
+        gv[p][0] = ok ? gib[j] : 0.f; gv[p][1] = ok ? gib[H + j] : 0.f; gv[p][2] = ok ? gib[2 * H + j] : 0.f;
+        hpv[p] = (ok && hprev) ? hprev[(int64_t)b * H + j] : 0.f;
+    }
+    bb[0] = jok ? b_hh[j] : 0.f; bb[1] = jok ? b_hh[H + j] : 0.f; bb[2] = jok ? b_hh[2 * H + j] : 0.f;
+    // fragments of K step ks: chunk 2 ks + (lane >> 5), row (lane & 15) of the tile, 16-B half (lane >> 4) & 1
+    const int spw = (nsteps + 7) / 8, s0 = wid * spw, my = max(0, min(nsteps, s0 + spw) - s0);
+    const unsigned short* ah = Hh + (int64_t)(lane >> 5) * pitchH + (int64_t)(row0 + (lane & 15)) * 16 + ((lane >> 4) & 1) * 8;
+    const unsigned short* al = Hl + (int64_t)(lane >> 5) * pitchH + (int64_t)(row0 + (lane & 15)) * 16 + ((lane >> 4) & 1) * 8;
+    const int wrow = min(u0 + (lane & 15), H - 1);
+    const unsigned short* bh = Wh + (int64_t)(lane >> 5) * pitchW + (int64_t)wrow * 16 + ((lane >> 4) & 1) * 8;
+    const unsigned short* bl = Wl + (int64_t)(lane >> 5) * pitchW + (int64_t)wrow * 16 + ((lane >> 4) & 1) * 8;
+    g_f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[m][g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int SB = TERMS == 3 ? 2 : 4;                          // K steps whose fragments are in flight together (28 loads of 16 B per lane)
+    for (int sb = 0; sb < my; sb += SB) {
+        g_bf16x8 fah[SB][4], fal[SB][4], fbh[SB][3], fbl[SB][3];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            if (sb + i < my) {
+                const int64_t ka = (int64_t)(s0 + sb + i) * 2 * pitchH, kb = (int64_t)(s0 + sb + i) * 2 * pitchW;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    fah[i][m] = *reinterpret_cast<const g_bf16x8*>(ah + ka + m * 256);
+                    if (TERMS == 3) fal[i][m] = *reinterpret_cast<const g_bf16x8*>(al + ka + m * 256);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    fbh[i][g] = *reinterpret_cast<const g_bf16x8*>(bh + kb + (int64_t)g * H * 16);
+                    if (TERMS == 3) fbl[i][g] = *reinterpret_cast<const g_bf16x8*>(bl + kb + (int64_t)g * H * 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            if (sb + i < my) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        if (TERMS == 3) {
+                            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i][m], fbh[i][g], acc[m][g], 0, 0, 0);
+                            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i][m], fbl[i][g], acc[m][g], 0, 0, 0);
+                        }
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i][m], fbh[i][g], acc[m][g], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // C/D map of the 16x16 MFMA: column = lane & 15 (unit), row = 4 (lane >> 4) + reg.  Two halves of the rows; thread (er, ej) sums the eight waves' partials of its
+    // three gates in wave order and applies the gates
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p) __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[((wid * 6 + mm * 3 + g) * 4 + e) * 64 + lane] = acc[2 * p + mm][g][e];
+        __syncthreads();
+        const int mm = er >> 4, rr = er & 15;
+        const float* pp = part + ((mm * 3) * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + ej;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { g0 += pp[w * 6 * 256]; g1 += pp[w * 6 * 256 + 256]; g2 += pp[w * 6 * 256 + 512]; }
+        const int b = row0 + p * 32 + er;
+        if (jok && b < B) {
+            g0 += bb[0]; g1 += bb[1]; g2 += bb[2];
+            float r, z, n;
+            const float h = gru_gates(gv[p][0], gv[p][1], gv[p][2], g0, g1, g2, hpv[p], r, z, n);
+            const int64_t idx = (int64_t)b * H + j;
+            out[(int64_t)b * ld_out + j] = h;
+            if (h_tm) h_tm[idx] = h;
+            if (save) {
+                float* sv = save + (int64_t)b * 5 * H;
+                sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = g2; sv[4 * H + j] = h;
+            }
+            if (ph) store_planes(ph, pl, pitchP, b, j, h);
+        }
+    }
+}
+
 // ---- persistent forward (plain bf16, inference; round 6): ALL time steps in ONE launch ----------------------------------------------------------
 // The per-step kernel above re-streams its slice of W_hh (96 KiB) through LDS every step and pays a kernel boundary per step: ~12 us a step at
 // B = 256, H = 1 024 for 0.3 us of MFMA work.  Here a workgroup (64 batch rows x 16 hidden units, 4 waves) keeps its W_hh slice in LDS for the
@@ -503,8 +613,25 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
             attr_dev = dev;
         }
     }
+    // per-step kernel: the K-split form (round 6) unless the caller asks for the ring form (CTI_TUNE_GRU_PERSISTENT = 2: the persistent form's bit-exact reference;
+    // CTI_GRU_STEP_RING=1: A/B)
+    static const bool ring_env = [] { const char* e = getenv("CTI_GRU_STEP_RING"); return e && e[0] == '1'; }();
+    const bool ks_form = fused && !ring_env && tuning_gru_persistent() != 2;
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prev = cur ^ 1;
+        if (ks_form && t) {
+            const dim3 grid((H + 15) / 16, (B + 63) / 64);
+            if (terms == 3)
+                hipLaunchKernelGGL(gru_step_ks_kernel<3>, grid, dim3(512), 0, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, gi + (size_t)t * H3, (int64_t)T * H3, b_hh,
+                                   h_tm + (size_t)(t - 1) * B * H, out + (size_t)t * H, (int64_t)T * H, h_tm + (size_t)t * B * H, save ? save + (size_t)t * B * 5 * H : nullptr,
+                                   hp_[cur], hl_[cur], rh * 16, B, H);
+            else
+                hipLaunchKernelGGL(gru_step_ks_kernel<1>, grid, dim3(512), 0, st, hp_[prev], hl_[prev], rh * 16, whh, whl, rw * 16, KpH / 32, gi + (size_t)t * H3, (int64_t)T * H3, b_hh,
+                                   h_tm + (size_t)(t - 1) * B * H, out + (size_t)t * H, (int64_t)T * H, h_tm + (size_t)t * B * H, save ? save + (size_t)t * B * 5 * H : nullptr,
+                                   hp_[cur], hl_[cur], rh * 16, B, H);
+            rc = launch_status("cti_gru_forward/K-split step"); if (rc) return rc;
+            continue;
+        }
         if (fused && t) {
             const dim3 grid((H + 15) / 16, (B + 63) / 64);
 #define CTI_GF(TR) CTI_GF2(TR, 1)

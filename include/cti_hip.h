@@ -71,7 +71,8 @@ enum { CTI_TUNE_GEMM_CFG = 1, CTI_TUNE_TRI_CHUNK = 2, CTI_TUNE_GUARD_RHO_BF16X3 
                                       device's compute units) runs ALL its steps as ONE launch whose workgroups meet between steps at counters in the workspace.  Such a
                                       launch needs every one of its workgroups resident: the caller must not let two of them share the device (same stream, or
                                       ordered by events); a workgroup that waits beyond CTI_GRU_PERSISTENT_SPINS polls (default 400 000) NaN-fills its outputs
-                                      instead of hanging.  Default 0 (one launch per step) */ };
+                                      instead of hanging.  2 = one launch per step with the LDS-ring step kernel of rounds 3-5 (the persistent form's bit-exact reference: same
+                                      accumulation order).  Default 0: one launch per step, K split over the workgroup's waves (round 6) */ };
 int cti_set_tuning(int key, int64_t value);
 int64_t cti_get_tuning(int key);
 

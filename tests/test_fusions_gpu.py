@@ -1023,8 +1023,11 @@ def test_persistent_gru_is_bit_identical_to_one_launch_per_step(B, Tn, I, H, pre
 
     def run():
         return ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
-    ref = run()
     assert lib.cti_get_tuning(ops.L.TUNE_GRU_PERSISTENT) == 0
+    kssplit = run()                                                     # the default: per-step launches, K split over the waves (partial sums in another order)
+    ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 2), "cti_set_tuning")     # per-step launches of the ring kernel: the persistent form's accumulation order
+    ref = run()
+    assert float((kssplit - ref).abs().max()) < 2e-3
     ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
     try:
         outs = [run() for _ in range(20)]
@@ -1056,6 +1059,7 @@ def test_persistent_gru_under_graph_replay(precision):
     x = torch.randn(B, Tn, I, device=DEV)
     w_ih, w_hh = (torch.rand(3 * H, I, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, H, device=DEV) * 2 - 1) * k
     b_ih, b_hh = (torch.rand(3 * H, device=DEV) * 2 - 1) * k, (torch.rand(3 * H, device=DEV) * 2 - 1) * k
+    ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 2), "cti_set_tuning")
     ref = ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
     ops.L.check(lib.cti_set_tuning(ops.L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
     try:
@@ -1098,5 +1102,33 @@ def test_bi_logits_without_a_barrier_in_the_k_loop(B, G, V, Q, D, mode, tol, pre
             assert out.shape == (B, G, V, Q)
             assert float((out.double() - ref).abs().max() / ref.abs().max()) < tol
             assert torch.equal(out, ops.bi_logits(v, qt, h, hs, hb))
+    finally:
+        ops.set_precision(old)
+
+
+@pytest.mark.parametrize("B,Tn,I,H", [(256, 12, 600, 1024), (100, 4, 300, 1000), (3, 3, 20, 48), (65, 2, 8, 16)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_gru_step_with_k_split_over_the_waves(B, Tn, I, H, mode, tol, precision):
+    """Round 6: gru_step_ks_kernel (eight waves, an eighth of K each, operands straight from global memory, partial tiles summed in LDS in wave order) against
+    torch's nn.GRU in float64 on the CPU for full and ragged shapes (rows beyond the batch, units beyond H, K shorter than eight steps), both arithmetic modes,
+    with the training path's saved gates; the same bits on every run."""
+    if precision != "bf16x3":
+        pytest.skip("mode set explicitly below; run once")
+    torch.manual_seed(B + H)
+    ref = torch.nn.GRU(I, H, 1, batch_first=True).double()
+    x = torch.randn(B, Tn, I)
+    with torch.no_grad():
+        yr, _ = ref(x.double())
+    ps = [getattr(ref, n).detach().float().to(DEV) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    old = ops.get_precision()
+    try:
+        ops.set_precision(mode)
+        for want_save in (False, True):
+            out, save = ops.gru_forward(x.to(DEV), *ps, want_save=want_save)
+            assert float((out.double().cpu() - yr).abs().max()) < tol * max(1.0, float(yr.abs().max()))
+            out2, save2 = ops.gru_forward(x.to(DEV), *ps, want_save=want_save)
+            assert torch.equal(out, out2)
+            if want_save:
+                assert torch.equal(save, save2) and torch.equal(save[:, :, 4, :].transpose(0, 1), out)
     finally:
         ops.set_precision(old)

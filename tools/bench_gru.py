@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The GRU forward of the plain-bf16 mode: one launch per step against the persistent form (CTI_TUNE_GRU_PERSISTENT), same inputs, every bit compared;
+"""The GRU forward of the plain-bf16 mode: one launch per step (K-split step kernel = the default; LDS-ring step kernel of rounds 3-5) against the persistent form
+(CTI_TUNE_GRU_PERSISTENT), same inputs, the persistent form compared bit for bit with the ring form;
 time per call from torch events around back-to-back calls.
 
     python tools/bench_gru.py [reps]"""
@@ -38,6 +39,8 @@ def main(reps=20):
         b_ih = (torch.rand(3 * H, device="cuda") * 2 - 1) * k; b_hh = (torch.rand(3 * H, device="cuda") * 2 - 1) * k
         run = lambda: ops.gru_forward(x, w_ih, w_hh, b_ih, b_hh, prec="bf16")[0]
         L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 0), "tuning")
+        ks = run(); tk = timeit(run, reps)
+        L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 2), "tuning")
         ref = run(); t0 = timeit(run, reps)
         L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 1), "tuning")
         got = run(); torch.cuda.synchronize()
@@ -46,8 +49,8 @@ def main(reps=20):
             same = same and bool(torch.equal(ref, run()))
         t1 = timeit(run, reps)
         L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 0), "tuning")
-        print(json.dumps(dict(B=B, T=T, I=I, H=H, per_step_launches_us=round(t0, 1), persistent_us=round(t1, 1), bit_identical=same, nan=nan,
-                              max_abs_diff=float((ref - got).abs().max()))), flush=True)
+        print(json.dumps(dict(B=B, T=T, I=I, H=H, per_step_k_split_us=round(tk, 1), per_step_ring_us=round(t0, 1), persistent_us=round(t1, 1),
+                              persistent_bit_identical_to_ring=same, nan=nan, k_split_vs_ring_max_abs_diff=float((ref - ks).abs().max()))), flush=True)
 
 
 if __name__ == "__main__":
