@@ -138,7 +138,7 @@ int split_planes16(const unsigned short* x, int64_t ld, int64_t rows, int K, uns
 int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
 // cti_gemm16.hip: the plain-bf16 (terms = 1) products of the 256 x 256 tile with fp32-row or planes epilogues
 bool gemm16_eligible(const PlaneGemmArgs& a);
-int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st);
+int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st, int cfg = 2);      // cfg: the tile of gemm_nt_planes()'s model (0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256)
 size_t gemm16_sk_workspace_bytes();
 // planes of x^T for x (M x n) row-major: rows = n, depth = Mp >= M (multiple of 16, zero-filled)
 int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, unsigned short* hi, unsigned short* lo, int64_t rows_alloc, hipStream_t st);

@@ -78,16 +78,19 @@ enum { G16_EPI_F32 = 0, G16_EPI_PLANES = 1, G16_EPI_BF16 = 2 };
 
 // Geometry: 8 waves as 2 (M) x 4 (N); a wave owns TMW x TNW MFMA tiles of 16 x 16: workgroup tile (32 TMW) x (64 TNW).  (8, 4) = 256 x 256;
 // (9, 3) = 288 x 192 (9216 x 3072 outputs: 512 tiles = two full rounds of 256 workgroups instead of 432 tiles = 1.69 rounds of the square tile).
-template <int TMW_, int TNW_>
+template <int TMW_, int TNW_, int NS_ = G16_NS>
 struct G16Geo {
+    // NS (round 6): slots of the LDS ring.  A stage's operands land ~2.4 us after their issue under load, so a tile's K loop runs at (stages in flight) / 2.4 us whatever the
+    // tile's size: the big tiles are bound by the ring's BYTES (4 x 32 KiB), the small ones -- 16 or 24 KiB a stage -- take a deeper ring in the same LDS
+    static constexpr int NS = NS_;
     static constexpr int TMW = TMW_, TNW = TNW_, BM = 32 * TMW_, BN = 64 * TNW_;
     static constexpr int PA = BM / 16, PB = BN / 16, P = PA + PB;                // LDS-DMA pieces (16 rows x 64 B) per stage
     static constexpr int UMAX = (P + 7) / 8, CQ = P / 8, CR = P % 8;             // waves < CR issue CQ + 1 pieces per stage, the others CQ
     static constexpr int STAGE = (BM + BN) * G16_ROWB;
-    static constexpr int LDS = G16_NS * STAGE + G16_EPI_LDS;
+    static constexpr int LDS = NS * STAGE + G16_EPI_LDS;
     static constexpr int NSTORE = TMW * TNW;                                     // fp32 / bf16-row epilogue: one store per accumulator tile
     static_assert(LDS <= 160 * 1024 && TNW <= 4, "ring + epilogue constants must fit the CU's LDS; a wave's columns fit one 64-lane dword piece");
-    static_assert((G16_NS - 2) * (CQ + 1) + NSTORE < 64, "the store window must fit vmcnt's six bits");
+    static_assert(NS >= 4 && NS <= 8 && (NS - 2) * (CQ + 1) + NSTORE < 64, "the store window must fit vmcnt's six bits");
 };
 
 // Stream-K range of workgroup w = x + 8 s: XCD x's chunk of the tile order holds total / 8 (+ 1 for x < total % 8) tiles, its first dp_tiles / 8 slots are whole
@@ -105,7 +108,7 @@ __device__ __forceinline__ void sk_range(int total, int dp_tiles, int nk, int w,
 
 template <int EPI, class G, bool AROW>
 __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
-    constexpr int NS = G16_NS, STAGE = G::STAGE, BM = G::BM, BN = G::BN, TMW = G::TMW, TNW = G::TNW, UMAX = G::UMAX, NSTORE = G::NSTORE;
+    constexpr int NS = G::NS, STAGE = G::STAGE, BM = G::BM, BN = G::BN, TMW = G::TMW, TNW = G::TNW, UMAX = G::UMAX, NSTORE = G::NSTORE;
     constexpr bool SK = EPI != G16_EPI_PLANES;                       // stream-K pieces exist for the row epilogues only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -204,20 +207,20 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         for (int u = 0; u < UMAX; ++u)
             if (pv[u]) g16_dma16((pa[u] ? Ab : Bb) + voff[u], sb + u * 8192);
     };
-    // all but this wave's youngest `stages` stages of pieces (and, with `st`, the NSTORE unconditional stores issued behind them) have landed
+    // all but this wave's youngest min(`stages`, NS - 2) stages of pieces (and, with `st`, the NSTORE unconditional stores issued behind them) have landed
+    constexpr int D = NS - 2;                                        // stages in flight behind the one awaited
     auto wait_stages = [&](int stages, bool st) {
         constexpr int CH = G::CQ + 1, CL = G::CQ;
-        if (hiw) {
-            if (stages >= 2) { if (st) g16_wait<2 * CH + NSTORE>(); else g16_wait<2 * CH>(); }
-            else if (stages == 1) { if (st) g16_wait<CH + NSTORE>(); else g16_wait<CH>(); }
-            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
-        } else {
-            if (stages >= 2) { if (st) g16_wait<2 * CL + NSTORE>(); else g16_wait<2 * CL>(); }
-            else if (stages == 1) { if (st) g16_wait<CL + NSTORE>(); else g16_wait<CL>(); }
-            else { if (st) g16_wait<NSTORE>(); else g16_wait<0>(); }
-        }
+#define G16_W(n_) { if (hiw) { if (st) g16_wait<(n_) * CH + NSTORE>(); else g16_wait<(n_) * CH>(); } else { if (st) g16_wait<(n_) * CL + NSTORE>(); else g16_wait<(n_) * CL>(); } }
+        if (stages >= D) G16_W(D)
+        else if (D > 5 && stages == 5) G16_W(D > 5 ? 5 : 0)
+        else if (D > 4 && stages == 4) G16_W(D > 4 ? 4 : 0)
+        else if (D > 3 && stages == 3) G16_W(D > 3 ? 3 : 0)
+        else if (D > 2 && stages == 2) G16_W(D > 2 ? 2 : 0)
+        else if (stages == 1) G16_W(1)
+        else G16_W(0)
+#undef G16_W
     };
-    static_assert(NS == 4, "wait_stages is written for two stages in flight behind the one awaited");
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         return epilogue(z, tm, tn, cpi & 1, ckind);
     };
     int slot_rd = 0, slot_wr = (NS - 1) * STAGE, rem = total - 2;    // byte offsets of the slot read / filled; stages issued behind the one this interval's wait awaits
-    bool evt = rem < 2;
+    bool evt = rem < D;
     for (int i = 0; i < total; ++i) {
         // ================= LOAD interval =================
         {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
             cpi = __builtin_amdgcn_readfirstlane(cpi); st_left = __builtin_amdgcn_readfirstlane(st_left); sig_left = __builtin_amdgcn_readfirstlane(sig_left);
             wait_stages(rem, st_left > 0);
         } else {
-            wait_stages(2, st_left > 0);
+            wait_stages(D, st_left > 0);
         }
         G16_BAR();
         // ================= COMPUTE interval: the MFMAs, and between them the scalar bookkeeping of the NEXT interval =================
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(512) void gemm16_planes_kernel(G16P p) {
         --kleft; --rem;
         st_left = st_left > 0 ? st_left - 1 : 0;
         sig_left = sig_left > 0 ? sig_left - 1 : sig_left;
-        evt = kleft == 0 || rem < 2 || sig_left == 0;
+        evt = kleft == 0 || rem < D || sig_left == 0;
         // one bookkeeping instruction behind each MFMA: issued while the matrix pipe is busy with it, instead of in a row in front of the first / behind the last
 #pragma unroll
         for (int k = 0; k < TMW * TNW; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x006, 1, 0); }
@@ -505,6 +508,8 @@ int g16_launch(G16P& p, int nb, int ncols, void* sk_ws, size_t sk_ws_bytes, hipS
 
 using G16Sq = G16Geo<8, 4>;                    // 256 x 256
 using G16Wide = G16Geo<9, 3>;                  // 288 x 192
+using G16Small = G16Geo<4, 2, 8>;              // 128 x 128, 8-slot ring (round 6: the model forwards' mid-size products, which the makespan model gives the small tiles)
+using G16Tall = G16Geo<8, 2, 6>;               // 256 x 128, 6-slot ring
 
 }  // namespace
 
@@ -537,7 +542,7 @@ bool gemm16_eligible(const PlaneGemmArgs& a) {
     return true;
 }
 
-int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
+int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st, int cfg) {
     G16P p{};
     p.Ah = a.Abf ? reinterpret_cast<const char*>(a.Abf) : reinterpret_cast<const char*>(a.Ah); p.Bh = reinterpret_cast<const char*>(a.Bh);
     p.C = a.C; p.Ph = a.Ph; p.Pl = a.Pl; p.scale = a.scale; p.bias = a.bias;
@@ -548,6 +553,17 @@ int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.nb2 = a.nb2 > 0 ? a.nb2 : 1; p.M = a.M; p.N = a.N; p.Np = a.Np; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
     const int ncols = a.epi == 1 ? a.Np : a.N;
     const int nb = a.nb1 * p.nb2;
+    // cfg 0 / 1 (round 6): the 128 x 128 and 256 x 128 tiles of gemm_nt_planes()'s makespan model on THIS kernel -- the same two-group loop, 2 or 3 LDS-DMA pieces per wave
+    // and stage.  The 128 x 128 planes kernel of cti_gemm_bf16x3.hip took ~0.6 us per 32-deep stage with one product per pair (a barrier round per stage for 4
+    // MFMAs a wave): 3072 x 1024 x 1024 x 2 batches 38 us.
+    if (cfg == 0 || cfg == 1) {
+#define G16_GO_S(EPI) (cfg == 0 ? (a.Abf ? g16_launch<EPI, G16Small, true>(p, nb, ncols, nullptr, 0, st) : g16_launch<EPI, G16Small, false>(p, nb, ncols, nullptr, 0, st)) \
+                                : (a.Abf ? g16_launch<EPI, G16Tall, true>(p, nb, ncols, nullptr, 0, st) : g16_launch<EPI, G16Tall, false>(p, nb, ncols, nullptr, 0, st)))
+        if (a.epi == 1) return cfg == 0 ? g16_launch<G16_EPI_PLANES, G16Small, false>(p, nb, ncols, nullptr, 0, st) : g16_launch<G16_EPI_PLANES, G16Tall, false>(p, nb, ncols, nullptr, 0, st);
+        if (a.epi == 5) return G16_GO_S(G16_EPI_BF16);
+        return G16_GO_S(G16_EPI_F32);
+#undef G16_GO_S
+    }
     if (a.epi == 1) return g16_launch<G16_EPI_PLANES, G16Sq, false>(p, nb, ncols, nullptr, 0, st);
     // Tile: 256 x 256.  The 288 x 192 geometry (CTI_GEMM16_TILE=1; 9216 x 3072 outputs = 512 tiles = two FULL rounds of the 256 workgroups instead of 1.69)
     // is built and under test but measured no faster where its rounds are fewer (126.0 vs 128.5 us at 9216 x 3072 x 2048) and 20 % slower where they are equal

@@ -805,6 +805,10 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     p.Ph = a.Ph; p.Pl = a.Pl; p.pitchP = a.rows_allocP * 16; p.Np = a.Np; p.gdiv = a.gdiv > 0 ? a.gdiv : 1;
     p.Af = a.Af; p.ldaf = a.ldaf; p.Kreal = a.Kreal;
     if (a.f6out) p.F6 = *a.f6out;
+    // CTI_GEMM_TRACE=1 (debugging aid): one line per product on stderr -- which shapes a model forward really runs
+    static const bool trace = [] { const char* e = getenv("CTI_GEMM_TRACE"); return e && e[0] == '1'; }();
+    if (trace) fprintf(stderr, "gemm_nt_planes M=%d N=%d Kp=%d nb=%dx%d terms=%d epi=%d ksplit=%d Af=%d Abf=%d scale=%d bias=%d relu=%d\n", a.M, a.N, a.Kp, a.nb1, a.nb2, a.terms, a.epi,
+                       a.ksplit, a.Af != nullptr, a.Abf != nullptr, a.scale != nullptr, a.bias != nullptr, a.relu);
     if (a.ksplit > 1) {
         if (a.nb1 < 1 || a.nb2 != 1 || a.epi != 0 || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
@@ -851,7 +855,10 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     if (tuning_gemm_cfg() >= 0) cfg = tuning_gemm_cfg();                   // cti_set_tuning(CTI_TUNE_GEMM_CFG): tests reach every geometry at small shapes
     // plain-bf16 products on the 256 x 256 tile: the round-4 kernel (cti_gemm16.hip; CTI_GEMM16=0 keeps this file's kernel: A/B)
     static const bool use16 = [] { const char* e = getenv("CTI_GEMM16"); return !(e && e[0] == '0'); }();
-    if (use16 && cfg == 2 && gemm16_eligible(a)) return gemm16_planes(a, st);
+    // round 6: the smaller tiles' plain-bf16 products as well (G16Geo<4, 2, 8> / <8, 2, 6> in cti_gemm16.hip: c3 566 -> 522 us, profiles/r06_gemm_mid_size.txt;
+    // CTI_GEMM16_SMALL=0: this file's kernel for them, A/B)
+    static const bool small16 = [] { const char* e = getenv("CTI_GEMM16_SMALL"); return !(e && e[0] == '0'); }();
+    if (use16 && (cfg == 2 || small16) && gemm16_eligible(a)) return gemm16_planes(a, st, cfg);
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
     const int key = (a.terms == 3 ? 4 : 0) + epi;
     switch (key) {
