@@ -140,6 +140,10 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st);
 bool gemm16_eligible(const PlaneGemmArgs& a);
 int gemm16_planes(const PlaneGemmArgs& a, hipStream_t st, int cfg = 2);      // cfg: the tile of gemm_nt_planes()'s model (0 = 128 x 128, 1 = 256 x 128, 2 = 256 x 256)
 size_t gemm16_sk_workspace_bytes();
+// cti_gemm_skinny.hip: few rows x long K (what callers plan a split-K for) as ONE launch: K split over a workgroup's waves, partial tiles summed in LDS
+bool gemm_skinny_enabled();
+bool gemm_skinny_eligible(const PlaneGemmArgs& a);
+int gemm_skinny(const PlaneGemmArgs& a, hipStream_t st);
 // planes of x^T for x (M x n) row-major: rows = n, depth = Mp >= M (multiple of 16, zero-filled)
 int split_planes_t(const float* x, int64_t ld, int64_t M, int n, int64_t Mp, unsigned short* hi, unsigned short* lo, int64_t rows_alloc, hipStream_t st);
 int plan_ksplit_tn(int64_t M, int N, int K);

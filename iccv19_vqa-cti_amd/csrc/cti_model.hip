@@ -431,10 +431,13 @@ int cti_linear_residual_pb(const float* x, int64_t ldx, const void* W_planes, co
     if (af32) { g.Af = x; g.ldaf = ldx; g.Kreal = K; }
     g.Ah = ah; g.Al = al_; g.Bh = bh; g.Bl = bl; g.rows_allocA = ra; g.rows_allocB = rb; g.nb1 = 1; g.nb2 = 1;
     g.M = B; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
-    const int S = plan_ksplit(B, N, Kp, 1);
+    int S = plan_ksplit(B, N, Kp, 1);
     g.C = part; g.ldc_m = N; g.ldc_n = 1;                        // S == 1: the plain product lands where the partials would
-    if (S > 1) { g.ksplit = S; g.partial = part; g.partials_only = 1; }
-    rc = gemm_nt_planes(g, st); if (rc) return rc;
+    if (S > 1 && tuning_gemm_cfg() < 0 && gemm_skinny_eligible(g)) { S = 1; rc = gemm_skinny(g, st); if (rc) return rc; }      // round 6: ONE launch, ONE slab (cti_gemm_skinny.hip)
+    else {
+        if (S > 1) { g.ksplit = S; g.partial = part; g.partials_only = 1; }
+        rc = gemm_nt_planes(g, st); if (rc) return rc;
+    }
     const int64_t items = (int64_t)B * (N / 4);
     hipLaunchKernelGGL(linear_residual_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, part, S > 1 ? S : 1, scale, scale ? scale_div : 1, bias, seq, out,
                        acc, beta, B, L, N);
@@ -449,6 +452,8 @@ int cti_gemm_pb_partials_count(int M, int N, int K) {
     // 128 x 128 workgroup per CU and K ranges of at least 128.  plan_ksplit() leaves products of more than 96 tiles unsplit: 256 x 7 168 x 1 024, the unrolled
     // BAN loop's first product, then ran on 112 workgroups for 27 us.
     const int Kp = planes_kp(K);
+    // round 6: batch-sized products run as ONE launch that splits K over a workgroup's waves (cti_gemm_skinny.hip) and leaves ONE slab
+    if (gemm_skinny_enabled() && tuning_gemm_cfg() < 0 && M <= 512 && N >= 16 && Kp >= 256) return 1;
     const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     int best = 1;
     for (int s = 2; s <= 16; s *= 2) {
@@ -486,6 +491,8 @@ int cti_gemm_pb_partials(const float* x, int64_t ldx, const void* W_planes, int 
     g.M = M; g.N = N; g.Kp = Kp; g.terms = prec == CTI_PREC_BF16X3 ? 3 : 1; g.epi = 0; g.gdiv = 1; g.scale_div = 1;
     g.C = partials; g.ldc_m = N; g.ldc_n = 1;
     if (S > 1) { g.ksplit = S; g.partial = partials; g.partials_only = 1; }       // (the plane GEMM takes the split it is given)
+    else if (af32 && K != Kp) { g.Af = nullptr; rc = split_planes(x, ldx, M, K, ah, prec == CTI_PREC_BF16 ? nullptr : al_, ra, st); if (rc) return rc; }   // (a K tail: through planes)
+    if (S == 1 && tuning_gemm_cfg() < 0 && gemm_skinny_eligible(g)) return gemm_skinny(g, st);
     return gemm_nt_planes(g, st);
 }
 

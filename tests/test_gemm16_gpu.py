@@ -209,3 +209,35 @@ def test_fp32_rows_read_directly_by_the_plain_bf16_product(M, N, K):
     ref = torch.relu(a.double() @ w.double().t() + b.double())
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err < 3e-6, err
+
+
+@pytest.mark.parametrize("M,nb,N,K", [(256, 1, 2048, 1024), (256, 2, 1024, 2048), (256, 1, 3129, 2048), (100, 1, 72, 256), (33, 3, 16, 288), (512, 1, 1024, 1024), (256, 1, 1024, 8192)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-5), ("bf16", 1e-2)])
+def test_skinny_products_in_one_launch(M, nb, N, K, mode, tol):
+    """Round 6: the products a caller plans a split-K for (few rows, long K: the classifier and residual layers at the batch's 256 rows) run as ONE launch of
+    cti_gemm_skinny.hip -- K split over a workgroup's eight waves, A from the fp32 rows or from planes, partial tiles summed in LDS in wave order -- against float64,
+    with scale / bias / ReLU, batches, ragged M and N, in both arithmetic modes; CTI_TUNE_GEMM_CFG keeps the split-K path reachable (same result within rounding);
+    the same bits on every run."""
+    import cti_amd
+    ops = cti_amd.pkg.ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(nb * N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(nb * N, generator=g).cuda()
+    scale = (torch.rand(nb, generator=g) + 0.5).cuda()
+    old = cti_amd.get_precision()
+    try:
+        cti_amd.set_precision(mode)
+        wp = ops.split_operand(w)
+        ref = torch.relu((a.double() @ w.double().t()).view(M, nb, N) * scale.double().view(1, nb, 1) + bias.double().view(1, nb, N)).permute(1, 0, 2)
+
+        def run():
+            return ops.gemm_nt(a, w, nb1=nb, rA1=0, rB1=N, M=M, N=N, scale=scale, scale_div=N, scale_bs=1, bias=bias, bias_bs=N, relu=True, B_planes=wp)
+        out = run()
+        assert float((out.double().reshape(ref.shape) - ref).abs().max() / ref.abs().max()) < tol
+        assert torch.equal(out, run())
+        with ops.tuning(gemm_cfg=0):                                    # the split-K path of rounds 1-5
+            old_path = run()
+        assert float((out.double() - old_path.double()).abs().max() / ref.abs().max()) < tol
+    finally:
+        cti_amd.set_precision(old)

@@ -92,7 +92,13 @@ def test_raw_split_k_partials_sum_to_the_product(prec, tol, M, N, K, pad):
     ref = xw[:, :K].astype(np.float64) @ wt.astype(np.float64).T
     assert O.norm_max_err(slabs.sum(0).cpu().numpy(), ref) < tol
     if K >= 4096 and M == 256:
-        assert S > 1                                                          # the shapes of the unrolled loop really are split
+        # round 6: batch-sized products leave ONE slab (K is split over the waves of cti_gemm_skinny.hip's workgroups and summed in LDS); with a forced tile
+        # geometry -- the split-K path of rounds 1-5 -- the shapes of the unrolled loop really are split into slabs
+        assert S == 1
+        with ops.tuning(gemm_cfg=0):
+            old = ops.gemm_pb_partials(x, planes, N)
+            assert old.shape[0] > 1 and old.shape[0] == ops.L.lib().cti_gemm_pb_partials_count(M, N, K)
+            assert O.norm_max_err(old.sum(0).cpu().numpy(), ref) < tol
     # the reduced product of the same operands agrees with the sum of the slabs
     full = ops.gemm_nt(x, T(wt), B_planes=planes)
     assert O.norm_max_err(slabs.sum(0).cpu().numpy(), full.cpu().numpy().astype(np.float64)) < tol

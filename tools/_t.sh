@@ -1,5 +1,6 @@
-for rep in 1 2; do for cfg in c3 c4; do for v in "CTI_GEMM_RS=0 CTI_GEMM16_SMALL=0" "CTI_GEMM_RS=0 CTI_GEMM16_SMALL=1" "CTI_GEMM_RS=1 CTI_GEMM16_SMALL=1"; do
-  env $v python bench.py --config $cfg --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
+timeout 1500 python -m pytest tests/test_unrolled_ops_gpu.py tests/test_fusions_gpu.py tests/test_models_gpu.py tests/test_gemm16_gpu.py -m gpu -x -q 2>&1 | tail -3
+for rep in 1 2; do for cfg in c3 c4; do for v in 0 1; do
+  CTI_GEMM_SKINNY=$v python bench.py --config $cfg --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$cfg $v', round(d['value']), 'samples/s', round(d['ms_per_step']*1e3,1), 'us')"
+d=json.loads(sys.stdin.read()); print('$cfg CTI_GEMM_SKINNY=$v', round(d['value']), 'samples/s', round(d['ms_per_step']*1e3,1), 'us')"
 done; done; done
