@@ -167,6 +167,8 @@ int gemm_skinny(const PlaneGemmArgs& a, hipStream_t st) {
     p.M = a.M; p.N = a.N; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
     // 32 x 64 tiles when they still give the chip a workgroup per compute unit, else 32 x 32
     const long long rows = (a.M + 31) / 32;
+    // (measured and dropped: the 32 x 64 tile for K >= 4 096 whatever the workgroup count -- a third fewer operand bytes through the L2s, half the workgroups:
+    // c4 1 369 -> 1 394 us)
     const bool wide = rows * ((a.N + 63) / 64) * a.nb1 >= 200;
     const dim3 grid((unsigned)((a.N + (wide ? 63 : 31)) / (wide ? 64 : 32)), (unsigned)rows, (unsigned)a.nb1);
 #define SK_GO(T, F) { if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<T, F, 4>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((gemm_skinny_kernel<T, F, 2>), grid, dim3(512), 0, st, p); }

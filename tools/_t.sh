@@ -1,6 +1,5 @@
-timeout 1500 python -m pytest tests/test_unrolled_ops_gpu.py tests/test_fusions_gpu.py tests/test_models_gpu.py tests/test_gemm16_gpu.py -m gpu -x -q 2>&1 | tail -3
-for rep in 1 2; do for cfg in c3 c4; do for v in 0 1; do
-  CTI_GEMM_SKINNY=$v python bench.py --config $cfg --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
+for rep in 1 2; do for v in 1000000 4096 2048; do
+  CTI_SKINNY_WIDE_K=$v python bench.py --config c4 --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('$cfg CTI_GEMM_SKINNY=$v', round(d['value']), 'samples/s', round(d['ms_per_step']*1e3,1), 'us')"
-done; done; done
+d=json.loads(sys.stdin.read()); print('c4 CTI_SKINNY_WIDE_K=$v', round(d['value']), 'samples/s', round(d['ms_per_step']*1e3,1), 'us')"
+done; done
