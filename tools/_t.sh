@@ -1,5 +1,6 @@
-for rep in 1 2; do for v in 1000000 4096 2048; do
-  CTI_SKINNY_WIDE_K=$v python bench.py --config c4 --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
+python bench.py --mode train --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('c4 CTI_SKINNY_WIDE_K=$v', round(d['value']), 'samples/s', round(d['ms_per_step']*1e3,1), 'us')"
-done; done
+d=json.loads(sys.stdin.read()); print('train', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms')"
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-fp32-exact --no-subrecords 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('headline', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms')"
