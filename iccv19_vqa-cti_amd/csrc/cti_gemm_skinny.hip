@@ -154,7 +154,6 @@ bool gemm_skinny_eligible(const PlaneGemmArgs& a) {
     if (!gemm_skinny_enabled() || !(a.terms == 1 || a.terms == 3) || a.epi != 0 || a.Abf || a.f6out || a.partials_only || a.ldc_n != 1) return false;
     if ((a.nb2 > 1) || a.nb1 < 1 || a.nb1 > 64 || a.M < 1 || a.M > 512 || a.N < 16 || a.Kp % 32 != 0 || a.Kp < 256) return false;
     if (a.Af && ((a.ldaf & 3) || (reinterpret_cast<uintptr_t>(a.Af) & 15) || a.Kreal != a.Kp)) return false;     // (no K tail in the fp32 rows: every step reads 32 real values)
-    if (a.Af && a.nb1 > 1 && a.rA1 != 0) return false;               // (fp32 A: one matrix shared by the batches)
     return true;
 }
 
@@ -163,7 +162,7 @@ int gemm_skinny(const PlaneGemmArgs& a, hipStream_t st) {
     p.Af = a.Af; p.ldaf = a.ldaf; p.Ah = a.Ah; p.Al = a.Al; p.pitchA = a.rows_allocA * 16;
     p.Bh = a.Bh; p.Bl = a.Bl; p.pitchB = a.rows_allocB * 16;
     p.C = a.C; p.scale = a.scale; p.bias = a.bias;
-    p.rA1 = a.Af ? 0 : a.rA1; p.rB1 = a.rB1; p.ldc_m = a.ldc_m; p.sC1 = a.sC1; p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
+    p.rA1 = a.rA1; p.rB1 = a.rB1; p.ldc_m = a.ldc_m; p.sC1 = a.sC1; p.scale_bs = a.scale_bs; p.bias_bs = a.bias_bs;
     p.M = a.M; p.N = a.N; p.nk = a.Kp / 32; p.scale_div = a.scale_div > 0 ? a.scale_div : 1; p.relu = a.relu;
     // 32 x 64 tiles when they still give the chip a workgroup per compute unit, else 32 x 32
     const long long rows = (a.M + 31) / 32;

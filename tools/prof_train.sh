@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pt; mkdir -p gpurun_out/pt
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pt -o m -- python3 bench.py --mode train --steps 20 --warmup 5 > gpurun_out/pt/log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pt -o m -- python3 bench.py --mode train --steps 20 --warmup 5 --no-graph > gpurun_out/pt/log 2>&1
 tail -1 gpurun_out/pt/log | cut -c1-300
 python3 - <<'PY'
 import csv,glob
