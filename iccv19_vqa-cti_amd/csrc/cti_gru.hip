@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256) void gru_step_fused_kernel(const unsigned shor
 // computes the whole tile (4 row tiles x 3 gates = 12 accumulators): its A fragments (h_{t-1} planes) and B fragments (W_hh planes) come straight from global
 // memory as 16-B loads, all of a batch in flight at once (28 loads), no LDS staging, no barrier; the eight partial tiles meet in LDS (two halves of 48 KiB, fixed
 // order: deterministic), where thread (row, unit) finds the three gates of its output.  The gate inputs (gi, h_{t-1}, b_hh) are loaded BEFORE the K loop.
+#ifndef CTI_GRU_KS_SB
+#define CTI_GRU_KS_SB 2        // K steps of fragments in flight per batch in the plain-bf16 step kernel.  2: <= 128 registers, TWO workgroups per compute unit -- the steps of
+                               // two GRUs (question / answer, BAN / CTI on sibling streams) share the chip instead of alternating: c4 1 400 -> 1 358 us, c3 unchanged; alone a step
+                               // is ~1 us longer than with 4 (one more round trip): profiles/r06_gru_step_k_split.txt
+#endif
 template <int TERMS>
-__global__ __launch_bounds__(512) void gru_step_ks_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
+__global__ __launch_bounds__(512, (CTI_GRU_KS_SB == 2 ? 4 : 2)) void gru_step_ks_kernel(const unsigned short* __restrict__ Hh, const unsigned short* __restrict__ Hl, int64_t pitchH,
                                                           const unsigned short* __restrict__ Wh, const unsigned short* __restrict__ Wl, int64_t pitchW,
                                                           int nsteps, const float* __restrict__ gi, int64_t ld_gi, const float* __restrict__ b_hh,
                                                           const float* __restrict__ hprev, float* __restrict__ out, int64_t ld_out,
@@ -261,9 +266,7 @@ __global__ __launch_bounds__(512) void gru_step_ks_kernel(const unsigned short* 
         const bool ok = jok && b < B;
         const float* gib = gi + (int64_t)(ok ? b : 0) * ld_gi;
         gv[p][0] = ok ? gib[j] : 0.f; gv[p][1] = ok ? gib[H + j] : 0.f; gv[p][2] = ok ? gib[2 * H + j] : 0.f;
-        hpv[p] = (ok && hprev) ? hprev[(int64_t)b * H + j] : 0.f;
     }
-    bb[0] = jok ? b_hh[j] : 0.f; bb[1] = jok ? b_hh[H + j] : 0.f; bb[2] = jok ? b_hh[2 * H + j] : 0.f;
     // fragments of K step ks: chunk 2 ks + (lane >> 5), row (lane & 15) of the tile, 16-B half (lane >> 4) & 1
     const int spw = (nsteps + 7) / 8, s0 = wid * spw, my = max(0, min(nsteps, s0 + spw) - s0);
     const unsigned short* ah = Hh + (int64_t)(lane >> 5) * pitchH + (int64_t)(row0 + (lane & 15)) * 16 + ((lane >> 4) & 1) * 8;
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(512) void gru_step_ks_kernel(const unsigned short* 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[m][g] = g_f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int SB = TERMS == 3 ? 2 : 4;                          // K steps whose fragments are in flight together (28 loads of 16 B per lane)
+    constexpr int SB = TERMS == 3 ? (CTI_GRU_KS_SB == 2 ? 1 : 2) : CTI_GRU_KS_SB;      // K steps whose fragments are in flight together (28 loads of 16 B per lane at the default)
     for (int sb = 0; sb < my; sb += SB) {
         g_bf16x8 fah[SB][4], fal[SB][4], fbh[SB][3], fbl[SB][3];
 #pragma unroll
@@ -313,6 +316,9 @@ __global__ __launch_bounds__(512) void gru_step_ks_kernel(const unsigned short* 
     }
     // C/D map of the 16x16 MFMA: column = lane & 15 (unit), row = 4 (lane >> 4) + reg.  Two halves of the rows; thread (er, ej) sums the eight waves' partials of its
     // three gates in wave order and applies the gates
+    bb[0] = jok ? b_hh[j] : 0.f; bb[1] = jok ? b_hh[H + j] : 0.f; bb[2] = jok ? b_hh[2 * H + j] : 0.f;      // (in flight across the first barrier below: three registers the K loop does not carry)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { const int b = row0 + p * 32 + er; hpv[p] = (jok && b < B && hprev) ? hprev[(int64_t)b * H + j] : 0.f; }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if (p) __syncthreads();

@@ -1,4 +1,5 @@
-timeout 1500 python -m pytest tests/test_unrolled_ops_gpu.py tests/test_fusions_gpu.py tests/test_models_gpu.py tests/test_gemm16_gpu.py tests/test_parity_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_fusions_gpu.py tests/test_models_gpu.py tests/test_backward_gpu.py -m gpu -x -q -k "gru or GRU or persistent" 2>&1 | tail -2
+python tools/bench_gru.py 30 2>&1 | grep '^{' | head -3
 for rep in 1 2; do for cfg in c3 c4; do
   python bench.py --config $cfg --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "
 import json,sys
