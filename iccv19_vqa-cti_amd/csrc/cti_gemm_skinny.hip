@@ -10,6 +10,11 @@
 // K-split step kernel (cti_gru.hip) and the BiAttention logits (cti_attention.hip).
 #include "cti_common.h"
 
+#ifndef CTI_SKINNY_LB
+#define CTI_SKINNY_LB 2          // launch bound: minimum waves per SIMD.  (Measured: 4 -- two workgroups per compute unit, <= 128 registers, with CTI_SKINNY_SB = 2 --
+                                 // c3 476 -> 470 us but c4 1 344 -> 1 406 us: the long-K products of the BAN loop lose more to the extra round trips than co-residency returns)
+#endif
+
 namespace cti {
 namespace {
 
@@ -37,7 +42,7 @@ __device__ __forceinline__ void sk_cvt(const float4 a, const float4 b, sk_bf16x8
 
 // TERMS: 1 = one bf16 product per pair, 3 = hi*hi + hi*lo + lo*hi (fp32-grade).  AF32: A = fp32 rows (else planes).  NT: 16-column tiles per workgroup (2 or 4).
 template <int TERMS, bool AF32, int NT>
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmSkP p) {
+__global__ __launch_bounds__(512, (CTI_SKINNY_LB)) void gemm_skinny_kernel(GemmSkP p) {
     __shared__ __attribute__((aligned(16))) float part[8 * 2 * NT * 64 * 4];      // [wave][tile = mt * NT + j][lane][4]: 16 B per lane and tile
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -66,7 +71,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmSkP p) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[mt][j] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int SB = (TERMS == 3 || NT == 4) ? 2 : 4;             // K steps whose fragments are in flight together
+#ifndef CTI_SKINNY_SB
+#define CTI_SKINNY_SB 4
+#endif
+    constexpr int SB = (TERMS == 3 || NT == 4) ? 2 : CTI_SKINNY_SB;  // K steps whose fragments are in flight together
     for (int sb = 0; sb < my; sb += SB) {
         float4 ra[SB][2][2]; sk_bf16x8 pa[SB][2], pal[SB][2], pb[SB][NT], pbl[SB][NT];
 #pragma unroll
