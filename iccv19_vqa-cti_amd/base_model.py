@@ -253,7 +253,11 @@ def _ban_unrolled_prep(self):
             kvec[g] = ops.gemm_nt(csum.view(1, H), Wq[g], prec="fp32").view(D)
         Wfin = torch.cat([float(G - j) * PpT[j].t() for j in range(G)], 1).contiguous()   # (H, G D)
         e_const = sum(float(G - j) * c[j] for j in range(G)).contiguous()
-        val = dict(cat_planes=[None if t is None else ops.split_operand(t) for t in cats], kvec=kvec, Wfin=Wfin, Wfin_planes=ops.split_operand(Wfin), e_const=e_const, D=D, H=H)
+        # round 6: the same C[g][j] stacked per SOURCE glimpse j -- cols[j] = [C[j+1][j]; ...; C[G-1][j]] ((G-1-j) D, D): everything b_j contributes to later glimpses is
+        # ONE product of K = D, taken as soon as b_j exists (see _ban_forward_unrolled)
+        cols = [torch.cat([cats[g][:, j * D:(j + 1) * D] for g in range(j + 1, G)], 0).contiguous() for j in range(G - 1)]
+        val = dict(cat_planes=[None if t is None else ops.split_operand(t) for t in cats], kvec=kvec, Wfin=Wfin, Wfin_planes=ops.split_operand(Wfin), e_const=e_const, D=D, H=H,
+                   cols=cols, col_planes=[ops.split_operand(t) for t in cols])
     object.__setattr__(self, "_unroll_key", key)
     object.__setattr__(self, "_unroll_val", val)
     return val
@@ -279,17 +283,30 @@ def _ban_forward_unrolled(self, q_emb, att, vp, Hq):
         return None
     bembs = torch.empty((B, G * D), device=q_emb.device, dtype=torch.float32)       # the pooled vectors side by side: every later product's K-concatenated operand
     slabs = None
+    # Round 6: per SOURCE glimpse instead of per target.  The K-concatenated product of glimpse g re-reads b_0 .. b_{g-1} (K = g D: 24 us a glimpse on average, all of it
+    # on the chain between two pools); stacked the other way, contrib[j] = b_j [C[j+1][j]; ...; C[G-1][j]]^T is ONE product of K = D per glimpse whose first D columns are
+    # what the next pool waits for, and pool g adds the g column blocks contrib[j][:, (g-1-j) D : (g-j) D] (and k_g) as it loads its operands.  Same products, same
+    # roundings of the operands; the sum over j is taken in fp32 by the pool instead of inside one accumulator.  CTI_BAN_KCONCAT=1: the round-5 form (A/B).
+    by_source = not _BAN_KCONCAT
+    contrib = []
     for g in range(G):
         adds = []
-        if g > 0:
+        if g > 0 and by_source:
+            adds = [(P["kvec"][g].data_ptr(), 0)] + [(contrib[j].data_ptr() + (g - 1 - j) * D * 4, (G - 1 - j) * D) for j in range(g)]
+        elif g > 0:
             S = slabs.shape[0]
             adds = [(P["kvec"][g].data_ptr(), 0)] + [(slabs.data_ptr() + s_ * B * D * 4, D) for s_ in range(S)]
         if len(adds) > 32 or not ops.bi_pool_shift_multi(vp[g], Hq[g], adds, att[:, g, :, :].float(), bembs[:, g * D:(g + 1) * D]):
             return None if g == 0 else _unrolled_bail(g)
-        if g < G - 1:
+        if g < G - 1 and by_source:
+            contrib.append(ops.gemm_nt(bembs[:, g * D:(g + 1) * D], P["cols"][g], B_planes=P["col_planes"][g]))      # (B, (G-1-g) D)
+        elif g < G - 1:
             slabs = ops.gemm_pb_partials(bembs[:, :(g + 1) * D], P["cat_planes"][g + 1], D)      # (S, B, D): shift_{g+1} - k_{g+1}, still in its K ranges
     E = ops.gemm_nt(bembs, P["Wfin"], bias=P["e_const"], B_planes=P["Wfin_planes"])
     return ops.joint_sums(q_emb, float(G), Dq=E, dq=float(Lq))
+
+
+_BAN_KCONCAT = __import__("os").environ.get("CTI_BAN_KCONCAT", "0") == "1"
 
 
 class _UnrolledLoopLost(Exception):

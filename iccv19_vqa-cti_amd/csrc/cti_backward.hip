@@ -585,8 +585,7 @@ extern "C" int cti_gemm_nt_pb(const float* A, int64_t lda, int64_t rowsA_total, 
     // plain bf16 -> cti_gemm16.hip on a hi plane; bf16x3 -> the planes kernel, whose fp32-A form measured slower at that size)
     const long long tiles256 = (long long)nb1 * ((M + 255) / 256) * ((N + 255) / 256);
     // (round 6: batches of batch-sized products too -- cti_gemm_skinny.hip reads the fp32 rows of every batch itself: no split launch in front of it)
-    const bool skinny_rows = gemm_skinny_enabled() && tuning_gemm_cfg() < 0 && M <= 512 && K == Kp && Kp >= 256 && (int64_t)nb1 * M <= 4 * af32_rows() && rowsA_total <= 8192 &&
-                             plan_ksplit(M, N, Kp, nb1) > 1;      // (exactly the products the planner below hands to that kernel)
+    const bool skinny_rows = gemm_skinny_enabled() && tuning_gemm_cfg() < 0 && M <= 512 && K == Kp && Kp >= 256 && (int64_t)nb1 * M <= 4 * af32_rows() && rowsA_total <= 8192;      // (exactly the products gemm_nt_planes() hands to that kernel)
     const bool af32 = (af32_pb() || (int64_t)nb1 * M <= af32_rows() || skinny_rows) && tiles256 < 128 && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     int rc = CTI_OK;
     if (!af32) { rc = split_planes(A, lda, rowsA_total, K, ah, prec == CTI_PREC_BF16 ? nullptr : al, ra, as_stream(stream)); if (rc) return rc; }   // plain bf16: the products read the hi plane only

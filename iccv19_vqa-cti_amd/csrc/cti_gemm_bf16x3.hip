@@ -811,7 +811,7 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
                        a.ksplit, a.Af != nullptr, a.Abf != nullptr, a.scale != nullptr, a.bias != nullptr, a.relu);
     // round 6: a product its caller planned a split-K for (few rows, long K) is ONE launch of cti_gemm_skinny.hip instead of K ranges + partials + a reduce launch
     // (CTI_GEMM_SKINNY=0: off, A/B; a forced tile geometry -- the tests' cti_set_tuning -- keeps the split-K path reachable)
-    if (a.ksplit > 1 && tuning_gemm_cfg() < 0 && gemm_skinny_eligible(a)) return gemm_skinny(a, st);
+    if ((a.ksplit > 1 || a.M <= 512) && tuning_gemm_cfg() < 0 && gemm_skinny_eligible(a)) return gemm_skinny(a, st);     // (any product of at most 512 rows: planned split or not)
     if (a.ksplit > 1) {
         if (a.nb1 < 1 || a.nb2 != 1 || a.epi != 0 || !a.partial || a.ldc_n != 1 || a.Kp % (a.ksplit * KPAD) != 0)
             return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: split-K needs one fp32 row-major GEMM (ksplit=%d Kp=%d epi=%d)", a.ksplit, a.Kp, a.epi);
