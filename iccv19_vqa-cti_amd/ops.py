@@ -231,6 +231,7 @@ def aux_stream_object(device, which=0):
 
 
 _sib = {}
+_MAIN_AUX = _os.environ.get("CTI_SIBLINGS_MAIN_AUX", "0") == "1"
 _no_nested_fork = [False]       # set while run_concurrently's functions run: their models fork no auxiliary stream of their own
 
 
@@ -263,7 +264,9 @@ def run_concurrently(*fns):
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             outs[i + 1] = no_aux(fns[i + 1])
-    outs[0] = no_aux(fns[0])
+    # (round 6, re-measured: CTI_SIBLINGS_MAIN_AUX=1 lets fns[0] -- on the caller's stream, which may fork as any single model's capture does -- keep its auxiliary
+    # streams: configs[3] 1 330 -> 1 448 us.  A third chain still adds contention, not overlap; default off)
+    outs[0] = fns[0]() if _MAIN_AUX else no_aux(fns[0])
     for i, s in enumerate(_sib[key]):
         cur.wait_stream(s)
         if not capturing:                        # (a capture's private pool keeps its blocks for the graph's lifetime)
