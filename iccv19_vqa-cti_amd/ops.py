@@ -1727,12 +1727,12 @@ def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=
     if persistent:
         L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
     try:
-      with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
-        L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
-                                    b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
-                                    _ptr(w_planes[0]) if w_planes and pr != L.PREC_F32 else 0,
-                                    _ptr(w_planes[1]) if w_planes and pr != L.PREC_F32 else 0,
-                                    ws.data_ptr(), wsb, _stream()), "cti_gru_forward")
+        with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
+            L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                        b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
+                                        _ptr(w_planes[0]) if w_planes and pr != L.PREC_F32 else 0,
+                                        _ptr(w_planes[1]) if w_planes and pr != L.PREC_F32 else 0,
+                                        ws.data_ptr(), wsb, _stream()), "cti_gru_forward")
     finally:
         if persistent:
             L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 0), "cti_set_tuning")
