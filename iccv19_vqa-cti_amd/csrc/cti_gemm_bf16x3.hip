@@ -861,6 +861,10 @@ int gemm_nt_planes(const PlaneGemmArgs& a, hipStream_t st) {
     // round 6: the smaller tiles' plain-bf16 products as well (G16Geo<4, 2, 8> / <8, 2, 6> in cti_gemm16.hip: c3 566 -> 522 us, profiles/r06_gemm_mid_size.txt;
     // CTI_GEMM16_SMALL=0: this file's kernel for them, A/B)
     static const bool small16 = [] { const char* e = getenv("CTI_GEMM16_SMALL"); return !(e && e[0] == '0'); }();
+    if (a.Abf) {                                                     // a row-major bf16 A operand exists on cti_gemm16.hip only, whatever the tile and the A/B switches
+        if (!gemm16_eligible(a)) return fail(CTI_E_UNSUPPORTED, "gemm_nt_planes: a bf16-row A operand needs a product cti_gemm16.hip takes (terms=%d epi=%d Kp=%d)", a.terms, a.epi, a.Kp);
+        return gemm16_planes(a, st, cfg);
+    }
     if (use16 && (cfg == 2 || small16) && gemm16_eligible(a)) return gemm16_planes(a, st, cfg);
     const int epi = (a.epi == 3 && p.gdiv == 2 && a.ldc_n == 2) ? 2 : a.epi;
     const int key = (a.terms == 3 ? 4 : 0) + epi;

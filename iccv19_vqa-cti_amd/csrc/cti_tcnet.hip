@@ -400,8 +400,20 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
             PlaneGemmArgs r{};
             r.Bh = p.wr[0].hi; r.Bl = p.wr[0].lo;
             if (v16) {                                           // bf16 rows: the hi plane as it stands, a zero lo plane for the three-product form
-                int r1 = split_planes16(reinterpret_cast<const unsigned short*>(v_tucked), ld_vt, rows[0] / v_rep, h, p.tp[0].hi, terms == 3 ? p.tp[0].lo : nullptr, p.tp[0].rows_alloc, ss); if (r1) return r1;
-                r.Ah = p.tp[0].hi; r.Al = p.tp[0].lo; r.rows_allocA = p.tp[0].rows_alloc;
+                // (round 6) plain bf16: cti_gemm16.hip reads the bf16 rows themselves where it takes the product (the small tiles are its own now): no split launch
+                bool rows_direct = false;
+                if (terms == 1) {
+                    PlaneGemmArgs t = r;
+                    t.Abf = v_tucked; t.ldabf = ld_vt; t.rows_allocA = rows[0] / v_rep; t.rows_allocB = p.wr[0].rows_alloc; t.nb1 = 1; t.nb2 = 1;
+                    t.M = (int)(rows[0] / v_rep); t.N = h; t.Kp = planes_kp(h); t.terms = 1; t.scale = p.scale_r[0]; t.scale_div = hr; t.bias = rank_b[0]; t.relu = relu;
+                    t.epi = 0; t.C = p.Vr; t.ldc_m = h; t.ldc_n = 1;
+                    rows_direct = planes_kp(h) == h && gemm16_eligible(t);
+                }
+                if (rows_direct) { r.Abf = v_tucked; r.ldabf = ld_vt; r.rows_allocA = rows[0] / v_rep; }
+                else {
+                    int r1 = split_planes16(reinterpret_cast<const unsigned short*>(v_tucked), ld_vt, rows[0] / v_rep, h, p.tp[0].hi, terms == 3 ? p.tp[0].lo : nullptr, p.tp[0].rows_alloc, ss); if (r1) return r1;
+                    r.Ah = p.tp[0].hi; r.Al = p.tp[0].lo; r.rows_allocA = p.tp[0].rows_alloc;
+                }
             } else if (terms == 3) { r.Af = v_tucked; r.ldaf = ld_vt; r.Kreal = h; r.rows_allocA = rows[0] / v_rep + PLANE_SLACK_ROWS; }   // (the fp32-A operand path exists for the 3-term mode)
             else {
                 int r1 = split_planes(v_tucked, ld_vt, rows[0] / v_rep, h, p.tp[0].hi, p.tp[0].lo, p.tp[0].rows_alloc, ss); if (r1) return r1;

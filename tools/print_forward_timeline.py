@@ -9,8 +9,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 emb = [i for i, r in enumerate(rows) if 'embedding_fwd' in r['Kernel_Name']]
-# a forward starts at an embedding kernel that follows a kernel which is not part of a GRU prologue: group embeddings closer than 40 launches
-starts = [e for j, e in enumerate(emb) if j == 0 or e - emb[j - 1] > 40]
+# a forward starts at an embedding kernel whose predecessor embedding is more than GAP launches back (the embeddings of one forward -- question, answer, the second model's --
+# sit within ~20 launches of each other; round 6: a c3 forward is ~45 launches, so the gap from its last embedding to the next forward's first is ~28)
+GAP = 24
+starts = [e for j, e in enumerate(emb) if j == 0 or e - emb[j - 1] > GAP]
 a, b = starts[-back - 1], starts[-back]
 t0 = int(rows[a]['Start_Timestamp'])
 
