@@ -339,7 +339,11 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     const int relu = act == CTI_ACT_RELU;
 
     if (p.guard) { rc = guard_reset(p.guard, st); if (rc) return rc; }
-    if (zero_mask) {
+    // the all-zero-object mask (one pass over v): in front of everything -- except on the few-answer path with an auxiliary stream, where only the fused core's softmax
+    // reads it and the main stream's chain (the a side) is the SHORTER of the two: there it is launched behind that chain, beside the auxiliary stream's v / q sides
+    // (round 6: ~10 us off the critical chain of a c3 forward)
+    const bool mask_late = zero_mask && aux_stream && prec != CTI_PREC_F32 && small_a(d);
+    if (zero_mask && !mask_late) {
         rc = v16 ? cti_zero_row_mask_bf16(v, v_dim, zero_mask, rows[0], v_dim, stream) : cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream);
         if (rc) return rc;
     }
@@ -529,6 +533,10 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         // few answer tokens: chain B ends with the rank nets; modes 1 + 2 + 3 are one kernel behind the join, M is never written
         if (aux_stream) (void)hipEventRecord(ev_join, sb);
         rc = side(2, st); if (rc) return finish(rc);
+        if (mask_late) {
+            rc = v16 ? cti_zero_row_mask_bf16(v, v_dim, zero_mask, rows[0], v_dim, stream) : cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream);
+            if (rc) return finish(rc);
+        }
         if (aux_stream) (void)hipStreamWaitEvent(st, ev_join, 0);
         if (ev_core_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_core_begin), st);
         rc = mbuild_core_small(p.Vr, p.Qr, p.Tt, p.Ar32, out, B, V, Q, A, R, hr, G, st, p_fused ? zero_mask : nullptr, p_fused, hoisted_v ? v_rep : 1, terms, p.Tk);   // p_fused: + the masked softmax
