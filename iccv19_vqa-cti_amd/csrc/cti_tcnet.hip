@@ -338,11 +338,18 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     const int64_t rows[3] = {(int64_t)B * V, (int64_t)B * Q, (int64_t)B * A};
     const int relu = act == CTI_ACT_RELU;
 
-    if (p.guard) { rc = guard_reset(p.guard, st); if (rc) return rc; }
     // the all-zero-object mask (one pass over v): in front of everything -- except on the few-answer path with an auxiliary stream, where only the fused core's softmax
     // reads it and the main stream's chain (the a side) is the SHORTER of the two: there it is launched behind that chain, beside the auxiliary stream's v / q sides
     // (round 6: ~10 us off the critical chain of a c3 forward)
     const bool mask_late = zero_mask && aux_stream && prec != CTI_PREC_F32 && small_a(d);
+    // (experiments' switches, read once; they place the guard's kernels on the main stream)
+    static const bool order1_env = [] { const char* e = getenv("CTI_F6_ORDER"); return e && e[0] == '1'; }();
+    static const bool join_before_rank = [] { const char* e = getenv("CTI_F6_JOIN"); return e && e[0] == 'r'; }();
+    static const bool guard_front_env = [] { const char* e = getenv("CTI_F6_GUARD_FRONT"); return e && e[0] == '1'; }();
+    // the guard block's reset: on chain B's stream where every guard kernel runs there or behind an event of it (round 6: as the main stream's first launch it sat
+    // ~10 us in front of the encoding pass of `a`); on the main stream otherwise
+    const bool reset_on_b = p.guard && aux_stream && !order1_env && !join_before_rank && !guard_front_env && !guard_late();
+    if (p.guard && !reset_on_b) { rc = guard_reset(p.guard, st); if (rc) return rc; }
     if (zero_mask && !mask_late) {
         rc = v16 ? cti_zero_row_mask_bf16(v, v_dim, zero_mask, rows[0], v_dim, stream) : cti_zero_row_mask(v, v_dim, zero_mask, rows[0], v_dim, stream);
         if (rc) return rc;
@@ -385,6 +392,7 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
         (void)hipEventRecord(ev_fork, st);                  // scales, T_eff (and the mask) precede both chains
         (void)hipStreamWaitEvent(sb, ev_fork, 0);
     }
+    if (reset_on_b) { rc = guard_reset(p.guard, sb); if (rc) { (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_at); (void)hipEventDestroy(ev_guard); return rc; } }
     auto finish = [&](int code) {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -481,7 +489,6 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // CTI_F6_ORDER=1 (round 6 experiment; f16f6 with an auxiliary stream and the direct-encoding M build): the v / q sides run FIRST, alone, on the main stream
     // (~0.1 ms), then the M build -- MFMA / vector-ALU bound, 256 workgroups -- runs on the auxiliary stream BESIDE the encoding pass of `a` (HBM bound) instead of
     // behind the a side's last product, where nothing overlaps it (0.27 ms + the scans in front of the mode-3 product: profiles/r05_step_timeline.txt)
-    static const bool order1_env = [] { const char* e = getenv("CTI_F6_ORDER"); return e && e[0] == '1'; }();
     const bool order1 = order1_env && f6 && aux_stream && !fused_core && !guard_late() && !p.Mf32;
     // chain B on the auxiliary stream (or first, on the main stream)
     rc = side(0, order1 ? st : sb); if (rc) return finish(rc);
@@ -573,8 +580,6 @@ static int tcnet_forward_impl(const float* v, const float* q, const float* a, co
     // fp32 sweeps) + the cancellation estimate + the verdict run on the auxiliary stream BESIDE the mode-3 product, behind the M build and an event of the
     // rank nets' product; the main stream meets them again in front of the NaN fill.  (Rounds 3-5: early / middle / final scans in front of the product,
     // 0.10-0.15 ms of the step by the guard-off A/B, profiles/r05_guard_ab.txt; CTI_F6_GUARD_FRONT=1 restores that placement for the A/B.)
-    static const bool join_before_rank = [] { const char* e = getenv("CTI_F6_JOIN"); return e && e[0] == 'r'; }();
-    static const bool guard_front_env = [] { const char* e = getenv("CTI_F6_GUARD_FRONT"); return e && e[0] == '1'; }();
     const bool early_join = f6 && aux_stream && join_before_rank;
     const bool guard_beside = f6 && aux_stream && p.guard && !guard_front_env && !guard_late() && !early_join;
     if (f6 && aux_stream) {

@@ -9,9 +9,7 @@ f = glob.glob('gpurun_out/step_trace/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 q = [i for i, r in enumerate(rows) if 'quantize_rows_f16f6' in r['Kernel_Name']]
 a, b = q[-3], q[-2]
-# a step starts a few launches before the encoder pass: walk back to the guard reset
-while a > 0 and 'guard_reset' not in rows[a]['Kernel_Name']: a -= 1
-while b > 0 and 'guard_reset' not in rows[b]['Kernel_Name']: b -= 1
+# (round 6: the encoder pass of `a` IS the step's first launch -- the guard block's reset moved to the auxiliary stream)
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
     n = re.sub(r'cti::\(anonymous namespace\)::', '', r['Kernel_Name']); n = re.sub(r'^void ', '', n)[:80]
