@@ -70,8 +70,10 @@ SIGNATURES = {
     "cti_adamax_step": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _int, _vp, _vp]),
     "cti_optim_workspace_bytes": (_sz, []),
     "cti_embedding_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _vp]),
+    "cti_embedding_fwd_bf16": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _i64, _vp]),
     "cti_embedding_bwd": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _int, _i64, _i64, _vp]),
     "cti_gru_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cti_gru_forward_x16": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "cti_operand_planes_bytes": (_sz, [_i64, _int]),
     "cti_split_operand": (_int, [_vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "cti_gemm_nt_pb": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _int, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),

@@ -149,7 +149,7 @@ class BanModel(nn.Module):
                 v_att = lg.v_net(v)
                 mask = ops.zero_row_mask(v)
                 vp = self._v_hoist.maybe(v)
-            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
+            q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))                   # [batch, q_len, q_dim]
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
                 for t_ in [v_att, mask] + (vp or []):
@@ -158,8 +158,7 @@ class BanModel(nn.Module):
             att, logits = self.v_att._forward_all(v, q_emb, True, v_att, mask)      # b x g x v x q
             join()
         else:
-            w_emb = self.w_emb(q)
-            q_emb = self.q_emb.forward_all(w_emb)                           # [batch, q_len, q_dim]
+            q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))           # [batch, q_len, q_dim]
             att, logits = self.v_att.forward_all(v, q_emb)                  # b x g x v x q
             vp = self._v_hoist.maybe(v)
             Hq = self._hoist_prepare(q_emb, vp)
@@ -343,19 +342,19 @@ class _TriModel(nn.Module):
             cur = torch.cuda.current_stream()
             _refresh_scales(v.device)
             side.wait_stream(cur)
-            ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
-            q_emb = self.q_emb.forward_all(self.w_emb(q))
+            ans_emb = self.ans_emb.forward_all(self.wa_emb.rows16(ans))
+            q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))
         elif side is not None:
             # inference: the answer GRU (a few short, latency-bound steps) runs on the auxiliary stream beside the question GRU
             cur = torch.cuda.current_stream()
             _refresh_scales(v.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
-            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
+                ans_emb = self.ans_emb.forward_all(self.wa_emb.rows16(ans))
+            q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))                   # [batch, q_len, q_dim]
         else:
-            q_emb = self.q_emb.forward_all(self.w_emb(q))                   # [batch, q_len, q_dim]
-            ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+            q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))                   # [batch, q_len, q_dim]
+            ans_emb = self.ans_emb.forward_all(self.wa_emb.rows16(ans))
         if not hasattr(self, "_v_hoist"):
             # N1: the v projections of the glimpses' pooling networks AND of the attention (512 wide, zero-padded to their 1 024) as one batched GEMM:
             # `v` is read and split into operand planes once
@@ -636,8 +635,8 @@ class MCBanModel(nn.Module):
     def forward(self, v, b, q, ans):
         if v.dtype == torch.bfloat16:
             v = ops.widen_bf16(v)                                           # (this model's attentions read fp32 rows)
-        q_emb = self.q_emb.forward_all(self.w_emb(q))
-        ans_emb = self.ans_emb.forward_all(self.wa_emb(ans))
+        q_emb = self.q_emb.forward_all(self.w_emb.rows16(q))
+        ans_emb = self.ans_emb.forward_all(self.wa_emb.rows16(ans))
         att, logits = self.v_att.forward_all(v, q_emb)                      # b x g x v x q
         va_att, va_logits = self.va_att.forward_all(v, ans_emb)
         if not hasattr(self, "_v_hoist"):

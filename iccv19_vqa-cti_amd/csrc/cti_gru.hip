@@ -526,10 +526,33 @@ static bool gru_persistent_fits(int B, int H, int prec, const float* save) {
     return (H / 16) * (B / 64) <= cus;
 }
 
+static int gru_forward_impl(const float* x, const void* x16, int64_t ldx16, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                            int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
                     int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
                     void* stream) {
-    CTI_REQUIRE_PTR(x); CTI_REQUIRE_PTR(w_ih); CTI_REQUIRE_PTR(w_hh); CTI_REQUIRE_PTR(b_ih); CTI_REQUIRE_PTR(b_hh); CTI_REQUIRE_PTR(out);
+    CTI_REQUIRE_PTR(x);
+    return gru_forward_impl(x, nullptr, 0, w_ih, w_hh, b_ih, b_hh, out, save, B, T, I, H, prec, w_ih_planes, w_hh_planes, workspace, workspace_bytes, stream);
+}
+
+// x as bf16 rows (B * T rows of pitch ldx = I rounded up to a multiple of 32, zero beyond I; 16-B aligned): the plain-bf16 mode's input-side product reads them as they
+// stand (cti_embedding_fwd_bf16 writes them): no fp32 word vectors, no split pass
+int cti_gru_forward_x16(const void* x_bf16, int64_t ldx, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                        int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    CTI_REQUIRE_PTR(x_bf16);
+    CTI_REQUIRE(prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gru_forward_x16: prec=%d (bf16 word vectors are the plain-bf16 mode's)", prec);
+    CTI_REQUIRE(I > 0 && ldx == planes_kp(I) && (reinterpret_cast<uintptr_t>(x_bf16) & 15) == 0, CTI_E_ALIGN,
+                "cti_gru_forward_x16: rows of pitch %d (I = %d rounded up to 32) and a 16-B aligned base are required (ldx=%lld)", planes_kp(I > 0 ? I : 1), I, (long long)ldx);
+    return gru_forward_impl(nullptr, x_bf16, ldx, w_ih, w_hh, b_ih, b_hh, out, save, B, T, I, H, prec, w_ih_planes, w_hh_planes, workspace, workspace_bytes, stream);
+}
+
+static int gru_forward_impl(const float* x, const void* x16, int64_t ldx16, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                            int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    CTI_REQUIRE_PTR(w_ih); CTI_REQUIRE_PTR(w_hh); CTI_REQUIRE_PTR(b_ih); CTI_REQUIRE_PTR(b_hh); CTI_REQUIRE_PTR(out);
     CTI_REQUIRE(B > 0 && T > 0 && I > 0 && H > 0 && (int64_t)B * T < (1ll << 31), CTI_E_SHAPE, "cti_gru_forward: B=%d T=%d I=%d H=%d", B, T, I, H);
     CTI_REQUIRE(prec == CTI_PREC_F32 || prec == CTI_PREC_BF16X3 || prec == CTI_PREC_BF16, CTI_E_UNSUPPORTED, "cti_gru_forward: prec=%d", prec);
     CTI_REQUIRE_PTR(workspace);
@@ -572,7 +595,8 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
     unsigned short* hp_[2]; unsigned short* hl_[2];
     for (int i = 0; i < 2; ++i) { hp_[i] = ws.take<unsigned short>(planes_bytes(rh, H)); hl_[i] = hp_[i] + (size_t)rh * KpH; }
     unsigned* sync_words = ws.take<unsigned>(GP_SYNC_BYTES);
-    int rc = split_planes(x, I, (int64_t)B * T, I, xh, xl, rx, st); if (rc) return rc;
+    int rc = CTI_OK;
+    if (!x16) { rc = split_planes(x, I, (int64_t)B * T, I, xh, xl, rx, st); if (rc) return rc; }
     if (w_ih_planes) { wih = static_cast<unsigned short*>(const_cast<void*>(w_ih_planes)); wil = wih + (size_t)rw * KpI; }   // resident planes
     else { rc = split_planes(w_ih, I, H3, I, wih, wil, rw, st); if (rc) return rc; }
     if (w_hh_planes) { whh = static_cast<unsigned short*>(const_cast<void*>(w_hh_planes)); whl = whh + (size_t)rw * KpH; }
@@ -583,6 +607,14 @@ int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const 
     {
         PlaneGemmArgs g{};
         g.Ah = xh; g.Al = xl; g.Bh = wih; g.Bl = wil; g.rows_allocA = rx; g.rows_allocB = rw; g.nb1 = 1; g.nb2 = 1;
+        if (x16) {
+            g.Abf = x16; g.ldabf = ldx16; g.rows_allocA = (int64_t)B * T;
+            g.M = B * T; g.N = H3; g.Kp = KpI; g.terms = terms; g.epi = 0; g.C = gi; g.ldc_m = H3; g.ldc_n = 1; g.scale_div = 1; g.bias = b_ih;
+            if (!gemm16_eligible(g)) {                              // (a shape cti_gemm16.hip refuses, e.g. K < 128 with a bias: the rows through planes after all)
+                g.Abf = nullptr; g.ldabf = 0; g.rows_allocA = rx;
+                rc = split_planes16(static_cast<const unsigned short*>(x16), ldx16, (int64_t)B * T, KpI, xh, nullptr, rx, st); if (rc) return rc;
+            }
+        }
         g.M = B * T; g.N = H3; g.Kp = KpI; g.terms = terms; g.epi = 0; g.C = gi; g.ldc_m = H3; g.ldc_n = 1; g.scale_div = 1; g.bias = b_ih;
         rc = gemm_nt_planes(g, st); if (rc) return rc;
     }

@@ -23,6 +23,22 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ tok, const floa
     }
 }
 
+// The same lookup as bf16 rows of pitch ld (>= width, zero-filled beyond it): the A operand of the GRU's input-side product as it stands (round 6: no fp32 rows, no split
+// pass in front of that product in the plain-bf16 mode)
+__global__ void embedding_fwd_bf16_kernel(const int64_t* __restrict__ tok, const float* __restrict__ t0, const float* __restrict__ t1,
+                                          unsigned short* __restrict__ out, int64_t ld, int64_t n, int dim, int64_t rows) {
+    const int width = t1 ? 2 * dim : dim;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t k = tok[i];
+        const bool ok = k >= 0 && k < rows;
+        for (int c = threadIdx.x; c < (int)ld; c += blockDim.x) {
+            float x = 0.f;
+            if (c < width) x = ok ? (c < dim ? t0[k * dim + c] : t1[k * dim + (c - dim)]) : __builtin_nanf("");
+            out[i * ld + c] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+        }
+    }
+}
+
 // dtable[tok[i], c] += dout[i, col_off + c]; the padding row receives nothing (nn.Embedding(padding_idx)).
 // DETERMINISTIC: no atomics.  The workgroup of position i scans the token list in chunks of 256 (one ballot per wave, the four masks shared
 // through LDS); if the first occurrence of its token is not i it has nothing to do, otherwise it alone owns table row tok[i] and adds the
@@ -324,6 +340,17 @@ int cti_embedding_fwd(const int64_t* tokens, const float* table0, const float* t
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, as_stream(stream), tokens, table0,
                        table1, out, n, dim, rows);
     return launch_status("cti_embedding_fwd");
+}
+
+int cti_embedding_fwd_bf16(const int64_t* tokens, const float* table0, const float* table1, void* out_bf16, int64_t ld_out, int64_t n, int dim, int64_t rows,
+                           void* stream) {
+    CTI_REQUIRE_PTR(tokens); CTI_REQUIRE_PTR(table0); CTI_REQUIRE_PTR(out_bf16);
+    CTI_REQUIRE(n >= 0 && dim > 0 && rows > 0 && ld_out >= (table1 ? 2 : 1) * (int64_t)dim && ld_out < (1 << 20), CTI_E_SHAPE,
+                "cti_embedding_fwd_bf16: n=%lld dim=%d rows=%lld ld=%lld", (long long)n, dim, (long long)rows, (long long)ld_out);
+    if (n == 0) return CTI_OK;
+    hipLaunchKernelGGL(embedding_fwd_bf16_kernel, dim3((unsigned)(n < 65535 ? n : 65535)), dim3(256), 0, as_stream(stream), tokens, table0, table1,
+                       static_cast<unsigned short*>(out_bf16), ld_out, n, dim, rows);
+    return launch_status("cti_embedding_fwd_bf16");
 }
 
 int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout, int col_off, float* dtable, int64_t n, int dim,

@@ -10,6 +10,8 @@ import torch.nn as nn
 from . import autograd as AG
 from . import ops
 
+_ROWS16 = __import__("os").environ.get("CTI_EMB_ROWS16", "1") == "1"      # 0: fp32 word vectors + a split pass in front of the GRU's input product (rounds 1-5; A/B)
+
 
 class WordEmbedding(nn.Module):
     """Token ids -> word vectors; row `ntoken` of each table is the padding row (src/language_model.py:13-17).  With 'c' in `op` a second,
@@ -53,6 +55,14 @@ class WordEmbedding(nn.Module):
             table[:second.size(0)] = second
             self.emb_.weight.data[:self.ntoken] = table.to(dev)
 
+    def rows16(self, x):
+        """Inference in the plain-bf16 mode: the word vectors as the bf16 rows QuestionEmbedding.forward_all multiplies as they stand (ops.embedding_rows16); the fp32
+        vectors of forward() otherwise."""
+        if (self.training or torch.is_grad_enabled() or ops.get_precision() != "bf16" or not x.is_cuda or not _ROWS16):
+            return self.forward(x)
+        second = self.emb_.weight if self._concat else None
+        return ops.embedding_rows16(x, self.emb.weight.detach(), None if second is None else second.detach())
+
     def forward(self, x):
         second = self.emb_.weight if self._concat else None
         if torch.is_grad_enabled() and (self.emb.weight.requires_grad or (second is not None and second.requires_grad)):
@@ -92,6 +102,8 @@ class QuestionEmbedding(nn.Module):
         self._check()
         r = self.rnn
         ps = (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        if x.dtype == torch.bfloat16 and (torch.is_grad_enabled() or ops.get_precision() != "bf16"):
+            x = ops.widen_bf16(x[:, :, :self.in_dim]).contiguous()         # (rows16 outside the mode it is for)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ps)):
             return AG.GRUFn.apply(x, *ps)
         key = (ps[0].data_ptr(), ps[0]._version, ps[1].data_ptr(), ps[1]._version, ops._param_epoch[0], ops.get_precision())

@@ -1673,6 +1673,26 @@ def embedding(tokens, table0, table1=None):
     return out
 
 
+def embedding_rows16(tokens, table0, table1=None):
+    """tokens (...,) int64 -> bf16 rows (..., ld), ld = the row's width rounded up to a multiple of 32 (zero beyond the width): the GRU's input-side operand as
+    the plain-bf16 mode multiplies it (gru_forward takes it as it stands: no fp32 word vectors, no split pass)."""
+    _req(tokens, "tokens", torch.int64); _req(table0, "table0")
+    tok = tokens.contiguous()
+    rows, dim = table0.shape
+    t0 = table0.contiguous()
+    t1 = None
+    if table1 is not None:
+        _req(table1, "table1")
+        if tuple(table1.shape) != (rows, dim):
+            raise ValueError("the two embedding tables differ in shape: %s vs %s" % (tuple(table0.shape), tuple(table1.shape)))
+        t1 = table1.contiguous()
+    width = (2 if t1 is not None else 1) * dim
+    ld = (width + 31) // 32 * 32
+    out = torch.empty(tuple(tok.shape) + (ld,), device=tok.device, dtype=torch.bfloat16)
+    L.check(L.lib().cti_embedding_fwd_bf16(tok.data_ptr(), t0.data_ptr(), _ptr(t1), out.data_ptr(), ld, tok.numel(), dim, rows, _stream()), "cti_embedding_fwd_bf16")
+    return out
+
+
 def embedding_bwd(tokens, dout, col_off, rows, dim, padding_idx):
     """-> dtable (rows, dim) = scatter-add of dout[..., col_off:col_off+dim] by token (the padding row stays zero)."""
     tok = tokens.contiguous()
@@ -1712,8 +1732,13 @@ def gru_persistent_ok():
 def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=None):
     """One-layer, one-direction nn.GRU(batch_first=True) from a zero state: x (B,T,in) -> every hidden state (B,T,H), in ONE library
     call (the time loop lives behind the C ABI).  want_save: also returns save (T,B,5,H) = (r, z, n, W_hn h + b_hn, h_t)."""
-    _req(x, "x")
+    x16 = x.dtype == torch.bfloat16                                   # embedding_rows16's rows: (B, T, I rounded up to 32), the plain-bf16 mode only
+    _req(x, "x", torch.bfloat16 if x16 else torch.float32)
     B, T, I = x.shape
+    if x16:
+        I = w_ih.shape[1]
+        if _prec(prec) != L.PREC_BF16 or want_save or x.shape[2] != (I + 31) // 32 * 32:
+            x, x16 = widen_bf16(x[:, :, :I]).contiguous(), False
     H = w_hh.shape[1]
     out = torch.empty((B, T, H), device=x.device, dtype=torch.float32)
     save = torch.empty((T, B, 5, H), device=x.device, dtype=torch.float32) if want_save else None
@@ -1728,6 +1753,12 @@ def gru_forward(x, w_ih, w_hh, b_ih, b_hh, want_save=False, prec=None, w_planes=
         L.check(lib.cti_set_tuning(L.TUNE_GRU_PERSISTENT, 1), "cti_set_tuning")
     try:
         with _timed("gru_forward_%dx%dx%d->%d" % (B, T, I, H)):
+            if x16:
+                L.check(lib.cti_gru_forward_x16(x.contiguous().data_ptr(), x.shape[2], w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
+                                                b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), 0, B, T, I, H, pr,
+                                                _ptr(w_planes[0]) if w_planes else 0, _ptr(w_planes[1]) if w_planes else 0,
+                                                ws.data_ptr(), wsb, _stream()), "cti_gru_forward_x16")
+                return out, save
             L.check(lib.cti_gru_forward(x.contiguous().data_ptr(), w_ih.contiguous().data_ptr(), w_hh.contiguous().data_ptr(),
                                         b_ih.contiguous().data_ptr(), b_hh.contiguous().data_ptr(), out.data_ptr(), _ptr(save), B, T, I, H, pr,
                                         _ptr(w_planes[0]) if w_planes and pr != L.PREC_F32 else 0,

@@ -564,6 +564,10 @@ size_t cti_optim_workspace_bytes(void);
  * tables: (rows, dim) contiguous; a token outside [0, rows) produces NaNs (torch raises IndexError there). */
 int cti_embedding_fwd(const int64_t* tokens, const float* table0, const float* table1, float* out, int64_t n, int dim, int64_t rows,
                       void* stream);
+/* The same lookup as bf16 rows of pitch ld_out (>= the row's width, zero-filled beyond it; reference src/language_model.py:40-46): the operand
+ * cti_gru_forward_x16 reads as it stands (round 6: the plain-bf16 mode's word vectors never exist as fp32 rows). */
+int cti_embedding_fwd_bf16(const int64_t* tokens, const float* table0, const float* table1, void* out_bf16, int64_t ld_out, int64_t n, int dim, int64_t rows,
+                           void* stream);
 /* dtable[tokens[i], :] += dout[i, col_off : col_off + dim] (atomic adds; the caller zeroes dtable); row padding_idx receives
  * nothing, like nn.Embedding(padding_idx = ntoken) (src/language_model.py:19). */
 int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout, int col_off, float* dtable, int64_t n, int dim,
@@ -577,6 +581,11 @@ int cti_embedding_bwd(const int64_t* tokens, const float* dout, int64_t ld_dout,
 int cti_gru_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
                     int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* cti_gru_forward with x as bf16 rows: (B * T) rows of pitch ldx = I rounded up to a multiple of 32, zero beyond column I, 16-B aligned base
+ * (what cti_embedding_fwd_bf16 writes).  CTI_PREC_BF16 only: the input-side product reads the rows as they stand -- no split pass. */
+int cti_gru_forward_x16(const void* x_bf16, int64_t ldx, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* out, float* save,
+                        int B, int T, int I, int H, int prec, const void* w_ih_planes, const void* w_hh_planes, void* workspace, size_t workspace_bytes,
+                        void* stream);
 size_t cti_gru_forward_workspace_bytes(int B, int T, int I, int H, int prec);
 /* Back-propagation through time.  dout (B,T,H) contiguous; writes the pre-activation gradients dgi (B,T,3H) (input side: dx = dgi W_ih,
  * dW_ih = dgi^T x, db_ih = column sums) and dgh (T,B,3H) (hidden side, time-major: dW_hh = sum_t dgh_t^T h_{t-1}, db_hh = column

@@ -1132,3 +1132,45 @@ def test_gru_step_with_k_split_over_the_waves(B, Tn, I, H, mode, tol, precision)
                 assert torch.equal(save, save2) and torch.equal(save[:, :, 4, :].transpose(0, 1), out)
     finally:
         ops.set_precision(old)
+
+
+@pytest.mark.parametrize("B,Tn,dim,H,concat", [(256, 12, 300, 1024, True), (64, 6, 300, 512, False), (3, 5, 20, 48, True)])
+def test_bf16_word_vectors_straight_into_the_gru(B, Tn, dim, H, concat, precision):
+    """Round 6 (a first step): in the plain-bf16 mode the word embedding writes bf16 rows (pitch = width rounded up to 32, zeros beyond) and the GRU's
+    input-side product reads them as they stand -- no fp32 word vectors, no split pass.  The same bf16 operands as the fp32-vectors path (the split pass rounds the same
+    values to the same bf16), padding token rows included; outside the plain-bf16 mode the rows are widened and the result is the fp32 path's."""
+    if precision != "bf16x3":
+        pytest.skip("mode set explicitly below; run once")
+    torch.manual_seed(B + dim)
+    ntoken = 500
+    emb = cti_amd.WordEmbedding(ntoken, dim, 0.0, op='c' if concat else '').to(DEV).eval()
+    gru = cti_amd.QuestionEmbedding((2 if concat else 1) * dim, H, 1, False, 0.0).to(DEV).eval()
+    with torch.no_grad():
+        emb.emb.weight.normal_(); emb.emb.weight[ntoken].zero_()
+        if concat:
+            emb.emb_.weight.normal_(); emb.emb_.weight[ntoken].zero_()
+    tok = torch.randint(0, ntoken + 1, (B, Tn), device=DEV)
+    old = ops.get_precision()
+    try:
+        ops.set_precision("bf16")
+        with torch.no_grad():
+            rows = emb.rows16(tok)
+            assert rows.dtype == torch.bfloat16 and rows.shape == (B, Tn, ((2 if concat else 1) * dim + 31) // 32 * 32)
+            x32 = emb(tok)
+            assert torch.equal(rows[:, :, :x32.shape[2]].float(), x32.to(torch.bfloat16).float())
+            assert float(rows[:, :, x32.shape[2]:].float().abs().max() if rows.shape[2] > x32.shape[2] else 0.0) == 0.0
+            a = gru.forward_all(rows)
+            b = gru.forward_all(x32)
+            # the same bf16 operands either way; at the model shape both input-side products run on the same kernel (every bit equal), at small shapes the fp32
+            # path's product is the skinny kernel (another summation order: fp32 rounding, amplified by the recurrence's bf16 roundings of h)
+            if B * Tn >= 1024:
+                assert torch.equal(a, b)
+            assert float((a - b).abs().max()) < 2e-3
+        ops.set_precision("bf16x3")
+        with torch.no_grad():
+            assert emb.rows16(tok).dtype == torch.float32                      # not this mode's operand: the fp32 vectors
+            c = gru.forward_all(rows)                                           # bf16 rows handed in anyway are widened
+            d = gru.forward_all(rows[:, :, :x32.shape[2]].float().contiguous())
+            assert torch.equal(c, d)
+    finally:
+        ops.set_precision(old)
